@@ -1,0 +1,452 @@
+"""ORACLE (test infrastructure, NOT product code): per-kernel specifications.
+
+One torch-CPU function per C-ABI entry point of libscasr (include/scasr.h),
+with the same argument meaning and the same buffer layouts, so that
+
+* tests can run the product's host logic (speechcatcher_amd.engine) on CPU
+  against the reference-port oracle (oracle/ref_port.py) without a GPU, and
+* every HIP kernel is checked op-by-op against its spec on the GPU
+  (tests/test_gpu_ops.py).
+
+The arithmetic follows the reference (citations on each op, paths relative to
+/root/reference); the decomposition (K/V caches, ancestor tables, ping-pong
+hypothesis buffers) follows DESIGN.md.  Only tests/ may import this module.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOGZERO = -10000000000.0
+
+
+def _rows(t2d, rows):
+    """Gather rows (index -1 -> zero row)."""
+    rows = rows.to(torch.long)
+    out = t2d[rows.clamp(min=0)]
+    out = out.clone()
+    out[rows < 0] = 0
+    return out
+
+
+class SpecBackend:
+    name = "spec"
+
+    # ------------------------------------------------------------------
+    # frontend: speechcatcher/model/frontend/stft_frontend.py:87-154 +
+    # MVN / trimming of speechcatcher/speech2text_streaming.py:355-389
+    # ------------------------------------------------------------------
+    def logmel(self, w, pcm, pcap, jobs, n_jobs, max_keep, featbuf):
+        cfg = w.cfg
+        jobs = jobs.cpu().numpy()
+        for j in range(n_jobs):
+            s, seg_start, seg_len, eff_len, lo, n, dst0, _ = [int(v) for v in jobs[j]]
+            x = torch.zeros(eff_len)
+            x[:seg_len] = pcm[s, seg_start:seg_start + seg_len]
+            st = torch.stft(x.unsqueeze(0), n_fft=cfg.n_fft, hop_length=cfg.hop_length,
+                            win_length=cfg.win_length, window=w.window, center=True,
+                            normalized=False, onesided=True, return_complex=True).transpose(1, 2)
+            power = st.real ** 2 + st.imag ** 2
+            mel = torch.clamp(torch.matmul(power, w.mel_fb), min=1e-10).log()[0]
+            if w.has_mvn:
+                if w.mvn_is_f64:
+                    mel = ((mel.to(torch.float64) - w.mean64) / w.std64).to(torch.float32)
+                else:
+                    mel = (mel - w.mean64.to(torch.float32)) / w.std64.to(torch.float32)
+            featbuf[dst0:dst0 + n] = mel[lo:lo + n]
+
+    # ------------------------------------------------------------------
+    # Conv2dSubsampling: speechcatcher/model/encoder/subsampling.py:87-98
+    # ------------------------------------------------------------------
+    def conv1(self, w, featbuf, jobs, n_jobs, max_t1, c1):
+        cfg = w.cfg
+        d, F1 = cfg.d_model, cfg.conv_freq1
+        jobs = jobs.cpu().numpy()
+        wt = w.conv1_w.view(d, 1, 3, 3)
+        c1v = c1.view(-1, F1, d)
+        for j in range(n_jobs):
+            src0, t_in, r0, t1 = [int(v) for v in jobs[j]]
+            x = featbuf[src0:src0 + t_in].view(1, 1, t_in, cfg.n_mels)
+            y = torch.relu(F.conv2d(x, wt, w.conv1_b, stride=2))[0]  # (d, t1, F1)
+            c1v[r0:r0 + t1] = y.permute(1, 2, 0)
+
+    def gemm(self, A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, relu=False,
+             conv_f1=0, residual=False):
+        """C[c_rows[m], :N] (+)= A[a_rows[m], :] . W^T + bias.
+
+        A is addressed as a flat buffer: element (m, k) lives at
+        a_rows[m]*lda + kofs(k) where kofs(k) = k, or for the implicit conv
+        (conv_f1 > 0, lda = channels): tap = k // lda, kofs = ((tap//3)*conv_f1
+        + tap%3)*lda + k%lda.  ``residual`` adds the previous content of C."""
+        Af = A.reshape(-1)
+        if a_rows is None:
+            base = torch.arange(M, dtype=torch.long) * lda
+        else:
+            base = a_rows.to(torch.long)[:M] * lda
+        k = torch.arange(K, dtype=torch.long)
+        if conv_f1 > 0:
+            tap = k // lda
+            kofs = ((tap // 3) * conv_f1 + tap % 3) * lda + k % lda
+        else:
+            kofs = k
+        a = Af[base.unsqueeze(1) + kofs.unsqueeze(0)]
+        out = F.linear(a, W[:N, :K], bias)
+        if relu:
+            out = torch.relu(out)
+        Cf = C.reshape(-1)
+        if c_rows is None:
+            cb = torch.arange(M, dtype=torch.long) * ldc
+        else:
+            cb = c_rows.to(torch.long)[:M] * ldc
+        idx = cb.unsqueeze(1) + torch.arange(N, dtype=torch.long).unsqueeze(0)
+        if residual:
+            out = Cf[idx] + out
+        Cf[idx] = out
+
+    def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
+        dst[dst_rows.to(torch.long)[:n]] = src[src_rows.to(torch.long)[:n]].clone()
+
+    def layernorm(self, src, src_rows, dst, dst_rows, M, g, b, eps=1e-12):
+        """speechcatcher/model/layers/normalization.py:7-24"""
+        x = src[:M] if src_rows is None else _rows(src, src_rows[:M])
+        y = F.layer_norm(x, (x.size(-1),), g, b, eps)
+        if dst_rows is None:
+            dst[:M] = y
+        else:
+            dst[dst_rows.to(torch.long)[:M]] = y
+
+    def log_softmax_rows(self, x, rows, n, V):
+        r = rows.to(torch.long)[:n]
+        x[r] = torch.log_softmax(x[r], dim=-1)
+
+    # ------------------------------------------------------------------
+    # block assembly: contextual_block_transformer_encoder.py:354-380
+    # ------------------------------------------------------------------
+    def block_pack(self, w, subbuf, jobs, nb, R, xblk):
+        cfg = w.cfg
+        d = cfg.d_model
+        jobs = jobs.cpu().numpy()
+        x = xblk[:nb * R].view(nb, R, d)
+        sq = math.sqrt(d)
+        for b in range(nb):
+            src0, clen, pe_f, pe_c, short, _ = [int(v) for v in jobs[b]]
+            chunk = subbuf[src0:src0 + clen]
+            if short:
+                x[b, :clen] = chunk * sq + w.pe[pe_f:pe_f + clen]
+                continue
+            x[b] = 0
+            x[b, 1:clen + 1] = chunk * sq + w.pe[pe_f:pe_f + clen]
+            x[b, R - 1] = chunk.mean(0) * sq + w.pe[pe_c]
+
+    def ctx_handoff(self, x, R, jobs, ns, state, layer):
+        """contextual_block_encoder_layer.py:253-269 (also the prev_addin
+        chain of contextual_block_transformer_encoder.py:370-380)."""
+        d = x.size(-1)
+        jobs = jobs.cpu().numpy()
+        for j in range(ns):
+            b0, nbk, srow, has = [int(v) for v in jobs[j]]
+            xv = x[b0 * R:(b0 + nbk) * R].view(nbk, R, d)
+            v = state[srow + layer].clone() if has else xv[0, R - 1].clone()
+            last = xv[:, R - 1].clone()
+            xv[0, 0] = v
+            if nbk > 1:
+                xv[1:, 0] = last[:-1]
+            state[srow + layer] = last[-1]
+
+    def enc_attention(self, qkv, att, nblk, R, H, masked):
+        """multi_head_attention.py:92-133 on (nblk, R, d) blocks.  masked:
+        query row 0 fully masked (-> zeros), key column R-1 masked
+        (contextual_block_transformer_encoder.py:524-528)."""
+        d = att.size(-1)
+        dk = d // H
+        q, k, v = qkv[:nblk * R].view(nblk, R, 3, H, dk).unbind(2)
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+        scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
+        if masked:
+            mask = torch.zeros(R, R)
+            mask[1:, :R - 1] = 1
+            mask = mask.view(1, 1, R, R)
+            scores = scores.masked_fill(mask == 0, torch.finfo(scores.dtype).min)
+            p = torch.softmax(scores, dim=-1).masked_fill(mask == 0, 0.0)
+        else:
+            p = torch.softmax(scores, dim=-1)
+        o = torch.matmul(p, v).transpose(1, 2).reshape(nblk * R, d)
+        att[:nblk * R] = o
+
+    def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
+        """contextual_block_encoder_layer.py:215-271 x n_layers"""
+        cfg = w.cfg
+        d, Fd, M = cfg.d_model, cfg.ffn_dim, nblk * R
+        for li, lw in enumerate(w.enc):
+            self.layernorm(x, None, xn, None, M, lw["ln1_g"], lw["ln1_b"])
+            self.gemm(xn, None, d, lw["wqkv"], lw["bqkv"], qkv, None, 3 * d, M, 3 * d, d)
+            self.enc_attention(qkv, att, nblk, R, cfg.enc_heads, masked)
+            self.gemm(att, None, d, lw["wo"], lw["bo"], x, None, d, M, d, d, residual=True)
+            self.layernorm(x, None, xn, None, M, lw["ln2_g"], lw["ln2_b"])
+            self.gemm(xn, None, d, lw["w1"], lw["b1"], ffh, None, Fd, M, Fd, d, relu=True)
+            self.gemm(ffh, None, Fd, lw["w2"], lw["b2"], x, None, d, M, d, Fd, residual=True)
+            if masked:
+                self.ctx_handoff(x, R, jobs, ns, past_ctx, li)
+
+    # ------------------------------------------------------------------
+    # search-side ops.  ``sb`` is the StreamBatch (buffers + ctrl).
+    # ------------------------------------------------------------------
+    def ctc_extend_state(self, sb):
+        """ctc_prefix_score_full.py:349-368"""
+        ctrl = sb.ctrl.cpu().numpy()
+        V = sb.cfg.vocab_size
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, told = [int(v) for v in ctrl[s]]
+            if not act or not has or told >= T:
+                continue
+            xb = sb.ctcx.view(sb.S, sb.TCAP, V)[s, :, sb.cfg.blank_id]
+            r = sb.ctc_r[cur, s]
+            for t in range(max(told, 1), T):
+                r[t, 0, :nh] = LOGZERO
+                r[t, 1, :nh] = r[t - 1, 1, :nh] + xb[t]
+
+    def dec_embed(self, sb):
+        """transformer_decoder.py:231 + positional_encoding.py:64-74"""
+        w, cfg = sb.w, sb.cfg
+        ctrl = sb.ctrl.cpu().numpy()
+        sq = math.sqrt(cfg.d_model)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            tok = sb.yseq[cur, s, :nh, L - 1].to(torch.long)
+            sb.dx[s * sb.W:s * sb.W + nh] = w.embed[tok] * sq + w.pe[L - 1]
+
+    def dec_self_attn(self, sb, li):
+        """decoder_layer.py:85-101 with a true K/V cache: the new K/V row is
+        appended at position L-1 of slot h; older rows are found through the
+        ancestor table.  (A14: identical to re-projecting the output cache.)"""
+        cfg = sb.cfg
+        d, H, W = cfg.d_model, cfg.dec_heads, sb.W
+        dk = d // H
+        ctrl = sb.ctrl.cpu().numpy()
+        skv = sb.skv.view(sb.S, cfg.dec_layers, sb.LCAP, W, 2 * d)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            rows = slice(s * W, s * W + nh)
+            qkv = sb.dqkv[rows]
+            skv[s, li, L - 1, :nh] = qkv[:, d:]
+            anc = sb.anc[cur, s, :L, :nh].to(torch.long).clone()   # (L, nh)
+            anc[L - 1] = torch.arange(nh)
+            pos = torch.arange(L).unsqueeze(1).expand(L, nh)
+            kv = skv[s, li][pos, anc]                               # (L, nh, 2d)
+            k = kv[..., :d].permute(1, 0, 2).reshape(nh, L, H, dk).transpose(1, 2)
+            v = kv[..., d:].permute(1, 0, 2).reshape(nh, L, H, dk).transpose(1, 2)
+            q = qkv[:, :d].reshape(nh, 1, H, dk).transpose(1, 2)
+            sc = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
+            p = torch.softmax(sc, dim=-1)
+            sb.datt[rows] = torch.matmul(p, v).transpose(1, 2).reshape(nh, d)
+
+    def dec_cross_attn(self, sb, li):
+        """decoder_layer.py:106-115, K/V projected once per encoder frame and
+        shared by all hypotheses of the stream."""
+        cfg = sb.cfg
+        d, H, W = cfg.d_model, cfg.dec_heads, sb.W
+        dk = d // H
+        ctrl = sb.ctrl.cpu().numpy()
+        ckv = sb.ckv.view(sb.S, cfg.dec_layers, sb.TCAP, 2 * d)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            rows = slice(s * W, s * W + nh)
+            kv = ckv[s, li, :T]
+            k = kv[:, :d].reshape(1, T, H, dk).transpose(1, 2)
+            v = kv[:, d:].reshape(1, T, H, dk).transpose(1, 2)
+            q = sb.dq[rows].reshape(nh, 1, H, dk).transpose(1, 2)
+            sc = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
+            p = torch.softmax(sc, dim=-1)
+            sb.datt[rows] = torch.matmul(p, v).transpose(1, 2).reshape(nh, d)
+
+    def decoder_layers(self, sb):
+        w, cfg = sb.w, sb.cfg
+        d, Fd, n = cfg.d_model, cfg.ffn_dim, sb.S * sb.W
+        for li, lw in enumerate(w.dec):
+            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln1_g"], lw["ln1_b"])
+            self.gemm(sb.dxn, None, d, lw["wqkv"], lw["bqkv"], sb.dqkv, None, 3 * d, n, 3 * d, d)
+            self.dec_self_attn(sb, li)
+            self.gemm(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d, residual=True)
+            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln2_g"], lw["ln2_b"])
+            self.gemm(sb.dxn, None, d, lw["wq"], lw["bq"], sb.dq, None, d, n, d, d)
+            self.dec_cross_attn(sb, li)
+            self.gemm(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d, residual=True)
+            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln3_g"], lw["ln3_b"])
+            self.gemm(sb.dxn, None, d, lw["w1"], lw["b1"], sb.dffh, None, Fd, n, Fd, d, relu=True)
+            self.gemm(sb.dffh, None, Fd, lw["w2"], lw["b2"], sb.dx, None, d, n, d, Fd, residual=True)
+
+    def logsoftmax_topk(self, sb):
+        """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
+        logp = log_softmax(logits); ids = top-K of fl(w_dec * logp), descending,
+        ties -> lowest index."""
+        n, V, K = sb.S * sb.W, sb.cfg.vocab_size, sb.K
+        sb.logp[:n] = torch.log_softmax(sb.logits[:n], dim=-1)
+        wd = torch.tensor(sb.search.decoder_weight, dtype=torch.float32)
+        key = (wd * sb.logp[:n])
+        # stable descending sort == lowest index first among ties
+        order = torch.sort(key, dim=-1, descending=True, stable=True).indices
+        sb.pre_ids[:n] = order[:, :K].to(torch.int32)
+
+    def ctc_prefix_scan(self, sb):
+        """CTCPrefixScoreTH.__call__ (ctc_prefix_score_full.py:88-291) for the
+        K pre-beam candidates of every live hypothesis.  Outputs
+        psi[(s,h),k] = log_psi of candidate k (blank candidate -> logzero,
+        eos candidate -> r_sum[T-1]), psi_eos[(s,h)] = r_sum[T-1],
+        ctc_rnew[s,t,:,h*K+k] = r."""
+        cfg = sb.cfg
+        V, W, K = cfg.vocab_size, sb.W, sb.K
+        ctrl = sb.ctrl.cpu().numpy()
+        X = sb.ctcx.view(sb.S, sb.TCAP, V)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            x = X[s, :T]
+            xb = x[:, cfg.blank_id]
+            ids = sb.pre_ids[s * W:s * W + nh].to(torch.long)        # (nh, K)
+            last = sb.yseq[cur, s, :nh, L - 1].to(torch.long)
+            if has:
+                r_prev = sb.ctc_r[cur, s, :T, :, :nh]                 # (T, 2, nh)
+            else:
+                r_prev = torch.full((T, 2, nh), LOGZERO)
+                r_prev[:, 1] = torch.cumsum(xb, 0).unsqueeze(1)
+            r_sum = torch.logsumexp(r_prev, 1)                       # (T, nh)
+            xn = x[:, ids.reshape(-1)].view(T, nh, K)
+            log_phi = r_sum.unsqueeze(2).repeat(1, 1, K)
+            same = ids == last.unsqueeze(1)                          # (nh, K)
+            log_phi = torch.where(same.unsqueeze(0), r_prev[:, 1].unsqueeze(2).expand(T, nh, K), log_phi)
+            r = torch.full((T, 2, nh, K), LOGZERO)
+            out_len = L - 1
+            if out_len == 0:
+                r[0, 0] = xn[0]
+            start = min(max(out_len, 1), T)
+            for t in range(start, T):
+                rp = r[t - 1]
+                r[t, 0] = torch.logsumexp(torch.stack([rp[0], log_phi[t - 1]]), 0) + xn[t]
+                r[t, 1] = torch.logsumexp(torch.stack([rp[0], rp[1]]), 0) + xb[t]
+            log_phi_x = torch.cat((log_phi[0].unsqueeze(0), log_phi[:-1]), 0) + xn
+            psi = torch.logsumexp(torch.cat((log_phi_x[start:T], r[start - 1, 0].unsqueeze(0)), 0), 0)
+            eos_val = r_sum[T - 1]                                   # (nh,)
+            psi = torch.where(ids == cfg.eos_id, eos_val.unsqueeze(1).expand(nh, K), psi)
+            psi = torch.where(ids == cfg.blank_id, torch.full_like(psi, LOGZERO), psi)
+            sb.psi[s * W:s * W + nh] = psi
+            sb.psi_eos[s * W:s * W + nh] = eos_val
+            sb.ctc_rnew[s, :T, :, :nh * K] = r.reshape(T, 2, nh * K)
+
+    def fuse_topw(self, sb):
+        """beam_search.py:113-185 fusion + :723 per-hypothesis top-W.
+        combined[v] = fl(fl(wd*logp[v]) + fl(wc*ctc[v])), ctc[v] = logpsi[v] - s_prev."""
+        cfg = sb.cfg
+        V, W, K = cfg.vocab_size, sb.W, sb.K
+        ctrl = sb.ctrl.cpu().numpy()
+        wd = torch.tensor(sb.search.decoder_weight, dtype=torch.float32)
+        wc = torch.tensor(sb.search.ctc_weight, dtype=torch.float32)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            rows = slice(s * W, s * W + nh)
+            ids = sb.pre_ids[rows].to(torch.long)
+            lpsi = torch.full((nh, V), LOGZERO)
+            lpsi.scatter_(1, ids, sb.psi[rows])
+            lpsi[:, cfg.eos_id] = sb.psi_eos[rows]
+            lpsi[:, cfg.blank_id] = LOGZERO
+            s_prev = sb.ctc_s[cur, s, :nh].unsqueeze(1) if has else torch.zeros(nh, 1)
+            ctc = lpsi - s_prev
+            comb = wd * sb.logp[rows] + wc * ctc
+            order = torch.sort(comb, dim=-1, descending=True, stable=True).indices[:, :W]
+            sb.cand_tok[rows] = order.to(torch.int32)
+            sb.cand_score[rows] = comb.gather(1, order)
+            sb.cand_ctc[rows] = ctc.gather(1, order)
+
+    def beam_prune(self, sb):
+        """beam_search.py:721-809 + hypothesis.py:132-142: expand, stable
+        descending sort on float64 totals, keep W, bookkeeping, stop flags."""
+        cfg = sb.cfg
+        W, K = sb.W, sb.K
+        ctrl = sb.ctrl.cpu().numpy()
+        flags = torch.zeros(sb.S, dtype=torch.int32)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            o = 1 - cur
+            cands = []
+            for h in range(nh):
+                for j in range(W):
+                    tot = float(sb.score[cur, s, h]) + float(sb.cand_score[s * W + h, j])
+                    cands.append((tot, h, j))
+            cands = sorted(cands, key=lambda c: c[0], reverse=True)[:W]
+            any_eos = all_eos = best_eos = rep = False
+            all_eos = True
+            for i, (tot, h, j) in enumerate(cands):
+                tok = int(sb.cand_tok[s * W + h, j])
+                sb.yseq[o, s, i, :L] = sb.yseq[cur, s, h, :L]
+                sb.yseq[o, s, i, L] = tok
+                sb.xpos[o, s, i, :L] = sb.xpos[cur, s, h, :L]
+                sb.xpos[o, s, i, L] = T - 1
+                sb.score[o, s, i] = tot
+                sb.sc_dec[o, s, i] = float(sb.sc_dec[cur, s, h]) + float(sb.logp[s * W + h, tok])
+                sb.sc_ctc[o, s, i] = float(sb.sc_ctc[cur, s, h]) + float(sb.cand_ctc[s * W + h, j])
+                if L - 1 > 0:
+                    sb.anc[o, s, :L - 1, i] = sb.anc[cur, s, :L - 1, h]
+                sb.anc[o, s, L - 1, i] = h
+                ids = sb.pre_ids[s * W + h].tolist()
+                k = ids.index(tok) if tok in ids else -1
+                if tok == cfg.blank_id:
+                    sval = LOGZERO
+                elif tok == cfg.eos_id:
+                    sval = float(sb.psi_eos[s * W + h])
+                elif k >= 0:
+                    sval = float(sb.psi[s * W + h, k])
+                else:
+                    sval = LOGZERO
+                sb.ctc_s[o, s, i] = sval
+                sb.sel[s, i, 0] = h
+                sb.sel[s, i, 1] = max(k, 0)
+                is_eos = tok == cfg.eos_id
+                any_eos |= is_eos
+                all_eos &= is_eos
+                if i == 0:
+                    best_eos = is_eos
+                if tok != cfg.sos_id and tok != cfg.eos_id:
+                    if tok in sb.yseq[o, s, i, 1:L].tolist():
+                        rep = True
+            flags[s] = (1 if any_eos else 0) | (2 if best_eos else 0) | (4 if all_eos else 0) | (8 if rep else 0)
+        sb.flags.copy_(flags)
+
+    def ctc_gather_state(self, sb):
+        """CTCPrefixScorer.select_state (scorers.py:382-431)."""
+        W, K = sb.W, sb.K
+        ctrl = sb.ctrl.cpu().numpy()
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            o = 1 - cur
+            nout = min(W, nh * W)
+            for i in range(nout):
+                h, k = int(sb.sel[s, i, 0]), int(sb.sel[s, i, 1])
+                sb.ctc_r[o, s, :T, :, i] = sb.ctc_rnew[s, :T, :, h * K + k]
+
+    def decode_step(self, sb):
+        """One beam-search step for every active stream
+        (beam_search.py:701-758)."""
+        w, cfg = sb.w, sb.cfg
+        n, d = sb.S * sb.W, cfg.d_model
+        self.dec_embed(sb)
+        self.decoder_layers(sb)
+        self.layernorm(sb.dx, None, sb.dxn, None, n, w.dec_norm_g, w.dec_norm_b)
+        self.gemm(sb.dxn, None, d, w.out_w, w.out_b, sb.logits, None, cfg.vocab_size, n, cfg.vocab_size, d)
+        self.logsoftmax_topk(sb)
+        self.ctc_prefix_scan(sb)
+        self.fuse_topw(sb)
+        self.beam_prune(sb)
+        self.ctc_gather_state(sb)

@@ -1,0 +1,646 @@
+"""Host side of the MI355X streaming engine: per-stream integer bookkeeping
+(the three nested carry-over buffers, the block schedule, the blockwise-
+synchronous beam-search control flow) for S concurrent streams, driving
+batched device ops through a ``Backend`` (speechcatcher_amd.hip_backend in
+the product; a torch spec backend in tests).
+
+All arithmetic happens in the backend's kernels; this file only decides WHAT
+to launch.  It replaces, for S streams at once:
+
+* Speech2TextStreaming.apply_frontend        speechcatcher/speech2text_streaming.py:278-400
+* ContextualBlockTransformerEncoder.forward_infer
+                                             speechcatcher/model/encoder/contextual_block_transformer_encoder.py:241-419
+* BlockwiseSynchronousBeamSearch.process_block / _decode_one_block
+                                             speechcatcher/beam_search/beam_search.py:507-653,655-838
+(paths relative to /root/reference).  SURVEY.md Appendix D/E describe the
+exact buffering arithmetic restated here.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .config import ModelConfig, SearchConfig
+from .weights import PackedWeights
+
+# flags returned by the beam_prune kernel
+F_ANY_EOS, F_BEST_EOS, F_ALL_EOS, F_REPEAT = 1, 2, 4, 8
+# ctrl columns (int32 [S, 8])
+C_ACTIVE, C_CUR, C_FINAL, C_T, C_L, C_NHYP, C_HAS, C_TOLD = range(8)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+@dataclass
+class StreamState:
+    """Host mirror of one stream's scalar state (everything else is in HBM)."""
+    # frontend (apply_frontend)
+    fe_started: bool = False      # prev_states is not None
+    pcm_start: int = 0            # first un-consumed sample in the device pcm buffer
+    pcm_end: int = 0              # one past the last received sample
+    # encoder (forward_infer)
+    enc_started: bool = False     # prev_states is not None
+    fpp: int = 0                  # ping-pong index of the pre-subsampling feature buffer
+    nfeat: int = 0                # rows held in buffer_before_downsampling
+    upp: int = 0
+    nsub: int = 0                 # rows held in buffer_after_downsampling (-1: None)
+    has_sub: bool = False
+    n_blocks: int = 0             # n_processed_blocks
+    has_addin: bool = False
+    has_ctx: bool = False
+    short_pos: int = 0            # StreamPositionalEncoding counter (never reset: A13)
+    # search (BlockwiseSynchronousBeamSearch)
+    T_enc: int = 0                # len(encoder_buffer)
+    processed_block: int = 0
+    process_idx: int = 0
+    prev_valid: bool = False
+    started: bool = False         # running_hyps initialised
+    cur: int = 0                  # which ping-pong hypothesis buffer is live
+    L: int = 1                    # tokens per live hypothesis (incl. sos)
+    nhyp: int = 1
+    has_ctc: bool = False         # live hypotheses carry a CTC state
+    T_ctc: int = 0                # rows in the CTC table / cross-KV cache
+    output_index: int = 0
+    n_steps_total: int = 0
+
+
+class StreamBatch:
+    """S independent streams sharing one weight replica on one GPU."""
+
+    def __init__(self, weights: PackedWeights, backend, n_streams: int,
+                 search: SearchConfig = SearchConfig(), max_frames: int = 1600,
+                 max_tokens: int = 640, pcm_capacity: int = 1 << 20,
+                 max_chunk_samples: int = 32768, strict_reference: bool = True):
+        self.w = weights
+        self.cfg = cfg = weights.cfg
+        self.be = backend
+        self.S = S = n_streams
+        self.search = search
+        self.W = W = search.beam_size
+        self.K = K = min(search.pre_beam, cfg.vocab_size)
+        if W > K:
+            raise EngineError("beam_size must not exceed the pre-beam size (40)")
+        self.TCAP, self.LCAP, self.PCAP = max_frames, max_tokens, pcm_capacity
+        self.strict_reference = strict_reference
+        dev = weights.device
+        d, V, F = cfg.d_model, cfg.vocab_size, cfg.ffn_dim
+        self.dev = dev
+        f32, i32, f64 = torch.float32, torch.int32, torch.float64
+        z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+
+        # ---- frontend / encoder buffers
+        self.max_feat_new = 2 + max_chunk_samples // cfg.hop_length + 8
+        self.FCAP = self.max_feat_new + 16
+        self.UCAP = cfg.block_size + self.FCAP // 4 + 8
+        self.pcm = z(S, self.PCAP)
+        self.featbuf = z(2 * S * self.FCAP, cfg.n_mels)
+        self.subbuf = z(2 * S * self.UCAP, d)
+        self.prev_addin = z(S, d)
+        self.past_ctx = z(S * cfg.enc_layers, d)
+        self.enc = z(S * self.TCAP, d)
+        # scratch for one encoder call over all streams
+        self.max_t1 = (self.FCAP - 3) // 2 + 1
+        self.max_t2 = (self.max_t1 - 3) // 2 + 1
+        self.c1 = z(S * self.max_t1 * cfg.conv_freq1, d)
+        self.c2 = z(S * self.max_t2 * cfg.conv_freq2, d)
+        self.max_blocks = S * (self.UCAP // cfg.hop_size + 1)
+        R = cfg.block_size + 2
+        m_enc = self.max_blocks * R
+        self.xblk = z(m_enc, d)
+        self.ws_xn = z(m_enc, d)
+        self.ws_qkv = z(m_enc, 3 * d)
+        self.ws_att = z(m_enc, d)
+        self.ws_ffh = z(m_enc, F)
+        # ---- search state
+        self.ctcx = z(S * self.TCAP, V)
+        self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d)
+        self.skv = z(S * cfg.dec_layers * self.LCAP * W, 2 * d)
+        self.yseq = z(2, S, W, self.LCAP, dtype=i32)
+        self.xpos = z(2, S, W, self.LCAP, dtype=i32)
+        self.anc = z(2, S, self.LCAP, W, dtype=i32)
+        self.score = z(2, S, W, dtype=f64)
+        self.sc_dec = z(2, S, W, dtype=f64)
+        self.sc_ctc = z(2, S, W, dtype=f64)
+        self.ctc_r = z(2, S, self.TCAP, 2, W)
+        self.ctc_s = z(2, S, W)
+        self.ctc_rnew = z(S, self.TCAP, 2, W * K)
+        self.ctrl = z(S, 8, dtype=i32)
+        self.flags = z(S, dtype=i32)
+        n = S * W
+        self.dx = z(n, d)
+        self.dxn = z(n, d)
+        self.dqkv = z(n, 3 * d)
+        self.datt = z(n, d)
+        self.dq = z(n, d)
+        self.dffh = z(n, F)
+        self.logits = z(n, V)
+        self.logp = z(n, V)
+        self.pre_ids = z(n, K, dtype=i32)
+        self.psi = z(n, K)
+        self.psi_eos = z(n)
+        self.cand_score = z(n, W)
+        self.cand_tok = z(n, W, dtype=i32)
+        self.cand_ctc = z(n, W)
+        self.sel = z(S, W, 2, dtype=i32)
+        self.xchunk = 256
+        nch = (self.TCAP + self.xchunk - 1) // self.xchunk
+        self.xpart = z(n * cfg.dec_heads * nch, (d // cfg.dec_heads) + 2)
+
+        self.st = [StreamState() for _ in range(S)]
+        self._nhyp_prev: Dict[int, int] = {}
+        self._hasctc_prev: Dict[int, bool] = {}
+        self.reset_all()
+        self.stats = {"enc_calls": 0, "dec_steps": 0, "dec_blocks": 0}
+
+    # ------------------------------------------------------------------
+    def _itensor(self, arr) -> torch.Tensor:
+        a = np.ascontiguousarray(arr, dtype=np.int32)
+        return torch.from_numpy(a).to(self.dev, non_blocking=False)
+
+    def reset(self, s: int):
+        """Speech2TextStreaming.reset + BlockwiseSynchronousBeamSearch.reset
+        (speech2text_streaming.py:252-263, beam_search.py:343-356).  Unlike
+        the reference, the CTC table is dropped too (the reference keeps its
+        stale scorer.impl - see DESIGN.md "Deliberate deviations")."""
+        old = self.st[s]
+        ns = StreamState()
+        if self.strict_reference:
+            ns.short_pos = old.short_pos  # A13: counter survives reset()
+        self.st[s] = ns
+        self._init_hyp(s)
+
+    def reset_all(self):
+        for s in range(self.S):
+            self.reset(s)
+
+    def _init_hyp(self, s: int):
+        # create_initial_hypothesis (hypothesis.py:75-91): yseq=[sos], xpos=[0]
+        self.yseq[0, s, 0, 0] = self.cfg.sos_id
+        self.xpos[0, s, 0, 0] = 0
+        self.score[0, s, 0] = 0.0
+        self.sc_dec[0, s, 0] = 0.0
+        self.sc_ctc[0, s, 0] = 0.0
+
+    # ------------------------------------------------------------------
+    # frontend planning  (apply_frontend)
+    # ------------------------------------------------------------------
+    def _plan_frontend(self, st: StreamState, is_final: bool):
+        """Returns None (nothing to emit) or (seg_start, seg_len, eff_len,
+        keep_lo, keep_n) and updates pcm_start / fe_started exactly like
+        apply_frontend (speech2text_streaming.py:300-400)."""
+        cfg = self.cfg
+        win, hop = cfg.win_length, cfg.hop_length
+        N = st.pcm_end - st.pcm_start
+        first = not st.fe_started
+        seg_start = st.pcm_start
+        trim = math.ceil(math.ceil(win / hop) / 2)
+        if not N > win and not is_final:
+            st.fe_started = True          # next_states = {"waveform_buffer": speech}
+            return None
+        if is_final:
+            eff = N if N > win else win   # zero-pad up to win_length
+            total = 1 + eff // hop
+            lo, n = 0, total
+            if not first and total > trim:
+                lo, n = trim, total - trim
+            st.fe_started = False         # next_states = None
+            st.pcm_start = st.pcm_end
+            return seg_start, N, eff, lo, n
+        n_frames = (N - (win - hop)) // hop
+        n_res = (N - (win - hop)) % hop
+        proc = (win - hop) + n_frames * hop
+        total = 1 + proc // hop
+        st.pcm_start = st.pcm_end - (win - hop) - n_res
+        st.fe_started = True
+        if first:
+            n = total - trim if total > trim else total
+            return seg_start, proc, proc, 0, n
+        if total > 2 * trim:
+            return seg_start, proc, proc, trim, total - 2 * trim
+        return None                       # "too short after trimming": frames are lost
+
+    # ------------------------------------------------------------------
+    def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]],
+             pcm_resident: bool = False):
+        """One chunk step for the listed streams: (stream, samples, is_final).
+
+        ``samples`` is 1-D float PCM in +-1 (np.ndarray / torch tensor); with
+        ``pcm_resident`` the samples are already in ``self.pcm`` and the
+        tuple carries the sample COUNT instead (bench path: inputs resident
+        in HBM).  Mirrors Speech2TextStreaming.__call__ for raw audio.
+        Returns {stream: has_output} where has_output=False reproduces the
+        reference's early ``return []`` (speech2text_streaming.py:432-433).
+        """
+        cfg = self.cfg
+        fe_jobs = []
+        feat_new: Dict[int, int] = {}
+        finals: Dict[int, bool] = {}
+        for s, samples, is_final in chunks:
+            st = self.st[s]
+            finals[s] = bool(is_final)
+            n_new = int(samples) if pcm_resident else int(len(samples))
+            if st.pcm_end + n_new > self.PCAP:
+                self._compact_pcm(s)
+                if st.pcm_end + n_new > self.PCAP:
+                    raise EngineError("pcm buffer capacity exceeded")
+            if not pcm_resident and n_new > 0:
+                t = torch.as_tensor(samples, dtype=torch.float32)
+                self.pcm[s, st.pcm_end: st.pcm_end + n_new].copy_(t, non_blocking=False)
+            st.pcm_end += n_new
+            plan = self._plan_frontend(st, is_final)
+            if plan is None:
+                continue
+            seg_start, seg_len, eff_len, lo, n = plan
+            if n > self.max_feat_new:
+                raise EngineError("chunk produces more feature frames than max_chunk_samples allows")
+            # encoder buffer_before_downsampling lives at rows [0, nfeat) of the
+            # live ping-pong half; new frames are appended behind it.
+            nbuf = st.nfeat if st.enc_started else 0
+            dst_row0 = (st.fpp * self.S + s) * self.FCAP + nbuf
+            fe_jobs.append((s, seg_start, seg_len, eff_len, lo, n, dst_row0, 0))
+            feat_new[s] = n
+        if fe_jobs:
+            jobs = self._itensor(np.array(fe_jobs, np.int32))
+            self.be.logmel(self.w, self.pcm, self.PCAP, jobs, len(fe_jobs),
+                           max(j[5] for j in fe_jobs), self.featbuf)
+        out = {s: (s in feat_new) for s, _, _ in chunks}
+        if feat_new:
+            self._process_features(feat_new, finals)
+        return out
+
+    def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]]):
+        """2-D (T, n_mels) already-normalised features (the reference's 2-D /
+        3-D input path, speech2text_streaming.py:438-449)."""
+        feat_new, finals = {}, {}
+        for s, feats, is_final in items:
+            st = self.st[s]
+            n = feats.shape[0]
+            nbuf = st.nfeat if st.enc_started else 0
+            r0 = (st.fpp * self.S + s) * self.FCAP + nbuf
+            self.featbuf[r0:r0 + n].copy_(torch.as_tensor(feats, dtype=torch.float32))
+            feat_new[s] = n
+            finals[s] = bool(is_final)
+        self._process_features(feat_new, finals)
+
+    def _compact_pcm(self, s: int):
+        st = self.st[s]
+        n = st.pcm_end - st.pcm_start
+        if st.pcm_start > 0:
+            self.pcm[s, :n] = self.pcm[s, st.pcm_start:st.pcm_end].clone()
+            st.pcm_start, st.pcm_end = 0, n
+
+    # ------------------------------------------------------------------
+    # process_block: encoder + decode schedule
+    # ------------------------------------------------------------------
+    def _process_features(self, feat_new: Dict[int, int], finals: Dict[int, bool]):
+        cfg = self.cfg
+        for s in feat_new:
+            st = self.st[s]
+            if not st.started:
+                st.started = True  # running_hyps = [initial hypothesis]
+        enc_streams = [s for s, n in feat_new.items() if n >= 3]
+        # n < 3: encoder skipped, frames discarded (beam_search.py:551-559)
+        if enc_streams:
+            self._encode(enc_streams, feat_new, finals)
+        # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
+        pending = list(feat_new.keys())
+        done_final = set()
+        while True:
+            todo = []
+            for s in pending:
+                st = self.st[s]
+                if s in done_final:
+                    continue
+                cur_end = cfg.block_size - cfg.look_ahead + cfg.hop_size * st.processed_block
+                if st.T_enc > 0 and cur_end < st.T_enc:
+                    todo.append((s, cur_end, False))
+                elif finals[s] and st.T_enc > 0:
+                    todo.append((s, st.T_enc, True))
+                    done_final.add(s)
+            if not todo:
+                break
+            self._decode_blocks(todo)
+            for s, _, fin in todo:
+                if not fin:
+                    self.st[s].processed_block += 1
+
+    # ------------------------------------------------------------------
+    def _encode(self, streams: List[int], feat_new: Dict[int, int], finals: Dict[int, bool]):
+        """forward_infer for every listed stream, batched.  SURVEY Appendix D.2-3."""
+        cfg, S = self.cfg, self.S
+        d = cfg.d_model
+        F1, F2 = cfg.conv_freq1, cfg.conv_freq2
+        sub = cfg.subsample
+        be, w = self.be, self.w
+        conv_jobs = []      # (src_row0, T_in, c1_row0, T1)
+        a_rows = []         # conv2 implicit-GEMM A row indices into c1 (rows of width d)
+        lin_dst = []        # dst rows in subbuf for the subsampling Linear output
+        feat_copy = ([], [])
+        c1_rows = 0
+        per = {}
+        # ---- stage 1: buffer_before_downsampling + Conv2dSubsampling (:278-311)
+        for s in streams:
+            st = self.st[s]
+            fin = finals[s]
+            nbuf = st.nfeat if st.enc_started else 0
+            Tf = nbuf + feat_new[s]
+            base = (st.fpp * S + s) * self.FCAP
+            st.enc_started = True
+            if fin:
+                t_use, keep = Tf, 0
+                if Tf < 7:
+                    # the reference dies inside Conv2d with RuntimeError (A3)
+                    raise RuntimeError(
+                        "Calculated padded input size per channel is smaller than the 3x3 "
+                        f"subsampling kernel (stream {s}: {Tf} feature frames in a final chunk)")
+            else:
+                n_s = Tf // sub - 1
+                if n_s < 2:
+                    st.nfeat = Tf
+                    continue
+                keep = Tf % sub + sub * 2
+                t_use = n_s * sub
+            t1 = (t_use - 3) // 2 + 1
+            t2 = (t1 - 3) // 2 + 1
+            conv_jobs.append((base, t_use, c1_rows, t1))
+            tt, ff = np.meshgrid(np.arange(t2), np.arange(F2), indexing="ij")
+            a_rows.append(((c1_rows + 2 * tt) * F1 + 2 * ff).reshape(-1))
+            c1_rows += t1
+            if keep:
+                # residual feature rows move to the other ping-pong half
+                obase = ((1 - st.fpp) * S + s) * self.FCAP
+                feat_copy[0].append(base + Tf - keep + np.arange(keep))
+                feat_copy[1].append(obase + np.arange(keep))
+                st.fpp = 1 - st.fpp
+            st.nfeat = keep
+            nsub = st.nsub if st.has_sub else 0
+            ubase = (st.upp * S + s) * self.UCAP
+            if nsub + t2 > self.UCAP:
+                raise EngineError("subsampled-frame buffer capacity exceeded")
+            lin_dst.append(ubase + nsub + np.arange(t2))
+            per[s] = (t2, nsub, ubase)
+        if not conv_jobs:
+            return
+        self.stats["enc_calls"] += 1
+        cj = self._itensor(np.array(conv_jobs, np.int32))
+        be.conv1(w, self.featbuf, cj, len(conv_jobs), max(j[3] for j in conv_jobs), self.c1)
+        a_rows = np.concatenate(a_rows)
+        be.gemm(self.c1, self._itensor(a_rows), d, w.conv2_w, w.conv2_b, self.c2, None, d,
+                int(a_rows.shape[0]), d, 9 * d, relu=True, conv_f1=F1)
+        lin_dst = np.concatenate(lin_dst)
+        be.gemm(self.c2, None, F2 * d, w.sub_out_w, w.sub_out_b, self.subbuf, self._itensor(lin_dst), d,
+                int(lin_dst.shape[0]), d, F2 * d)
+        if feat_copy[0]:
+            src = np.concatenate(feat_copy[0])
+            be.copy_rows(self.featbuf, self._itensor(src), self.featbuf,
+                         self._itensor(np.concatenate(feat_copy[1])), int(src.size), cfg.n_mels)
+
+        # ---- stage 2: buffer_after_downsampling, block extraction (:313-380)
+        R = cfg.block_size + 2
+        offset = cfg.block_size - cfg.look_ahead - cfg.hop_size
+        blk_jobs = []          # (src_row0, chunk_len, pe_off_frames, pe_off_ctx, short, 0)
+        sjobs = []             # (b0, nblk, stream, has_addin, has_ctx)
+        emit_src, emit_dst = [], []
+        sub_copy = ([], [])
+        short_jobs = []
+        for s in streams:
+            if s not in per:
+                continue
+            st = self.st[s]
+            fin = finals[s]
+            t2, nsub, ubase = per[s]
+            U = nsub + t2
+            if fin:
+                nb = math.ceil(float(U - offset - cfg.look_ahead) / float(cfg.hop_size))
+                if st.n_blocks == 0 and U <= cfg.block_size:
+                    short_jobs.append((s, ubase, U))
+                    continue
+            else:
+                if U <= cfg.block_size:
+                    st.has_sub, st.nsub = True, U
+                    continue
+                overlap = cfg.block_size - cfg.hop_size
+                nb = max(0, U - overlap) // cfg.hop_size
+                res = U - cfg.hop_size * nb
+                obase = ((1 - st.upp) * S + s) * self.UCAP
+                sub_copy[0].append(ubase + U - res + np.arange(res))
+                sub_copy[1].append(obase + np.arange(res))
+                st.upp = 1 - st.upp
+                st.has_sub, st.nsub = True, res
+            nb = max(nb, 0)
+            b0 = len(blk_jobs)
+            for i in range(nb):
+                cur_hop = i * cfg.hop_size
+                clen = min(cfg.block_size, U - cur_hop)
+                blk_jobs.append((ubase + cur_hop, clen, cur_hop + cfg.hop_size * st.n_blocks,
+                                 i + st.n_blocks, 0, 0))
+            if nb > 0:
+                sjobs.append((b0, nb, s, int(st.has_addin), int(st.has_ctx)))
+                st.has_addin = st.has_ctx = True
+            # output extraction (_extract_output_from_blocks_infer :500-522)
+            first = st.n_blocks == 0
+            if fin:
+                y_len = U if first else U - offset
+            else:
+                y_len = nb * cfg.hop_size + (offset if first else 0)
+            src = np.full(y_len, -1, np.int64)
+            if first and nb > 0:
+                src[0:offset] = (b0 * R) + 1 + np.arange(offset)
+            for i in range(nb):
+                cur_hop = i * cfg.hop_size + (offset if first else 0)
+                if i == nb - 1 and fin:
+                    clen = min(cfg.block_size - offset, y_len - cur_hop)
+                else:
+                    clen = cfg.hop_size
+                src[cur_hop:cur_hop + clen] = (b0 + i) * R + 1 + offset + np.arange(clen)
+            if st.T_enc + y_len > self.TCAP:
+                raise EngineError("encoder-frame capacity (max_frames) exceeded")
+            emit_src.append(src)
+            emit_dst.append(s * self.TCAP + st.T_enc + np.arange(y_len))
+            st.T_enc += y_len
+            st.n_blocks += nb
+        if blk_jobs:
+            nbk = len(blk_jobs)
+            if nbk > self.max_blocks:
+                raise EngineError("too many encoder blocks in one call")
+            be.block_pack(w, self.subbuf, self._itensor(np.array(blk_jobs, np.int32)), nbk, R, self.xblk)
+            sj = np.array(sjobs, np.int32)
+            # slot-0 chain from prev_addin (:370-380)
+            j_add = np.stack([sj[:, 0], sj[:, 1], sj[:, 2], sj[:, 3]], 1)
+            be.ctx_handoff(self.xblk, R, self._itensor(j_add), len(sjobs), self.prev_addin, 0)
+            j_ctx = np.stack([sj[:, 0], sj[:, 1], sj[:, 2] * cfg.enc_layers, sj[:, 4]], 1)
+            be.encoder_layers(w, self.xblk, nbk, R, True, self._itensor(j_ctx), len(sjobs), self.past_ctx,
+                              self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
+        if emit_src:
+            src = np.concatenate(emit_src)
+            if src.size:
+                be.layernorm(self.xblk, self._itensor(src), self.enc,
+                             self._itensor(np.concatenate(emit_dst)), int(src.size),
+                             w.enc_norm_g, w.enc_norm_b)
+        for s, ubase, U in short_jobs:
+            self._encode_short(s, ubase, U)
+        if sub_copy[0]:
+            src = np.concatenate(sub_copy[0])
+            be.copy_rows(self.subbuf, self._itensor(src), self.subbuf,
+                         self._itensor(np.concatenate(sub_copy[1])), int(src.size), d)
+        # final call: next_states = None (:407-408)
+        for s in streams:
+            if finals[s]:
+                st = self.st[s]
+                st.enc_started = False
+                st.nfeat = st.nsub = st.n_blocks = 0
+                st.has_sub = st.has_addin = st.has_ctx = False
+
+    def _encode_short(self, s: int, ubase: int, U: int):
+        """Short-segment path (:345-351): one un-blocked pass, no mask, no
+        context slots, StreamPositionalEncoding's internal counter (A13)."""
+        cfg, w, be = self.cfg, self.w, self.be
+        st = self.st[s]
+        d = cfg.d_model
+        job = np.array([[ubase, U, st.short_pos, 0, 1, 0]], np.int32)
+        st.short_pos += U
+        be.block_pack(w, self.subbuf, self._itensor(job), 1, U, self.xblk)
+        be.encoder_layers(w, self.xblk, 1, U, False, None, 0, self.past_ctx,
+                          self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
+        if st.T_enc + U > self.TCAP:
+            raise EngineError("encoder-frame capacity (max_frames) exceeded")
+        dst = s * self.TCAP + st.T_enc + np.arange(U)
+        be.layernorm(self.xblk, self._itensor(np.arange(U)), self.enc, self._itensor(dst), U,
+                     w.enc_norm_g, w.enc_norm_b)
+        st.T_enc += U
+
+    # ------------------------------------------------------------------
+    # _decode_one_block for a lock-step group of streams
+    # ------------------------------------------------------------------
+    def _decode_blocks(self, todo: List[Tuple[int, int, bool]]):
+        cfg, be, w = self.cfg, self.be, self.w
+        S, W = self.S, self.W
+        d, Ld = cfg.d_model, cfg.dec_layers
+        self.stats["dec_blocks"] += len(todo)
+        ctrl = np.zeros((S, 8), np.int32)
+        part = {}
+        a_rows, c_rows, kv_rows, lsm_rows = [], [], [], []
+        for s, T, fin in todo:
+            st = self.st[s]
+            if T > self.TCAP:
+                raise EngineError("max_frames exceeded")
+            part[s] = (T, fin)
+            t_old = st.T_ctc
+            if T > t_old:
+                rows = s * self.TCAP + np.arange(t_old, T)
+                a_rows.append(rows)
+                c_rows.append(rows)
+                kv_rows.append((s * Ld) * self.TCAP + np.arange(t_old, T))
+                if t_old == 0:
+                    lsm_rows.append(rows)  # quirk A1: only the first block is log-softmaxed
+            ctrl[s] = (1, st.cur, int(fin), T, st.L, st.nhyp, int(st.has_ctc), t_old)
+            st.T_ctc = max(T, t_old)
+        # ---- extend_scorers (:403-464): CTC rows, cross-attention K/V rows, r states
+        if a_rows:
+            ar = self._itensor(np.concatenate(a_rows))
+            m = int(ar.shape[0])
+            be.gemm(self.enc, ar, d, w.ctc_w, w.ctc_b, self.ctcx, ar, cfg.vocab_size, m, cfg.vocab_size, d)
+            if lsm_rows:
+                lr = np.concatenate(lsm_rows)
+                be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+            kv0 = np.concatenate(kv_rows)
+            for li in range(Ld):
+                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
+                        self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+        self.ctrl.copy_(torch.from_numpy(ctrl))
+        be.ctc_extend_state(self)
+        # ---- step loop (:701-821)
+        live = {s: True for s in part}
+        saved = {s: False for s in part}        # prev_hyps refreshed in THIS block
+        took_out = {s: False for s in part}     # loop left with state = H_out of a non-accepted step
+        for s in part:
+            self.st[s].output_index = 0
+        while True:
+            act = [s for s in part if live[s] and self.st[s].process_idx < self.search.max_length]
+            for s in part:
+                if live[s] and s not in act:
+                    live[s] = False
+            if not act:
+                break
+            for s in part:
+                st = self.st[s]
+                T, fin = part[s]
+                ctrl[s] = (1 if s in act else 0, st.cur, int(fin), T, st.L, st.nhyp, int(st.has_ctc), 0)
+            for s in range(S):
+                if s not in part:
+                    ctrl[s, C_ACTIVE] = 0
+            self.ctrl.copy_(torch.from_numpy(ctrl))
+            for s in act:
+                if self.st[s].L + 1 > self.LCAP:
+                    raise EngineError("max_tokens exceeded")
+            self.stats["dec_steps"] += 1
+            be.decode_step(self)
+            flags = self.flags.cpu().numpy()
+            for s in act:
+                st = self.st[s]
+                T, fin = part[s]
+                st.output_index += 1
+                st.n_steps_total += 1
+                f = int(flags[s])
+                nh_out = min(W, st.nhyp * W)
+                stop = False
+                if f & F_ANY_EOS:
+                    if not fin or (f & F_BEST_EOS):
+                        stop = True
+                        self._take_out(s, nh_out)
+                        took_out[s] = True
+                if not stop and self.search.use_bbd and not fin and (f & F_REPEAT):
+                    st.output_index -= 1
+                    stop = True   # state stays H_in
+                if not stop and (f & F_ALL_EOS) and fin:
+                    stop = True
+                    self._take_out(s, nh_out)
+                    took_out[s] = True
+                if stop:
+                    live[s] = False
+                    continue
+                # accepted: prev_hyps = copy(H_out); process_idx += 1
+                self._take_out(s, nh_out)
+                st.prev_valid = True
+                saved[s] = True
+                st.process_idx += 1
+        # ---- rewind (:827-836)
+        for s in part:
+            st = self.st[s]
+            if st.process_idx > 1 and st.prev_valid:
+                if took_out[s]:
+                    # live state is the non-accepted H_out; prev_hyps = its H_in
+                    st.cur = 1 - st.cur
+                    st.L -= 1
+                    st.nhyp = self._nhyp_prev[s]
+                    st.has_ctc = self._hasctc_prev[s]
+                st.process_idx -= 1
+                st.prev_valid = False
+
+    def _take_out(self, s: int, nh_out: int):
+        st = self.st[s]
+        self._nhyp_prev[s] = st.nhyp
+        self._hasctc_prev[s] = st.has_ctc
+        st.cur = 1 - st.cur
+        st.L += 1
+        st.nhyp = nh_out
+        st.has_ctc = True
+
+    # ------------------------------------------------------------------
+    def hypotheses(self, s: int):
+        """Live hypotheses of stream s: list of dicts (yseq, score, scores, xpos)."""
+        st = self.st[s]
+        if not st.started:
+            return []
+        c, n, L = st.cur, st.nhyp, st.L
+        ys = self.yseq[c, s, :n, :L].cpu().numpy()
+        xp = self.xpos[c, s, :n, :L].cpu().numpy()
+        sc = self.score[c, s, :n].cpu().numpy()
+        sd = self.sc_dec[c, s, :n].cpu().numpy()
+        scc = self.sc_ctc[c, s, :n].cpu().numpy()
+        return [{"yseq": ys[i].tolist(), "score": float(sc[i]), "score_dec": float(sd[i]),
+                 "score_ctc": float(scc[i]), "xpos": xp[i].tolist()} for i in range(n)]

@@ -1,0 +1,116 @@
+"""ESPnet state dict -> packed fp32 tensors laid out for the HIP kernels.
+
+PyTorch is used here only to load / hold weight tensors (north_star:
+"PyTorch-ROCm only for checkpoint load/weight tensors").  Layout choices
+(see DESIGN.md "Data layout in HBM"):
+
+* every Linear keeps its [out, in] row-major weight: the GEMM kernel computes
+  C = A . W^T with both operands K-contiguous;
+* Q/K/V projections are concatenated to one [3d, d] matrix (encoder self-attn,
+  decoder self-attn) and K/V to [2d, d] (decoder src-attn);
+* Conv2d #2 weight [co, ci, kh, kw] is permuted to [co, (kh, kw, ci)] so the
+  implicit-GEMM K axis walks contiguous channels of the channels-last conv1
+  output;
+* the subsampling output Linear [d, c*F2 + f] is permuted to [d, f*d + c] to
+  consume conv2's (t, f, c) output without a transpose.
+
+reference schema: SURVEY.md Appendix B /
+speechcatcher/model/checkpoint_loader.py:134-149.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .config import ModelConfig
+from .mel import (fft_twiddles, hann_window_periodic, melscale_fbanks_slaney,
+                  positional_encoding_table)
+
+
+class PackedWeights:
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
+                 mean=None, std=None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        d, F2 = cfg.d_model, cfg.conv_freq2
+
+        def dev(t):
+            return t.detach().to(torch.float32).contiguous().to(self.device)
+
+        g = lambda k: sd[k].detach().to(torch.float32)  # noqa: E731
+        # --- frontend tables
+        self.window = dev(hann_window_periodic(cfg.win_length))
+        self.mel_fb = dev(melscale_fbanks_slaney(cfg.n_fft // 2 + 1, 0.0, cfg.sample_rate / 2.0,
+                                                 cfg.n_mels, cfg.sample_rate))
+        self.twiddle = dev(torch.from_numpy(fft_twiddles(cfg.n_fft)))
+        self.pe = dev(positional_encoding_table(cfg.pe_max_len, d))
+        # MVN in float64, as numpy does in the reference (A11)
+        if mean is None or std is None:
+            self.has_mvn = False
+            mean = np.zeros(cfg.n_mels)
+            std = np.ones(cfg.n_mels)
+        else:
+            self.has_mvn = True
+        self.mvn_is_f64 = (np.asarray(mean).dtype == np.float64)
+        self.mean64 = torch.from_numpy(np.asarray(mean, dtype=np.float64)).to(self.device)
+        self.std64 = torch.from_numpy(np.asarray(std, dtype=np.float64)).to(self.device)
+        # --- subsampling
+        self.conv1_w = dev(g("encoder.embed.conv.0.weight").reshape(d, 9))
+        self.conv1_b = dev(g("encoder.embed.conv.0.bias"))
+        w2 = g("encoder.embed.conv.2.weight")  # [co, ci, kh, kw]
+        self.conv2_w = dev(w2.permute(0, 2, 3, 1).reshape(d, 9 * d))
+        self.conv2_b = dev(g("encoder.embed.conv.2.bias"))
+        wo = g("encoder.embed.out.weight")  # [d, c*F2 + f]
+        self.sub_out_w = dev(wo.view(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d))
+        self.sub_out_b = dev(g("encoder.embed.out.bias"))
+        # --- encoder layers
+        self.enc = []
+        for i in range(cfg.enc_layers):
+            p = f"encoder.encoders.{i}"
+            a = p + ".self_attn"
+            self.enc.append(dict(
+                ln1_g=dev(g(p + ".norm1.weight")), ln1_b=dev(g(p + ".norm1.bias")),
+                wqkv=dev(torch.cat([g(a + ".linear_q.weight"), g(a + ".linear_k.weight"), g(a + ".linear_v.weight")], 0)),
+                bqkv=dev(torch.cat([g(a + ".linear_q.bias"), g(a + ".linear_k.bias"), g(a + ".linear_v.bias")], 0)),
+                wo=dev(g(a + ".linear_out.weight")), bo=dev(g(a + ".linear_out.bias")),
+                ln2_g=dev(g(p + ".norm2.weight")), ln2_b=dev(g(p + ".norm2.bias")),
+                w1=dev(g(p + ".feed_forward.w_1.weight")), b1=dev(g(p + ".feed_forward.w_1.bias")),
+                w2=dev(g(p + ".feed_forward.w_2.weight")), b2=dev(g(p + ".feed_forward.w_2.bias")),
+            ))
+        self.enc_norm_g = dev(g("encoder.after_norm.weight"))
+        self.enc_norm_b = dev(g("encoder.after_norm.bias"))
+        # --- decoder
+        self.embed = dev(g("decoder.embed.0.weight"))
+        self.dec = []
+        for i in range(cfg.dec_layers):
+            p = f"decoder.decoders.{i}"
+            a, c = p + ".self_attn", p + ".src_attn"
+            self.dec.append(dict(
+                ln1_g=dev(g(p + ".norm1.weight")), ln1_b=dev(g(p + ".norm1.bias")),
+                wqkv=dev(torch.cat([g(a + ".linear_q.weight"), g(a + ".linear_k.weight"), g(a + ".linear_v.weight")], 0)),
+                bqkv=dev(torch.cat([g(a + ".linear_q.bias"), g(a + ".linear_k.bias"), g(a + ".linear_v.bias")], 0)),
+                wo=dev(g(a + ".linear_out.weight")), bo=dev(g(a + ".linear_out.bias")),
+                ln2_g=dev(g(p + ".norm2.weight")), ln2_b=dev(g(p + ".norm2.bias")),
+                wq=dev(g(c + ".linear_q.weight")), bq=dev(g(c + ".linear_q.bias")),
+                wkv=dev(torch.cat([g(c + ".linear_k.weight"), g(c + ".linear_v.weight")], 0)),
+                bkv=dev(torch.cat([g(c + ".linear_k.bias"), g(c + ".linear_v.bias")], 0)),
+                wo2=dev(g(c + ".linear_out.weight")), bo2=dev(g(c + ".linear_out.bias")),
+                ln3_g=dev(g(p + ".norm3.weight")), ln3_b=dev(g(p + ".norm3.bias")),
+                w1=dev(g(p + ".feed_forward.w_1.weight")), b1=dev(g(p + ".feed_forward.w_1.bias")),
+                w2=dev(g(p + ".feed_forward.w_2.weight")), b2=dev(g(p + ".feed_forward.w_2.bias")),
+            ))
+        self.dec_norm_g = dev(g("decoder.after_norm.weight"))
+        self.dec_norm_b = dev(g("decoder.after_norm.bias"))
+        self.out_w = dev(g("decoder.output_layer.weight"))
+        self.out_b = dev(g("decoder.output_layer.bias"))
+        self.ctc_w = dev(g("ctc.ctc_lo.weight"))
+        self.ctc_b = dev(g("ctc.ctc_lo.bias"))
+
+    def n_bytes(self, part="all") -> int:
+        def tot(ds):
+            return sum(t.numel() * t.element_size() for dct in ds for t in dct.values())
+        enc = tot(self.enc) + sum(t.numel() * 4 for t in (self.conv1_w, self.conv1_b, self.conv2_w, self.conv2_b,
+                                                            self.sub_out_w, self.sub_out_b, self.enc_norm_g, self.enc_norm_b))
+        dec = tot(self.dec) + sum(t.numel() * 4 for t in (self.embed, self.dec_norm_g, self.dec_norm_b, self.out_w,
+                                                           self.out_b, self.ctc_w, self.ctc_b))
+        return {"enc": enc, "dec": dec, "all": enc + dec}[part]

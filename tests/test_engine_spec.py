@@ -1,0 +1,125 @@
+"""Host logic of the product engine (speechcatcher_amd.engine) driven by the
+torch per-kernel spec backend (oracle/kernel_spec.py), checked against the
+fixtures produced by the real reference.  CPU only: validates the buffering
+arithmetic, block schedule, beam bookkeeping (ancestor tables, ping-pong
+hypothesis buffers, rewind) and the kernel decomposition itself."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case
+from speechcatcher_amd import synth
+from speechcatcher_amd.config import TINY, XL, SearchConfig
+from speechcatcher_amd.engine import StreamBatch
+from speechcatcher_amd.weights import PackedWeights
+
+CFGS = {"TINY": TINY, "XL": XL}
+
+
+def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", **kw):
+    from oracle.kernel_spec import SpecBackend
+    cfg = CFGS[cfg_name]
+    sd = synth.make_state_dict(cfg, seed)
+    mean, std = synth.stats_to_mean_std(synth.make_stats(cfg, kind=stats))
+    w = PackedWeights(sd, cfg, device, mean, std)
+    sc = SearchConfig(beam_size=beam, use_bbd=bbd)
+    return StreamBatch(w, backend or SpecBackend(), n_streams, sc, **kw)
+
+
+def check_against_blocks(sb, s, block, score_tol=2e-3):
+    hyps = sb.hypotheses(s)
+    assert [h["yseq"] for h in hyps] == block["yseq"]
+    assert [h["xpos"] for h in hyps] == block["xpos"]
+    np.testing.assert_allclose([h["score"] for h in hyps], block["score"], rtol=1e-5, atol=score_tol)
+    np.testing.assert_allclose([h["score_dec"] for h in hyps], block["score_dec"], rtol=1e-5, atol=score_tol)
+    np.testing.assert_allclose([h["score_ctc"] for h in hyps], block["score_ctc"], rtol=1e-5, atol=score_tol)
+    assert sb.st[s].process_idx == block["process_idx"]
+
+
+def run_case(name, n_streams=1, stream=0, score_tol=2e-3, **kw):
+    js, npz = load_case(name)
+    meta = js["meta"]
+    sb = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"],
+                    n_streams=n_streams, max_frames=256, max_tokens=160, pcm_capacity=1 << 18, **kw)
+    audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
+    chunk = meta["chunk"]
+    pos, nblk = 0, 0
+    for call in js["calls"]:
+        end = min(pos + chunk, len(audio))
+        sb.push([(stream, audio[pos:end], end >= len(audio))])
+        pos = end
+        nblk += call["n_blocks"]
+        assert sb.st[stream].T_enc == call["enc_buffer_len"]
+        assert sb.st[stream].processed_block == call["processed_block"]
+        if call["n_blocks"]:
+            check_against_blocks(sb, stream, js["blocks"][nblk - 1], score_tol)
+    return sb, js, npz
+
+
+TINY_CASES = [f"tiny_c{c}_b{b}_bbd{d}" for c in (8192, 10240) for b in (1, 10) for d in (0, 1)] + ["tiny_c25600_b10_bbd0"]
+
+
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_engine_matches_reference_trajectories(name):
+    sb, js, npz = run_case(name)
+    if npz is not None:
+        T = sb.st[0].T_enc
+        enc = sb.enc[:T].numpy()
+        np.testing.assert_allclose(enc, npz["enc"][:T], atol=5e-4, rtol=0)
+
+
+def test_engine_other_stream_slot_and_float64_stats():
+    # run the same utterance in slot 2 of a 3-stream batch
+    run_case("tiny_stats64_b5", n_streams=3, stream=2)
+
+
+def test_engine_short_utterances():
+    js = json.loads((GOLDEN / "tiny_short.json").read_text())
+    for n in (3000, 9000, 20000):
+        sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=128, max_tokens=600, pcm_capacity=1 << 16)
+        sb.push([(0, synth.synth_audio(3, n), True)])
+        ref = js[str(n)]
+        check_against_blocks(sb, 0, ref["blocks"][-1])
+        enc = np.load(GOLDEN / f"tiny_short_{n}.npz")["enc"]
+        enc = enc.reshape(-1, enc.shape[-1])
+        np.testing.assert_allclose(sb.enc[:sb.st[0].T_enc].numpy(), enc, atol=5e-4, rtol=0)
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=128, max_tokens=64, pcm_capacity=1 << 16)
+    with pytest.raises(RuntimeError):
+        sb.push([(0, synth.synth_audio(3, 700), True)])
+
+
+def test_engine_two_streams_ragged():
+    """Two different utterances interleaved with different chunk sizes in one
+    batch give the same trajectories as when run alone."""
+    js_a, _ = load_case("tiny_c8192_b10_bbd0")
+    js_b, _ = load_case("tiny_c10240_b10_bbd0")
+    sb = make_batch("TINY", 1234, "meanstd", 10, False, n_streams=2, max_frames=256, max_tokens=160,
+                    pcm_capacity=1 << 18)
+    audio = synth.synth_audio(0, js_a["meta"]["n_samples"])
+    n = len(audio)
+    pa = pb = 0
+    ba = bb = 0
+    ia = ib = 0
+    while pa < n or pb < n:
+        items = []
+        if pa < n:
+            ea = min(pa + 8192, n)
+            items.append((0, audio[pa:ea], ea >= n))
+        if pb < n:
+            eb = min(pb + 10240, n)
+            items.append((1, audio[pb:eb], eb >= n))
+        sb.push(items)
+        if pa < n:
+            pa = ea
+            ba += js_a["calls"][ia]["n_blocks"]
+            if js_a["calls"][ia]["n_blocks"]:
+                check_against_blocks(sb, 0, js_a["blocks"][ba - 1])
+            ia += 1
+        if pb < n:
+            pb = eb
+            bb += js_b["calls"][ib]["n_blocks"]
+            if js_b["calls"][ib]["n_blocks"]:
+                check_against_blocks(sb, 1, js_b["blocks"][bb - 1])
+            ib += 1
