@@ -1,0 +1,189 @@
+/*
+ * libscasr - C ABI of the MI355X (gfx950) streaming-ASR hot path.
+ *
+ * Drop-in boundary for speechcatcher's native decoder path.
+ * The reference is pure Python/PyTorch and has no FFI of its own; each entry
+ * point below replaces the torch-op call sites of one reference function and
+ * cites it (paths relative to the reference repository root).  The host side
+ * (speechcatcher_amd/engine.py, Python like the reference) binds these with
+ * ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless marked HOST.
+ *   - all functions are asynchronous launches on `stream` (a hipStream_t
+ *     passed as void*); return 0 on success, a negative code on error and
+ *     never throw.  sc_last_error() returns a thread-local message.
+ *   - caller owns all memory; nothing is allocated or freed by the library.
+ *   - "rows" tables are int32 ROW indices into a 2-D buffer (multiplied by the
+ *     leading dimension inside the kernel); NULL means the identity mapping;
+ *     -1 in a gather table reads a zero row.
+ *   - all floating point is fp32 (IEEE, no fast-math); hypothesis scores are
+ *     accumulated in fp64 like the reference's Python floats.
+ */
+#ifndef SCASR_H
+#define SCASR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_ARG (-1)
+#define SC_ERR_LAUNCH (-2)
+
+/* flags of sc_gemm */
+#define SC_GEMM_RELU 1
+#define SC_GEMM_RESIDUAL 2
+#define SC_GEMM_NAIVE 4 /* force the scalar reference kernel (debugging) */
+
+/* beam_prune stop flags (one int32 per stream) */
+#define SC_F_ANY_EOS 1
+#define SC_F_BEST_EOS 2
+#define SC_F_ALL_EOS 4
+#define SC_F_REPEAT 8
+
+/* ctrl row (int32[8]) per stream, uploaded by the host before every search op */
+#define SC_C_ACTIVE 0 /* stream takes part in this launch */
+#define SC_C_CUR 1    /* live ping-pong hypothesis buffer (0/1); outputs go to 1-cur */
+#define SC_C_FINAL 2
+#define SC_C_T 3    /* encoder frames visible to this decode block */
+#define SC_C_L 4    /* tokens per live hypothesis, incl. sos */
+#define SC_C_NHYP 5 /* live hypotheses (1 or W) */
+#define SC_C_HAS 6  /* live hypotheses carry a CTC state */
+#define SC_C_TOLD 7 /* rows the CTC states covered before this block */
+
+typedef struct sc_enc_layer {
+  const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
+  const float *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+} sc_enc_layer;
+
+typedef struct sc_dec_layer {
+  const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
+  const float *ln2_g, *ln2_b, *wq, *bq, *wo2, *bo2;
+  const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;
+} sc_dec_layer;
+
+/* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
+typedef struct sc_search {
+  int32_t S, W, K, V, d, H, F, n_layers, TCAP, LCAP, xchunk;
+  int32_t blank, eos, sos;
+  float w_dec, w_ctc, ln_eps;
+  const int32_t *ctrl; /* [S][8] */
+  int32_t *flags;      /* [S] */
+  const float *ctcx;   /* [S][TCAP][V]  CTC posterior table (quirk A1 rows) */
+  const float *ckv;    /* [S][n_layers][TCAP][2d] cross-attention K|V */
+  float *skv;          /* [S][n_layers][LCAP][W][2d] self-attention K|V, append-only */
+  int32_t *yseq, *xpos; /* [2][S][W][LCAP] */
+  int32_t *anc;         /* [2][S][LCAP][W] slot of the ancestor's K/V row per position */
+  double *score, *sc_dec, *sc_ctc; /* [2][S][W] */
+  float *ctc_r;    /* [2][S][TCAP][2][W] forward variables r^n, r^b per hypothesis */
+  float *ctc_s;    /* [2][S][W] prefix score log_psi of the chosen token */
+  float *ctc_rnew; /* [S][TCAP][2][W*K] r of every (hypothesis, candidate) */
+  float *dx, *dxn, *dqkv, *datt, *dq, *dffh, *logits, *logp; /* [S*W][...] */
+  int32_t *pre_ids;       /* [S*W][K] */
+  float *psi, *psi_eos;   /* [S*W][K], [S*W] */
+  float *cand_score;      /* [S*W][W] */
+  int32_t *cand_tok;      /* [S*W][W] */
+  float *cand_ctc;        /* [S*W][W] */
+  int32_t *sel;           /* [S][W][2] (parent hypothesis, candidate index) */
+  float *xpart;           /* [S*W*H*nchunk][dk+2] cross-attention partials */
+  const float *embed, *pe, *dec_norm_g, *dec_norm_b, *out_w, *out_b;
+  const sc_dec_layer *layers; /* HOST array [n_layers] */
+} sc_search;
+
+const char *sc_last_error(void);
+int sc_version(void);
+
+/* ---- generic building blocks -------------------------------------------- */
+
+/* C[c_rows[m], n] (+)= sum_k A[a_rows[m]*lda + kofs(k)] * W[n*K + k] + bias[n]
+ * (torch.nn.Linear call sites: multi_head_attention.py:81-83,133,
+ * feed_forward.py:50, subsampling.py:98, ctc.py:40, transformer_decoder.py:249;
+ * with conv_f1 > 0 the second Conv2d of subsampling.py:87-93 as an implicit
+ * GEMM: lda = channels, tap = k / lda, kofs = ((tap/3)*conv_f1 + tap%3)*lda + k%lda).
+ * f32 MFMA (v_mfma_f32_32x32x2_f32), K must be a multiple of 32. */
+int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W, const float *bias,
+            float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
+            void *stream);
+
+/* LayerNorm over rows (model/layers/normalization.py:7-24, eps 1e-12). */
+int sc_layernorm(const float *src, const int32_t *src_rows, int lds, float *dst,
+                 const int32_t *dst_rows, int ldd, int M, int d, const float *gamma,
+                 const float *beta, float eps, void *stream);
+
+int sc_copy_rows(const float *src, const int32_t *src_rows, float *dst, const int32_t *dst_rows,
+                 int n, int width, void *stream);
+
+/* in-place log_softmax of selected rows (scorers.py:133-134, first block only) */
+int sc_log_softmax_rows(float *x, const int32_t *rows, int n, int V, void *stream);
+
+/* ---- frontend ------------------------------------------------------------ */
+
+/* STFTFrontend.forward (model/frontend/stft_frontend.py:87-154) fused with the
+ * global MVN and frame trimming of Speech2TextStreaming.apply_frontend
+ * (speech2text_streaming.py:355-389).  jobs[j] = {stream, seg_start, seg_len,
+ * eff_len, keep_lo, keep_n, dst_row0, 0}.  mvn_mode: 0 none, 1 fp32, 2 fp64. */
+int sc_logmel(const float *pcm, int pcm_stride, const int32_t *jobs, int n_jobs, int max_keep,
+              const float *window, const float *mel_fb, const float *twiddle, const double *mean,
+              const double *stdv, int mvn_mode, int n_fft, int hop, int win, int n_mels,
+              float *feat, void *stream);
+
+/* ---- encoder --------------------------------------------------------------- */
+
+/* first Conv2d(1->d,3,stride 2)+ReLU (subsampling.py:87-93), channels-last out.
+ * jobs[j] = {src_row0, T_in, c1_row0, T1}. */
+int sc_conv1(const float *feat, int n_mels, const int32_t *jobs, int n_jobs, int max_t1,
+             const float *w, const float *b, int d, float *c1, void *stream);
+
+/* block assembly (contextual_block_transformer_encoder.py:354-380).
+ * jobs[b] = {src_row0, chunk_len, pe_off_frames, pe_off_ctx, short, 0}. */
+int sc_block_pack(const float *sub, const int32_t *jobs, int nb, int R, const float *pe, int d,
+                  float *xblk, void *stream);
+
+/* context hand-off (contextual_block_encoder_layer.py:253-269).
+ * jobs[j] = {b0, nblk, state_row, has_state}; state row used = state_row + layer. */
+int sc_ctx_handoff(float *x, int R, const int32_t *jobs, int ns, float *state, int layer, int d,
+                   void *stream);
+
+/* masked block self-attention (multi_head_attention.py:92-133 with the mask of
+ * contextual_block_transformer_encoder.py:524-528). */
+int sc_enc_attention(const float *qkv, float *att, int nblk, int R, int H, int d, int masked,
+                     void *stream);
+
+/* all encoder layers on (nblk, R, d) blocks (contextual_block_encoder_layer.py:178-271). */
+int sc_encoder_layers(const sc_enc_layer *layers /*HOST*/, int n_layers, float *x, int nblk, int R,
+                      int masked, const int32_t *jobs, int ns, float *past_ctx, float *xn,
+                      float *qkv, float *att, float *ffh, int d, int H, int F, float eps,
+                      void *stream);
+
+/* ---- search ---------------------------------------------------------------- */
+
+/* CTCPrefixScoreTH.extend_state (ctc_prefix_score_full.py:349-368) */
+int sc_ctc_extend_state(const sc_search *sb /*HOST*/, void *stream);
+/* embed*sqrt(d)+PE of the newest token (transformer_decoder.py:231) */
+int sc_dec_embed(const sc_search *sb, void *stream);
+/* decoder self-attention with K/V cache + ancestor table (decoder_layer.py:85-101) */
+int sc_dec_self_attn(const sc_search *sb, int layer, void *stream);
+/* decoder cross-attention over the shared per-stream K/V (decoder_layer.py:106-115) */
+int sc_dec_cross_attn(const sc_search *sb, int layer, void *stream);
+int sc_decoder_layers(const sc_search *sb, void *stream);
+/* log_softmax + pre-beam top-K (transformer_decoder.py:249, beam_search.py:150-154) */
+int sc_logsoftmax_topk(const sc_search *sb, void *stream);
+/* CTCPrefixScoreTH.__call__ on the K candidates (ctc_prefix_score_full.py:88-291) */
+int sc_ctc_prefix_scan(const sc_search *sb, void *stream);
+/* score fusion + per-hypothesis top-W (beam_search.py:113-185,723) */
+int sc_fuse_topw(const sc_search *sb, void *stream);
+/* expand / prune / bookkeeping / stop flags (beam_search.py:721-809, hypothesis.py:132-142) */
+int sc_beam_prune(const sc_search *sb, void *stream);
+/* CTCPrefixScorer.select_state (scorers.py:382-431) */
+int sc_ctc_gather_state(const sc_search *sb, void *stream);
+/* one full beam-search step = all of the above in order (beam_search.py:701-758) */
+int sc_decode_step(const sc_search *sb, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCASR_H */

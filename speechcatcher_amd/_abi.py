@@ -1,0 +1,122 @@
+"""ctypes binding of libscasr.so (the C ABI declared in include/scasr.h).
+
+cffi is not installed in the target image, so the
+"thin C-ABI cffi layer" of the north star is ctypes in ABI mode; the binding
+is plain C, nothing torch-specific crosses it.
+
+The library is built in-tree (speechcatcher_amd/libscasr.so) by
+``build()`` / ``__graft_entry__.build()``; loading fails LOUDLY when it is
+missing - there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libscasr.so"
+CSRC = HERE / "csrc"
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+c_double_p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class EncLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
+                                  "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
+                                  "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
+                                  "ln3_g", "ln3_b", "w1", "b1", "w2", "b2")]
+
+
+class Search(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("S", "W", "K", "V", "d", "H", "F", "n_layers", "TCAP", "LCAP",
+                                  "xchunk", "blank", "eos", "sos")]
+        + [(n, C.c_float) for n in ("w_dec", "w_ctc", "ln_eps")]
+        + [(n, vp) for n in ("ctrl", "flags", "ctcx", "ckv", "skv", "yseq", "xpos", "anc", "score",
+                             "sc_dec", "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv",
+                             "datt", "dq", "dffh", "logits", "logp", "pre_ids", "psi", "psi_eos",
+                             "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
+                             "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers")]
+    )
+
+
+_SIGS = {
+    "sc_last_error": (C.c_char_p, []),
+    "sc_version": (C.c_int, []),
+    "sc_gemm": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.c_int, C.c_int, vp]),
+    "sc_layernorm": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp]),
+    "sc_copy_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "sc_log_softmax_rows": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "sc_logmel": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int,
+                            C.c_int, C.c_int, C.c_int, vp, vp]),
+    "sc_conv1": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "sc_block_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "sc_ctx_handoff": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "sc_enc_attention": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "sc_encoder_layers": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp,
+                                    vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "sc_ctc_extend_state": (C.c_int, [vp, vp]),
+    "sc_dec_embed": (C.c_int, [vp, vp]),
+    "sc_dec_self_attn": (C.c_int, [vp, C.c_int, vp]),
+    "sc_dec_cross_attn": (C.c_int, [vp, C.c_int, vp]),
+    "sc_decoder_layers": (C.c_int, [vp, vp]),
+    "sc_logsoftmax_topk": (C.c_int, [vp, vp]),
+    "sc_ctc_prefix_scan": (C.c_int, [vp, vp]),
+    "sc_fuse_topw": (C.c_int, [vp, vp]),
+    "sc_beam_prune": (C.c_int, [vp, vp]),
+    "sc_ctc_gather_state": (C.c_int, [vp, vp]),
+    "sc_decode_step": (C.c_int, [vp, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+class ScasrError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into speechcatcher_amd/libscasr.so."""
+    cmd = ["make", "-C", str(CSRC), "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise ScasrError("building libscasr.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load the library; raise if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ScasrError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().sc_last_error()
+        raise ScasrError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

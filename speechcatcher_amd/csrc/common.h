@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of libscasr.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/scasr.h"
+
+#define SC_LOGZERO (-10000000000.0f)  // ctc_prefix_score_full.py:58
+
+void sc_set_error(const char *fmt, ...);
+
+#define SC_CHECK_ARG(cond, msg)      \
+  do {                               \
+    if (!(cond)) {                   \
+      sc_set_error("%s: %s", __func__, msg); \
+      return SC_ERR_ARG;             \
+    }                                \
+  } while (0)
+
+#define SC_CHECK_LAUNCH()                                              \
+  do {                                                                 \
+    hipError_t e__ = hipGetLastError();                                \
+    if (e__ != hipSuccess) {                                           \
+      sc_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return SC_ERR_LAUNCH;                                            \
+    }                                                                  \
+  } while (0)
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.
+__device__ __forceinline__ float lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}

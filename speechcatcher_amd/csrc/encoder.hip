@@ -1,0 +1,434 @@
+// Frontend + encoder-side kernels of libscasr (gfx950).
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void sc_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *sc_last_error(void) { return g_err; }
+extern "C" int sc_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one wave per row, float4 lanes, two-pass mean / variance.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *src, const int *src_rows,
+                                                        int lds, float *dst, const int *dst_rows,
+                                                        int ldd, int M, int d, const float *gamma,
+                                                        const float *beta, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  int srow = src_rows ? src_rows[m] : m;
+  int drow = dst_rows ? dst_rows[m] : m;
+  if (drow < 0) return;
+  const float *x = src + (long)(srow < 0 ? 0 : srow) * lds;
+  float *y = dst + (long)drow * ldd;
+  // d <= 1024: up to 4 float4 per lane
+  float4 v[4];
+  float s = 0.f;
+  const int nv = d >> 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = srow < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4 *>(x)[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + e * e);
+    }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      float4 gm = reinterpret_cast<const float4 *>(gamma)[c];
+      float4 bt = reinterpret_cast<const float4 *>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      reinterpret_cast<float4 *>(y)[c] = o;
+    }
+  }
+}
+
+extern "C" int sc_layernorm(const float *src, const int32_t *src_rows, int lds, float *dst,
+                            const int32_t *dst_rows, int ldd, int M, int d, const float *gamma,
+                            const float *beta, float eps, void *stream) {
+  SC_CHECK_ARG(src && dst && gamma && beta, "null pointer");
+  SC_CHECK_ARG(d % 4 == 0 && d <= 1024 && lds % 4 == 0 && ldd % 4 == 0, "d must be a multiple of 4, <= 1024");
+  if (M <= 0) return SC_OK;
+  layernorm_kernel<<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(src, src_rows, lds, dst, dst_rows,
+                                                                ldd, M, d, gamma, beta, eps);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void copy_rows_kernel(const float *src, const int *src_rows, float *dst,
+                                 const int *dst_rows, int n, int width) {
+  int r = blockIdx.x;
+  const float *s = src + (long)src_rows[r] * width;
+  float *d = dst + (long)dst_rows[r] * width;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) d[c] = s[c];
+}
+
+extern "C" int sc_copy_rows(const float *src, const int32_t *src_rows, float *dst,
+                            const int32_t *dst_rows, int n, int width, void *stream) {
+  SC_CHECK_ARG(src && dst && src_rows && dst_rows, "null pointer");
+  if (n <= 0) return SC_OK;
+  copy_rows_kernel<<<n, 256, 0, (hipStream_t)stream>>>(src, src_rows, dst, dst_rows, n, width);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// in-place log_softmax of selected rows: x - max - log(sum(exp(x - max)))
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(float *x, const int *rows, int V) {
+  __shared__ float red[8];
+  float *p = x + (long)rows[blockIdx.x] * V;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, p[c]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += expf(p[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  s = (red[4] + red[5]) + (red[6] + red[7]);
+  const float ls = logf(s);
+  for (int c = tid; c < V; c += 256) p[c] = (p[c] - m) - ls;
+}
+
+extern "C" int sc_log_softmax_rows(float *x, const int32_t *rows, int n, int V, void *stream) {
+  SC_CHECK_ARG(x && rows, "null pointer");
+  if (n <= 0) return SC_OK;
+  log_softmax_rows_kernel<<<n, 256, 0, (hipStream_t)stream>>>(x, rows, V);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// log-mel frontend: one workgroup per kept frame.
+//   reflect-pad(n_fft/2) framing, periodic Hann(win) centred in the n_fft
+//   frame, radix-2 FFT in LDS, |X|^2, mel matmul, clamp 1e-10, log, MVN.
+// ---------------------------------------------------------------------------
+struct LogmelArgs {
+  const float *pcm;
+  int pcm_stride;
+  const int *jobs;
+  const float *window, *mel_fb, *twiddle;
+  const double *mean, *stdv;
+  int mvn_mode, n_fft, log2n, hop, win, n_mels;
+  float *feat;
+};
+
+__global__ __launch_bounds__(256) void logmel_kernel(LogmelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int *job = a.jobs + blockIdx.y * 8;
+  const int keep_n = job[5];
+  if ((int)blockIdx.x >= keep_n) return;
+  const int s = job[0], seg_start = job[1], seg_len = job[2], eff_len = job[3];
+  const int frame = job[4] + blockIdx.x;
+  const long dst_row = (long)job[6] + blockIdx.x;
+  const int N = a.n_fft, half = N >> 1;
+  float *re = smem, *im = smem + N, *pw = smem + 2 * N;
+  const float *x = a.pcm + (long)s * a.pcm_stride + seg_start;
+  const int woff = (N - a.win) / 2;
+  const int tid = threadIdx.x;
+  // load (bit-reversed) windowed samples
+  for (int i = tid; i < N; i += blockDim.x) {
+    int n = frame * a.hop + i - half;  // index into the (zero-padded) segment
+    if (n < 0) n = -n;                 // reflect
+    if (n >= eff_len) n = 2 * (eff_len - 1) - n;
+    float v = (n >= 0 && n < seg_len) ? x[n] : 0.f;
+    int wi = i - woff;
+    float wv = (wi >= 0 && wi < a.win) ? a.window[wi] : 0.f;
+    int rev = __brev((unsigned)i) >> (32 - a.log2n);
+    re[rev] = v * wv;
+    im[rev] = 0.f;
+  }
+  __syncthreads();
+  for (int sft = 1; sft <= a.log2n; ++sft) {
+    const int m = 1 << sft, hm = m >> 1, tstep = N >> sft;
+    for (int t = tid; t < half; t += blockDim.x) {
+      int grp = t / hm, j = t % hm;
+      int i0 = grp * m + j, i1 = i0 + hm;
+      float wr = a.twiddle[2 * (j * tstep)], wi = a.twiddle[2 * (j * tstep) + 1];
+      float xr = re[i1], xi = im[i1];
+      float vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+      float ur = re[i0], ui = im[i0];
+      re[i0] = ur + vr;
+      im[i0] = ui + vi;
+      re[i1] = ur - vr;
+      im[i1] = ui - vi;
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k <= half; k += blockDim.x) pw[k] = re[k] * re[k] + im[k] * im[k];
+  __syncthreads();
+  for (int mth = tid; mth < a.n_mels; mth += blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k <= half; ++k) acc = fmaf(pw[k], a.mel_fb[k * a.n_mels + mth], acc);
+    float v = logf(fmaxf(acc, 1e-10f));
+    if (a.mvn_mode == 2)
+      v = (float)(((double)v - a.mean[mth]) / a.stdv[mth]);
+    else if (a.mvn_mode == 1)
+      v = (v - (float)a.mean[mth]) / (float)a.stdv[mth];
+    a.feat[dst_row * a.n_mels + mth] = v;
+  }
+}
+
+extern "C" int sc_logmel(const float *pcm, int pcm_stride, const int32_t *jobs, int n_jobs,
+                         int max_keep, const float *window, const float *mel_fb,
+                         const float *twiddle, const double *mean, const double *stdv,
+                         int mvn_mode, int n_fft, int hop, int win, int n_mels, float *feat,
+                         void *stream) {
+  SC_CHECK_ARG(pcm && jobs && window && mel_fb && twiddle && feat, "null pointer");
+  SC_CHECK_ARG(n_fft >= 64 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0, "n_fft must be a power of two");
+  SC_CHECK_ARG(win <= n_fft, "win_length > n_fft");
+  if (n_jobs <= 0 || max_keep <= 0) return SC_OK;
+  int log2n = 0;
+  while ((1 << log2n) < n_fft) ++log2n;
+  LogmelArgs a{pcm, pcm_stride, jobs, window, mel_fb, twiddle, mean, stdv,
+               mvn_mode, n_fft, log2n, hop, win, n_mels, feat};
+  size_t smem = (size_t)(2 * n_fft + n_fft / 2 + 4) * sizeof(float);
+  logmel_kernel<<<dim3(max_keep, n_jobs), 256, smem, (hipStream_t)stream>>>(a);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// conv1: Conv2d(1 -> d, 3x3, stride 2) + ReLU, channels-last output
+//   c1[(c1_row0 + t1) * F1 + f1][co]
+// ---------------------------------------------------------------------------
+__global__ void conv1_kernel(const float *feat, int n_mels, const int *jobs, const float *w,
+                             const float *b, int d, int F1, float *c1) {
+  const int *job = jobs + blockIdx.z * 4;
+  const int src0 = job[0], r0 = job[2], T1 = job[3];
+  const int t1 = blockIdx.y, f1 = blockIdx.x;
+  if (t1 >= T1) return;
+  float xin[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+      xin[kh * 3 + kw] = feat[(long)(src0 + 2 * t1 + kh) * n_mels + 2 * f1 + kw];
+  float *out = c1 + ((long)(r0 + t1) * F1 + f1) * d;
+  for (int co = threadIdx.x; co < d; co += blockDim.x) {
+    const float *wc = w + co * 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc = fmaf(xin[q], wc[q], acc);
+    out[co] = fmaxf(acc + b[co], 0.f);
+  }
+}
+
+extern "C" int sc_conv1(const float *feat, int n_mels, const int32_t *jobs, int n_jobs, int max_t1,
+                        const float *w, const float *b, int d, float *c1, void *stream) {
+  SC_CHECK_ARG(feat && jobs && w && b && c1, "null pointer");
+  if (n_jobs <= 0 || max_t1 <= 0) return SC_OK;
+  const int F1 = (n_mels - 3) / 2 + 1;
+  conv1_kernel<<<dim3(F1, max_t1, n_jobs), d < 256 ? d : 256, 0, (hipStream_t)stream>>>(
+      feat, n_mels, jobs, w, b, d, F1, c1);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// block_pack: x*sqrt(d)+PE into (nb, R, d) blocks, context slot = mean
+// ---------------------------------------------------------------------------
+__global__ void block_pack_kernel(const float *sub, const int *jobs, int R, const float *pe, int d,
+                                  float sq, float *xblk) {
+  const int *job = jobs + blockIdx.x * 6;
+  const int src0 = job[0], clen = job[1], pe_f = job[2], pe_c = job[3], shrt = job[4];
+  float *x = xblk + (long)blockIdx.x * R * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float sum = 0.f;
+    const int off = shrt ? 0 : 1;
+    for (int r = 0; r < clen; ++r) {
+      float v = sub[(long)(src0 + r) * d + c];
+      sum += v;
+      x[(long)(r + off) * d + c] = v * sq + pe[(long)(pe_f + r) * d + c];
+    }
+    if (!shrt) {
+      x[c] = 0.f;
+      for (int r = clen + 1; r < R - 1; ++r) x[(long)r * d + c] = 0.f;
+      x[(long)(R - 1) * d + c] = (sum / (float)clen) * sq + pe[(long)pe_c * d + c];
+    }
+  }
+}
+
+extern "C" int sc_block_pack(const float *sub, const int32_t *jobs, int nb, int R, const float *pe,
+                             int d, float *xblk, void *stream) {
+  SC_CHECK_ARG(sub && jobs && pe && xblk, "null pointer");
+  if (nb <= 0) return SC_OK;
+  block_pack_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(sub, jobs, R, pe, d, sqrtf((float)d), xblk);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// ctx_handoff: slot 0 of every block <- context vector chain (one WG / stream)
+// ---------------------------------------------------------------------------
+__global__ void ctx_handoff_kernel(float *x, int R, const int *jobs, float *state, int layer, int d) {
+  const int *job = jobs + blockIdx.x * 4;
+  const int b0 = job[0], nbk = job[1], srow = job[2] + layer, has = job[3];
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float *xb = x + (long)b0 * R * d + c;
+    float prev = has ? state[(long)srow * d + c] : xb[(long)(R - 1) * d];
+    for (int i = 0; i < nbk; ++i) {
+      float last = xb[((long)i * R + (R - 1)) * d];
+      xb[(long)i * R * d] = prev;
+      prev = last;
+    }
+    state[(long)srow * d + c] = prev;
+  }
+}
+
+extern "C" int sc_ctx_handoff(float *x, int R, const int32_t *jobs, int ns, float *state, int layer,
+                              int d, void *stream) {
+  SC_CHECK_ARG(x && jobs && state, "null pointer");
+  if (ns <= 0) return SC_OK;
+  ctx_handoff_kernel<<<ns, 256, 0, (hipStream_t)stream>>>(x, R, jobs, state, layer, d);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// encoder block attention: one wave per (block, head); K/V of the head staged
+// in LDS, lane = query row, online softmax over <= 64 keys.
+// ---------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void enc_attention_kernel(const float *qkv, float *att, int nblk,
+                                                            int R, int H, int d, int masked) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= nblk * H) return;  // whole wave exits; each wave only touches its own LDS slice
+  const int blk = unit / H, head = unit % H;
+  float *Ks = smem + wave * (2 * 64 * DK);
+  float *Vs = Ks + 64 * DK;
+  const float *base = qkv + (long)blk * R * 3 * d + head * DK;
+  for (int e = lane; e < R * (DK / 4); e += 64) {
+    int r = e / (DK / 4), c4 = e % (DK / 4);
+    const float *row = base + (long)r * 3 * d;
+    reinterpret_cast<float4 *>(Ks)[r * (DK / 4) + c4] = reinterpret_cast<const float4 *>(row + d)[c4];
+    reinterpret_cast<float4 *>(Vs)[r * (DK / 4) + c4] = reinterpret_cast<const float4 *>(row + 2 * d)[c4];
+  }
+  // a wave's DS operations execute in order, so its own ds_writes are visible
+  // to its later ds_reads; only compiler reordering has to be prevented.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane >= R) return;
+  float q[DK];
+  const float *qrow = base + (long)lane * 3 * d;
+#pragma unroll
+  for (int c = 0; c < DK; c += 4) {
+    float4 t = reinterpret_cast<const float4 *>(qrow)[c / 4];
+    q[c] = t.x; q[c + 1] = t.y; q[c + 2] = t.z; q[c + 3] = t.w;
+  }
+  float acc[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float scale = sqrtf((float)DK);
+  const int nkeys = masked ? R - 1 : R;
+  const bool row_masked = masked && lane == 0;
+  if (!row_masked) {
+    for (int j = 0; j < nkeys; ++j) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) sdot = fmaf(q[c], Ks[j * DK + c], sdot);
+      sdot = sdot / scale;
+      float mn = fmaxf(m, sdot);
+      float corr = expf(m - mn);
+      float p = expf(sdot - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) acc[c] = acc[c] * corr + p * Vs[j * DK + c];
+      m = mn;
+    }
+  }
+  float inv = row_masked ? 0.f : 1.0f / l;
+  float *o = att + ((long)blk * R + lane) * d + head * DK;
+#pragma unroll
+  for (int c = 0; c < DK; c += 4)
+    reinterpret_cast<float4 *>(o)[c / 4] =
+        make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+}
+
+extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, int H, int d,
+                                int masked, void *stream) {
+  SC_CHECK_ARG(qkv && att, "null pointer");
+  SC_CHECK_ARG(R >= 1 && R <= 64, "R must be <= 64");
+  SC_CHECK_ARG(d % H == 0, "d % H");
+  if (nblk <= 0) return SC_OK;
+  const int dk = d / H;
+  const int grid = cdiv(nblk * H, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dk == 32) {
+    enc_attention_kernel<32><<<grid, 256, 4 * 2 * 64 * 32 * sizeof(float), st>>>(qkv, att, nblk, R, H, d, masked);
+  } else if (dk == 16) {
+    enc_attention_kernel<16><<<grid, 256, 4 * 2 * 64 * 16 * sizeof(float), st>>>(qkv, att, nblk, R, H, d, masked);
+  } else if (dk == 64) {
+    enc_attention_kernel<64><<<grid, 256, 4 * 2 * 64 * 64 * sizeof(float), st>>>(qkv, att, nblk, R, H, d, masked);
+  } else {
+    sc_set_error("sc_enc_attention: unsupported head dim %d", dk);
+    return SC_ERR_ARG;
+  }
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// all encoder layers
+// ---------------------------------------------------------------------------
+extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, int nblk, int R,
+                                 int masked, const int32_t *jobs, int ns, float *past_ctx,
+                                 float *xn, float *qkv, float *att, float *ffh, int d, int H, int F,
+                                 float eps, void *stream) {
+  SC_CHECK_ARG(L && x && xn && qkv && att && ffh, "null pointer");
+  const int M = nblk * R;
+  if (M <= 0) return SC_OK;
+  int rc;
+#define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
+  for (int li = 0; li < n_layers; ++li) {
+    const sc_enc_layer &w = L[li];
+    SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln1_g, w.ln1_b, eps, stream));
+    SC_TRY(sc_gemm(xn, nullptr, d, w.wqkv, w.bqkv, qkv, nullptr, 3 * d, M, 3 * d, d, 0, 0, stream));
+    SC_TRY(sc_enc_attention(qkv, att, nblk, R, H, d, masked, stream));
+    SC_TRY(sc_gemm(att, nullptr, d, w.wo, w.bo, x, nullptr, d, M, d, d, SC_GEMM_RESIDUAL, 0, stream));
+    SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
+    SC_TRY(sc_gemm(xn, nullptr, d, w.w1, w.b1, ffh, nullptr, F, M, F, d, SC_GEMM_RELU, 0, stream));
+    SC_TRY(sc_gemm(ffh, nullptr, F, w.w2, w.b2, x, nullptr, d, M, d, F, SC_GEMM_RESIDUAL, 0, stream));
+    if (masked && ns > 0) SC_TRY(sc_ctx_handoff(x, R, jobs, ns, past_ctx, li, d, stream));
+  }
+#undef SC_TRY
+  return SC_OK;
+}

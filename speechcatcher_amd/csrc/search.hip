@@ -1,0 +1,609 @@
+// Search-side kernels of libscasr (gfx950): decoder attention with K/V caches,
+// log-softmax + pre-beam top-K, CTC prefix scan, score fusion, beam pruning.
+// Every kernel is batched over S streams x W hypotheses and masked by the
+// per-stream ctrl rows (see scasr.h), so one launch serves all streams.
+#include "common.h"
+
+#define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
+
+// per-index helpers for the ping-pong buffers
+#define YSEQ(pp, s, h) (sb.yseq + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
+#define XPOS(pp, s, h) (sb.xpos + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
+#define ANC(pp, s) (sb.anc + ((long)(pp) * sb.S + (s)) * sb.LCAP * sb.W)
+#define CTCR(pp, s) (sb.ctc_r + ((long)(pp) * sb.S + (s)) * sb.TCAP * 2 * sb.W)
+
+// ---------------------------------------------------------------------------
+// CTC state extension: r^n[t] = logzero, r^b[t] = r^b[t-1] + x[t, blank]
+// ---------------------------------------------------------------------------
+__global__ void ctc_extend_state_kernel(sc_search sb) {
+  const int s = blockIdx.x, h = threadIdx.x;
+  if (!CTRL(s, SC_C_ACTIVE) || !CTRL(s, SC_C_HAS)) return;
+  const int T = CTRL(s, SC_C_T), told = CTRL(s, SC_C_TOLD), nh = CTRL(s, SC_C_NHYP);
+  if (h >= nh || told >= T) return;
+  float *r = CTCR(CTRL(s, SC_C_CUR), s);
+  const float *x = sb.ctcx + (long)s * sb.TCAP * sb.V;
+  const int t0 = told < 1 ? 1 : told;
+  float rb = r[((long)(t0 - 1) * 2 + 1) * sb.W + h];
+  for (int t = t0; t < T; ++t) {
+    rb = rb + x[(long)t * sb.V + sb.blank];
+    r[((long)t * 2 + 0) * sb.W + h] = SC_LOGZERO;
+    r[((long)t * 2 + 1) * sb.W + h] = rb;
+  }
+}
+
+extern "C" int sc_ctc_extend_state(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  ctc_extend_state_kernel<<<sbp->S, 64, 0, (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void dec_embed_kernel(sc_search sb, float sq) {
+  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int L = CTRL(s, SC_C_L);
+  const int tok = YSEQ(CTRL(s, SC_C_CUR), s, h)[L - 1];
+  for (int c = threadIdx.x; c < sb.d; c += blockDim.x)
+    sb.dx[(long)row * sb.d + c] = sb.embed[(long)tok * sb.d + c] * sq + sb.pe[(long)(L - 1) * sb.d + c];
+}
+
+extern "C" int sc_dec_embed(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  dec_embed_kernel<<<sbp->S * sbp->W, 256, 0, (hipStream_t)stream>>>(*sbp, sqrtf((float)sbp->d));
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decoder self-attention: one wave per (stream, hyp, head).  Lanes stride the
+// L cached positions (ancestor-table gather), online softmax per lane, then a
+// cross-lane merge through LDS.
+// ---------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li) {
+  __shared__ float part[4][64][DK + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  const int H = sb.H, d = sb.d, W = sb.W;
+  if (unit >= sb.S * W * H) return;
+  const int row = unit / H, head = unit % H;
+  const int s = row / W, h = row % W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  const float *qkv = sb.dqkv + (long)row * 3 * d + head * DK;
+  float *skv = sb.skv + ((long)s * sb.n_layers + li) * sb.LCAP * W * 2 * d;
+  // append this token's K|V row at (position L-1, slot h)
+  if (lane < DK) {
+    float *dst = skv + ((long)(L - 1) * W + h) * 2 * d + head * DK;
+    dst[lane] = qkv[d + lane];
+    dst[d + lane] = qkv[2 * d + lane];
+  }
+  float q[DK];
+#pragma unroll
+  for (int c = 0; c < DK; c += 4) {
+    float4 t = reinterpret_cast<const float4 *>(qkv)[c / 4];
+    q[c] = t.x; q[c + 1] = t.y; q[c + 2] = t.z; q[c + 3] = t.w;
+  }
+  const int *anc = ANC(cur, s);
+  const float scale = sqrtf((float)DK);
+  float m = -INFINITY, l = 0.f;
+  float acc[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
+  for (int p = lane; p < L; p += 64) {
+    const float *kr, *vr;
+    if (p == L - 1) {
+      kr = qkv + d;
+      vr = qkv + 2 * d;
+    } else {
+      const int slot = anc[(long)p * W + h];
+      kr = skv + ((long)p * W + slot) * 2 * d + head * DK;
+      vr = kr + d;
+    }
+    float sdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      float4 k4 = reinterpret_cast<const float4 *>(kr)[c / 4];
+      sdot = fmaf(q[c], k4.x, sdot);
+      sdot = fmaf(q[c + 1], k4.y, sdot);
+      sdot = fmaf(q[c + 2], k4.z, sdot);
+      sdot = fmaf(q[c + 3], k4.w, sdot);
+    }
+    sdot = sdot / scale;
+    const float mn = fmaxf(m, sdot);
+    const float corr = expf(m - mn), pe = expf(sdot - mn);
+    l = l * corr + pe;
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      float4 v4 = reinterpret_cast<const float4 *>(vr)[c / 4];
+      acc[c] = acc[c] * corr + pe * v4.x;
+      acc[c + 1] = acc[c + 1] * corr + pe * v4.y;
+      acc[c + 2] = acc[c + 2] * corr + pe * v4.z;
+      acc[c + 3] = acc[c + 3] * corr + pe * v4.w;
+    }
+    m = mn;
+  }
+  // merge the 64 per-lane partials (lanes with no position have l = 0)
+  const float M = wave_max(m);
+  const float sc = (l > 0.f) ? expf(m - M) : 0.f;
+  const float Lt = wave_sum(l * sc);
+#pragma unroll
+  for (int c = 0; c < DK; ++c) part[wave][lane][c] = acc[c] * sc;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < DK) {
+    float o = 0.f;
+    for (int j = 0; j < 64; ++j) o += part[wave][j][lane];
+    sb.datt[(long)row * d + head * DK + lane] = o / Lt;
+  }
+}
+
+extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  const sc_search &sb = *sbp;
+  const int dk = sb.d / sb.H;
+  const int grid = cdiv(sb.S * sb.W * sb.H, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dk == 32) dec_self_attn_kernel<32><<<grid, 256, 0, st>>>(sb, layer);
+  else if (dk == 16) dec_self_attn_kernel<16><<<grid, 256, 0, st>>>(sb, layer);
+  else { sc_set_error("sc_dec_self_attn: unsupported head dim %d", dk); return SC_ERR_ARG; }
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decoder cross-attention, flash-decoding style.  Grid (chunk, head, stream):
+// one workgroup reads 256 encoder frames of K|V ONCE for all W hypotheses of
+// the stream; a second kernel merges the per-chunk partials.
+// ---------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void dec_cross_attn_part_kernel(sc_search sb, int li) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int chunk = blockIdx.x, head = blockIdx.y, s = blockIdx.z;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int T = CTRL(s, SC_C_T), nh = CTRL(s, SC_C_NHYP);
+  const int c0 = chunk * 256;
+  if (c0 >= T) return;
+  const int W = sb.W, d = sb.d, H = sb.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *qs = smem;                  // [W][DK]
+  float *sc = qs + W * DK;           // [W][256]
+  float *Vs = sc + W * 256;          // [256][DK+1]
+  float *mw = Vs + 256 * (DK + 1);   // [W]
+  float *lw = mw + W;                // [W]
+  for (int e = tid; e < nh * DK; e += 256) {
+    int w = e / DK, c = e % DK;
+    qs[e] = sb.dq[((long)s * W + w) * d + head * DK + c];
+  }
+  __syncthreads();
+  const int f = c0 + tid;
+  const bool valid = f < T;
+  const float *kv = sb.ckv + (((long)s * sb.n_layers + li) * sb.TCAP + (valid ? f : 0)) * 2 * d + head * DK;
+  float k[DK];
+#pragma unroll
+  for (int c = 0; c < DK; c += 4) {
+    float4 t = reinterpret_cast<const float4 *>(kv)[c / 4];
+    k[c] = t.x; k[c + 1] = t.y; k[c + 2] = t.z; k[c + 3] = t.w;
+  }
+#pragma unroll
+  for (int c = 0; c < DK; c += 4) {
+    float4 t = reinterpret_cast<const float4 *>(kv + d)[c / 4];
+    Vs[tid * (DK + 1) + c] = t.x;
+    Vs[tid * (DK + 1) + c + 1] = t.y;
+    Vs[tid * (DK + 1) + c + 2] = t.z;
+    Vs[tid * (DK + 1) + c + 3] = t.w;
+  }
+  const float scale = sqrtf((float)DK);
+  for (int w = 0; w < nh; ++w) {
+    float sdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) sdot = fmaf(qs[w * DK + c], k[c], sdot);
+    sc[w * 256 + tid] = valid ? sdot / scale : -INFINITY;
+  }
+  __syncthreads();
+  // softmax statistics: wave wv owns hypotheses wv, wv+4, ...
+  for (int w = wave; w < nh; w += 4) {
+    float v0 = sc[w * 256 + lane], v1 = sc[w * 256 + lane + 64];
+    float v2 = sc[w * 256 + lane + 128], v3 = sc[w * 256 + lane + 192];
+    float m = wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+    float p0 = expf(v0 - m), p1 = expf(v1 - m), p2 = expf(v2 - m), p3 = expf(v3 - m);
+    float l = wave_sum((p0 + p1) + (p2 + p3));
+    sc[w * 256 + lane] = p0;
+    sc[w * 256 + lane + 64] = p1;
+    sc[w * 256 + lane + 128] = p2;
+    sc[w * 256 + lane + 192] = p3;
+    if (lane == 0) { mw[w] = m; lw[w] = l; }
+  }
+  __syncthreads();
+  const int nch = cdiv(sb.TCAP, 256);
+  for (int o = tid; o < nh * DK; o += 256) {
+    const int w = o / DK, c = o % DK;
+    float acc = 0.f;
+    const float *pw = sc + w * 256;
+    for (int t = 0; t < 256; ++t) acc = fmaf(pw[t], Vs[t * (DK + 1) + c], acc);
+    float *dst = sb.xpart + ((((long)s * W + w) * H + head) * nch + chunk) * (DK + 2);
+    dst[c] = acc;
+    if (c == 0) { dst[DK] = mw[w]; dst[DK + 1] = lw[w]; }
+  }
+}
+
+template <int DK>
+__global__ void dec_cross_attn_merge_kernel(sc_search sb) {
+  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int T = CTRL(s, SC_C_T);
+  const int nch_all = cdiv(sb.TCAP, 256), nch = cdiv(T, 256);
+  for (int o = threadIdx.x; o < sb.H * DK; o += blockDim.x) {
+    const int head = o / DK, c = o % DK;
+    const float *p = sb.xpart + (((long)row * sb.H + head) * nch_all) * (DK + 2);
+    float M = -INFINITY;
+    for (int j = 0; j < nch; ++j) M = fmaxf(M, p[j * (DK + 2) + DK]);
+    float num = 0.f, den = 0.f;
+    for (int j = 0; j < nch; ++j) {
+      float e = expf(p[j * (DK + 2) + DK] - M);
+      num += p[j * (DK + 2) + c] * e;
+      den += p[j * (DK + 2) + DK + 1] * e;
+    }
+    sb.datt[(long)row * sb.d + head * DK + c] = num / den;
+  }
+}
+
+extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(sb.xchunk == 256, "xchunk must be 256");
+  const int dk = sb.d / sb.H;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(sb.TCAP, 256), sb.H, sb.S);
+  size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 2 * sb.W) * sizeof(float);
+  SC_CHECK_ARG(smem <= 64 * 1024, "beam too wide for the cross-attention LDS tile");
+  if (dk == 32) {
+    dec_cross_attn_part_kernel<32><<<grid, 256, smem, st>>>(sb, layer);
+    dec_cross_attn_merge_kernel<32><<<sb.S * sb.W, 256, 0, st>>>(sb);
+  } else if (dk == 16) {
+    dec_cross_attn_part_kernel<16><<<grid, 256, smem, st>>>(sb, layer);
+    dec_cross_attn_merge_kernel<16><<<sb.S * sb.W, 256, 0, st>>>(sb);
+  } else {
+    sc_set_error("sc_dec_cross_attn: unsupported head dim %d", dk);
+    return SC_ERR_ARG;
+  }
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers, "null");
+  const sc_search &sb = *sbp;
+  const int n = sb.S * sb.W, d = sb.d, F = sb.F;
+  int rc;
+#define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
+  for (int li = 0; li < sb.n_layers; ++li) {
+    const sc_dec_layer &w = sb.layers[li];
+    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln1_g, w.ln1_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wqkv, w.bqkv, sb.dqkv, nullptr, 3 * d, n, 3 * d, d, 0, 0, stream));
+    SC_TRY(sc_dec_self_attn(sbp, li, stream));
+    SC_TRY(sc_gemm(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0, stream));
+    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln2_g, w.ln2_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wq, w.bq, sb.dq, nullptr, d, n, d, d, 0, 0, stream));
+    SC_TRY(sc_dec_cross_attn(sbp, li, stream));
+    SC_TRY(sc_gemm(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0, stream));
+    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln3_g, w.ln3_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.w1, w.b1, sb.dffh, nullptr, F, n, F, d, SC_GEMM_RELU, 0, stream));
+    SC_TRY(sc_gemm(sb.dffh, nullptr, F, w.w2, w.b2, sb.dx, nullptr, d, n, d, F, SC_GEMM_RESIDUAL, 0, stream));
+  }
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rank-count selection shared by the pre-beam and the per-hypothesis top-W:
+// rank(i) = #{j : key[j] > key[i] or (key[j] == key[i] and j < i)}.
+// Descending order, ties broken towards the lowest index.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rank_of(const float *key, int V, int i) {
+  const float ki = key[i];
+  int rank = 0;
+  for (int j = 0; j < V; j += 4) {
+    float4 kj = *reinterpret_cast<const float4 *>(key + j);
+    rank += (kj.x > ki) || (kj.x == ki && j < i);
+    rank += (kj.y > ki) || (kj.y == ki && j + 1 < i);
+    rank += (kj.z > ki) || (kj.z == ki && j + 2 < i);
+    rank += (kj.w > ki) || (kj.w == ki && j + 3 < i);
+  }
+  return rank;
+}
+
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(sc_search sb) {
+  extern __shared__ __attribute__((aligned(16))) float key[];
+  __shared__ float red[8];
+  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int V = sb.V, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *x = sb.logits + (long)row * V;
+  float m = -INFINITY;
+  for (int c = tid; c < V; c += 256) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < V; c += 256) sum += expf(x[c] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float ls = logf(sum);
+  for (int c = tid; c < V; c += 256) {
+    float lp = (x[c] - m) - ls;
+    sb.logp[(long)row * V + c] = lp;
+    key[c] = __fmul_rn(sb.w_dec, lp);
+  }
+  __syncthreads();
+  for (int i = tid; i < V; i += 256) {
+    int rk = rank_of(key, V, i);
+    if (rk < sb.K) sb.pre_ids[(long)row * sb.K + rk] = i;
+  }
+}
+
+extern "C" int sc_logsoftmax_topk(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  SC_CHECK_ARG(sbp->V % 4 == 0, "V % 4");
+  logsoftmax_topk_kernel<<<sbp->S * sbp->W, 256, sbp->V * sizeof(float), (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CTC prefix scan (Watanabe Alg. 2): one lane per (hypothesis, candidate),
+// sequential over encoder frames, log-domain, logzero = -1e10.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
+  const int s = blockIdx.y;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int nh = CTRL(s, SC_C_NHYP), K = sb.K, W = sb.W, V = sb.V;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nh * K) return;
+  const int h = e / K, k = e % K;
+  const int T = CTRL(s, SC_C_T), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  const bool has = CTRL(s, SC_C_HAS);
+  const long row = (long)s * W + h;
+  const int c = sb.pre_ids[row * K + k];
+  const int last = YSEQ(cur, s, h)[L - 1];
+  const bool same = (c == last);
+  const float *x = sb.ctcx + (long)s * sb.TCAP * V;
+  const float *rp = CTCR(cur, s);
+  float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
+  const int WK = W * K;
+  const int out_len = L - 1;
+  int start = out_len > 1 ? out_len : 1;
+  if (start > T) start = T;
+  // rows before start-1 are never read again; keep them at logzero
+  for (int t = 0; t < start - 1; ++t) {
+    rn[((long)t * 2) * WK + e] = SC_LOGZERO;
+    rn[((long)t * 2 + 1) * WK + e] = SC_LOGZERO;
+  }
+  float r_n = (out_len == 0) ? x[c] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
+  float r_b = SC_LOGZERO;
+  rn[((long)(start - 1) * 2) * WK + e] = r_n;
+  rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b;
+  // previous-prefix forward variables at t-1
+  float cum = 0.f;  // running blank log-prob sum for the initial (state None) hypothesis
+  if (!has)
+    for (int t = 0; t < start; ++t) cum += x[(long)t * V + sb.blank];
+  auto prev_at = [&](int t, float &pn, float &pb) {
+    if (has) {
+      pn = rp[((long)t * 2) * W + h];
+      pb = rp[((long)t * 2 + 1) * W + h];
+    } else {
+      pn = SC_LOGZERO;
+      pb = cum;  // caller keeps cum == sum_{tau<=t} x[tau, blank]
+    }
+  };
+  // psi accumulates logsumexp over {phi[t-1] + x[t,c]} and r[start-1][n]
+  float pm = r_n, ps = 1.f;
+  float pn, pb;
+  prev_at(start - 1, pn, pb);
+  for (int t = start; t < T; ++t) {
+    const float phi = same ? pb : lse2(pn, pb);
+    const float xc = x[(long)t * V + c], xb = x[(long)t * V + sb.blank];
+    const float nr_n = lse2(r_n, phi) + xc;
+    const float nr_b = lse2(r_n, r_b) + xb;
+    r_n = nr_n;
+    r_b = nr_b;
+    rn[((long)t * 2) * WK + e] = r_n;
+    rn[((long)t * 2 + 1) * WK + e] = r_b;
+    const float v = phi + xc;
+    if (v > pm) {
+      ps = ps * expf(pm - v) + 1.f;
+      pm = v;
+    } else {
+      ps += expf(v - pm);
+    }
+    if (!has) cum += xb;
+    prev_at(t, pn, pb);
+  }
+  float psi = pm + logf(ps);
+  // (pn, pb) hold r_prev[T-1]: from the last loop iteration, or from
+  // prev_at(start-1) with start == T when the loop did not run.
+  const float rsum_last = lse2(pn, pb);
+  if (c == sb.eos) psi = rsum_last;
+  if (c == sb.blank) psi = SC_LOGZERO;
+  sb.psi[row * K + k] = psi;
+  if (k == 0) sb.psi_eos[row] = rsum_last;
+}
+
+extern "C" int sc_ctc_prefix_scan(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  dim3 grid(cdiv(sbp->W * sbp->K, 256), sbp->S);
+  ctc_prefix_scan_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// score fusion + per-hypothesis top-W
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fuse_topw_kernel(sc_search sb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int V = sb.V, K = sb.K, W = sb.W, tid = threadIdx.x;
+  float *comb = smem, *ctc = smem + V;
+  const float s_prev = CTRL(s, SC_C_HAS) ? sb.ctc_s[((long)CTRL(s, SC_C_CUR) * sb.S + s) * W + h] : 0.f;
+  for (int v = tid; v < V; v += 256) ctc[v] = SC_LOGZERO;
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) ctc[sb.pre_ids[(long)row * K + k]] = sb.psi[(long)row * K + k];
+  __syncthreads();
+  if (tid == 0) {
+    ctc[sb.eos] = sb.psi_eos[row];
+    ctc[sb.blank] = SC_LOGZERO;
+  }
+  __syncthreads();
+  for (int v = tid; v < V; v += 256) {
+    const float cv = __fsub_rn(ctc[v], s_prev);
+    ctc[v] = cv;
+    comb[v] = __fadd_rn(__fmul_rn(sb.w_dec, sb.logp[(long)row * V + v]), __fmul_rn(sb.w_ctc, cv));
+  }
+  __syncthreads();
+  for (int i = tid; i < V; i += 256) {
+    int rk = rank_of(comb, V, i);
+    if (rk < W) {
+      sb.cand_tok[(long)row * W + rk] = i;
+      sb.cand_score[(long)row * W + rk] = comb[i];
+      sb.cand_ctc[(long)row * W + rk] = ctc[i];
+    }
+  }
+}
+
+extern "C" int sc_fuse_topw(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  fuse_topw_kernel<<<sbp->S * sbp->W, 256, 2 * sbp->V * sizeof(float), (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// beam_prune: one workgroup per stream.  Candidates (h, j) are ranked by the
+// float64 total (stable, hypothesis-major order), the best W become the next
+// hypotheses; all bookkeeping of Hypothesis objects happens here.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
+  extern __shared__ __attribute__((aligned(16))) double tot[];
+  __shared__ int fl_any, fl_all, fl_best, fl_rep;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int W = sb.W, K = sb.K;
+  const int nh = CTRL(s, SC_C_NHYP), L = CTRL(s, SC_C_L), T = CTRL(s, SC_C_T);
+  const int cur = CTRL(s, SC_C_CUR), o = 1 - cur;
+  const int n = nh * W, nout = n < W ? n : W;
+  if (tid == 0) { fl_any = 0; fl_all = 1; fl_best = 0; fl_rep = 0; }
+  for (int e = tid; e < n; e += 256) {
+    const int h = e / W, j = e % W;
+    tot[e] = sb.score[((long)cur * sb.S + s) * W + h] + (double)sb.cand_score[((long)s * W + h) * W + j];
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const double te = tot[e];
+    int rk = 0;
+    for (int j = 0; j < n; ++j) rk += (tot[j] > te) || (tot[j] == te && j < e);
+    if (rk >= nout) continue;
+    const int h = e / W, j = e % W, i = rk;
+    const long prow = (long)s * W + h;
+    const int tok = sb.cand_tok[prow * W + j];
+    const int *ysrc = YSEQ(cur, s, h), *xsrc = XPOS(cur, s, h);
+    int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
+    bool rep = false;
+    for (int p = 0; p < L; ++p) {
+      const int y = ysrc[p];
+      ydst[p] = y;
+      xdst[p] = xsrc[p];
+      if (p >= 1 && y == tok) rep = true;
+    }
+    ydst[L] = tok;
+    xdst[L] = T - 1;
+    const long oi = ((long)o * sb.S + s) * W + i, ci = ((long)cur * sb.S + s) * W + h;
+    sb.score[oi] = te;
+    sb.sc_dec[oi] = sb.sc_dec[ci] + (double)sb.logp[prow * sb.V + tok];
+    sb.sc_ctc[oi] = sb.sc_ctc[ci] + (double)sb.cand_ctc[prow * W + j];
+    const int *asrc = ANC(cur, s);
+    int *adst = ANC(o, s);
+    for (int p = 0; p < L - 1; ++p) adst[(long)p * W + i] = asrc[(long)p * W + h];
+    adst[(long)(L - 1) * W + i] = h;
+    int kk = -1;
+    for (int q = 0; q < K; ++q)
+      if (sb.pre_ids[prow * K + q] == tok) { kk = q; break; }
+    float sval;
+    if (tok == sb.blank) sval = SC_LOGZERO;
+    else if (tok == sb.eos) sval = sb.psi_eos[prow];
+    else if (kk >= 0) sval = sb.psi[prow * K + kk];
+    else sval = SC_LOGZERO;
+    sb.ctc_s[oi] = sval;
+    sb.sel[((long)s * W + i) * 2] = h;
+    sb.sel[((long)s * W + i) * 2 + 1] = kk < 0 ? 0 : kk;
+    const bool is_eos = tok == sb.eos;
+    if (is_eos) atomicOr(&fl_any, 1);
+    else atomicAnd(&fl_all, 0);
+    if (i == 0 && is_eos) atomicOr(&fl_best, 1);
+    if (rep && tok != sb.sos && tok != sb.eos) atomicOr(&fl_rep, 1);
+  }
+  __syncthreads();
+  if (tid == 0)
+    sb.flags[s] = (fl_any ? SC_F_ANY_EOS : 0) | (fl_best ? SC_F_BEST_EOS : 0) |
+                  (fl_all ? SC_F_ALL_EOS : 0) | (fl_rep ? SC_F_REPEAT : 0);
+}
+
+extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  size_t smem = (size_t)sbp->W * sbp->W * sizeof(double);
+  beam_prune_kernel<<<sbp->S, 256, smem, (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void ctc_gather_state_kernel(sc_search sb) {
+  const int s = blockIdx.y;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int W = sb.W, K = sb.K, T = CTRL(s, SC_C_T), nh = CTRL(s, SC_C_NHYP);
+  const int nout = nh * W < W ? nh * W : W;
+  const int o = 1 - CTRL(s, SC_C_CUR);
+  float *dst = CTCR(o, s);
+  const float *src = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
+  const long total = (long)T * 2 * nout;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int i = idx % nout;
+    const long t2 = idx / nout;  // t*2 + {n,b}
+    const int hsel = sb.sel[((long)s * W + i) * 2], ksel = sb.sel[((long)s * W + i) * 2 + 1];
+    dst[t2 * W + i] = src[t2 * (W * K) + hsel * K + ksel];
+  }
+}
+
+extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  int gx = cdiv(sbp->TCAP * 2 * sbp->W, 256);
+  if (gx > 64) gx = 64;
+  ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp, "null");
+  const sc_search &sb = *sbp;
+  const int n = sb.S * sb.W;
+  int rc;
+  SC_TRY(sc_dec_embed(sbp, stream));
+  SC_TRY(sc_decoder_layers(sbp, stream));
+  SC_TRY(sc_layernorm(sb.dx, nullptr, sb.d, sb.dxn, nullptr, sb.d, n, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, stream));
+  SC_TRY(sc_gemm(sb.dxn, nullptr, sb.d, sb.out_w, sb.out_b, sb.logits, nullptr, sb.V, n, sb.V, sb.d, 0, 0, stream));
+  SC_TRY(sc_logsoftmax_topk(sbp, stream));
+  SC_TRY(sc_ctc_prefix_scan(sbp, stream));
+  SC_TRY(sc_fuse_topw(sbp, stream));
+  SC_TRY(sc_beam_prune(sbp, stream));
+  SC_TRY(sc_ctc_gather_state(sbp, stream));
+  return SC_OK;
+}

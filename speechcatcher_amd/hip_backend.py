@@ -1,0 +1,160 @@
+"""Backend that runs every engine op as hand-written HIP kernels through the
+C ABI of libscasr.so (include/scasr.h).  torch is used only as the owner of
+device memory and of the HIP stream; every pointer handed to the library is a
+raw device address."""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _abi.ScasrError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.lib = _abi.load()
+        self.device = torch.device(device)
+        self._enc_layers = {}
+        self._search = {}
+        self._keep = []
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            _abi.check(rc, what)
+
+    # ------------------------------------------------------------------
+    def logmel(self, w, pcm, pcap, jobs, n_jobs, max_keep, featbuf):
+        cfg = w.cfg
+        mode = 0 if not w.has_mvn else (2 if w.mvn_is_f64 else 1)
+        self._chk(self.lib.sc_logmel(_p(pcm), pcap, _p(jobs), n_jobs, max_keep, _p(w.window), _p(w.mel_fb),
+                                     _p(w.twiddle), _p(w.mean64), _p(w.std64), mode, cfg.n_fft,
+                                     cfg.hop_length, cfg.win_length, cfg.n_mels, _p(featbuf),
+                                     self._stream()), "sc_logmel")
+
+    def conv1(self, w, featbuf, jobs, n_jobs, max_t1, c1):
+        cfg = w.cfg
+        self._chk(self.lib.sc_conv1(_p(featbuf), cfg.n_mels, _p(jobs), n_jobs, max_t1, _p(w.conv1_w),
+                                    _p(w.conv1_b), cfg.d_model, _p(c1), self._stream()), "sc_conv1")
+
+    def gemm(self, A, a_rows, lda, W, bias, Cm, c_rows, ldc, M, N, K, relu=False, conv_f1=0,
+             residual=False, naive=False):
+        flags = (1 if relu else 0) | (2 if residual else 0) | (4 if naive else 0)
+        self._chk(self.lib.sc_gemm(_p(A), _p(a_rows), lda, _p(W), _p(bias), _p(Cm), _p(c_rows), ldc,
+                                   M, N, K, flags, conv_f1, self._stream()), "sc_gemm")
+
+    def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
+        self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
+                                        self._stream()), "sc_copy_rows")
+
+    def layernorm(self, src, src_rows, dst, dst_rows, M, g, b, eps=1e-12):
+        self._chk(self.lib.sc_layernorm(_p(src), _p(src_rows), src.shape[-1], _p(dst), _p(dst_rows),
+                                        dst.shape[-1], M, g.numel(), _p(g), _p(b), eps,
+                                        self._stream()), "sc_layernorm")
+
+    def log_softmax_rows(self, x, rows, n, V):
+        self._chk(self.lib.sc_log_softmax_rows(_p(x), _p(rows), n, V, self._stream()), "sc_log_softmax_rows")
+
+    def block_pack(self, w, subbuf, jobs, nb, R, xblk):
+        self._chk(self.lib.sc_block_pack(_p(subbuf), _p(jobs), nb, R, _p(w.pe), w.cfg.d_model, _p(xblk),
+                                         self._stream()), "sc_block_pack")
+
+    def ctx_handoff(self, x, R, jobs, ns, state, layer):
+        self._chk(self.lib.sc_ctx_handoff(_p(x), R, _p(jobs), ns, _p(state), layer, x.shape[-1],
+                                          self._stream()), "sc_ctx_handoff")
+
+    def enc_attention(self, qkv, att, nblk, R, H, masked):
+        self._chk(self.lib.sc_enc_attention(_p(qkv), _p(att), nblk, R, H, att.shape[-1], int(masked),
+                                            self._stream()), "sc_enc_attention")
+
+    def _enc_layer_table(self, w):
+        key = id(w)
+        if key not in self._enc_layers:
+            arr = (_abi.EncLayer * len(w.enc))()
+            for i, lw in enumerate(w.enc):
+                for name in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2"):
+                    setattr(arr[i], name, lw[name].data_ptr())
+            self._enc_layers[key] = arr
+        return self._enc_layers[key]
+
+    def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
+        cfg = w.cfg
+        tab = self._enc_layer_table(w)
+        self._chk(self.lib.sc_encoder_layers(C.cast(tab, C.c_void_p), len(w.enc), _p(x), nblk, R, int(masked),
+                                             _p(jobs), ns, _p(past_ctx), _p(xn), _p(qkv), _p(att), _p(ffh),
+                                             cfg.d_model, cfg.enc_heads, cfg.ffn_dim, cfg.ln_eps,
+                                             self._stream()), "sc_encoder_layers")
+
+    # ------------------------------------------------------------------
+    def search_struct(self, sb):
+        key = id(sb)
+        if key in self._search:
+            return self._search[key][0]
+        w, cfg = sb.w, sb.cfg
+        layers = (_abi.DecLayer * len(w.dec))()
+        for i, lw in enumerate(w.dec):
+            for name, _ in _abi.DecLayer._fields_:
+                setattr(layers[i], name, lw[name].data_ptr())
+        s = _abi.Search()
+        s.S, s.W, s.K, s.V, s.d, s.H, s.F = sb.S, sb.W, sb.K, cfg.vocab_size, cfg.d_model, cfg.dec_heads, cfg.ffn_dim
+        s.n_layers, s.TCAP, s.LCAP, s.xchunk = cfg.dec_layers, sb.TCAP, sb.LCAP, sb.xchunk
+        s.blank, s.eos, s.sos = cfg.blank_id, cfg.eos_id, cfg.sos_id
+        s.w_dec, s.w_ctc, s.ln_eps = sb.search.decoder_weight, sb.search.ctc_weight, cfg.ln_eps
+        for name in ("ctrl", "flags", "ctcx", "ckv", "skv", "yseq", "xpos", "anc", "score", "sc_dec",
+                     "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv", "datt", "dq", "dffh",
+                     "logits", "logp", "pre_ids", "psi", "psi_eos", "cand_score", "cand_tok", "cand_ctc",
+                     "sel", "xpart"):
+            setattr(s, name, getattr(sb, name).data_ptr())
+        s.embed, s.pe = w.embed.data_ptr(), w.pe.data_ptr()
+        s.dec_norm_g, s.dec_norm_b = w.dec_norm_g.data_ptr(), w.dec_norm_b.data_ptr()
+        s.out_w, s.out_b = w.out_w.data_ptr(), w.out_b.data_ptr()
+        s.layers = C.cast(layers, C.c_void_p).value
+        self._search[key] = (s, layers)
+        return s
+
+    def _sb_call(self, fn, sb, *extra):
+        s = self.search_struct(sb)
+        self._chk(getattr(self.lib, fn)(C.addressof(s), *extra, self._stream()), fn)
+
+    def ctc_extend_state(self, sb):
+        self._sb_call("sc_ctc_extend_state", sb)
+
+    def dec_embed(self, sb):
+        self._sb_call("sc_dec_embed", sb)
+
+    def dec_self_attn(self, sb, li):
+        self._sb_call("sc_dec_self_attn", sb, li)
+
+    def dec_cross_attn(self, sb, li):
+        self._sb_call("sc_dec_cross_attn", sb, li)
+
+    def decoder_layers(self, sb):
+        self._sb_call("sc_decoder_layers", sb)
+
+    def logsoftmax_topk(self, sb):
+        self._sb_call("sc_logsoftmax_topk", sb)
+
+    def ctc_prefix_scan(self, sb):
+        self._sb_call("sc_ctc_prefix_scan", sb)
+
+    def fuse_topw(self, sb):
+        self._sb_call("sc_fuse_topw", sb)
+
+    def beam_prune(self, sb):
+        self._sb_call("sc_beam_prune", sb)
+
+    def ctc_gather_state(self, sb):
+        self._sb_call("sc_ctc_gather_state", sb)
+
+    def decode_step(self, sb):
+        self._sb_call("sc_decode_step", sb)

@@ -41,8 +41,9 @@ def check_against_blocks(sb, s, block, score_tol=2e-3):
 def run_case(name, n_streams=1, stream=0, score_tol=2e-3, **kw):
     js, npz = load_case(name)
     meta = js["meta"]
+    kw.setdefault("max_tokens", 200 if meta["model"] == "XL" else 160)
     sb = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"],
-                    n_streams=n_streams, max_frames=256, max_tokens=160, pcm_capacity=1 << 18, **kw)
+                    n_streams=n_streams, max_frames=256, pcm_capacity=1 << 18, **kw)
     audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
     chunk = meta["chunk"]
     pos, nblk = 0, 0
