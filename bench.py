@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the streaming-ASR hot path on MI355X.
+
+One "step" = one chunk step (10 240 samples = 640 ms of 16 kHz audio) of the
+whole path - log-mel frontend, Conv2d subsampling, contextual-block encoder,
+blockwise-synchronous beam search (decoder + CTC prefix scorer) - for EVERY
+stream of the batch (S streams per GPU, default 128 = BASELINE.json
+configs[2]; `--streams 1` gives configs[1]).  Weights: de_streaming_
+transformer_xl dimensions, seeded synthetic (no checkpoints offline); audio:
+seeded Gaussian noise, already resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
+
+Prints ONE JSON line (rank 0).  value = whole-job audio-seconds processed per
+wall-clock second = number of concurrent real-time streams the job sustains.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from speechcatcher_amd import synth  # noqa: E402
+from speechcatcher_amd.config import XL, SearchConfig  # noqa: E402
+
+CHUNK = 10240
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def build_batch(n_streams, beam, bbd, n_steps_total, device):
+    from speechcatcher_amd.engine import StreamBatch
+    from speechcatcher_amd.hip_backend import HipBackend
+    from speechcatcher_amd.weights import PackedWeights
+    sd = synth.make_state_dict(XL, 1234)
+    mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
+    w = PackedWeights(sd, XL, device, mean, std)
+    be = HipBackend(device)
+    frames = 16 * (n_steps_total + 2) + 64
+    tokens = min(1024, 14 * (n_steps_total + 2) + 32)
+    sb = StreamBatch(w, be, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd),
+                     max_frames=frames, max_tokens=tokens,
+                     pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK)
+    return sb, be
+
+
+def preload_audio(sb, n_steps_total, stream_offset=0):
+    """Synthetic audio for every stream, resident in HBM before timing."""
+    n = CHUNK * n_steps_total
+    for s in range(sb.S):
+        a = synth.synth_audio(stream_offset + s, n)
+        sb.pcm[s, :n].copy_(torch.from_numpy(a))
+    torch.cuda.synchronize()
+
+
+def run_steps(sb, n):
+    items = [(s, CHUNK, False) for s in range(sb.S)]
+    for _ in range(n):
+        sb.push(items, pcm_resident=True)
+
+
+def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
+    """The oracle (port of the reference path) timed on this box's host cores."""
+    from oracle.ref_port import RefPortModel, RefPortStreaming
+    from speechcatcher_amd.mel import melscale_fbanks_slaney
+    sd = synth.make_state_dict(XL, 1234)
+    mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
+    mel = melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000)
+    model = RefPortModel(sd, XL, mel, mean, std)
+    s = RefPortStreaming(model, beam_size=beam, ctc_weight=0.3, use_bbd=bbd)
+    audio = synth.synth_audio(0, CHUNK * (warm_calls + max_steps))
+    for i in range(warm_calls):
+        s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and time.perf_counter() - t0 < budget_s:
+        i = warm_calls + n
+        s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * CHUNK / 16000.0 / dt, 4), "unit": "audio_s/s",
+            "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 stream, chunk steps {warm_calls}..{warm_calls + n - 1} of stream 0 "
+                      f"({n} steps, {dt:.1f} s wall), beam {beam}, bbd {int(bbd)}, XL dims, torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
+    ap.add_argument("--beam", type=int, default=10)
+    ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=4, help="sample every n-th GEMM launch with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+
+    total_steps = args.warmup + args.steps
+    sb, be = build_batch(args.streams, args.beam, bool(args.bbd), total_steps, device)
+    preload_audio(sb, total_steps, stream_offset=rank * args.streams)
+
+    run_steps(sb, args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    steps0 = sum(st.n_steps_total for st in sb.st)
+    be.lib.sc_prof_enable(args.prof_every)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(sb, args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    be.lib.sc_prof_enable(0)
+    ms = (C.c_double * 4)()
+    fl = (C.c_double * 4)()
+    nn = (C.c_longlong * 4)()
+    be.lib.sc_prof_collect(ms, fl, nn)
+    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(args.streams)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the path's single collective: gather of final token ids
+        best = torch.zeros(args.streams, 64, dtype=torch.int32, device=device)
+        for s in range(min(args.streams, 4)):
+            h = sb.hypotheses(s)
+            if h:
+                ids = h[0]["yseq"][:64]
+                best[s, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        gathered = [torch.zeros_like(best) for _ in range(world)]
+        dist.all_gather(gathered, best)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    audio_s = world * args.streams * args.steps * CHUNK / 16000.0
+    value = audio_s / elapsed
+    # dominant kernel: the f32-MFMA GEMM; pick the variant that took the most time
+    v = max(range(4), key=lambda i: ms[i])
+    roof = None
+    if nn[v] > 0:
+        ach = fl[v] / (ms[v] * 1e-3) / 1e12
+        allf = sum(fl[i] for i in range(1, 4))
+        allms = sum(ms[i] for i in range(1, 4))
+        roof = {"bound": "mfma", "kernel": ["gemm_naive", "gemm_mfma<32,128>", "gemm_mfma<128,128>", "gemm_mfma<64,64>"][v],
+                "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(ms[v] * 1e3 / nn[v], 2), "sampled_launches": int(nn[v]),
+                "all_gemm_variants_tflops": round(allf / (allms * 1e-3) / 1e12, 3) if allms > 0 else None,
+                "gemm_time_share_of_step": round(sum(ms[i] for i in range(4)) * args.prof_every / (elapsed * 1e3), 3)}
+
+    single = None
+    if not args.no_single_stream and world == 1:
+        sb1, _ = build_batch(1, args.beam, bool(args.bbd), total_steps, device)
+        preload_audio(sb1, total_steps)
+        run_steps(sb1, args.warmup)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(sb1, args.steps)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        hop_s = CHUNK / 16000.0
+        single = {"ms_per_hop": round(e1 / args.steps * 1e3, 3), "rtf": round(e1 / (args.steps * hop_s), 5),
+                  "x_realtime": round(args.steps * hop_s / e1, 1)}
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            cpu = cpu_baseline(beam=args.beam, bbd=bool(args.bbd))
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
+
+    out = {
+        "metric": "concurrent real-time streams (audio-seconds/s), de_xl dims, 640 ms (10240-sample) chunk steps, beam 10 CTC+attention",
+        "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
+                               f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
+                   "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
+                   "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
+        "chunk_steps_per_s": round(world * args.streams * args.steps / elapsed, 2),
+        "decode_steps_per_hop": round(dec_steps / max(args.steps, 1), 2),
+        "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,14 @@ int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W, cons
             float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
             void *stream);
 
+/* Optional per-launch timing of sc_gemm with HIP events on the launch stream
+ * (every `sample_every`-th launch; 0 disables).  sc_prof_collect synchronises
+ * and returns, per kernel variant v (0 scalar, 1 = 32x128 tile, 2 = 128x128,
+ * 3 = 64x64): summed milliseconds, summed algorithmic flops (2*M*N*K) and the
+ * number of sampled launches.  All three pointers are HOST arrays of 4. */
+int sc_prof_enable(int sample_every);
+int sc_prof_collect(double *ms, double *flops, long long *n);
+
 /* LayerNorm over rows (model/layers/normalization.py:7-24, eps 1e-12). */
 int sc_layernorm(const float *src, const int32_t *src_rows, int lds, float *dst,
                  const int32_t *dst_rows, int ldd, int M, int d, const float *gamma,

@@ -286,13 +286,19 @@ class SpecBackend:
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
         logp = log_softmax(logits); ids = top-K of fl(w_dec * logp), descending,
         ties -> lowest index."""
-        n, V, K = sb.S * sb.W, sb.cfg.vocab_size, sb.K
-        sb.logp[:n] = torch.log_softmax(sb.logits[:n], dim=-1)
+        V, K, W = sb.cfg.vocab_size, sb.K, sb.W
+        ctrl = sb.ctrl.cpu().numpy()
         wd = torch.tensor(sb.search.decoder_weight, dtype=torch.float32)
-        key = (wd * sb.logp[:n])
-        # stable descending sort == lowest index first among ties
-        order = torch.sort(key, dim=-1, descending=True, stable=True).indices
-        sb.pre_ids[:n] = order[:, :K].to(torch.int32)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act:
+                continue
+            rows = slice(s * W, s * W + nh)
+            sb.logp[rows] = torch.log_softmax(sb.logits[rows], dim=-1)
+            key = wd * sb.logp[rows]
+            # stable descending sort == lowest index first among ties
+            order = torch.sort(key, dim=-1, descending=True, stable=True).indices
+            sb.pre_ids[rows] = order[:, :K].to(torch.int32)
 
     def ctc_prefix_scan(self, sb):
         """CTCPrefixScoreTH.__call__ (ctc_prefix_score_full.py:88-291) for the

@@ -52,6 +52,8 @@ _SIGS = {
     "sc_version": (C.c_int, []),
     "sc_gemm": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, vp]),
+    "sc_prof_enable": (C.c_int, [C.c_int]),
+    "sc_prof_collect": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_longlong)]),
     "sc_layernorm": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp]),
     "sc_copy_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "sc_log_softmax_rows": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

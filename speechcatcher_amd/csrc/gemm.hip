@@ -12,6 +12,7 @@
 // Row gather (a_rows) / scatter (c_rows) tables let ragged per-stream buffers
 // be consumed and produced without staging copies.
 #include "common.h"
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -193,6 +194,37 @@ __global__ void gemm_naive_kernel(GemmArgs g) {
 
 static int g_force_naive = -1;
 
+// ---- optional per-launch timing with HIP events (bench.py roofline leg) ----
+struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+static std::vector<ProfRec> g_recs;
+static int g_prof_every = 0;
+static long long g_gemm_calls = 0;
+
+extern "C" int sc_prof_enable(int sample_every) {
+  g_prof_every = sample_every;
+  g_gemm_calls = 0;
+  return SC_OK;
+}
+
+// ms[v], flops[v], n[v] for v = 0 naive, 1 = 32x128 tile, 2 = 128x128, 3 = 64x64
+extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { sc_set_error("sc_prof_collect: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  for (int v = 0; v < 4; ++v) { ms[v] = 0; flops[v] = 0; n[v] = 0; }
+  for (auto &r : g_recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ms[r.variant] += t;
+      flops[r.variant] += r.flops;
+      n[r.variant] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_recs.clear();
+  return SC_OK;
+}
+
 extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W,
                        const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
                        int K, int flags, int conv_f1, void *stream) {
@@ -207,15 +239,33 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   hipStream_t st = (hipStream_t)stream;
   bool aligned = (K % 32 == 0) && (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                  (((uintptr_t)W & 15) == 0) && (conv_f1 == 0 || lda % 32 == 0);
-  if ((flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) {
+  int variant;
+  if ((flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) variant = 0;
+  else if (M <= 32) variant = 1;
+  else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) variant = 2;
+  else variant = 3;
+  ProfRec rec;
+  const bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
+  if (sample) {
+    (void)hipEventCreate(&rec.a);
+    (void)hipEventCreate(&rec.b);
+    rec.flops = 2.0 * M * N * K;
+    rec.variant = variant;
+    (void)hipEventRecord(rec.a, st);
+  }
+  if (variant == 0) {
     long total = (long)M * N;
     gemm_naive_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(g);
-  } else if (M <= 32) {
+  } else if (variant == 1) {
     gemm_mfma_kernel<32, 128, 1, 4><<<dim3(cdiv(N, 128), cdiv(M, 32)), 256, 0, st>>>(g);
-  } else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) {
+  } else if (variant == 2) {
     gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128)), 256, 0, st>>>(g);
   } else {
     gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64)), 256, 0, st>>>(g);
+  }
+  if (sample) {
+    (void)hipEventRecord(rec.b, st);
+    g_recs.push_back(rec);
   }
   SC_CHECK_LAUNCH();
   return SC_OK;

@@ -21,9 +21,6 @@ class HipBackend:
             raise _abi.ScasrError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.lib = _abi.load()
         self.device = torch.device(device)
-        self._enc_layers = {}
-        self._search = {}
-        self._keep = []
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -78,14 +75,15 @@ class HipBackend:
                                             self._stream()), "sc_enc_attention")
 
     def _enc_layer_table(self, w):
-        key = id(w)
-        if key not in self._enc_layers:
+        # cached ON the weights object (never keyed by id(): ids are recycled)
+        arr = getattr(w, "_sc_enc_layer_table", None)
+        if arr is None:
             arr = (_abi.EncLayer * len(w.enc))()
             for i, lw in enumerate(w.enc):
                 for name in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2"):
                     setattr(arr[i], name, lw[name].data_ptr())
-            self._enc_layers[key] = arr
-        return self._enc_layers[key]
+            w._sc_enc_layer_table = arr
+        return arr
 
     def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
         cfg = w.cfg
@@ -97,9 +95,9 @@ class HipBackend:
 
     # ------------------------------------------------------------------
     def search_struct(self, sb):
-        key = id(sb)
-        if key in self._search:
-            return self._search[key][0]
+        cached = getattr(sb, "_sc_search_struct", None)
+        if cached is not None:
+            return cached[0]
         w, cfg = sb.w, sb.cfg
         layers = (_abi.DecLayer * len(w.dec))()
         for i, lw in enumerate(w.dec):
@@ -119,7 +117,7 @@ class HipBackend:
         s.dec_norm_g, s.dec_norm_b = w.dec_norm_g.data_ptr(), w.dec_norm_b.data_ptr()
         s.out_w, s.out_b = w.out_w.data_ptr(), w.out_b.data_ptr()
         s.layers = C.cast(layers, C.c_void_p).value
-        self._search[key] = (s, layers)
+        sb._sc_search_struct = (s, layers)
         return s
 
     def _sb_call(self, fn, sb, *extra):

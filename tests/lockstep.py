@@ -23,6 +23,8 @@ class LockstepBackend(SpecBackend):
         self.report = {}       # op -> max abs diff seen
         self.failures = []
         self.int_mismatch = []
+        self.calls = {}
+        self._synced = False
 
     def attach(self, sb_cpu, sb_gpu):
         self.sb_cpu, self.sb_gpu = sb_cpu, sb_gpu
@@ -55,37 +57,72 @@ class LockstepBackend(SpecBackend):
             return a.to(self.sb_gpu.dev)
         return a
 
-    def _compare(self, op):
-        worst = 0.0
-        for k in self._names:
-            c = getattr(self.sb_cpu, k)
-            g = getattr(self.sb_gpu, k).cpu()
-            if c.dtype in (torch.int32, torch.int64):
-                if not torch.equal(c, g):
-                    self.int_mismatch.append((op, k, int((c != g).sum())))
-                continue
-            c64, g64 = c.double(), g.double()
-            if torch.isnan(g64).any() and not torch.isnan(c64).any():
-                self.failures.append((op, k, "nan"))
-                continue
-            diff = (c64 - g64).abs()
-            diff[c64 == g64] = 0.0     # identical sentinels / infinities
-            tol = self.atol + self.rtol * c64.abs()
-            bad = diff > tol
-            if bad.any():
-                self.failures.append((op, k, float(diff[bad].max()), int(bad.sum())))
-            else:
-                worst = max(worst, float(diff.max()) if diff.numel() else 0.0)
-        self.report[op] = max(self.report.get(op, 0.0), worst)
+    # buffers each op writes: attribute names of the batch, or positional args
+    OUTPUTS = {
+        "logmel": ["featbuf"], "conv1": ["c1"], "gemm": [5], "copy_rows": [2], "layernorm": [2],
+        "log_softmax_rows": [0], "block_pack": ["xblk"], "ctx_handoff": [0, 4], "enc_attention": [1],
+        "ctc_extend_state": ["ctc_r"], "dec_embed": ["dx"], "dec_self_attn": ["datt", "skv"],
+        "dec_cross_attn": ["datt"], "logsoftmax_topk": ["logp", "pre_ids"],
+        "ctc_prefix_scan": ["psi", "psi_eos", "ctc_rnew"],
+        "fuse_topw": ["cand_tok", "cand_score", "cand_ctc"],
+        "beam_prune": ["yseq", "xpos", "score", "sc_dec", "sc_ctc", "anc", "ctc_s", "sel", "flags"],
+        "ctc_gather_state": ["ctc_r"],
+    }
+    FULL_SYNC = ("logmel", "ctc_extend_state", "dec_embed")
+
+    def _compare_one(self, op, name, c, g):
+        g = g.cpu()
+        if name == "pre_ids":
+            # the pre-beam is a SET of candidates; fp32 exp/log differences of
+            # ~1e-6 may swap near-tied neighbours.  Compare as sets and accept
+            # a boundary swap only when the two keys are within 1e-5.
+            lp = self.sb_cpu.logp
+            for r in range(c.shape[0]):
+                sc_, sg_ = set(c[r].tolist()), set(g[r].tolist())
+                if sc_ != sg_:
+                    only = sorted((sc_ - sg_) | (sg_ - sc_))
+                    vals = [float(lp[r, v]) for v in only if 0 <= v < lp.shape[1]]
+                    if len(only) > 4 or (max(vals) - min(vals)) > 1e-5:
+                        self.int_mismatch.append((op, name, r, only))
+            return 0.0
+        if c.dtype in (torch.int32, torch.int64):
+            if not torch.equal(c, g):
+                self.int_mismatch.append((op, name, int((c != g).sum())))
+            return 0.0
+        c64, g64 = c.double(), g.double()
+        if torch.isnan(g64).any() and not torch.isnan(c64).any():
+            self.failures.append((op, name, "nan"))
+            return 0.0
+        diff = (c64 - g64).abs()
+        diff[c64 == g64] = 0.0     # identical sentinels / infinities
+        bad = diff > (self.atol + self.rtol * c64.abs())
+        if bad.any():
+            self.failures.append((op, name, float(diff[bad].max()), int(bad.sum())))
+            return 0.0
+        return float(diff.max()) if diff.numel() else 0.0
 
     def _both(self, op, args, kwargs):
-        self._sync_to_gpu()
+        if op in self.FULL_SYNC or not self._synced:
+            self._sync_to_gpu()
+            self._synced = True
+        else:
+            self.sb_gpu.ctrl.copy_(self.sb_cpu.ctrl)
         gargs = [self._xlate(a) for a in args]
         gkw = {k: self._xlate(v) for k, v in kwargs.items()}
         getattr(self.hip, op)(*gargs, **gkw)
         torch.cuda.synchronize()
         getattr(SpecBackend, op)(self, *args, **kwargs)
-        self._compare(op)
+        worst = 0.0
+        for o in self.OUTPUTS[op]:
+            if isinstance(o, int):
+                c, g, name = args[o], gargs[o], f"arg{o}"
+                name = self._cpu_ptr.get(c.data_ptr(), name)
+            else:
+                c, g, name = getattr(self.sb_cpu, o), getattr(self.sb_gpu, o), o
+            worst = max(worst, self._compare_one(op, name, c, g))
+            g.copy_(c)   # keep the mirror identical to the CPU state: no error propagation
+        self.report[op] = max(self.report.get(op, 0.0), worst)
+        self.calls[op] = self.calls.get(op, 0) + 1
 
 
 def _make(op):

@@ -114,6 +114,16 @@ def _lockstep_run(hip, case, n_calls=None, **kw):
     return ls
 
 
+def _dump(ls, name):
+    import os
+    rep = {"max_abs_diff": ls.report, "calls": ls.calls, "failures": ls.failures[:50],
+           "int_mismatch": ls.int_mismatch[:50]}
+    print(json.dumps(rep, indent=1))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/{name}.json", "w") as f:
+        json.dump(rep, f, indent=1)
+
+
 ALL_OPS = {"logmel", "conv1", "gemm", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
            "dec_self_attn", "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw",
            "beam_prune", "ctc_gather_state", "ctc_extend_state", "dec_embed", "copy_rows",
@@ -124,7 +134,7 @@ def test_every_kernel_lockstep_tiny(hip):
     """Whole tiny utterance, beam 10: each launched HIP kernel is compared with
     its spec on identical inputs (fp32 tolerance 2e-4 abs+rel; ints exact)."""
     ls = _lockstep_run(hip, "tiny_c10240_b10_bbd0")
-    print("max |diff| per op:", json.dumps(ls.report, indent=1))
+    _dump(ls, "lockstep_tiny")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
     assert set(ls.report) >= ALL_OPS
@@ -139,6 +149,6 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
 def test_every_kernel_lockstep_xl(hip):
     """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance."""
     ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
-    print("max |diff| per op:", json.dumps(ls.report, indent=1))
+    _dump(ls, "lockstep_xl")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
