@@ -104,6 +104,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it FIRST so that libscasr
+    # binds to the same HIP runtime instance (two runtimes in one process do
+    # not see each other's device / streams).
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise ScasrError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "

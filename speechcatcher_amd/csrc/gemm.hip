@@ -51,24 +51,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kq = tid & 7, lr = tid >> 3;
 
+  // Loads are UNCONDITIONAL (rows clamped into range): out-of-range rows and
+  // columns compute garbage that the epilogue never stores.  Only the "-1 =
+  // zero row" gather entries need masking, done with a select on the VALUE so
+  // that hipcc does not branch around each load (which costs a vmcnt(0) wait
+  // per load and serialises the whole K loop).
   long abase[AI];
-  bool aval[AI];
+  float amask[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     int m = m0 + lr + 32 * i;
-    bool v = m < g.M;
-    int row = v ? (g.a_rows ? g.a_rows[m] : m) : 0;
-    if (row < 0) { v = false; row = 0; }
-    aval[i] = v;
-    abase[i] = (long)row * g.lda;
+    m = m < g.M ? m : g.M - 1;
+    int row = g.a_rows ? g.a_rows[m] : m;
+    amask[i] = row < 0 ? 0.f : 1.f;
+    abase[i] = (long)(row < 0 ? 0 : row) * g.lda;
   }
   long wbase[BI];
-  bool bval[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     int n = n0 + lr + 32 * i;
-    bval[i] = n < g.N;
-    wbase[i] = (long)(bval[i] ? n : 0) * g.K;
+    wbase[i] = (long)(n < g.N ? n : g.N - 1) * g.K;
   }
 
   f32x16 acc[TM][TN];
@@ -80,26 +82,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[AI], rb[BI];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   {
     long ko = gemm_kofs(g, 0);
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-      ra[i] = aval[i] ? *reinterpret_cast<const float4 *>(g.A + abase[i] + ko + kq * 4) : zero4;
+      ra[i] = *reinterpret_cast<const float4 *>(g.A + abase[i] + ko + kq * 4);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      rb[i] = bval[i] ? *reinterpret_cast<const float4 *>(g.W + wbase[i] + kq * 4) : zero4;
+      rb[i] = *reinterpret_cast<const float4 *>(g.W + wbase[i] + kq * 4);
   }
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       float *p = As + (kq * 4) * LDA_S + lr + 32 * i;
-      p[0] = ra[i].x;
-      p[LDA_S] = ra[i].y;
-      p[2 * LDA_S] = ra[i].z;
-      p[3 * LDA_S] = ra[i].w;
+      p[0] = ra[i].x * amask[i];
+      p[LDA_S] = ra[i].y * amask[i];
+      p[2 * LDA_S] = ra[i].z * amask[i];
+      p[3 * LDA_S] = ra[i].w * amask[i];
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       long ko = gemm_kofs(g, k0 + BK);
 #pragma unroll
       for (int i = 0; i < AI; ++i)
-        ra[i] = aval[i] ? *reinterpret_cast<const float4 *>(g.A + abase[i] + ko + kq * 4) : zero4;
+        ra[i] = *reinterpret_cast<const float4 *>(g.A + abase[i] + ko + kq * 4);
 #pragma unroll
       for (int i = 0; i < BI; ++i)
-        rb[i] = bval[i] ? *reinterpret_cast<const float4 *>(g.W + wbase[i] + (k0 + BK) + kq * 4) : zero4;
+        rb[i] = *reinterpret_cast<const float4 *>(g.W + wbase[i] + (k0 + BK) + kq * 4);
     }
     const float *ap = As + (lane >> 5) * LDA_S + wm * (TM * 32) + (lane & 31);
     const float *bp = Bs + (lane >> 5) * LDB_S + wn * (TN * 32) + (lane & 31);
@@ -138,27 +139,41 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
-  // row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Row-table and residual loads are
+  // issued unconditionally on clamped addresses (16 in flight, one wait);
+  // only the stores are predicated.
   const bool relu = g.flags & SC_GEMM_RELU, resid = g.flags & SC_GEMM_RESIDUAL;
+  const bool has_rows = g.c_rows != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    long roff[16];
+    bool rok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const bool mv = m < g.M;
+      const int mm = mv ? m : g.M - 1;
+      const int crow = has_rows ? g.c_rows[mm] : mm;
+      rok[r] = mv && crow >= 0;
+      roff[r] = (long)(crow < 0 ? 0 : crow) * g.ldc;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-      const float bv = (g.bias && n < g.N) ? g.bias[n] : 0.f;
+      const bool nv = n < g.N;
+      const int nn = nv ? n : g.N - 1;
+      const float bv = g.bias ? g.bias[nn] : 0.f;
+      float old[16];
+      if (resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = g.C[roff[r] + nn];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M && n < g.N) {
-          int crow = g.c_rows ? g.c_rows[m] : m;
-          if (crow >= 0) {
-            float *p = g.C + (long)crow * g.ldc + n;
-            float v = acc[i][j][r] + bv;
-            if (relu) v = fmaxf(v, 0.f);
-            if (resid) v = *p + v;
-            *p = v;
-          }
-        }
+        float v = acc[i][j][r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (resid) v = old[r] + v;
+        if (rok[r] && nv) g.C[roff[r] + nn] = v;
       }
     }
   }
