@@ -24,6 +24,7 @@
 #ifndef SCASR_H
 #define SCASR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -97,6 +98,13 @@ typedef struct sc_search {
 const char *sc_last_error(void);
 int sc_version(void);
 
+/* hipGraph capture / replay of any sequence of the launches below on a
+ * non-default stream: begin, issue the launches, end -> executable graph. */
+int sc_graph_capture_begin(void *stream);
+int sc_graph_capture_end(void *stream, void **graph_exec /*HOST out*/);
+int sc_graph_launch(void *graph_exec, void *stream);
+int sc_graph_destroy(void *graph_exec);
+
 /* ---- generic building blocks -------------------------------------------- */
 
 /* C[c_rows[m], n] (+)= sum_k A[a_rows[m]*lda + kofs(k)] * W[n*K + k] + bias[n]
@@ -109,11 +117,16 @@ int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W, cons
             float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
             void *stream);
 
+/* Workspace (device memory, caller-owned) for the deterministic split-K path of
+ * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it
+ * sc_gemm never splits K. */
+int sc_set_workspace(void *ptr, size_t bytes);
+
 /* Optional per-launch timing of sc_gemm with HIP events on the launch stream
  * (every `sample_every`-th launch; 0 disables).  sc_prof_collect synchronises
  * and returns, per kernel variant v (0 scalar, 1 = 32x128 tile, 2 = 128x128,
  * 3 = 64x64): summed milliseconds, summed algorithmic flops (2*M*N*K) and the
- * number of sampled launches.  All three pointers are HOST arrays of 4. */
+ * number of sampled launches (variant 1 = skinny register-direct kernel for M <= 64).  All three pointers are HOST arrays of 4. */
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
 

@@ -52,6 +52,11 @@ _SIGS = {
     "sc_version": (C.c_int, []),
     "sc_gemm": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, vp]),
+    "sc_graph_capture_begin": (C.c_int, [vp]),
+    "sc_graph_capture_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "sc_graph_launch": (C.c_int, [vp, vp]),
+    "sc_graph_destroy": (C.c_int, [vp]),
+    "sc_set_workspace": (C.c_int, [vp, C.c_size_t]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_collect": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_longlong)]),
     "sc_layernorm": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp]),

@@ -17,6 +17,39 @@ extern "C" const char *sc_last_error(void) { return g_err; }
 extern "C" int sc_version(void) { return 1; }
 
 // ---------------------------------------------------------------------------
+// hipGraph capture / replay of a launch sequence (the ~190 launches of one
+// decode step are launch-bound for a single stream: replay costs one launch).
+// ---------------------------------------------------------------------------
+extern "C" int sc_graph_capture_begin(void *stream) {
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { sc_set_error("sc_graph_capture_begin: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  return SC_OK;
+}
+
+extern "C" int sc_graph_capture_end(void *stream, void **graph_exec) {
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+  if (e != hipSuccess || !graph) { sc_set_error("sc_graph_capture_end: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { sc_set_error("sc_graph_capture_end: instantiate: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  *graph_exec = (void *)exec;
+  return SC_OK;
+}
+
+extern "C" int sc_graph_launch(void *graph_exec, void *stream) {
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) { sc_set_error("sc_graph_launch: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
+  return SC_OK;
+}
+
+extern "C" int sc_graph_destroy(void *graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
 // LayerNorm: one wave per row, float4 lanes, two-pass mean / variance.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *src, const int *src_rows,

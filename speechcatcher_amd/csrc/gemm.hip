@@ -26,6 +26,8 @@ struct GemmArgs {
   const int *c_rows;
   int ldc;
   int M, N, K, flags, conv_f1;
+  float *part;  // split-K partial sums [ksplit][M][N] (workspace), or null
+  int kslice;   // K extent handled by one block along grid.z (multiple of 32)
 };
 
 __device__ __forceinline__ long gemm_kofs(const GemmArgs &g, int k0) {
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kq = tid & 7, lr = tid >> 3;
+  const int kbeg = blockIdx.z * g.kslice;
+  const int kend = (kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K;
 
   // Loads are UNCONDITIONAL (rows clamped into range): out-of-range rows and
   // columns compute garbage that the epilogue never stores.  Only the "-1 =
@@ -84,16 +88,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   float4 ra[AI], rb[BI];
 
   {
-    long ko = gemm_kofs(g, 0);
+    long ko = gemm_kofs(g, kbeg);
 #pragma unroll
     for (int i = 0; i < AI; ++i)
       ra[i] = *reinterpret_cast<const float4 *>(g.A + abase[i] + ko + kq * 4);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      rb[i] = *reinterpret_cast<const float4 *>(g.W + wbase[i] + kq * 4);
+      rb[i] = *reinterpret_cast<const float4 *>(g.W + wbase[i] + kbeg + kq * 4);
   }
 
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       float *p = As + (kq * 4) * LDA_S + lr + 32 * i;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       p[3 * LDB_S] = rb[i].w;
     }
     __syncthreads();
-    if (k0 + BK < g.K) {  // prefetch the next K tile into registers
+    if (k0 + BK < kend) {  // prefetch the next K tile into registers
       long ko = gemm_kofs(g, k0 + BK);
 #pragma unroll
       for (int i = 0; i < AI; ++i)
@@ -142,6 +146,21 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Row-table and residual loads are
   // issued unconditionally on clamped addresses (16 in flight, one wait);
   // only the stores are predicated.
+  if (g.part) {  // split-K: raw partial sums, reduced by gemm_splitk_reduce_kernel
+    float *pz = g.part + (long)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < g.M && n < g.N) pz[(long)m * g.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   const bool relu = g.flags & SC_GEMM_RELU, resid = g.flags & SC_GEMM_RESIDUAL;
   const bool has_rows = g.c_rows != nullptr;
 #pragma unroll
@@ -177,6 +196,132 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Skinny GEMM (M <= 64: one stream's decoder rows / one encoder block).  These
+// are weight-streaming, latency-bound problems: no LDS staging, no barriers in
+// the K loop.  Each lane loads its MFMA operands straight from global memory
+// as float4 (lane (i, half) reads k..k+3 of row i at column offset 4*half; the
+// 32x32x2 MFMA then pairs k with k+4, which is as good as any pairing), the 4
+// waves of a workgroup interleave 8-wide k groups, grid.y splits K further so
+// that >= ~256 workgroups stream the weight matrix concurrently.
+// ---------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float red[4][RT][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const int kbeg = blockIdx.y * g.kslice;
+  const int kend = (kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K;
+  long abase[RT];
+  float amask[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int m = rt * 32 + i;
+    m = m < g.M ? m : g.M - 1;
+    int row = g.a_rows ? g.a_rows[m] : m;
+    amask[rt] = row < 0 ? 0.f : 1.f;
+    abase[rt] = (long)(row < 0 ? 0 : row) * g.lda + 4 * half;
+  }
+  const int n = n0 + i;
+  const float *__restrict__ wp = g.W + (long)(n < g.N ? n : g.N - 1) * g.K + 4 * half;
+  const float *__restrict__ ap = g.A;
+  f32x16 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+  // two 8-wide k groups per trip: 2*(1+RT) independent 16-byte loads in flight
+  auto step = [&](const float4 &b4, const float4 (&a4)[RT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].x * amask[rt], b4.x, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].y * amask[rt], b4.y, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].z * amask[rt], b4.z, acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].w * amask[rt], b4.w, acc[rt], 0, 0, 0);
+    }
+  };
+  int k = kbeg + wave * 8;
+  for (; k + 32 < kend; k += 64) {
+    const long ko0 = gemm_kofs(g, k), ko1 = gemm_kofs(g, k + 32);
+    const float4 b0 = *reinterpret_cast<const float4 *>(wp + k);
+    const float4 b1 = *reinterpret_cast<const float4 *>(wp + k + 32);
+    float4 a0[RT], a1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      a0[rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko0);
+      a1[rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko1);
+    }
+    step(b0, a0);
+    step(b1, a1);
+  }
+  if (k < kend) {
+    const long ko0 = gemm_kofs(g, k);
+    const float4 b0 = *reinterpret_cast<const float4 *>(wp + k);
+    float4 a0[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko0);
+    step(b0, a0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][rt][r][lane] = acc[rt][r];
+  __syncthreads();
+  // wave w finishes accumulator registers r = w, w+4, w+8, w+12 (fixed order)
+  const bool relu = g.flags & SC_GEMM_RELU, resid = g.flags & SC_GEMM_RESIDUAL;
+  const float bv = (g.bias && n < g.N && !g.part) ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave + 4 * q;
+      float v = ((red[0][rt][r][lane] + red[1][rt][r][lane]) + red[2][rt][r][lane]) + red[3][rt][r][lane];
+      const int m = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= g.M || n >= g.N) continue;
+      if (g.part) {
+        g.part[((long)blockIdx.y * g.M + m) * g.N + n] = v;
+      } else {
+        const int crow = g.c_rows ? g.c_rows[m] : m;
+        if (crow < 0) continue;
+        float *p = g.C + (long)crow * g.ldc + n;
+        v += bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (resid) v = *p + v;
+        *p = v;
+      }
+    }
+  }
+}
+
+// out[c_rows[m], n] = epilogue(bias[n] + sum_z part[z][m][n]), z in fixed order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int ksplit) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = g.N >> 2;
+  if (idx >= (long)g.M * n4) return;
+  const int m = idx / n4, n = (idx % n4) * 4;
+  float4 acc = *reinterpret_cast<const float4 *>(g.part + (long)m * g.N + n);
+  for (int z = 1; z < ksplit; ++z) {
+    const float4 p = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  if (g.bias) {
+    const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  if (g.flags & SC_GEMM_RELU) {
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+  }
+  const int crow = g.c_rows ? g.c_rows[m] : m;
+  if (crow < 0) return;
+  float4 *dst = reinterpret_cast<float4 *>(g.C + (long)crow * g.ldc + n);
+  if (g.flags & SC_GEMM_RESIDUAL) {
+    const float4 o = *dst;
+    acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+  }
+  *dst = acc;
 }
 
 // scalar reference kernel: one thread per output, k-ordered fmaf chain
@@ -240,6 +385,15 @@ extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
   return SC_OK;
 }
 
+static float *g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+extern "C" int sc_set_workspace(void *ptr, size_t bytes) {
+  g_ws = (float *)ptr;
+  g_ws_bytes = bytes;
+  return SC_OK;
+}
+
 extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W,
                        const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
                        int K, int flags, int conv_f1, void *stream) {
@@ -250,17 +404,44 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
     const char *e = getenv("SC_GEMM_NAIVE");
     g_force_naive = (e && e[0] == '1') ? 1 : 0;
   }
-  GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1};
+  GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
   bool aligned = (K % 32 == 0) && (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                  (((uintptr_t)W & 15) == 0) && (conv_f1 == 0 || lda % 32 == 0);
+  // variant: 0 scalar, 1 skinny (M <= 64, register-direct), 2 = 128x128 tile, 3 = 64x64 tile
   int variant;
   if ((flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) variant = 0;
-  else if (M <= 32) variant = 1;
+  else if (M <= 64) variant = 1;
   else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) variant = 2;
   else variant = 3;
+  // deterministic split-K (partials in the caller-provided workspace, fixed-order reduce)
+  int ksplit = 1;
+  const bool can_split = g_ws && (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
+                         (!bias || (((uintptr_t)bias & 15) == 0));
+  if (can_split && variant == 1) {
+    const int ct = cdiv(N, 32);
+    ksplit = K / 64;
+    const int want = cdiv(256, ct);
+    if (ksplit > want) ksplit = want;
+  } else if (can_split && variant == 3 && K >= 512) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    ksplit = cdiv(384, tiles);
+    if (ksplit > K / 128) ksplit = K / 128;
+  }
+  if (ksplit > 1) {
+    while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > g_ws_bytes) --ksplit;
+  }
+  if (ksplit > 1) {
+    g.kslice = cdiv(K / 32, ksplit) * 32;
+    ksplit = cdiv(K, g.kslice);
+    if (ksplit > 1) g.part = g_ws; else g.kslice = K;
+  }
   ProfRec rec;
-  const bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
+  bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
+  if (sample) {  // never record timing events into a stream capture
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) sample = false;
+  }
   if (sample) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
@@ -272,11 +453,16 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
     long total = (long)M * N;
     gemm_naive_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(g);
   } else if (variant == 1) {
-    gemm_mfma_kernel<32, 128, 1, 4><<<dim3(cdiv(N, 128), cdiv(M, 32)), 256, 0, st>>>(g);
+    if (M <= 32) gemm_skinny_kernel<1><<<dim3(cdiv(N, 32), ksplit), 256, 0, st>>>(g);
+    else gemm_skinny_kernel<2><<<dim3(cdiv(N, 32), ksplit), 256, 0, st>>>(g);
   } else if (variant == 2) {
-    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128)), 256, 0, st>>>(g);
+    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), 1), 256, 0, st>>>(g);
   } else {
-    gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64)), 256, 0, st>>>(g);
+    gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
+  }
+  if (g.part) {
+    const long n4 = (long)M * (N / 4);
+    gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
   }
   if (sample) {
     (void)hipEventRecord(rec.b, st);

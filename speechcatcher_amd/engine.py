@@ -150,6 +150,9 @@ class StreamBatch:
         nch = (self.TCAP + self.xchunk - 1) // self.xchunk
         self.xpart = z(n * cfg.dec_heads * nch, (d // cfg.dec_heads) + 2)
 
+        # all device work of this batch runs on one dedicated (non-default) HIP
+        # stream, which also makes the decode step capturable as a hipGraph
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.st = [StreamState() for _ in range(S)]
         self._nhyp_prev: Dict[int, int] = {}
         self._hasctc_prev: Dict[int, bool] = {}
@@ -226,6 +229,14 @@ class StreamBatch:
     # ------------------------------------------------------------------
     def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]],
              pcm_resident: bool = False):
+        if self.stream is None:
+            return self._push(chunks, pcm_resident)
+        with torch.cuda.stream(self.stream):
+            out = self._push(chunks, pcm_resident)
+        self.stream.synchronize()
+        return out
+
+    def _push(self, chunks, pcm_resident=False):
         """One chunk step for the listed streams: (stream, samples, is_final).
 
         ``samples`` is 1-D float PCM in +-1 (np.ndarray / torch tensor); with
@@ -273,6 +284,13 @@ class StreamBatch:
         return out
 
     def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]]):
+        if self.stream is None:
+            return self._push_features(items)
+        with torch.cuda.stream(self.stream):
+            self._push_features(items)
+        self.stream.synchronize()
+
+    def _push_features(self, items):
         """2-D (T, n_mels) already-normalised features (the reference's 2-D /
         3-D input path, speech2text_streaming.py:438-449)."""
         feat_new, finals = {}, {}

@@ -16,11 +16,15 @@ def _p(t):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, device="cuda:0", use_graphs=True):
         if not torch.cuda.is_available():
             raise _abi.ScasrError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.lib = _abi.load()
         self.device = torch.device(device)
+        self.use_graphs = use_graphs
+        # split-K partial sums of sc_gemm live in this caller-owned workspace
+        self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        self._chk(self.lib.sc_set_workspace(self.workspace.data_ptr(), self.workspace.numel()), "sc_set_workspace")
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -155,4 +159,31 @@ class HipBackend:
         self._sb_call("sc_ctc_gather_state", sb)
 
     def decode_step(self, sb):
-        self._sb_call("sc_decode_step", sb)
+        """One beam-search step; replayed from a hipGraph after the first call
+        (all launch geometry depends only on S, W, V, TCAP, LCAP; the per-step
+        state is read from the device-side ctrl rows)."""
+        if not self.use_graphs:
+            self._sb_call("sc_decode_step", sb)
+            return
+        g = getattr(sb, "_sc_decode_graph", None)
+        st = self._stream()
+        if g is None:
+            if st == 0:
+                raise _abi.ScasrError("hipGraph capture needs a non-default stream (StreamBatch.stream)")
+            self._sb_call("sc_decode_step", sb)          # warm-up launch (also validates arguments)
+            self._chk(self.lib.sc_graph_capture_begin(st), "sc_graph_capture_begin")
+            try:
+                self._sb_call("sc_decode_step", sb)
+            finally:
+                out = C.c_void_p()
+                rc = self.lib.sc_graph_capture_end(st, C.byref(out))
+            self._chk(rc, "sc_graph_capture_end")
+            sb._sc_decode_graph = out
+            sb._sc_decode_graph_warm = True
+            return self._redo_after_capture(sb)
+        self._chk(self.lib.sc_graph_launch(g, st), "sc_graph_launch")
+
+    def _redo_after_capture(self, sb):
+        # the warm-up launch before capture already executed this step once;
+        # kernels only write the 1-cur side, so the captured graph is NOT launched again here.
+        return None
