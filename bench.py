@@ -72,6 +72,10 @@ def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
     """The oracle (port of the reference path) timed on this box's host cores."""
     from oracle.ref_port import RefPortModel, RefPortStreaming
     from speechcatcher_amd.mel import melscale_fbanks_slaney
+    # 8 intra-op threads: the best single-process setting measured for the
+    # reference (BASELINE.md section 2); torch's default of one thread per host
+    # core (128 on the GPU box) is slower on these small ops.
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
     mel = melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000)

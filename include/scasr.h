@@ -117,6 +117,15 @@ int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W, cons
             float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
             void *stream);
 
+/* sc_gemm followed by LayerNorm of the produced rows (pre-LN transformer:
+ * x += proj(...); xn = LN(x): decoder_layer.py:101-123, transformer_decoder.py:243).
+ * ln_out[m*ld_ln ..] = LN(C[c_rows[m]]).  The LayerNorm is fused into the
+ * split-K reduce when the workspace is set. */
+int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W, const float *bias,
+               float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
+               const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, int ld_ln,
+               void *stream);
+
 /* Workspace (device memory, caller-owned) for the deterministic split-K path of
  * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it
  * sc_gemm never splits K. */

@@ -266,21 +266,33 @@ class SpecBackend:
             p = torch.softmax(sc, dim=-1)
             sb.datt[rows] = torch.matmul(p, v).transpose(1, 2).reshape(nh, d)
 
+    def gemm_ln(self, A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, ln_g, ln_b, ln_out,
+                relu=False, conv_f1=0, residual=False, eps=1e-12):
+        """sc_gemm_ln: GEMM (+bias/ReLU/residual) then LayerNorm of the produced rows."""
+        self.gemm(A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, relu=relu, conv_f1=conv_f1, residual=residual)
+        self.layernorm(C, c_rows, ln_out, None, M, ln_g, ln_b, eps)
+
     def decoder_layers(self, sb):
+        """decoder_layer.py:60-132 x n_layers; leaves after_norm(x) in dxn
+        (every LayerNorm but the first is fused into the GEMM producing its input)."""
         w, cfg = sb.w, sb.cfg
         d, Fd, n = cfg.d_model, cfg.ffn_dim, sb.S * sb.W
+        self.layernorm(sb.dx, None, sb.dxn, None, n, w.dec[0]["ln1_g"], w.dec[0]["ln1_b"])
         for li, lw in enumerate(w.dec):
-            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln1_g"], lw["ln1_b"])
+            last = li + 1 == len(w.dec)
+            ng = w.dec_norm_g if last else w.dec[li + 1]["ln1_g"]
+            nb = w.dec_norm_b if last else w.dec[li + 1]["ln1_b"]
             self.gemm(sb.dxn, None, d, lw["wqkv"], lw["bqkv"], sb.dqkv, None, 3 * d, n, 3 * d, d)
             self.dec_self_attn(sb, li)
-            self.gemm(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d, residual=True)
-            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln2_g"], lw["ln2_b"])
+            self.gemm_ln(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d,
+                         lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True)
             self.gemm(sb.dxn, None, d, lw["wq"], lw["bq"], sb.dq, None, d, n, d, d)
             self.dec_cross_attn(sb, li)
-            self.gemm(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d, residual=True)
-            self.layernorm(sb.dx, None, sb.dxn, None, n, lw["ln3_g"], lw["ln3_b"])
+            self.gemm_ln(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d,
+                         lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True)
             self.gemm(sb.dxn, None, d, lw["w1"], lw["b1"], sb.dffh, None, Fd, n, Fd, d, relu=True)
-            self.gemm(sb.dffh, None, Fd, lw["w2"], lw["b2"], sb.dx, None, d, n, d, Fd, residual=True)
+            self.gemm_ln(sb.dffh, None, Fd, lw["w2"], lw["b2"], sb.dx, None, d, n, d, Fd, ng, nb, sb.dxn,
+                         residual=True)
 
     def logsoftmax_topk(self, sb):
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
@@ -448,8 +460,7 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = sb.S * sb.W, cfg.d_model
         self.dec_embed(sb)
-        self.decoder_layers(sb)
-        self.layernorm(sb.dx, None, sb.dxn, None, n, w.dec_norm_g, w.dec_norm_b)
+        self.decoder_layers(sb)      # leaves after_norm(x) in dxn
         self.gemm(sb.dxn, None, d, w.out_w, w.out_b, sb.logits, None, cfg.vocab_size, n, cfg.vocab_size, d)
         self.logsoftmax_topk(sb)
         self.ctc_prefix_scan(sb)

@@ -52,6 +52,8 @@ _SIGS = {
     "sc_version": (C.c_int, []),
     "sc_gemm": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_int, C.c_int, vp]),
+    "sc_gemm_ln": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_int, vp, vp, C.c_float, vp, C.c_int, vp]),
     "sc_graph_capture_begin": (C.c_int, [vp]),
     "sc_graph_capture_end": (C.c_int, [vp, C.POINTER(vp)]),
     "sc_graph_launch": (C.c_int, [vp, vp]),

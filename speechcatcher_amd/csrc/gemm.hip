@@ -213,13 +213,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
   const int n0 = blockIdx.x * 32;
+  const int mbase = blockIdx.z * (32 * RT);
   const int kbeg = blockIdx.y * g.kslice;
   const int kend = (kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K;
   long abase[RT];
   float amask[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    int m = rt * 32 + i;
+    int m = mbase + rt * 32 + i;
     m = m < g.M ? m : g.M - 1;
     int row = g.a_rows ? g.a_rows[m] : m;
     amask[rt] = row < 0 ? 0.f : 1.f;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     for (int q = 0; q < 4; ++q) {
       const int r = wave + 4 * q;
       float v = ((red[0][rt][r][lane] + red[1][rt][r][lane]) + red[2][rt][r][lane]) + red[3][rt][r][lane];
-      const int m = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = mbase + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (m >= g.M || n >= g.N) continue;
       if (g.part) {
         g.part[((long)blockIdx.y * g.M + m) * g.N + n] = v;
@@ -322,6 +323,74 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
     acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
   }
   *dst = acc;
+}
+
+// split-K reduce fused with the LayerNorm that follows the residual add:
+// one wave per row (N <= 1024).  C[m] = epilogue(sum_z part[z][m]),
+// ln_out[m] = LN(C[m]) * gamma + beta.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(GemmArgs g, int ksplit,
+                                                                    const float *gamma, const float *beta,
+                                                                    float eps, float *ln_out, int ld_ln) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M) return;
+  const int nv = g.N >> 2;
+  const int crow = g.c_rows ? g.c_rows[m] : m;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      float4 acc = reinterpret_cast<const float4 *>(g.part + (long)m * g.N)[c];
+      for (int z = 1; z < ksplit; ++z) {
+        const float4 p = reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N)[c];
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+      }
+      if (g.bias) {
+        const float4 b = reinterpret_cast<const float4 *>(g.bias)[c];
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+      }
+      if (g.flags & SC_GEMM_RELU) {
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+      }
+      if (crow >= 0) {
+        float4 *dst = reinterpret_cast<float4 *>(g.C + (long)crow * g.ldc) + c;
+        if (g.flags & SC_GEMM_RESIDUAL) {
+          const float4 o = *dst;
+          acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+        }
+        *dst = acc;
+      }
+      v[i] = acc;
+      s += (acc.x + acc.y) + (acc.z + acc.w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)g.N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.N + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv) {
+      const float4 gm = reinterpret_cast<const float4 *>(gamma)[c];
+      const float4 bt = reinterpret_cast<const float4 *>(beta)[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      reinterpret_cast<float4 *>(ln_out + (long)m * ld_ln)[c] = o;
+    }
+  }
 }
 
 // scalar reference kernel: one thread per output, k-ordered fmaf chain
@@ -394,48 +463,72 @@ extern "C" int sc_set_workspace(void *ptr, size_t bytes) {
   return SC_OK;
 }
 
+// Launches the main kernel.  force_part: always leave raw partial sums in the
+// workspace (ksplit >= 1) for a fused reduce epilogue.  Returns the number of
+// K slices through *ksplit_out (0: the kernel wrote the final result itself).
+static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *variant_out, hipStream_t st) {
+  const int M = g.M, N = g.N, K = g.K;
+  if (g_force_naive < 0) {
+    const char *e = getenv("SC_GEMM_NAIVE");
+    g_force_naive = (e && e[0] == '1') ? 1 : 0;
+  }
+  bool aligned = (K % 32 == 0) && (g.lda % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
+                 (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
+  // variant: 0 scalar, 1 skinny register-direct, 2 = 128x128 tile, 3 = 64x64 tile
+  int variant;
+  if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) variant = 0;
+  else if (M <= 64 || (M <= 4096 && N <= 256 && K <= 256)) variant = 1;
+  else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) variant = 2;
+  else variant = 3;
+  const bool can_part = g_ws && variant != 0 && (N % 4 == 0) && (g.ldc % 4 == 0) &&
+                        (((uintptr_t)g.C & 15) == 0) && (!g.bias || (((uintptr_t)g.bias & 15) == 0)) &&
+                        (size_t)M * N * sizeof(float) <= g_ws_bytes;
+  int ksplit = 1;
+  if (can_part && variant == 1 && M <= 64) {
+    const int ct = cdiv(N, 32);
+    ksplit = K / 64;
+    const int want = cdiv(256, ct);
+    if (ksplit > want) ksplit = want;
+    if (ksplit < 1) ksplit = 1;
+  } else if (can_part && variant == 3 && K >= 512) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    ksplit = cdiv(384, tiles);
+    if (ksplit > K / 128) ksplit = K / 128;
+    if (ksplit < 1) ksplit = 1;
+  }
+  while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > g_ws_bytes) --ksplit;
+  g.kslice = K;
+  if (ksplit > 1) {
+    g.kslice = cdiv(K / 32, ksplit) * 32;
+    ksplit = cdiv(K, g.kslice);
+  }
+  const bool part = can_part && (ksplit > 1 || force_part);
+  g.part = part ? g_ws : nullptr;
+  if (!part) { ksplit = 1; g.kslice = K; }
+  if (variant == 0) {
+    long total = (long)M * N;
+    gemm_naive_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(g);
+  } else if (variant == 1) {
+    if (M <= 32) gemm_skinny_kernel<1><<<dim3(cdiv(N, 32), ksplit, 1), 256, 0, st>>>(g);
+    else gemm_skinny_kernel<2><<<dim3(cdiv(N, 32), ksplit, cdiv(M, 64)), 256, 0, st>>>(g);
+  } else if (variant == 2) {
+    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), 1), 256, 0, st>>>(g);
+  } else {
+    gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
+  }
+  *ksplit_out = part ? ksplit : 0;
+  *variant_out = variant;
+  return SC_OK;
+}
+
 extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W,
                        const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
                        int K, int flags, int conv_f1, void *stream) {
   SC_CHECK_ARG(A && W && C, "null pointer");
   SC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda > 0 && ldc >= N, "bad dimensions");
   if (M == 0) return SC_OK;
-  if (g_force_naive < 0) {
-    const char *e = getenv("SC_GEMM_NAIVE");
-    g_force_naive = (e && e[0] == '1') ? 1 : 0;
-  }
   GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
-  bool aligned = (K % 32 == 0) && (lda % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
-                 (((uintptr_t)W & 15) == 0) && (conv_f1 == 0 || lda % 32 == 0);
-  // variant: 0 scalar, 1 skinny (M <= 64, register-direct), 2 = 128x128 tile, 3 = 64x64 tile
-  int variant;
-  if ((flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) variant = 0;
-  else if (M <= 64) variant = 1;
-  else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) variant = 2;
-  else variant = 3;
-  // deterministic split-K (partials in the caller-provided workspace, fixed-order reduce)
-  int ksplit = 1;
-  const bool can_split = g_ws && (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
-                         (!bias || (((uintptr_t)bias & 15) == 0));
-  if (can_split && variant == 1) {
-    const int ct = cdiv(N, 32);
-    ksplit = K / 64;
-    const int want = cdiv(256, ct);
-    if (ksplit > want) ksplit = want;
-  } else if (can_split && variant == 3 && K >= 512) {
-    const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    ksplit = cdiv(384, tiles);
-    if (ksplit > K / 128) ksplit = K / 128;
-  }
-  if (ksplit > 1) {
-    while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > g_ws_bytes) --ksplit;
-  }
-  if (ksplit > 1) {
-    g.kslice = cdiv(K / 32, ksplit) * 32;
-    ksplit = cdiv(K, g.kslice);
-    if (ksplit > 1) g.part = g_ws; else g.kslice = K;
-  }
   ProfRec rec;
   bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
   if (sample) {  // never record timing events into a stream capture
@@ -445,29 +538,49 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   if (sample) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
-    rec.flops = 2.0 * M * N * K;
-    rec.variant = variant;
     (void)hipEventRecord(rec.a, st);
   }
-  if (variant == 0) {
-    long total = (long)M * N;
-    gemm_naive_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(g);
-  } else if (variant == 1) {
-    if (M <= 32) gemm_skinny_kernel<1><<<dim3(cdiv(N, 32), ksplit), 256, 0, st>>>(g);
-    else gemm_skinny_kernel<2><<<dim3(cdiv(N, 32), ksplit), 256, 0, st>>>(g);
-  } else if (variant == 2) {
-    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), 1), 256, 0, st>>>(g);
-  } else {
-    gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
-  }
-  if (g.part) {
+  int ksplit = 0, variant = 0;
+  gemm_dispatch(g, false, &ksplit, &variant, st);
+  if (ksplit > 0) {
     const long n4 = (long)M * (N / 4);
     gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
   }
   if (sample) {
+    rec.flops = 2.0 * M * N * K;
+    rec.variant = variant;
     (void)hipEventRecord(rec.b, st);
     g_recs.push_back(rec);
   }
   SC_CHECK_LAUNCH();
   return SC_OK;
+}
+
+// GEMM whose output rows are immediately layer-normalised (pre-LN transformer:
+// x += proj(...); xn = LN(x)).  ln_out[m] (dense, leading dim ld_ln) receives
+// LN(C[c_rows[m]]).  Fused into the split-K reduce when possible, otherwise
+// GEMM followed by a LayerNorm launch.
+extern "C" int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W,
+                          const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
+                          int K, int flags, int conv_f1, const float *ln_g, const float *ln_b,
+                          float ln_eps, float *ln_out, int ld_ln, void *stream) {
+  SC_CHECK_ARG(A && W && C && ln_g && ln_b && ln_out, "null pointer");
+  SC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda > 0 && ldc >= N && ld_ln >= N, "bad dimensions");
+  if (M == 0) return SC_OK;
+  GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
+  hipStream_t st = (hipStream_t)stream;
+  const bool fusable = N <= 1024 && N % 4 == 0 && ld_ln % 4 == 0;
+  int ksplit = 0, variant = 0;
+  gemm_dispatch(g, fusable, &ksplit, &variant, st);
+  if (ksplit > 0 && fusable) {
+    gemm_splitk_reduce_ln_kernel<<<cdiv(M, 4), 256, 0, st>>>(g, ksplit, ln_g, ln_b, ln_eps, ln_out, ld_ln);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+  }
+  if (ksplit > 0) {
+    const long n4 = (long)M * (N / 4);
+    gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
+  }
+  SC_CHECK_LAUNCH();
+  return sc_layernorm(C, c_rows, ldc, ln_out, nullptr, ld_ln, M, N, ln_g, ln_b, ln_eps, stream);
 }

@@ -158,14 +158,16 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
 // one workgroup reads 256 encoder frames of K|V ONCE for all W hypotheses of
 // the stream; a second kernel merges the per-chunk partials.
 // ---------------------------------------------------------------------------
-template <int DK>
+// SEQ = true: one workgroup per (stream, head) walks all 256-frame chunks itself
+// and writes the final context (used when S*H workgroups already fill the chip:
+// no partials, no merge launch).  SEQ = false: grid.x = chunks, partials merged
+// by dec_cross_attn_merge_kernel (single-stream latency path).
+template <int DK, bool SEQ>
 __global__ __launch_bounds__(256) void dec_cross_attn_part_kernel(sc_search sb, int li) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int chunk = blockIdx.x, head = blockIdx.y, s = blockIdx.z;
+  const int head = blockIdx.y, s = blockIdx.z;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int T = CTRL(s, SC_C_T), nh = CTRL(s, SC_C_NHYP);
-  const int c0 = chunk * 256;
-  if (c0 >= T) return;
   const int W = sb.W, d = sb.d, H = sb.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *qs = smem;                  // [W][DK]
@@ -173,59 +175,88 @@ __global__ __launch_bounds__(256) void dec_cross_attn_part_kernel(sc_search sb, 
   float *Vs = sc + W * 256;          // [256][DK+1]
   float *mw = Vs + 256 * (DK + 1);   // [W]
   float *lw = mw + W;                // [W]
+  float *rm = lw + W;                // [W]      running max      (SEQ)
+  float *rl = rm + W;                // [W]      running sum      (SEQ)
+  float *racc = rl + W;              // [W][DK]  running context  (SEQ)
+  if (!SEQ && (int)blockIdx.x * 256 >= T) return;
   for (int e = tid; e < nh * DK; e += 256) {
     int w = e / DK, c = e % DK;
     qs[e] = sb.dq[((long)s * W + w) * d + head * DK + c];
+    if (SEQ) racc[e] = 0.f;
   }
+  if (SEQ && tid < nh) { rm[tid] = -INFINITY; rl[tid] = 0.f; }
   __syncthreads();
-  const int f = c0 + tid;
-  const bool valid = f < T;
-  const float *kv = sb.ckv + (((long)s * sb.n_layers + li) * sb.TCAP + (valid ? f : 0)) * 2 * d + head * DK;
-  float k[DK];
-#pragma unroll
-  for (int c = 0; c < DK; c += 4) {
-    float4 t = reinterpret_cast<const float4 *>(kv)[c / 4];
-    k[c] = t.x; k[c + 1] = t.y; k[c + 2] = t.z; k[c + 3] = t.w;
-  }
-#pragma unroll
-  for (int c = 0; c < DK; c += 4) {
-    float4 t = reinterpret_cast<const float4 *>(kv + d)[c / 4];
-    Vs[tid * (DK + 1) + c] = t.x;
-    Vs[tid * (DK + 1) + c + 1] = t.y;
-    Vs[tid * (DK + 1) + c + 2] = t.z;
-    Vs[tid * (DK + 1) + c + 3] = t.w;
-  }
   const float scale = sqrtf((float)DK);
-  for (int w = 0; w < nh; ++w) {
-    float sdot = 0.f;
-#pragma unroll
-    for (int c = 0; c < DK; ++c) sdot = fmaf(qs[w * DK + c], k[c], sdot);
-    sc[w * 256 + tid] = valid ? sdot / scale : -INFINITY;
-  }
-  __syncthreads();
-  // softmax statistics: wave wv owns hypotheses wv, wv+4, ...
-  for (int w = wave; w < nh; w += 4) {
-    float v0 = sc[w * 256 + lane], v1 = sc[w * 256 + lane + 64];
-    float v2 = sc[w * 256 + lane + 128], v3 = sc[w * 256 + lane + 192];
-    float m = wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-    float p0 = expf(v0 - m), p1 = expf(v1 - m), p2 = expf(v2 - m), p3 = expf(v3 - m);
-    float l = wave_sum((p0 + p1) + (p2 + p3));
-    sc[w * 256 + lane] = p0;
-    sc[w * 256 + lane + 64] = p1;
-    sc[w * 256 + lane + 128] = p2;
-    sc[w * 256 + lane + 192] = p3;
-    if (lane == 0) { mw[w] = m; lw[w] = l; }
-  }
-  __syncthreads();
   const int nch = cdiv(sb.TCAP, 256);
-  for (int o = tid; o < nh * DK; o += 256) {
-    const int w = o / DK, c = o % DK;
-    float acc = 0.f;
-    const float *pw = sc + w * 256;
-    for (int t = 0; t < 256; ++t) acc = fmaf(pw[t], Vs[t * (DK + 1) + c], acc);
-    float *dst = sb.xpart + ((((long)s * W + w) * H + head) * nch + chunk) * (DK + 2);
-    dst[c] = acc;
-    if (c == 0) { dst[DK] = mw[w]; dst[DK + 1] = lw[w]; }
+  const int chunk_beg = SEQ ? 0 : blockIdx.x, chunk_end = SEQ ? cdiv(T, 256) : blockIdx.x + 1;
+  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
+    const int f = chunk * 256 + tid;
+    const bool valid = f < T;
+    const float *kv = sb.ckv + (((long)s * sb.n_layers + li) * sb.TCAP + (valid ? f : 0)) * 2 * d + head * DK;
+    float k[DK];
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      float4 t = reinterpret_cast<const float4 *>(kv)[c / 4];
+      k[c] = t.x; k[c + 1] = t.y; k[c + 2] = t.z; k[c + 3] = t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      float4 t = reinterpret_cast<const float4 *>(kv + d)[c / 4];
+      Vs[tid * (DK + 1) + c] = t.x;
+      Vs[tid * (DK + 1) + c + 1] = t.y;
+      Vs[tid * (DK + 1) + c + 2] = t.z;
+      Vs[tid * (DK + 1) + c + 3] = t.w;
+    }
+    for (int w = 0; w < nh; ++w) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) sdot = fmaf(qs[w * DK + c], k[c], sdot);
+      sc[w * 256 + tid] = valid ? sdot / scale : -INFINITY;
+    }
+    __syncthreads();
+    // softmax statistics of this chunk: wave wv owns hypotheses wv, wv+4, ...
+    for (int w = wave; w < nh; w += 4) {
+      float v0 = sc[w * 256 + lane], v1 = sc[w * 256 + lane + 64];
+      float v2 = sc[w * 256 + lane + 128], v3 = sc[w * 256 + lane + 192];
+      float m = wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+      float p0 = expf(v0 - m), p1 = expf(v1 - m), p2 = expf(v2 - m), p3 = expf(v3 - m);
+      float l = wave_sum((p0 + p1) + (p2 + p3));
+      sc[w * 256 + lane] = p0;
+      sc[w * 256 + lane + 64] = p1;
+      sc[w * 256 + lane + 128] = p2;
+      sc[w * 256 + lane + 192] = p3;
+      if (lane == 0) { mw[w] = m; lw[w] = l; }
+    }
+    __syncthreads();
+    for (int o = tid; o < nh * DK; o += 256) {
+      const int w = o / DK, c = o % DK;
+      float acc = 0.f;
+      const float *pw = sc + w * 256;
+      for (int t = 0; t < 256; ++t) acc = fmaf(pw[t], Vs[t * (DK + 1) + c], acc);
+      if (SEQ) {
+        const float M = fmaxf(rm[w], mw[w]);
+        racc[o] = racc[o] * expf(rm[w] - M) + acc * expf(mw[w] - M);
+      } else {
+        float *dst = sb.xpart + ((((long)s * W + w) * H + head) * nch + chunk) * (DK + 2);
+        dst[c] = acc;
+        if (c == 0) { dst[DK] = mw[w]; dst[DK + 1] = lw[w]; }
+      }
+    }
+    if (SEQ) {
+      __syncthreads();
+      if (tid < nh) {
+        const float M = fmaxf(rm[tid], mw[tid]);
+        rl[tid] = rl[tid] * expf(rm[tid] - M) + lw[tid] * expf(mw[tid] - M);
+        rm[tid] = M;
+      }
+      __syncthreads();
+    }
+  }
+  if (SEQ) {
+    for (int o = tid; o < nh * DK; o += 256) {
+      const int w = o / DK, c = o % DK;
+      sb.datt[((long)s * W + w) * d + head * DK + c] = racc[o] / rl[w];
+    }
   }
 }
 
@@ -256,15 +287,26 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
   SC_CHECK_ARG(sb.xchunk == 256, "xchunk must be 256");
   const int dk = sb.d / sb.H;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(cdiv(sb.TCAP, 256), sb.H, sb.S);
-  size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 2 * sb.W) * sizeof(float);
+  bool seq = sb.S * sb.H >= 192;   // enough workgroups without splitting T
+  if (const char *e = getenv("SC_XATTN_MODE")) {   // test hook: "seq" / "split"
+    if (e[0] == 's' && e[1] == 'e') seq = true;
+    else if (e[0] == 's' && e[1] == 'p') seq = false;
+  }
+  dim3 grid(seq ? 1 : cdiv(sb.TCAP, 256), sb.H, sb.S);
+  size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 4 * sb.W + sb.W * dk) * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "beam too wide for the cross-attention LDS tile");
   if (dk == 32) {
-    dec_cross_attn_part_kernel<32><<<grid, 256, smem, st>>>(sb, layer);
-    dec_cross_attn_merge_kernel<32><<<sb.S * sb.W, 256, 0, st>>>(sb);
+    if (seq) dec_cross_attn_part_kernel<32, true><<<grid, 256, smem, st>>>(sb, layer);
+    else {
+      dec_cross_attn_part_kernel<32, false><<<grid, 256, smem, st>>>(sb, layer);
+      dec_cross_attn_merge_kernel<32><<<sb.S * sb.W, 256, 0, st>>>(sb);
+    }
   } else if (dk == 16) {
-    dec_cross_attn_part_kernel<16><<<grid, 256, smem, st>>>(sb, layer);
-    dec_cross_attn_merge_kernel<16><<<sb.S * sb.W, 256, 0, st>>>(sb);
+    if (seq) dec_cross_attn_part_kernel<16, true><<<grid, 256, smem, st>>>(sb, layer);
+    else {
+      dec_cross_attn_part_kernel<16, false><<<grid, 256, smem, st>>>(sb, layer);
+      dec_cross_attn_merge_kernel<16><<<sb.S * sb.W, 256, 0, st>>>(sb);
+    }
   } else {
     sc_set_error("sc_dec_cross_attn: unsupported head dim %d", dk);
     return SC_ERR_ARG;
@@ -280,19 +322,26 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   const int n = sb.S * sb.W, d = sb.d, F = sb.F;
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
+  // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
+  // fused into the GEMM that produces its input (sc_gemm_ln).
+  SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, sb.layers[0].ln1_g, sb.layers[0].ln1_b, sb.ln_eps, stream));
   for (int li = 0; li < sb.n_layers; ++li) {
     const sc_dec_layer &w = sb.layers[li];
-    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln1_g, w.ln1_b, sb.ln_eps, stream));
+    const bool last = li + 1 == sb.n_layers;
+    const float *ng = last ? sb.dec_norm_g : sb.layers[li + 1].ln1_g;
+    const float *nb = last ? sb.dec_norm_b : sb.layers[li + 1].ln1_b;
     SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wqkv, w.bqkv, sb.dqkv, nullptr, 3 * d, n, 3 * d, d, 0, 0, stream));
     SC_TRY(sc_dec_self_attn(sbp, li, stream));
-    SC_TRY(sc_gemm(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0, stream));
-    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln2_g, w.ln2_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+                      w.ln2_g, w.ln2_b, sb.ln_eps, sb.dxn, d, stream));
     SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wq, w.bq, sb.dq, nullptr, d, n, d, d, 0, 0, stream));
     SC_TRY(sc_dec_cross_attn(sbp, li, stream));
-    SC_TRY(sc_gemm(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0, stream));
-    SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, w.ln3_g, w.ln3_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+                      w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
     SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.w1, w.b1, sb.dffh, nullptr, F, n, F, d, SC_GEMM_RELU, 0, stream));
-    SC_TRY(sc_gemm(sb.dffh, nullptr, F, w.w2, w.b2, sb.dx, nullptr, d, n, d, F, SC_GEMM_RESIDUAL, 0, stream));
+    // FFN2 + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
+    SC_TRY(sc_gemm_ln(sb.dffh, nullptr, F, w.w2, w.b2, sb.dx, nullptr, d, n, d, F, SC_GEMM_RESIDUAL, 0,
+                      ng, nb, sb.ln_eps, sb.dxn, d, stream));
   }
   return SC_OK;
 }
@@ -631,8 +680,7 @@ extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   const int n = sb.S * sb.W;
   int rc;
   SC_TRY(sc_dec_embed(sbp, stream));
-  SC_TRY(sc_decoder_layers(sbp, stream));
-  SC_TRY(sc_layernorm(sb.dx, nullptr, sb.d, sb.dxn, nullptr, sb.d, n, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, stream));
+  SC_TRY(sc_decoder_layers(sbp, stream));  // leaves after_norm(x) in dxn
   SC_TRY(sc_gemm(sb.dxn, nullptr, sb.d, sb.out_w, sb.out_b, sb.logits, nullptr, sb.V, n, sb.V, sb.d, 0, 0, stream));
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
   SC_TRY(sc_ctc_prefix_scan(sbp, stream));

@@ -35,6 +35,26 @@ class EngineError(RuntimeError):
     pass
 
 
+_AR = np.arange(1 << 16, dtype=np.int64)
+_PAT_CACHE = {}
+
+
+def _ar(n: int) -> np.ndarray:
+    """arange(n) as a view of a cached array (n is small on this path)."""
+    return _AR[:n] if n <= _AR.shape[0] else np.arange(n, dtype=np.int64)
+
+
+def _conv2_pattern(t2: int, F1: int, F2: int) -> np.ndarray:
+    """Row offsets (into the channels-last conv1 output) of the top-left tap of
+    every (t2, f2) output position of the second 3x3/stride-2 convolution."""
+    key = (t2, F1, F2)
+    pat = _PAT_CACHE.get(key)
+    if pat is None:
+        pat = ((2 * _ar(t2))[:, None] * F1 + 2 * _ar(F2)[None, :]).reshape(-1)
+        _PAT_CACHE[key] = pat
+    return pat
+
+
 @dataclass
 class StreamState:
     """Host mirror of one stream's scalar state (everything else is in HBM)."""
@@ -154,8 +174,6 @@ class StreamBatch:
         # stream, which also makes the decode step capturable as a hipGraph
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.st = [StreamState() for _ in range(S)]
-        self._nhyp_prev: Dict[int, int] = {}
-        self._hasctc_prev: Dict[int, bool] = {}
         self.reset_all()
         self.stats = {"enc_calls": 0, "dec_steps": 0, "dec_blocks": 0}
 
@@ -385,21 +403,20 @@ class StreamBatch:
             t1 = (t_use - 3) // 2 + 1
             t2 = (t1 - 3) // 2 + 1
             conv_jobs.append((base, t_use, c1_rows, t1))
-            tt, ff = np.meshgrid(np.arange(t2), np.arange(F2), indexing="ij")
-            a_rows.append(((c1_rows + 2 * tt) * F1 + 2 * ff).reshape(-1))
+            a_rows.append(c1_rows * F1 + _conv2_pattern(t2, F1, F2))
             c1_rows += t1
             if keep:
                 # residual feature rows move to the other ping-pong half
                 obase = ((1 - st.fpp) * S + s) * self.FCAP
-                feat_copy[0].append(base + Tf - keep + np.arange(keep))
-                feat_copy[1].append(obase + np.arange(keep))
+                feat_copy[0].append(base + Tf - keep + _ar(keep))
+                feat_copy[1].append(obase + _ar(keep))
                 st.fpp = 1 - st.fpp
             st.nfeat = keep
             nsub = st.nsub if st.has_sub else 0
             ubase = (st.upp * S + s) * self.UCAP
             if nsub + t2 > self.UCAP:
                 raise EngineError("subsampled-frame buffer capacity exceeded")
-            lin_dst.append(ubase + nsub + np.arange(t2))
+            lin_dst.append(ubase + nsub + _ar(t2))
             per[s] = (t2, nsub, ubase)
         if not conv_jobs:
             return
@@ -445,8 +462,8 @@ class StreamBatch:
                 nb = max(0, U - overlap) // cfg.hop_size
                 res = U - cfg.hop_size * nb
                 obase = ((1 - st.upp) * S + s) * self.UCAP
-                sub_copy[0].append(ubase + U - res + np.arange(res))
-                sub_copy[1].append(obase + np.arange(res))
+                sub_copy[0].append(ubase + U - res + _ar(res))
+                sub_copy[1].append(obase + _ar(res))
                 st.upp = 1 - st.upp
                 st.has_sub, st.nsub = True, res
             nb = max(nb, 0)
@@ -467,18 +484,18 @@ class StreamBatch:
                 y_len = nb * cfg.hop_size + (offset if first else 0)
             src = np.full(y_len, -1, np.int64)
             if first and nb > 0:
-                src[0:offset] = (b0 * R) + 1 + np.arange(offset)
+                src[0:offset] = (b0 * R) + 1 + _ar(offset)
             for i in range(nb):
                 cur_hop = i * cfg.hop_size + (offset if first else 0)
                 if i == nb - 1 and fin:
                     clen = min(cfg.block_size - offset, y_len - cur_hop)
                 else:
                     clen = cfg.hop_size
-                src[cur_hop:cur_hop + clen] = (b0 + i) * R + 1 + offset + np.arange(clen)
+                src[cur_hop:cur_hop + clen] = (b0 + i) * R + 1 + offset + _ar(clen)
             if st.T_enc + y_len > self.TCAP:
                 raise EngineError("encoder-frame capacity (max_frames) exceeded")
             emit_src.append(src)
-            emit_dst.append(s * self.TCAP + st.T_enc + np.arange(y_len))
+            emit_dst.append(s * self.TCAP + st.T_enc + _ar(y_len))
             st.T_enc += y_len
             st.n_blocks += nb
         if blk_jobs:
@@ -526,8 +543,8 @@ class StreamBatch:
                           self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
         if st.T_enc + U > self.TCAP:
             raise EngineError("encoder-frame capacity (max_frames) exceeded")
-        dst = s * self.TCAP + st.T_enc + np.arange(U)
-        be.layernorm(self.xblk, self._itensor(np.arange(U)), self.enc, self._itensor(dst), U,
+        dst = s * self.TCAP + st.T_enc + _ar(U)
+        be.layernorm(self.xblk, self._itensor(_ar(U)), self.enc, self._itensor(dst), U,
                      w.enc_norm_g, w.enc_norm_b)
         st.T_enc += U
 
@@ -535,118 +552,103 @@ class StreamBatch:
     # _decode_one_block for a lock-step group of streams
     # ------------------------------------------------------------------
     def _decode_blocks(self, todo: List[Tuple[int, int, bool]]):
+        """_decode_one_block (beam_search.py:655-838) for a lock-step group of
+        streams.  Per-stream scalars are handled as numpy vectors so the host
+        cost per decode step is O(1) Python operations, not O(S)."""
         cfg, be, w = self.cfg, self.be, self.w
         S, W = self.S, self.W
         d, Ld = cfg.d_model, cfg.dec_layers
-        self.stats["dec_blocks"] += len(todo)
-        ctrl = np.zeros((S, 8), np.int32)
-        part = {}
-        a_rows, c_rows, kv_rows, lsm_rows = [], [], [], []
-        for s, T, fin in todo:
-            st = self.st[s]
-            if T > self.TCAP:
-                raise EngineError("max_frames exceeded")
-            part[s] = (T, fin)
-            t_old = st.T_ctc
-            if T > t_old:
-                rows = s * self.TCAP + np.arange(t_old, T)
-                a_rows.append(rows)
-                c_rows.append(rows)
-                kv_rows.append((s * Ld) * self.TCAP + np.arange(t_old, T))
-                if t_old == 0:
-                    lsm_rows.append(rows)  # quirk A1: only the first block is log-softmaxed
-            ctrl[s] = (1, st.cur, int(fin), T, st.L, st.nhyp, int(st.has_ctc), t_old)
-            st.T_ctc = max(T, t_old)
+        n = len(todo)
+        self.stats["dec_blocks"] += n
+        ids = np.fromiter((t[0] for t in todo), dtype=np.int64, count=n)
+        T = np.fromiter((t[1] for t in todo), dtype=np.int64, count=n)
+        fin = np.fromiter((t[2] for t in todo), dtype=bool, count=n)
+        sts = [self.st[s] for s in ids]
+        cur = np.fromiter((x.cur for x in sts), dtype=np.int64, count=n)
+        L = np.fromiter((x.L for x in sts), dtype=np.int64, count=n)
+        nhyp = np.fromiter((x.nhyp for x in sts), dtype=np.int64, count=n)
+        has = np.fromiter((x.has_ctc for x in sts), dtype=bool, count=n)
+        pidx = np.fromiter((x.process_idx for x in sts), dtype=np.int64, count=n)
+        pvalid = np.fromiter((x.prev_valid for x in sts), dtype=bool, count=n)
+        told = np.fromiter((x.T_ctc for x in sts), dtype=np.int64, count=n)
+        if (T > self.TCAP).any():
+            raise EngineError("max_frames exceeded")
         # ---- extend_scorers (:403-464): CTC rows, cross-attention K/V rows, r states
-        if a_rows:
-            ar = self._itensor(np.concatenate(a_rows))
-            m = int(ar.shape[0])
+        grow = T > told
+        if grow.any():
+            rows = np.concatenate([ids[i] * self.TCAP + _AR[told[i]:T[i]] for i in np.nonzero(grow)[0]])
+            kv0 = np.concatenate([ids[i] * Ld * self.TCAP + _AR[told[i]:T[i]] for i in np.nonzero(grow)[0]])
+            first = grow & (told == 0)
+            ar = self._itensor(rows)
+            m = int(rows.shape[0])
             be.gemm(self.enc, ar, d, w.ctc_w, w.ctc_b, self.ctcx, ar, cfg.vocab_size, m, cfg.vocab_size, d)
-            if lsm_rows:
-                lr = np.concatenate(lsm_rows)
+            if first.any():   # quirk A1: only the first block is log-softmaxed
+                lr = np.concatenate([ids[i] * self.TCAP + _AR[0:T[i]] for i in np.nonzero(first)[0]])
                 be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
-            kv0 = np.concatenate(kv_rows)
             for li in range(Ld):
                 be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
                         self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+        ctrl = np.zeros((S, 8), np.int32)
+        ctrl[ids] = np.stack([np.ones(n, np.int64), cur, fin, T, L, nhyp, has, told], 1)
         self.ctrl.copy_(torch.from_numpy(ctrl))
         be.ctc_extend_state(self)
+        for i, x in enumerate(sts):
+            x.T_ctc = int(max(T[i], told[i]))
+            x.output_index = 0
         # ---- step loop (:701-821)
-        live = {s: True for s in part}
-        saved = {s: False for s in part}        # prev_hyps refreshed in THIS block
-        took_out = {s: False for s in part}     # loop left with state = H_out of a non-accepted step
-        for s in part:
-            self.st[s].output_index = 0
+        live = np.ones(n, bool)
+        took_out = np.zeros(n, bool)     # loop left with a non-accepted H_out live
+        nhyp_prev = nhyp.copy()
+        has_prev = has.copy()
+        out_idx = np.zeros(n, np.int64)
+        nsteps = np.zeros(n, np.int64)
+        use_bbd = self.search.use_bbd
         while True:
-            act = [s for s in part if live[s] and self.st[s].process_idx < self.search.max_length]
-            for s in part:
-                if live[s] and s not in act:
-                    live[s] = False
-            if not act:
+            act = live & (pidx < self.search.max_length)
+            live &= act
+            if not act.any():
                 break
-            for s in part:
-                st = self.st[s]
-                T, fin = part[s]
-                ctrl[s] = (1 if s in act else 0, st.cur, int(fin), T, st.L, st.nhyp, int(st.has_ctc), 0)
-            for s in range(S):
-                if s not in part:
-                    ctrl[s, C_ACTIVE] = 0
+            if (L[act] + 1 > self.LCAP).any():
+                raise EngineError("max_tokens exceeded")
+            ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, np.zeros(n, np.int64)], 1)
             self.ctrl.copy_(torch.from_numpy(ctrl))
-            for s in act:
-                if self.st[s].L + 1 > self.LCAP:
-                    raise EngineError("max_tokens exceeded")
             self.stats["dec_steps"] += 1
             be.decode_step(self)
-            flags = self.flags.cpu().numpy()
-            for s in act:
-                st = self.st[s]
-                T, fin = part[s]
-                st.output_index += 1
-                st.n_steps_total += 1
-                f = int(flags[s])
-                nh_out = min(W, st.nhyp * W)
-                stop = False
-                if f & F_ANY_EOS:
-                    if not fin or (f & F_BEST_EOS):
-                        stop = True
-                        self._take_out(s, nh_out)
-                        took_out[s] = True
-                if not stop and self.search.use_bbd and not fin and (f & F_REPEAT):
-                    st.output_index -= 1
-                    stop = True   # state stays H_in
-                if not stop and (f & F_ALL_EOS) and fin:
-                    stop = True
-                    self._take_out(s, nh_out)
-                    took_out[s] = True
-                if stop:
-                    live[s] = False
-                    continue
-                # accepted: prev_hyps = copy(H_out); process_idx += 1
-                self._take_out(s, nh_out)
-                st.prev_valid = True
-                saved[s] = True
-                st.process_idx += 1
+            f = self.flags.cpu().numpy()[ids]
+            f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
+            out_idx += act
+            nsteps += act
+            stop_eos = act & f_any & (~fin | f_best)
+            stop_bbd = act & ~stop_eos & f_rep & ~fin if use_bbd else np.zeros(n, bool)
+            stop_all = act & ~stop_eos & ~stop_bbd & f_all & fin
+            accept = act & ~(stop_eos | stop_bbd | stop_all)
+            take = stop_eos | stop_all | accept
+            out_idx -= stop_bbd
+            nh_out = np.minimum(W, nhyp * W)
+            nhyp_prev = np.where(take, nhyp, nhyp_prev)
+            has_prev = np.where(take, has, has_prev)
+            cur = np.where(take, 1 - cur, cur)
+            L = L + take
+            nhyp = np.where(take, nh_out, nhyp)
+            has = has | take
+            took_out |= stop_eos | stop_all
+            live &= accept
+            pvalid |= accept          # prev_hyps = copy(H_out)
+            pidx += accept            # process_idx += 1
         # ---- rewind (:827-836)
-        for s in part:
-            st = self.st[s]
-            if st.process_idx > 1 and st.prev_valid:
-                if took_out[s]:
-                    # live state is the non-accepted H_out; prev_hyps = its H_in
-                    st.cur = 1 - st.cur
-                    st.L -= 1
-                    st.nhyp = self._nhyp_prev[s]
-                    st.has_ctc = self._hasctc_prev[s]
-                st.process_idx -= 1
-                st.prev_valid = False
-
-    def _take_out(self, s: int, nh_out: int):
-        st = self.st[s]
-        self._nhyp_prev[s] = st.nhyp
-        self._hasctc_prev[s] = st.has_ctc
-        st.cur = 1 - st.cur
-        st.L += 1
-        st.nhyp = nh_out
-        st.has_ctc = True
+        rw = (pidx > 1) & pvalid
+        r2 = rw & took_out            # live state is a non-accepted H_out: go back to its H_in
+        cur = np.where(r2, 1 - cur, cur)
+        L = L - r2
+        nhyp = np.where(r2, nhyp_prev, nhyp)
+        has = np.where(r2, has_prev, has)
+        pidx -= rw
+        pvalid &= ~rw
+        for i, x in enumerate(sts):
+            x.cur, x.L, x.nhyp, x.has_ctc = int(cur[i]), int(L[i]), int(nhyp[i]), bool(has[i])
+            x.process_idx, x.prev_valid = int(pidx[i]), bool(pvalid[i])
+            x.output_index = int(out_idx[i])
+            x.n_steps_total += int(nsteps[i])
 
     # ------------------------------------------------------------------
     def hypotheses(self, s: int):

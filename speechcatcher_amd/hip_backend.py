@@ -54,6 +54,13 @@ class HipBackend:
         self._chk(self.lib.sc_gemm(_p(A), _p(a_rows), lda, _p(W), _p(bias), _p(Cm), _p(c_rows), ldc,
                                    M, N, K, flags, conv_f1, self._stream()), "sc_gemm")
 
+    def gemm_ln(self, A, a_rows, lda, W, bias, Cm, c_rows, ldc, M, N, K, ln_g, ln_b, ln_out,
+                relu=False, conv_f1=0, residual=False, eps=1e-12):
+        flags = (1 if relu else 0) | (2 if residual else 0)
+        self._chk(self.lib.sc_gemm_ln(_p(A), _p(a_rows), lda, _p(W), _p(bias), _p(Cm), _p(c_rows), ldc,
+                                      M, N, K, flags, conv_f1, _p(ln_g), _p(ln_b), eps, _p(ln_out),
+                                      ln_out.shape[-1], self._stream()), "sc_gemm_ln")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")

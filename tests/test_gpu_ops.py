@@ -82,6 +82,22 @@ def test_gemm_row_tables_and_implicit_conv(hip):
     np.testing.assert_allclose(out.cpu()[c_rows.long()].numpy(), y.numpy(), atol=2e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(10, 256, 256), (10, 256, 2048), (42, 64, 64), (1280, 256, 256), (1280, 256, 2048), (300, 256, 512)])
+def test_gemm_ln_fused(hip, M, N, K):
+    """GEMM + residual + LayerNorm fused into the split-K reduce epilogue."""
+    from oracle.kernel_spec import SpecBackend
+    A, W, b = _rand(M, K, seed=21), _rand(N, K, seed=22, scale=K ** -0.5), _rand(N, seed=23)
+    g, be_ = 1 + 0.1 * _rand(N, seed=24), _rand(N, seed=25)
+    C0 = _rand(M, N, seed=26)
+    refC, refL = C0.clone(), torch.zeros(M, N)
+    SpecBackend().gemm_ln(A, None, K, W, b, refC, None, N, M, N, K, g, be_, refL, residual=True)
+    Cg, Lg = C0.cuda(), torch.zeros(M, N, device="cuda")
+    hip.gemm_ln(A.cuda(), None, K, W.cuda(), b.cuda(), Cg, None, N, M, N, K, g.cuda(), be_.cuda(), Lg, residual=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Cg.cpu().numpy(), refC.numpy(), atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=3e-4, rtol=3e-4)
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_layernorm(hip, d):
     M = 77
@@ -124,7 +140,7 @@ def _dump(ls, name):
         json.dump(rep, f, indent=1)
 
 
-ALL_OPS = {"logmel", "conv1", "gemm", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
+ALL_OPS = {"logmel", "conv1", "gemm", "gemm_ln", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
            "dec_self_attn", "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw",
            "beam_prune", "ctc_gather_state", "ctc_extend_state", "dec_embed", "copy_rows",
            "log_softmax_rows"}
@@ -144,6 +160,15 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
     ls = _lockstep_run(hip, "tiny_c25600_b10_bbd0")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
+
+
+def test_engine_with_sequential_cross_attention(hip, monkeypatch):
+    """Large batches use the one-workgroup-per-(stream, head) cross-attention
+    (no partials / merge); force it on a small batch and compare end to end."""
+    monkeypatch.setenv("SC_XATTN_MODE", "seq")
+    from test_engine_spec import run_case
+    run_case("tiny_c10240_b10_bbd0", backend=hip, device="cuda:0")
+    run_case("tiny_c25600_b10_bbd0", backend=hip, device="cuda:0")
 
 
 def test_every_kernel_lockstep_xl(hip):
