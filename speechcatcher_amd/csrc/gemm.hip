@@ -244,21 +244,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].w * amask[rt], b4.w, acc[rt], 0, 0, 0);
     }
   };
+  // batches of NB 8-wide k groups: all NB*(1+RT) 16-byte loads are issued
+  // before the first MFMA, so a K = 256 slice costs ONE memory round trip.
+  constexpr int NB = 8;
   int k = kbeg + wave * 8;
-  for (; k + 32 < kend; k += 64) {
-    const long ko0 = gemm_kofs(g, k), ko1 = gemm_kofs(g, k + 32);
-    const float4 b0 = *reinterpret_cast<const float4 *>(wp + k);
-    const float4 b1 = *reinterpret_cast<const float4 *>(wp + k + 32);
-    float4 a0[RT], a1[RT];
+  for (; k + 32 * (NB - 1) < kend; k += 32 * NB) {
+    float4 bq[NB], aq[NB][RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      a0[rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko0);
-      a1[rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko1);
+    for (int u = 0; u < NB; ++u) {
+      const long ko = gemm_kofs(g, k + 32 * u);
+      bq[u] = *reinterpret_cast<const float4 *>(wp + k + 32 * u);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) aq[u][rt] = *reinterpret_cast<const float4 *>(ap + abase[rt] + ko);
     }
-    step(b0, a0);
-    step(b1, a1);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) step(bq[u], aq[u]);
   }
-  if (k < kend) {
+  for (; k < kend; k += 32) {
     const long ko0 = gemm_kofs(g, k);
     const float4 b0 = *reinterpret_cast<const float4 *>(wp + k);
     float4 a0[RT];
@@ -476,27 +478,46 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
                  (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
   // variant: 0 scalar, 1 skinny register-direct, 2 = 128x128 tile, 3 = 64x64 tile
   int variant;
-  if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) variant = 0;
-  else if (M <= 64 || (M <= 4096 && N <= 256 && K <= 256)) variant = 1;
-  else if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) variant = 2;
-  else variant = 3;
-  const bool can_part = g_ws && variant != 0 && (N % 4 == 0) && (g.ldc % 4 == 0) &&
-                        (((uintptr_t)g.C & 15) == 0) && (!g.bias || (((uintptr_t)g.bias & 15) == 0)) &&
-                        (size_t)M * N * sizeof(float) <= g_ws_bytes;
+  const bool can_part_any = g_ws && (N % 4 == 0) && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) &&
+                            (!g.bias || (((uintptr_t)g.bias & 15) == 0)) &&
+                            (size_t)M * N * sizeof(float) <= g_ws_bytes;
   int ksplit = 1;
-  if (can_part && variant == 1 && M <= 64) {
-    const int ct = cdiv(N, 32);
-    ksplit = K / 64;
-    const int want = cdiv(256, ct);
-    if (ksplit > want) ksplit = want;
-    if (ksplit < 1) ksplit = 1;
-  } else if (can_part && variant == 3 && K >= 512) {
-    const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    ksplit = cdiv(384, tiles);
-    if (ksplit > K / 128) ksplit = K / 128;
-    if (ksplit < 1) ksplit = 1;
+  if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) {
+    variant = 0;
+  } else if (M <= 64 || (M <= 8192 && N <= 256 && K <= 256)) {
+    variant = 1;
+    if (can_part_any && M <= 64) {
+      const int ct = cdiv(N, 32);
+      ksplit = K / 64;
+      const int want = cdiv(256, ct);
+      if (ksplit > want) ksplit = want;
+      if (ksplit < 1) ksplit = 1;
+    }
+  } else {
+    // Tiled kernels.  The GEMMs of this path are small (a few tiles per CU), so
+    // wave quantisation dominates: 570 tiles on 512 resident slots run as long
+    // as 1024.  Pick (tile, split-K) by a small cost model in cycles:
+    //   rounds = ceil(tiles*ks / slots); per round (K/(32*ks) + c0) K-steps of
+    //   8192 cycles (128^2, 2 blocks/CU) or 4096 cycles (64^2, 4 blocks/CU);
+    //   split-K adds the partial-sum round trip through the workspace.
+    const double c0 = 4.0, hz_bytes = 2.0e3;  // ~4 TB/s at ~2 GHz -> bytes per cycle
+    double best = 1e30;
+    variant = 3;
+    for (int v = 2; v <= 3; ++v) {
+      const int bm = v == 2 ? 128 : 64;
+      const long tiles = (long)cdiv(M, bm) * cdiv(N, bm);
+      const double slots = v == 2 ? 512.0 : 1024.0, stepc = v == 2 ? 8192.0 : 4096.0;
+      const int ksmax = (can_part_any && K >= 256) ? (K / 128 < 8 ? K / 128 : 8) : 1;
+      for (int ks = 1; ks <= ksmax; ++ks) {
+        if ((size_t)ks * M * N * sizeof(float) > g_ws_bytes) break;
+        const double rounds = ceil((double)tiles * ks / slots);
+        double t = rounds * ((double)cdiv(K / 32, ks) + c0) * stepc;
+        if (ks > 1) t += (double)M * N * 4.0 * (ks + 2) / hz_bytes + 6000.0;
+        if (t < best) { best = t; variant = v; ksplit = ks; }
+      }
+    }
   }
-  while (ksplit > 1 && (size_t)ksplit * M * N * sizeof(float) > g_ws_bytes) --ksplit;
+  const bool can_part = can_part_any && variant != 0;
   g.kslice = K;
   if (ksplit > 1) {
     g.kslice = cdiv(K / 32, ksplit) * 32;
@@ -512,7 +533,7 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
     if (M <= 32) gemm_skinny_kernel<1><<<dim3(cdiv(N, 32), ksplit, 1), 256, 0, st>>>(g);
     else gemm_skinny_kernel<2><<<dim3(cdiv(N, 32), ksplit, cdiv(M, 64)), 256, 0, st>>>(g);
   } else if (variant == 2) {
-    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), 1), 256, 0, st>>>(g);
+    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), ksplit), 256, 0, st>>>(g);
   } else {
     gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
   }

@@ -25,6 +25,7 @@ class LockstepBackend(SpecBackend):
         self.int_mismatch = []
         self.calls = {}
         self._synced = False
+        self._in_spec = False
 
     def attach(self, sb_cpu, sb_gpu):
         self.sb_cpu, self.sb_gpu = sb_cpu, sb_gpu
@@ -102,6 +103,8 @@ class LockstepBackend(SpecBackend):
         return float(diff.max()) if diff.numel() else 0.0
 
     def _both(self, op, args, kwargs):
+        if self._in_spec:   # nested call from a composite spec op (e.g. gemm_ln -> gemm)
+            return getattr(SpecBackend, op)(self, *args, **kwargs)
         if op in self.FULL_SYNC or not self._synced:
             self._sync_to_gpu()
             self._synced = True
@@ -111,7 +114,11 @@ class LockstepBackend(SpecBackend):
         gkw = {k: self._xlate(v) for k, v in kwargs.items()}
         getattr(self.hip, op)(*gargs, **gkw)
         torch.cuda.synchronize()
-        getattr(SpecBackend, op)(self, *args, **kwargs)
+        self._in_spec = True
+        try:
+            getattr(SpecBackend, op)(self, *args, **kwargs)
+        finally:
+            self._in_spec = False
         worst = 0.0
         for o in self.OUTPUTS[op]:
             if isinstance(o, int):
