@@ -128,6 +128,8 @@ def main():
 
     run_steps(sb, args.warmup)
     torch.cuda.synchronize()
+    if sb.timing is not None:
+        sb.timing.clear()
     if dist is not None:
         dist.barrier()
     steps0 = sum(st.n_steps_total for st in sb.st)
@@ -151,14 +153,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the path's single collective: gather of final token ids
-        best = torch.zeros(args.streams, 64, dtype=torch.int32, device=device)
-        for s in range(min(args.streams, 4)):
-            h = sb.hypotheses(s)
-            if h:
-                ids = h[0]["yseq"][:64]
-                best[s, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
-        gathered = [torch.zeros_like(best) for _ in range(world)]
-        dist.all_gather(gathered, best)
+        from speechcatcher_amd.distributed import gather_final_hypotheses, pack_hypotheses
+        hy = [sb.hypotheses(s) for s in range(args.streams)]
+        ids, sc = pack_hypotheses([h[0]["yseq"] if h else [] for h in hy],
+                                  [h[0]["score"] if h else 0.0 for h in hy], 256, device)
+        gathered = gather_final_hypotheses(ids, sc, args.streams)
+        assert len(gathered) == world
 
     if rank != 0:
         if dist is not None:
@@ -215,6 +215,8 @@ def main():
         "decode_steps_per_hop": round(dec_steps / max(args.steps, 1), 2),
         "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
     }
+    if sb.timing is not None:
+        out["host_phase_ms_per_step"] = {k: round(v / args.steps * 1e3, 3) for k, v in sb.timing.items()}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -484,7 +484,7 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   int ksplit = 1;
   if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) {
     variant = 0;
-  } else if (M <= 64 || (M <= 8192 && N <= 256 && K <= 256)) {
+  } else if (M <= 64 || (M <= 2048 && N <= 256 && K <= 256)) {
     variant = 1;
     if (can_part_any && M <= 64) {
       const int ct = cdiv(N, 32);
@@ -500,19 +500,24 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
     //   rounds = ceil(tiles*ks / slots); per round (K/(32*ks) + c0) K-steps of
     //   8192 cycles (128^2, 2 blocks/CU) or 4096 cycles (64^2, 4 blocks/CU);
     //   split-K adds the partial-sum round trip through the workspace.
-    const double c0 = 4.0, hz_bytes = 2.0e3;  // ~4 TB/s at ~2 GHz -> bytes per cycle
+    const double c0 = 4.0, bytes_per_cycle = 2.0e3;  // ~4 TB/s at ~2 GHz
     double best = 1e30;
     variant = 3;
     for (int v = 2; v <= 3; ++v) {
       const int bm = v == 2 ? 128 : 64;
       const long tiles = (long)cdiv(M, bm) * cdiv(N, bm);
-      const double slots = v == 2 ? 512.0 : 1024.0, stepc = v == 2 ? 8192.0 : 4096.0;
+      const long slots = v == 2 ? 512 : 1024;        // resident workgroups on 256 CUs
+      const double step1 = v == 2 ? 4096.0 : 1024.0;   // cycles per K-step, one workgroup on a CU
+      const int per_cu = v == 2 ? 2 : 4;
       const int ksmax = (can_part_any && K >= 256) ? (K / 128 < 8 ? K / 128 : 8) : 1;
       for (int ks = 1; ks <= ksmax; ++ks) {
         if ((size_t)ks * M * N * sizeof(float) > g_ws_bytes) break;
-        const double rounds = ceil((double)tiles * ks / slots);
-        double t = rounds * ((double)cdiv(K / 32, ks) + c0) * stepc;
-        if (ks > 1) t += (double)M * N * 4.0 * (ks + 2) / hz_bytes + 6000.0;
+        const long work = tiles * ks;
+        const long full = work / slots, rest = work % slots;
+        const double steps = (double)cdiv(K / 32, ks) + c0;
+        double t = full * steps * step1 * per_cu;
+        if (rest) t += steps * step1 * (double)cdiv((int)rest, 256);
+        if (ks > 1) t += (double)M * N * 4.0 * (ks + 2) / bytes_per_cycle + 12000.0;  // reduce pass + its launch
         if (t < best) { best = t; variant = v; ksplit = ks; }
       }
     }

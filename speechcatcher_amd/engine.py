@@ -16,6 +16,8 @@ to launch.  It replaces, for S streams at once:
 exact buffering arithmetic restated here.
 """
 import math
+import os
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -176,8 +178,14 @@ class StreamBatch:
         self.st = [StreamState() for _ in range(S)]
         self.reset_all()
         self.stats = {"enc_calls": 0, "dec_steps": 0, "dec_blocks": 0}
+        # optional host-side phase timers (SC_TIMING=1): seconds per phase
+        self.timing = {} if os.environ.get("SC_TIMING") == "1" else None
 
     # ------------------------------------------------------------------
+    def _tick(self, name, t0):
+        if self.timing is not None:
+            self.timing[name] = self.timing.get(name, 0.0) + (time.perf_counter() - t0)
+
     def _itensor(self, arr) -> torch.Tensor:
         a = np.ascontiguousarray(arr, dtype=np.int32)
         return torch.from_numpy(a).to(self.dev, non_blocking=False)
@@ -265,6 +273,7 @@ class StreamBatch:
         reference's early ``return []`` (speech2text_streaming.py:432-433).
         """
         cfg = self.cfg
+        t_ph = time.perf_counter()
         fe_jobs = []
         feat_new: Dict[int, int] = {}
         finals: Dict[int, bool] = {}
@@ -297,6 +306,7 @@ class StreamBatch:
             self.be.logmel(self.w, self.pcm, self.PCAP, jobs, len(fe_jobs),
                            max(j[5] for j in fe_jobs), self.featbuf)
         out = {s: (s in feat_new) for s, _, _ in chunks}
+        self._tick("frontend_host", t_ph)
         if feat_new:
             self._process_features(feat_new, finals)
         return out
@@ -341,7 +351,9 @@ class StreamBatch:
         enc_streams = [s for s, n in feat_new.items() if n >= 3]
         # n < 3: encoder skipped, frames discarded (beam_search.py:551-559)
         if enc_streams:
+            t_ph = time.perf_counter()
             self._encode(enc_streams, feat_new, finals)
+            self._tick("encode_host", t_ph)
         # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
         pending = list(feat_new.keys())
         done_final = set()
@@ -359,19 +371,95 @@ class StreamBatch:
                     done_final.add(s)
             if not todo:
                 break
+            t_ph = time.perf_counter()
             self._decode_blocks(todo)
+            self._tick("decode_total", t_ph)
             for s, _, fin in todo:
                 if not fin:
                     self.st[s].processed_block += 1
 
     # ------------------------------------------------------------------
+    _ENC_STATE_FIELDS = ("enc_started", "nfeat", "fpp", "has_sub", "nsub", "upp", "n_blocks",
+                         "has_addin", "has_ctx", "T_enc")
+
     def _encode(self, streams: List[int], feat_new: Dict[int, int], finals: Dict[int, bool]):
-        """forward_infer for every listed stream, batched.  SURVEY Appendix D.2-3."""
+        """forward_infer for every listed stream, batched.
+
+        Planning is pure integer work.  When every stream of the call is in the
+        same buffering state (lock-step batches: the serving case) the plan is
+        computed for ONE stream and broadcast with per-stream offsets, so the
+        host cost does not grow with the number of streams."""
+        st0 = self.st[streams[0]]
+        sig0 = (finals[streams[0]], feat_new[streams[0]]) + tuple(getattr(st0, f) for f in self._ENC_STATE_FIELDS)
+        uniform = len(streams) > 2 and all(
+            (finals[s], feat_new[s]) + tuple(getattr(self.st[s], f) for f in self._ENC_STATE_FIELDS) == sig0
+            for s in streams[1:])
+        if uniform:
+            plan = self._encode_plan(streams[:1], feat_new, finals)
+            if plan is not None and not plan["short_jobs"]:
+                plan = self._broadcast_plan(plan, streams)
+                for s in streams[1:]:
+                    for f in self._ENC_STATE_FIELDS:
+                        setattr(self.st[s], f, getattr(st0, f))
+            elif plan is not None:
+                # short-segment path: plan the remaining streams the general way
+                rest = self._encode_plan(streams[1:], feat_new, finals)
+                self._encode_launch(plan)
+                plan = rest
+            else:
+                for s in streams[1:]:
+                    for f in self._ENC_STATE_FIELDS:
+                        setattr(self.st[s], f, getattr(st0, f))
+        else:
+            plan = self._encode_plan(streams, feat_new, finals)
+        if plan is not None:
+            self._encode_launch(plan)
+
+    def _broadcast_plan(self, p, streams):
+        """Replicate the single-stream plan of streams[0] to all streams."""
+        cfg = self.cfg
+        n = len(streams)
+        sv = np.asarray(streams, np.int64)
+        ds = sv - sv[0]                      # stream-id distance
+        j = np.arange(n, dtype=np.int64)     # dense position in this call
+        R = cfg.block_size + 2
+        F1 = cfg.conv_freq1
+        q = dict(p)
+        cj = np.asarray(p["conv_jobs"], np.int64)            # (1, 4)
+        t1 = int(cj[0, 3])
+        cjn = np.repeat(cj, n, 0)
+        cjn[:, 0] += ds * self.FCAP
+        cjn[:, 2] += j * t1
+        q["conv_jobs"] = cjn
+        q["a_rows"] = (p["a_rows"][None, :] + (j * t1 * F1)[:, None]).reshape(-1)
+        q["lin_dst"] = (p["lin_dst"][None, :] + (ds * self.UCAP)[:, None]).reshape(-1)
+        for key, stride in (("feat_copy", self.FCAP), ("sub_copy", self.UCAP)):
+            if p[key] is not None:
+                q[key] = tuple((a[None, :] + (ds * stride)[:, None]).reshape(-1) for a in p[key])
+        if p["blk_jobs"] is not None:
+            bj = p["blk_jobs"]                               # (nb, 6)
+            nb = bj.shape[0]
+            bjn = np.tile(bj, (n, 1))
+            bjn[:, 0] += np.repeat(ds * self.UCAP, nb)
+            q["blk_jobs"] = bjn
+            sj = np.repeat(p["sjobs"], n, 0)                 # (n, 5)
+            sj[:, 0] += j * nb
+            sj[:, 2] = sv
+            q["sjobs"] = sj
+        else:
+            nb = 0
+        if p["emit_src"] is not None:
+            es = p["emit_src"]
+            esn = np.tile(es, n)
+            add = np.repeat(j * nb * R, es.shape[0])
+            q["emit_src"] = np.where(esn >= 0, esn + add, esn)
+            q["emit_dst"] = (p["emit_dst"][None, :] + (ds * self.TCAP)[:, None]).reshape(-1)
+        return q
+
+    def _encode_plan(self, streams, feat_new, finals):
         cfg, S = self.cfg, self.S
-        d = cfg.d_model
         F1, F2 = cfg.conv_freq1, cfg.conv_freq2
         sub = cfg.subsample
-        be, w = self.be, self.w
         conv_jobs = []      # (src_row0, T_in, c1_row0, T1)
         a_rows = []         # conv2 implicit-GEMM A row indices into c1 (rows of width d)
         lin_dst = []        # dst rows in subbuf for the subsampling Linear output
@@ -419,21 +507,7 @@ class StreamBatch:
             lin_dst.append(ubase + nsub + _ar(t2))
             per[s] = (t2, nsub, ubase)
         if not conv_jobs:
-            return
-        self.stats["enc_calls"] += 1
-        cj = self._itensor(np.array(conv_jobs, np.int32))
-        be.conv1(w, self.featbuf, cj, len(conv_jobs), max(j[3] for j in conv_jobs), self.c1)
-        a_rows = np.concatenate(a_rows)
-        be.gemm(self.c1, self._itensor(a_rows), d, w.conv2_w, w.conv2_b, self.c2, None, d,
-                int(a_rows.shape[0]), d, 9 * d, relu=True, conv_f1=F1)
-        lin_dst = np.concatenate(lin_dst)
-        be.gemm(self.c2, None, F2 * d, w.sub_out_w, w.sub_out_b, self.subbuf, self._itensor(lin_dst), d,
-                int(lin_dst.shape[0]), d, F2 * d)
-        if feat_copy[0]:
-            src = np.concatenate(feat_copy[0])
-            be.copy_rows(self.featbuf, self._itensor(src), self.featbuf,
-                         self._itensor(np.concatenate(feat_copy[1])), int(src.size), cfg.n_mels)
-
+            return None
         # ---- stage 2: buffer_after_downsampling, block extraction (:313-380)
         R = cfg.block_size + 2
         offset = cfg.block_size - cfg.look_ahead - cfg.hop_size
@@ -498,30 +572,6 @@ class StreamBatch:
             emit_dst.append(s * self.TCAP + st.T_enc + _ar(y_len))
             st.T_enc += y_len
             st.n_blocks += nb
-        if blk_jobs:
-            nbk = len(blk_jobs)
-            if nbk > self.max_blocks:
-                raise EngineError("too many encoder blocks in one call")
-            be.block_pack(w, self.subbuf, self._itensor(np.array(blk_jobs, np.int32)), nbk, R, self.xblk)
-            sj = np.array(sjobs, np.int32)
-            # slot-0 chain from prev_addin (:370-380)
-            j_add = np.stack([sj[:, 0], sj[:, 1], sj[:, 2], sj[:, 3]], 1)
-            be.ctx_handoff(self.xblk, R, self._itensor(j_add), len(sjobs), self.prev_addin, 0)
-            j_ctx = np.stack([sj[:, 0], sj[:, 1], sj[:, 2] * cfg.enc_layers, sj[:, 4]], 1)
-            be.encoder_layers(w, self.xblk, nbk, R, True, self._itensor(j_ctx), len(sjobs), self.past_ctx,
-                              self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
-        if emit_src:
-            src = np.concatenate(emit_src)
-            if src.size:
-                be.layernorm(self.xblk, self._itensor(src), self.enc,
-                             self._itensor(np.concatenate(emit_dst)), int(src.size),
-                             w.enc_norm_g, w.enc_norm_b)
-        for s, ubase, U in short_jobs:
-            self._encode_short(s, ubase, U)
-        if sub_copy[0]:
-            src = np.concatenate(sub_copy[0])
-            be.copy_rows(self.subbuf, self._itensor(src), self.subbuf,
-                         self._itensor(np.concatenate(sub_copy[1])), int(src.size), d)
         # final call: next_states = None (:407-408)
         for s in streams:
             if finals[s]:
@@ -529,6 +579,55 @@ class StreamBatch:
                 st.enc_started = False
                 st.nfeat = st.nsub = st.n_blocks = 0
                 st.has_sub = st.has_addin = st.has_ctx = False
+        cat = lambda lst: np.concatenate(lst) if lst else None  # noqa: E731
+        return {
+            "conv_jobs": np.asarray(conv_jobs, np.int64),
+            "a_rows": np.concatenate(a_rows), "lin_dst": np.concatenate(lin_dst),
+            "feat_copy": (cat(feat_copy[0]), cat(feat_copy[1])) if feat_copy[0] else None,
+            "blk_jobs": np.asarray(blk_jobs, np.int64) if blk_jobs else None,
+            "sjobs": np.asarray(sjobs, np.int64) if sjobs else None,
+            "emit_src": cat(emit_src), "emit_dst": cat(emit_dst),
+            "sub_copy": (cat(sub_copy[0]), cat(sub_copy[1])) if sub_copy[0] else None,
+            "short_jobs": short_jobs,
+        }
+
+    def _encode_launch(self, p):
+        cfg, be, w = self.cfg, self.be, self.w
+        d, F1, F2 = cfg.d_model, cfg.conv_freq1, cfg.conv_freq2
+        R = cfg.block_size + 2
+        self.stats["enc_calls"] += 1
+        cj = p["conv_jobs"]
+        be.conv1(w, self.featbuf, self._itensor(cj), int(cj.shape[0]), int(cj[:, 3].max()), self.c1)
+        a_rows = p["a_rows"]
+        be.gemm(self.c1, self._itensor(a_rows), d, w.conv2_w, w.conv2_b, self.c2, None, d,
+                int(a_rows.shape[0]), d, 9 * d, relu=True, conv_f1=F1)
+        lin_dst = p["lin_dst"]
+        be.gemm(self.c2, None, F2 * d, w.sub_out_w, w.sub_out_b, self.subbuf, self._itensor(lin_dst), d,
+                int(lin_dst.shape[0]), d, F2 * d)
+        if p["feat_copy"] is not None:
+            src, dst = p["feat_copy"]
+            be.copy_rows(self.featbuf, self._itensor(src), self.featbuf, self._itensor(dst),
+                         int(src.size), cfg.n_mels)
+        if p["blk_jobs"] is not None:
+            bj, sj = p["blk_jobs"], p["sjobs"]
+            nbk = int(bj.shape[0])
+            if nbk > self.max_blocks:
+                raise EngineError("too many encoder blocks in one call")
+            be.block_pack(w, self.subbuf, self._itensor(bj), nbk, R, self.xblk)
+            # slot-0 chain from prev_addin (:370-380)
+            j_add = np.stack([sj[:, 0], sj[:, 1], sj[:, 2], sj[:, 3]], 1)
+            be.ctx_handoff(self.xblk, R, self._itensor(j_add), int(sj.shape[0]), self.prev_addin, 0)
+            j_ctx = np.stack([sj[:, 0], sj[:, 1], sj[:, 2] * cfg.enc_layers, sj[:, 4]], 1)
+            be.encoder_layers(w, self.xblk, nbk, R, True, self._itensor(j_ctx), int(sj.shape[0]), self.past_ctx,
+                              self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
+        if p["emit_src"] is not None and p["emit_src"].size:
+            be.layernorm(self.xblk, self._itensor(p["emit_src"]), self.enc, self._itensor(p["emit_dst"]),
+                         int(p["emit_src"].size), w.enc_norm_g, w.enc_norm_b)
+        for s, ubase, U in p["short_jobs"]:
+            self._encode_short(s, ubase, U)
+        if p["sub_copy"] is not None:
+            src, dst = p["sub_copy"]
+            be.copy_rows(self.subbuf, self._itensor(src), self.subbuf, self._itensor(dst), int(src.size), d)
 
     def _encode_short(self, s: int, ubase: int, U: int):
         """Short-segment path (:345-351): one un-blocked pass, no mask, no
@@ -613,8 +712,12 @@ class StreamBatch:
             ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, np.zeros(n, np.int64)], 1)
             self.ctrl.copy_(torch.from_numpy(ctrl))
             self.stats["dec_steps"] += 1
+            t_st = time.perf_counter()
             be.decode_step(self)
+            self._tick("decode_launch", t_st)
+            t_st = time.perf_counter()
             f = self.flags.cpu().numpy()[ids]
+            self._tick("decode_wait_flags", t_st)
             f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
             out_idx += act
             nsteps += act

@@ -136,3 +136,24 @@ def test_engine_two_streams_ragged():
             if js_b["calls"][ib]["n_blocks"]:
                 check_against_blocks(sb, 1, js_b["blocks"][bb - 1])
             ib += 1
+
+
+def test_engine_uniform_batch_fast_path():
+    """4 streams in the same buffering state take the broadcast planning path
+    (plan computed once, offsets per stream); every stream must still follow
+    the reference trajectory, including a multi-block-per-call chunk size."""
+    for name, chunk in (("tiny_c10240_b10_bbd0", 10240), ("tiny_c25600_b10_bbd0", 25600)):
+        js, _ = load_case(name)
+        meta = js["meta"]
+        sb = make_batch("TINY", 1234, "meanstd", 10, False, n_streams=4, max_frames=256, max_tokens=160,
+                        pcm_capacity=1 << 18)
+        audio = synth.synth_audio(0, meta["n_samples"])
+        pos, nblk = 0, 0
+        for call in js["calls"]:
+            end = min(pos + chunk, len(audio))
+            sb.push([(s, audio[pos:end], end >= len(audio)) for s in range(4)])
+            pos = end
+            nblk += call["n_blocks"]
+            if call["n_blocks"]:
+                for s in range(4):
+                    check_against_blocks(sb, s, js["blocks"][nblk - 1])
