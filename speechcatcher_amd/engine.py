@@ -137,6 +137,9 @@ class StreamBatch:
         self.ws_qkv = z(m_enc, 3 * d)
         self.ws_att = z(m_enc, d)
         self.ws_ffh = z(m_enc, F)
+        # persistent job tables (stable addresses: the launch sequences that read
+        # them are replayed from hipGraphs)
+        self.jobs_ctx = z(S, 4, dtype=torch.int32)
         # ---- search state
         self.ctcx = z(S * self.TCAP, V)
         self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d)
@@ -617,8 +620,10 @@ class StreamBatch:
             # slot-0 chain from prev_addin (:370-380)
             j_add = np.stack([sj[:, 0], sj[:, 1], sj[:, 2], sj[:, 3]], 1)
             be.ctx_handoff(self.xblk, R, self._itensor(j_add), int(sj.shape[0]), self.prev_addin, 0)
-            j_ctx = np.stack([sj[:, 0], sj[:, 1], sj[:, 2] * cfg.enc_layers, sj[:, 4]], 1)
-            be.encoder_layers(w, self.xblk, nbk, R, True, self._itensor(j_ctx), int(sj.shape[0]), self.past_ctx,
+            j_ctx = np.stack([sj[:, 0], sj[:, 1], sj[:, 2] * cfg.enc_layers, sj[:, 4]], 1).astype(np.int32)
+            ns = int(sj.shape[0])
+            self.jobs_ctx[:ns].copy_(torch.from_numpy(np.ascontiguousarray(j_ctx)))
+            be.encoder_layers(w, self.xblk, nbk, R, True, self.jobs_ctx, ns, self.past_ctx,
                               self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
         if p["emit_src"] is not None and p["emit_src"].size:
             be.layernorm(self.xblk, self._itensor(p["emit_src"]), self.enc, self._itensor(p["emit_dst"]),

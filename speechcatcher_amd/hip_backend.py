@@ -22,6 +22,7 @@ class HipBackend:
         self.lib = _abi.load()
         self.device = torch.device(device)
         self.use_graphs = use_graphs
+        self._enc_graphs = {}
         # split-K partial sums of sc_gemm live in this caller-owned workspace
         self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
         self._chk(self.lib.sc_set_workspace(self.workspace.data_ptr(), self.workspace.numel()), "sc_set_workspace")
@@ -97,12 +98,37 @@ class HipBackend:
         return arr
 
     def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
+        """All encoder layers.  The ~360 launches are replayed from a hipGraph
+        keyed by every argument that shapes the launch sequence (pointers
+        included, so a cached graph is only ever replayed with the exact
+        arguments it was captured with)."""
         cfg = w.cfg
         tab = self._enc_layer_table(w)
-        self._chk(self.lib.sc_encoder_layers(C.cast(tab, C.c_void_p), len(w.enc), _p(x), nblk, R, int(masked),
-                                             _p(jobs), ns, _p(past_ctx), _p(xn), _p(qkv), _p(att), _p(ffh),
-                                             cfg.d_model, cfg.enc_heads, cfg.ffn_dim, cfg.ln_eps,
-                                             self._stream()), "sc_encoder_layers")
+        st = self._stream()
+
+        def launch():
+            self._chk(self.lib.sc_encoder_layers(C.cast(tab, C.c_void_p), len(w.enc), _p(x), nblk, R, int(masked),
+                                                 _p(jobs), ns, _p(past_ctx), _p(xn), _p(qkv), _p(att), _p(ffh),
+                                                 cfg.d_model, cfg.enc_heads, cfg.ffn_dim, cfg.ln_eps,
+                                                 st), "sc_encoder_layers")
+
+        if not self.use_graphs or st == 0:
+            return launch()
+        key = (C.addressof(tab), _p(x), nblk, R, int(masked), _p(jobs), ns, _p(past_ctx), _p(xn), _p(qkv),
+               _p(att), _p(ffh), st)
+        g = self._enc_graphs.get(key)
+        if g is None:
+            if len(self._enc_graphs) >= 16:      # ragged callers: do not hoard graphs
+                return launch()
+            self._chk(self.lib.sc_graph_capture_begin(st), "sc_graph_capture_begin")
+            try:
+                launch()
+            finally:
+                out = C.c_void_p()
+                rc = self.lib.sc_graph_capture_end(st, C.byref(out))
+            self._chk(rc, "sc_graph_capture_end")
+            self._enc_graphs[key] = g = out
+        self._chk(self.lib.sc_graph_launch(g, st), "sc_graph_launch")
 
     # ------------------------------------------------------------------
     def search_struct(self, sb):

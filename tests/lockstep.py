@@ -112,6 +112,9 @@ class LockstepBackend(SpecBackend):
             self.sb_gpu.ctrl.copy_(self.sb_cpu.ctrl)
         gargs = [self._xlate(a) for a in args]
         gkw = {k: self._xlate(v) for k, v in kwargs.items()}
+        for a, g in zip(args, gargs):   # job tables the host wrote since the last full sync
+            if isinstance(a, torch.Tensor) and a.dtype == torch.int32 and a.data_ptr() in self._cpu_ptr:
+                g.copy_(a)
         getattr(self.hip, op)(*gargs, **gkw)
         torch.cuda.synchronize()
         self._in_spec = True
