@@ -155,6 +155,15 @@ class StreamBatch:
         self.ctc_rnew = z(S, self.TCAP, 2, W * K)
         self.ctrl = z(S, 8, dtype=i32)
         self.flags = z(S, dtype=i32)
+        # pinned host mirrors: the per-step ctrl upload / flag read-back are the
+        # only host<->device traffic of the decode loop
+        pin = dev.type == "cuda"
+        self._ctrl_host = torch.zeros(S, 8, dtype=i32, pin_memory=pin)
+        self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
+        self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
+        self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
+        self._ctrl_np = self._ctrl_host.numpy()
+        self._flags_np = self._flags_host.numpy()
         n = S * W
         self.dx = z(n, d)
         self.dxn = z(n, d)
@@ -188,6 +197,22 @@ class StreamBatch:
     def _tick(self, name, t0):
         if self.timing is not None:
             self.timing[name] = self.timing.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def _upload_ctrl(self):
+        """ctrl rows -> device (async from pinned memory when on a GPU; the
+        kernels that read them are ordered behind the copy on the same stream)."""
+        if self.stream is not None:
+            self.ctrl.copy_(self._ctrl_host, non_blocking=True)
+        else:
+            self.ctrl.copy_(self._ctrl_host)
+
+    def _read_flags(self) -> np.ndarray:
+        if self.stream is not None:
+            self._flags_host.copy_(self.flags, non_blocking=True)
+            self.stream.synchronize()
+        else:
+            self._flags_host.copy_(self.flags)
+        return self._flags_np
 
     def _itensor(self, arr) -> torch.Tensor:
         a = np.ascontiguousarray(arr, dtype=np.int32)
@@ -692,10 +717,13 @@ class StreamBatch:
             for li in range(Ld):
                 be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
                         self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
-        ctrl = np.zeros((S, 8), np.int32)
-        ctrl[ids] = np.stack([np.ones(n, np.int64), cur, fin, T, L, nhyp, has, told], 1)
-        self.ctrl.copy_(torch.from_numpy(ctrl))
+        ctrl0 = self._ctrl_np0             # (every earlier use was followed by a flag read-back sync)
+        ctrl0[:] = 0
+        ctrl0[ids] = np.stack([np.ones(n, np.int64), cur, fin, T, L, nhyp, has, told], 1)
+        self.ctrl.copy_(self._ctrl_host0, non_blocking=self.stream is not None)
         be.ctc_extend_state(self)
+        ctrl = self._ctrl_np
+        ctrl[:] = 0
         for i, x in enumerate(sts):
             x.T_ctc = int(max(T[i], told[i]))
             x.output_index = 0
@@ -707,6 +735,7 @@ class StreamBatch:
         out_idx = np.zeros(n, np.int64)
         nsteps = np.zeros(n, np.int64)
         use_bbd = self.search.use_bbd
+        zeros_n = np.zeros(n, np.int64)
         while True:
             act = live & (pidx < self.search.max_length)
             live &= act
@@ -714,14 +743,14 @@ class StreamBatch:
                 break
             if (L[act] + 1 > self.LCAP).any():
                 raise EngineError("max_tokens exceeded")
-            ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, np.zeros(n, np.int64)], 1)
-            self.ctrl.copy_(torch.from_numpy(ctrl))
+            ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, zeros_n], 1)
+            self._upload_ctrl()
             self.stats["dec_steps"] += 1
             t_st = time.perf_counter()
             be.decode_step(self)
             self._tick("decode_launch", t_st)
             t_st = time.perf_counter()
-            f = self.flags.cpu().numpy()[ids]
+            f = self._read_flags()[ids]
             self._tick("decode_wait_flags", t_st)
             f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
             out_idx += act
