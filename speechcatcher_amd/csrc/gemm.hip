@@ -456,6 +456,7 @@ extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
   return SC_OK;
 }
 
+static int g_skinny_max_m = 64;     // SC_SKINNY_MAX_M overrides (A-B tests: the LDS-tiled kernel wins for M > 64, profiles/r01_gemm_skinny_ab.txt)
 static float *g_ws = nullptr;
 static size_t g_ws_bytes = 0;
 
@@ -473,6 +474,7 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   if (g_force_naive < 0) {
     const char *e = getenv("SC_GEMM_NAIVE");
     g_force_naive = (e && e[0] == '1') ? 1 : 0;
+    if (const char *m = getenv("SC_SKINNY_MAX_M")) g_skinny_max_m = atoi(m);
   }
   bool aligned = (K % 32 == 0) && (g.lda % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
                  (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
@@ -484,13 +486,21 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   int ksplit = 1;
   if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) {
     variant = 0;
-  } else if (M <= 64 || (M <= 2048 && N <= 256 && K <= 256)) {
+  } else if (M <= 64 || (M <= g_skinny_max_m && (K <= 256 || can_part_any))) {
+    // register-direct kernel: one stream's rows, or the decoder rows of a
+    // batch (M = S*W <= ~2k).  K is split across workgroups so that every
+    // workgroup sees <= 256 of K (one memory round trip) and >= ~256
+    // workgroups stream the weights.
     variant = 1;
-    if (can_part_any && M <= 64) {
-      const int ct = cdiv(N, 32);
-      ksplit = K / 64;
-      const int want = cdiv(256, ct);
-      if (ksplit > want) ksplit = want;
+    if (can_part_any) {
+      if (M <= 64) {
+        const int ct = cdiv(N, 32);
+        ksplit = K / 64;
+        const int want = cdiv(256, ct);
+        if (ksplit > want) ksplit = want;
+      } else {
+        ksplit = K / 256;
+      }
       if (ksplit < 1) ksplit = 1;
     }
   } else {
