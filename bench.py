@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
-    ap.add_argument("--prof-every", type=int, default=4, help="sample every n-th GEMM launch with HIP events")
+    ap.add_argument("--roofline-steps", type=int, default=2,
+                    help="extra (untimed for `value`) steps with per-launch HIP-event timing of the GEMM kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +123,7 @@ def main():
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 
-    total_steps = args.warmup + args.steps
+    total_steps = args.warmup + args.steps + args.roofline_steps
     sb, be = build_batch(args.streams, args.beam, bool(args.bbd), total_steps, device)
     preload_audio(sb, total_steps, stream_offset=rank * args.streams)
 
@@ -133,7 +134,6 @@ def main():
     if dist is not None:
         dist.barrier()
     steps0 = sum(st.n_steps_total for st in sb.st)
-    be.lib.sc_prof_enable(args.prof_every)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(sb, args.steps)
@@ -141,12 +141,21 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    be.lib.sc_prof_enable(0)
+    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(args.streams)
+    # Roofline leg: the SAME workload continues for a few more steps with hipGraph
+    # replay switched off, so that every GEMM launch can be bracketed by HIP
+    # events on its launch stream (kernels inside a graph replay cannot be).
     ms = (C.c_double * 4)()
     fl = (C.c_double * 4)()
     nn = (C.c_longlong * 4)()
-    be.lib.sc_prof_collect(ms, fl, nn)
-    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(args.streams)
+    if args.roofline_steps > 0:
+        be.use_graphs = False
+        be.lib.sc_prof_enable(1)
+        run_steps(sb, args.roofline_steps)
+        torch.cuda.synchronize()
+        be.lib.sc_prof_enable(0)
+        be.lib.sc_prof_collect(ms, fl, nn)
+        be.use_graphs = True
 
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -167,24 +176,29 @@ def main():
 
     audio_s = world * args.streams * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
-    # dominant kernel: the f32-MFMA GEMM; pick the variant that took the most time
+    # dominant kernel of the path: the f32-MFMA GEMM (50-60 % of GPU time in the
+    # rocprofv3 summary under profiles/); report the tile variant that took most time
     v = max(range(4), key=lambda i: ms[i])
     roof = None
     if nn[v] > 0:
         ach = fl[v] / (ms[v] * 1e-3) / 1e12
         allf = sum(fl[i] for i in range(1, 4))
         allms = sum(ms[i] for i in range(1, 4))
-        roof = {"bound": "mfma", "kernel": ["gemm_naive", "gemm_mfma<32,128>", "gemm_mfma<128,128>", "gemm_mfma<64,64>"][v],
+        names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>"]
+        roof = {"bound": "mfma", "kernel": names[v],
                 "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(ms[v] * 1e3 / nn[v], 2), "sampled_launches": int(nn[v]),
+                "avg_launch_us": round(ms[v] * 1e3 / nn[v], 2), "launches_timed": int(nn[v]),
+                "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
+                "flops_unit": "MFLOP (2*M*N*K per launch)",
                 "all_gemm_variants_tflops": round(allf / (allms * 1e-3) / 1e12, 3) if allms > 0 else None,
-                "gemm_time_share_of_step": round(sum(ms[i] for i in range(4)) * args.prof_every / (elapsed * 1e3), 3)}
+                "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
+                                 "hipGraph replay off, HIP events around every launch"}
 
     single = None
     if not args.no_single_stream and world == 1:
-        sb1, _ = build_batch(1, args.beam, bool(args.bbd), total_steps, device)
-        preload_audio(sb1, total_steps)
+        sb1, _ = build_batch(1, args.beam, bool(args.bbd), args.warmup + args.steps, device)
+        preload_audio(sb1, args.warmup + args.steps)
         run_steps(sb1, args.warmup)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
