@@ -1,0 +1,128 @@
+"""API-level behaviour of the engine + result formatting (CPU, spec backend):
+what Speech2TextStreaming.__call__ returns per call, reset semantics, buffer
+compaction, capacity errors, degenerate chunk sizes, the 2-D feature input."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case
+from speechcatcher_amd import synth
+from speechcatcher_amd.engine import EngineError
+from speechcatcher_amd.speech2text_streaming import hyps_to_results
+from test_engine_spec import check_against_blocks, make_batch
+
+
+def _results(sb, s, is_final, finalize_all, fmt="native"):
+    return hyps_to_results(sb.hypotheses(s), is_final, finalize_all, None, fmt)
+
+
+@pytest.mark.parametrize("name", ["tiny_c10240_b10_bbd0", "tiny_c8192_b10_bbd1", "tiny_stats64_b5"])
+def test_per_call_results_match_reference_api(name):
+    """(text, tokens, ids) tuples of every call: non-final calls return only
+    EOS-terminated hypotheses with EMPTY text (A5), final calls the token ids."""
+    js, _ = load_case(name)
+    meta = js["meta"]
+    fa = meta.get("finalize_all", True)
+    sb = make_batch("TINY", meta["seed"], meta["stats"], meta["beam"], meta["bbd"], max_frames=256,
+                    max_tokens=160, pcm_capacity=1 << 18)
+    audio = synth.synth_audio(0, meta["n_samples"])
+    pos = 0
+    for call in js["calls"]:
+        end = min(pos + meta["chunk"], len(audio))
+        fin = end >= len(audio)
+        out = sb.push([(0, audio[pos:end], fin)])
+        pos = end
+        res = _results(sb, 0, fin, fa and fin) if out[0] else []
+        assert len(res) == len(call["results"])
+        for got, ref in zip(res, call["results"]):
+            assert got[2] == ref[2]                     # token ids
+            assert got[1] == [str(t) for t in ref[2]]   # no token list -> ids as strings
+        assert (sb.st[0].pcm_end - sb.st[0].pcm_start if sb.st[0].fe_started else -1) == call["waveform_buffer"]
+
+
+def test_espnet_result_format_has_positions_and_hyp():
+    js, _ = load_case("tiny_c10240_b10_bbd0")
+    sb = make_batch("TINY", 1234, "meanstd", 10, False, max_frames=256, max_tokens=160, pcm_capacity=1 << 18)
+    audio = synth.synth_audio(0, js["meta"]["n_samples"])
+    for pos in range(0, len(audio), 10240):
+        end = min(pos + 10240, len(audio))
+        sb.push([(0, audio[pos:end], end >= len(audio))])
+    res = _results(sb, 0, True, True, fmt="espnet")
+    text, toks, ids, tpos, hyp = res[0]
+    assert len(ids) == len(tpos) and len(res[0]) == 5
+    assert res[0][-3] == ids and res[0][-2] == tpos     # what the reference CLI indexes (speechcatcher.py:623-632)
+    ref = js["blocks"][-1]
+    keep = [(t, p) for t, p in zip(ref["yseq"][0][1:], ref["xpos"][0][1:]) if t not in (0, 1, 1023)]
+    assert ids == [t for t, _ in keep] and tpos == [p for _, p in keep]
+
+
+def test_reset_gives_fresh_state_and_small_pcm_buffer_compacts():
+    js, _ = load_case("tiny_c10240_b10_bbd0")
+    n = js["meta"]["n_samples"]
+    # pcm capacity of two chunks: every push has to compact the device buffer
+    sb = make_batch("TINY", 1234, "meanstd", 10, False, max_frames=256, max_tokens=160, pcm_capacity=2 * 10240 + 512)
+    audio = synth.synth_audio(0, n)
+    for rep in range(2):
+        sb.reset(0)
+        assert sb.st[0].T_enc == 0 and sb.st[0].processed_block == 0 and sb.st[0].L == 1
+        pos, nblk = 0, 0
+        for call in js["calls"]:
+            end = min(pos + 10240, n)
+            sb.push([(0, audio[pos:end], end >= n)])
+            pos = end
+            nblk += call["n_blocks"]
+            if call["n_blocks"]:
+                check_against_blocks(sb, 0, js["blocks"][nblk - 1])
+
+
+def test_capacity_limits_raise():
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=40, max_tokens=160, pcm_capacity=1 << 18)
+    audio = synth.synth_audio(0, 80000)
+    with pytest.raises(EngineError):
+        for pos in range(0, 80000, 10240):
+            sb.push([(0, audio[pos:pos + 10240], False)])
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=256, max_tokens=4, pcm_capacity=1 << 18)
+    with pytest.raises(EngineError):
+        for pos in range(0, 80000, 10240):
+            sb.push([(0, audio[pos:pos + 10240], False)])
+    with pytest.raises(EngineError):
+        make_batch("TINY", 1234, "meanstd", 41, False)    # beam wider than the pre-beam
+
+
+def test_degenerate_640_sample_chunks():
+    """Literal 640-sample calls: 2 frames per call, the encoder never runs and
+    the final call dies like the reference's Conv2d."""
+    js = json.loads((GOLDEN / "tiny_short.json").read_text())
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=64, max_tokens=64, pcm_capacity=1 << 16)
+    a = synth.synth_audio(4, 6400)
+    outs = []
+    for i in range(0, 6400 - 640, 640):
+        o = sb.push([(0, a[i:i + 640], False)])
+        outs.append(_results(sb, 0, False, False) if o[0] else [])
+    assert sb.stats["enc_calls"] == 0 and sb.st[0].T_enc == 0
+    assert [len(o) for o in outs] == [len(o) for o in js["640"]["results"]]
+    with pytest.raises(RuntimeError):
+        sb.push([(0, a[6400 - 640:], True)])
+
+
+def test_precomputed_feature_input_matches_oracle():
+    """2-D (T, 80) feature input (speech2text_streaming.py:438-446)."""
+    from helpers import oracle_model
+    from oracle.ref_port import RefPortStreaming
+    model = oracle_model("TINY", 1234, "meanstd")
+    g = torch.Generator().manual_seed(5)
+    feats = (torch.randn(150, 80, generator=g) * 2.0 - 8.0).numpy().astype(np.float32)
+    ora = RefPortStreaming(model, beam_size=5)
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=128, max_tokens=200, pcm_capacity=1 << 14,
+                    max_chunk_samples=32768)
+    for a, b in ((0, 70), (70, 150)):
+        fin = b == 150
+        ora(torch.from_numpy(feats[a:b]), is_final=fin, finalize_all=fin)
+        norm = ((feats[a:b] - model.mean) / model.std).astype(np.float32)
+        sb.push_features([(0, torch.from_numpy(norm), fin)])
+    got = sb.hypotheses(0)
+    ref = ora.running_hyps
+    assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref]
+    np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=2e-3)
