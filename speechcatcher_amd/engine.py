@@ -163,6 +163,13 @@ class StreamBatch:
         self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
         self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
         self._ctrl_np = self._ctrl_host.numpy()
+        # staging arena for the per-call job / row tables
+        self._arena_cap = (1 << 22) if pin else 0
+        self._arena_off = 0
+        if pin:
+            self._arena_host = torch.zeros(self._arena_cap, dtype=i32, pin_memory=True)
+            self._arena_np = self._arena_host.numpy()
+            self._arena_dev = torch.zeros(self._arena_cap, dtype=i32, device=dev)
         self._flags_np = self._flags_host.numpy()
         n = S * W
         self.dx = z(n, d)
@@ -215,8 +222,21 @@ class StreamBatch:
         return self._flags_np
 
     def _itensor(self, arr) -> torch.Tensor:
+        """Host int table -> device int32 tensor.  On a GPU the table is staged
+        in a pinned arena and copied asynchronously on the batch's stream (no
+        host sync: launches that read it are ordered behind the copy); the
+        arena is recycled at the start of every push, after the previous push's
+        final synchronisation."""
         a = np.ascontiguousarray(arr, dtype=np.int32)
-        return torch.from_numpy(a).to(self.dev, non_blocking=False)
+        n = a.size
+        if self.stream is None or self._arena_off + n > self._arena_cap:
+            return torch.from_numpy(a).to(self.dev, non_blocking=False)
+        off = self._arena_off
+        self._arena_off = off + ((n + 63) & ~63)
+        self._arena_np[off:off + n] = a.reshape(-1)
+        dst = self._arena_dev[off:off + n]
+        dst.copy_(self._arena_host[off:off + n], non_blocking=True)
+        return dst.view(a.shape)
 
     def reset(self, s: int):
         """Speech2TextStreaming.reset + BlockwiseSynchronousBeamSearch.reset
@@ -285,6 +305,7 @@ class StreamBatch:
              pcm_resident: bool = False):
         if self.stream is None:
             return self._push(chunks, pcm_resident)
+        self._arena_off = 0
         with torch.cuda.stream(self.stream):
             out = self._push(chunks, pcm_resident)
         self.stream.synchronize()
@@ -342,6 +363,7 @@ class StreamBatch:
     def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]]):
         if self.stream is None:
             return self._push_features(items)
+        self._arena_off = 0
         with torch.cuda.stream(self.stream):
             self._push_features(items)
         self.stream.synchronize()
