@@ -148,6 +148,7 @@ def main():
     ms = (C.c_double * 4)()
     fl = (C.c_double * 4)()
     nn = (C.c_longlong * 4)()
+    ev_over_ms = 0.0
     if args.roofline_steps > 0:
         be.use_graphs = False
         be.lib.sc_prof_enable(1)
@@ -156,6 +157,7 @@ def main():
         be.lib.sc_prof_enable(0)
         be.lib.sc_prof_collect(ms, fl, nn)
         be.use_graphs = True
+        ev_over_ms = float(be.lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
 
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -181,14 +183,18 @@ def main():
     v = max(range(4), key=lambda i: ms[i])
     roof = None
     if nn[v] > 0:
-        ach = fl[v] / (ms[v] * 1e-3) / 1e12
+        raw_us = ms[v] * 1e3 / nn[v]
+        # every sample carries one empty-event-pair of overhead; remove it
+        t_ms = max(ms[v] - nn[v] * ev_over_ms, 1e-9)
+        ach = fl[v] / (t_ms * 1e-3) / 1e12
         allf = sum(fl[i] for i in range(1, 4))
-        allms = sum(ms[i] for i in range(1, 4))
+        allms = max(sum(ms[i] - nn[i] * ev_over_ms for i in range(1, 4)), 1e-9)
         names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>"]
         roof = {"bound": "mfma", "kernel": names[v],
                 "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(ms[v] * 1e3 / nn[v], 2), "launches_timed": int(nn[v]),
+                "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
+                "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
                 "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
                 "flops_unit": "MFLOP (2*M*N*K per launch)",
                 "all_gemm_variants_tflops": round(allf / (allms * 1e-3) / 1e12, 3) if allms > 0 else None,

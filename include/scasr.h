@@ -138,6 +138,9 @@ int sc_set_workspace(void *ptr, size_t bytes);
  * number of sampled launches (variant 1 = skinny register-direct kernel for M <= 64).  All three pointers are HOST arrays of 4. */
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
+/* median duration (ms) of an empty event pair on `stream`: the bias that event
+ * bracketing adds to each sampled launch */
+double sc_prof_event_overhead_ms(void *stream);
 
 /* LayerNorm over rows (model/layers/normalization.py:7-24, eps 1e-12). */
 int sc_layernorm(const float *src, const int32_t *src_rows, int lds, float *dst,

@@ -437,6 +437,30 @@ extern "C" int sc_prof_enable(int sample_every) {
   return SC_OK;
 }
 
+// Median elapsed time of an EMPTY hipEvent pair on `stream` (what bracketing a
+// launch with events adds to its measured duration); used to de-bias
+// sc_prof_collect for kernels that only run a few microseconds.
+extern "C" double sc_prof_event_overhead_ms(void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int n = 64;
+  float t[n];
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventRecord(a, st);
+    (void)hipEventRecord(b, st);
+    (void)hipEventSynchronize(b);
+    t[i] = 0.f;
+    (void)hipEventElapsedTime(&t[i], a, b);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  for (int i = 1; i < n; ++i)  // insertion sort, n is tiny
+    for (int j = i; j > 0 && t[j] < t[j - 1]; --j) { float x = t[j]; t[j] = t[j - 1]; t[j - 1] = x; }
+  return (double)t[n / 2];
+}
+
 // ms[v], flops[v], n[v] for v = 0 naive, 1 = 32x128 tile, 2 = 128x128, 3 = 64x64
 extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
   hipError_t e = hipDeviceSynchronize();

@@ -1,0 +1,143 @@
+"""Multi-stream scheduler: turns independent client sessions into batched
+``StreamBatch.push`` calls (continuous batching across sessions, per-session
+chunk order preserved).
+
+This is the "next" row of SURVEY.md section 8(f) rank 1: it replaces the
+reference server's pool of full model copies, one per websocket client
+(``Speech2TextPool``, speechcatcher/speechcatcher_server.py:331-357) and its
+per-session call ``self.speech2text(speech=data, is_final=...)`` (:270) by
+slots of ONE weight replica whose chunk steps run batched on the GPU.  The
+network side (websockets, ffmpeg, Vosk JSON) stays out of scope.
+
+Parity note: the reference's output depends on the chunking of each stream, so
+the scheduler never re-chunks: one chunk fed by a session is one engine call
+for that stream, exactly as if the session owned a private Speech2TextStreaming.
+"""
+from collections import deque
+from typing import Deque, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .engine import StreamBatch
+from .speech2text_streaming import hyps_to_results
+
+
+class ServerBusy(RuntimeError):
+    """All stream slots are taken (the reference answers "Server busy",
+    speechcatcher_server.py:365-368)."""
+
+
+class StreamScheduler:
+    def __init__(self, batch: StreamBatch, token_list: Optional[List[str]] = None,
+                 result_format: str = "native"):
+        self.batch = batch
+        self.token_list = token_list
+        self.result_format = result_format
+        self._free: Deque[int] = deque(range(batch.S))
+        self._slot_of: Dict[int, int] = {}
+        self._queue: Dict[int, Deque[Tuple[np.ndarray, bool, bool]]] = {}
+        self._next_sid = 0
+
+    # ---- session lifecycle -------------------------------------------------
+    def open(self) -> int:
+        if not self._free:
+            raise ServerBusy("Server busy: all stream slots are in use")
+        slot = self._free.popleft()
+        self.batch.reset(slot)
+        sid = self._next_sid
+        self._next_sid += 1
+        self._slot_of[sid] = slot
+        self._queue[sid] = deque()
+        return sid
+
+    def close(self, sid: int):
+        slot = self._slot_of.pop(sid)
+        self._queue.pop(sid)
+        self.batch.reset(slot)
+        self._free.append(slot)
+
+    @property
+    def n_active(self) -> int:
+        return len(self._slot_of)
+
+    # ---- data path -----------------------------------------------------------
+    def feed(self, sid: int, pcm: np.ndarray, is_final: bool = False, finalize_all: bool = False):
+        """Queue one chunk of a session (float PCM in +-1, like the reference API)."""
+        self._queue[sid].append((np.asarray(pcm, dtype=np.float32), bool(is_final), bool(finalize_all)))
+
+    def pending(self) -> int:
+        return sum(1 for q in self._queue.values() if q)
+
+    def step(self) -> Dict[int, list]:
+        """One batched chunk step over every session that has a chunk queued
+        (at most one chunk per session: per-stream order is preserved).
+        Returns {session: results} in the reference's tuple format; a final
+        chunk resets the slot's stream state afterwards, like the reference
+        callers do (speechcatcher.py:618-619)."""
+        items, meta = [], {}
+        for sid, q in self._queue.items():
+            if q:
+                pcm, fin, fa = q.popleft()
+                slot = self._slot_of[sid]
+                items.append((slot, pcm, fin))
+                meta[sid] = (slot, fin, fa)
+        if not items:
+            return {}
+        has = self.batch.push(items)
+        out = {}
+        for sid, (slot, fin, fa) in meta.items():
+            if not has[slot]:
+                out[sid] = []
+            else:
+                out[sid] = hyps_to_results(self.batch.hypotheses(slot), fin, fa, self.token_list,
+                                           self.result_format)
+            if fin:
+                self.batch.reset(slot)
+        return out
+
+    def drain(self) -> Dict[int, list]:
+        """Run steps until every queue is empty; returns the LAST result of each session."""
+        last: Dict[int, list] = {}
+        while self.pending():
+            last.update(self.step())
+        return last
+
+
+def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tuple[int, int]],
+                       chunk_length: int = 8192, token_list: Optional[List[str]] = None,
+                       frames_per_second: float = 24.0) -> List[dict]:
+    """Decode the (start, end) sample ranges of one recording as PARALLEL streams
+    of one batch instead of the reference's process pool over segments
+    (speechcatcher/speechcatcher.py:474-497, chunk loop :574-592; SURVEY 8(f)
+    rank 2).  Every segment is fed in ``chunk_length`` pieces, the last one with
+    is_final=finalize_all=True.  Token timestamps follow the reference's
+    convention: encoder-frame position / 24.0 s + segment start
+    (speechcatcher.py:48,509-536)."""
+    sch = StreamScheduler(batch, token_list, result_format="espnet")
+    out: List[Optional[dict]] = [None] * len(segments)
+    todo = list(enumerate(segments))
+    sid_to_seg: Dict[int, int] = {}
+    while todo or sch.n_active:
+        while todo and sch._free:
+            idx, (a, b) = todo.pop(0)
+            sid = sch.open()
+            sid_to_seg[sid] = idx
+            seg = speech[a:b]
+            for pos in range(0, len(seg), chunk_length):
+                end = min(pos + chunk_length, len(seg))
+                last = end >= len(seg)
+                sch.feed(sid, seg[pos:end], is_final=last, finalize_all=last)
+        for sid, res in sch.step().items():
+            if not sch._queue[sid]:          # that was the final chunk of the session
+                idx = sid_to_seg.pop(sid)
+                start_s = segments[idx][0] / 16000.0
+                if res:
+                    text, toks, ids, pos, hyp = res[0]
+                    out[idx] = {"text": text, "tokens": toks, "token_ids": ids,
+                                "token_timestamps": [start_s + p / frames_per_second for p in pos],
+                                "score": hyp["score"], "start": start_s}
+                else:
+                    out[idx] = {"text": "", "tokens": [], "token_ids": [], "token_timestamps": [],
+                                "score": 0.0, "start": start_s}
+                sch.close(sid)
+    return out  # type: ignore[return-value]

@@ -1,0 +1,68 @@
+"""Multi-session scheduler on CPU with the spec backend:
+sessions with different chunk sizes and arrival patterns, batched together,
+get exactly the per-call results the reference returned for each stream alone."""
+import pytest
+
+from conftest import load_case
+from speechcatcher_amd import synth
+from speechcatcher_amd.scheduler import ServerBusy, StreamScheduler
+from test_engine_spec import make_batch
+
+
+def test_sessions_batched_with_different_chunking_match_reference():
+    cases = {"a": ("tiny_c8192_b10_bbd0", 8192), "b": ("tiny_c10240_b10_bbd0", 10240),
+             "c": ("tiny_c25600_b10_bbd0", 25600)}
+    sb = make_batch("TINY", 1234, "meanstd", 10, False, n_streams=3, max_frames=256, max_tokens=160,
+                    pcm_capacity=1 << 18)
+    sch = StreamScheduler(sb)
+    js = {k: load_case(v[0])[0] for k, v in cases.items()}
+    audio = synth.synth_audio(0, js["a"]["meta"]["n_samples"])
+    sid = {k: sch.open() for k in cases}
+    with pytest.raises(ServerBusy):
+        sch.open()
+    got = {k: [] for k in cases}
+    # session c starts two rounds late; all chunks of a session are fed up front
+    for k, (_, chunk) in cases.items():
+        for pos in range(0, len(audio), chunk):
+            end = min(pos + chunk, len(audio))
+            sch.feed(sid[k], audio[pos:end], is_final=end >= len(audio), finalize_all=end >= len(audio))
+    inv = {v: k for k, v in sid.items()}
+    while sch.pending():
+        for s, res in sch.step().items():
+            got[inv[s]].append(res)
+    for k in cases:
+        ref_calls = js[k]["calls"]
+        assert len(got[k]) == len(ref_calls)
+        for g, r in zip(got[k], ref_calls):
+            assert [x[2] for x in g] == [x[2] for x in r["results"]], k
+    # slots are recycled and start clean
+    sch.close(sid["a"])
+    s2 = sch.open()
+    assert sch.batch.st[sch._slot_of[s2]].T_enc == 0 and sch.n_active == 3
+
+
+def test_recognize_segments_in_parallel_equals_one_by_one():
+    """Segments of one recording decoded as parallel streams (2 slots for 3
+    segments: one slot is recycled) give the same tokens as decoding each
+    segment alone; timestamps = segment start + frame position / 24."""
+    import numpy as np
+    from speechcatcher_amd.scheduler import recognize_segments
+    speech = synth.synth_audio(21, 70000)
+    segs = [(0, 30000), (30000, 52000), (52000, 70000)]
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=2, max_frames=128, max_tokens=300,
+                    pcm_capacity=1 << 16)
+    res = recognize_segments(sb, speech, segs, chunk_length=8192)
+    assert len(res) == 3
+    for (a, b), r in zip(segs, res):
+        solo = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, max_frames=128, max_tokens=300,
+                          pcm_capacity=1 << 16)
+        seg = speech[a:b]
+        for pos in range(0, len(seg), 8192):
+            end = min(pos + 8192, len(seg))
+            solo.push([(0, seg[pos:end], end >= len(seg))])
+        h = solo.hypotheses(0)[0]
+        ids = [t for t in h["yseq"][1:] if t not in (0, 1, 1023)]
+        assert r["token_ids"] == ids
+        assert len(r["token_timestamps"]) == len(ids)
+        assert all(t >= a / 16000.0 for t in r["token_timestamps"])
+        assert np.all(np.diff(r["token_timestamps"]) >= 0)
