@@ -201,6 +201,21 @@ def main():
                 "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
                                  "hipGraph replay off, HIP events around every launch"}
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of
+    # this same command (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE), committed
+    # under profiles/; it cannot be collected from inside the process.
+    if roof is not None and args.streams == 128 and not args.bbd:
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_s128_pmc_hbm_traffic.csv")
+        key = {"gemm_mfma_kernel<64,64>": "gemm_mfma_kernelILi64ELi64E", "gemm_mfma_kernel<128,128>": "gemm_mfma_kernelILi128ELi128E"}.get(roof["kernel"])
+        if key and os.path.exists(tpath):
+            for line in open(tpath).read().splitlines()[1:]:
+                cols = line.split(",")
+                if key in cols[0]:
+                    roof["traffic"] = int(cols[-1])
+                    roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_bench_s128_pmc_hbm_traffic.csv)"
+                    roof["algorithmic_bytes_per_launch_avg"] = None
+                    break
+
     single = None
     if not args.no_single_stream and world == 1:
         sb1, _ = build_batch(1, args.beam, bool(args.bbd), args.warmup + args.steps, device)
