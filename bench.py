@@ -148,6 +148,7 @@ def main():
     ms = (C.c_double * 4)()
     fl = (C.c_double * 4)()
     nn = (C.c_longlong * 4)()
+    by = (C.c_double * 4)()
     ev_over_ms = 0.0
     if args.roofline_steps > 0:
         be.use_graphs = False
@@ -155,7 +156,7 @@ def main():
         run_steps(sb, args.roofline_steps)
         torch.cuda.synchronize()
         be.lib.sc_prof_enable(0)
-        be.lib.sc_prof_collect(ms, fl, nn)
+        be.lib.sc_prof_collect2(ms, fl, by, nn)
         be.use_graphs = True
         ev_over_ms = float(be.lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
 
@@ -213,7 +214,7 @@ def main():
                 if key in cols[0]:
                     roof["traffic"] = int(cols[-1])
                     roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_bench_s128_pmc_hbm_traffic.csv)"
-                    roof["algorithmic_bytes_per_launch_avg"] = None
+                    roof["algorithmic_bytes_per_launch_avg"] = int(by[v] / nn[v])
                     break
 
     single = None

@@ -138,6 +138,8 @@ int sc_set_workspace(void *ptr, size_t bytes);
  * number of sampled launches (variant 1 = skinny register-direct kernel for M <= 64).  All three pointers are HOST arrays of 4. */
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
+/* same, plus summed ALGORITHMIC bytes (A + W read once, C written; C read too with SC_GEMM_RESIDUAL) */
+int sc_prof_collect2(double *ms, double *flops, double *bytes, long long *n);
 /* median duration (ms) of an empty event pair on `stream`: the bias that event
  * bracketing adds to each sampled launch */
 double sc_prof_event_overhead_ms(void *stream);

@@ -61,6 +61,7 @@ _SIGS = {
     "sc_set_workspace": (C.c_int, [vp, C.c_size_t]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_collect": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_longlong)]),
+    "sc_prof_collect2": (C.c_int, [c_double_p, c_double_p, c_double_p, C.POINTER(C.c_longlong)]),
     "sc_prof_event_overhead_ms": (C.c_double, [vp]),
     "sc_layernorm": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp]),
     "sc_copy_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),

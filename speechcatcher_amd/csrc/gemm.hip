@@ -426,7 +426,7 @@ __global__ void gemm_naive_kernel(GemmArgs g) {
 static int g_force_naive = -1;
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg) ----
-struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int variant; };
 static std::vector<ProfRec> g_recs;
 static int g_prof_every = 0;
 static long long g_gemm_calls = 0;
@@ -462,15 +462,16 @@ extern "C" double sc_prof_event_overhead_ms(void *stream) {
 }
 
 // ms[v], flops[v], n[v] for v = 0 naive, 1 = 32x128 tile, 2 = 128x128, 3 = 64x64
-extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
+extern "C" int sc_prof_collect2(double *ms, double *flops, double *bytes, long long *n) {
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { sc_set_error("sc_prof_collect: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
-  for (int v = 0; v < 4; ++v) { ms[v] = 0; flops[v] = 0; n[v] = 0; }
+  for (int v = 0; v < 4; ++v) { ms[v] = 0; flops[v] = 0; n[v] = 0; if (bytes) bytes[v] = 0; }
   for (auto &r : g_recs) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
       ms[r.variant] += t;
       flops[r.variant] += r.flops;
+      if (bytes) bytes[r.variant] += r.bytes;
       n[r.variant] += 1;
     }
     (void)hipEventDestroy(r.a);
@@ -581,6 +582,10 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   return SC_OK;
 }
 
+extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
+  return sc_prof_collect2(ms, flops, nullptr, n);
+}
+
 extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W,
                        const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
                        int K, int flags, int conv_f1, void *stream) {
@@ -608,6 +613,8 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   }
   if (sample) {
     rec.flops = 2.0 * M * N * K;
+    // algorithmic bytes: read A and W once, write C (read it too for the residual form)
+    rec.bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * ((flags & SC_GEMM_RESIDUAL) ? 2.0 : 1.0));
     rec.variant = variant;
     (void)hipEventRecord(rec.b, st);
     g_recs.push_back(rec);
