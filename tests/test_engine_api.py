@@ -126,3 +126,24 @@ def test_precomputed_feature_input_matches_oracle():
     ref = ora.running_hyps
     assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref]
     np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=2e-3)
+
+
+def test_other_model_dimensions_spec_vs_oracle():
+    """d=128 / 4 heads / 3+2 layers: engine (spec backend) against the reference port."""
+    import helpers
+    import test_engine_spec
+    from oracle.ref_port import RefPortStreaming
+    from speechcatcher_amd.config import ModelConfig
+    helpers.CFGS["MID"] = test_engine_spec.CFGS["MID"] = ModelConfig(d_model=128, enc_heads=4, enc_layers=3,
+                                                                    dec_heads=4, dec_layers=2)
+    model = helpers.oracle_model("MID", 1234, "meanstd")
+    ora = RefPortStreaming(model, beam_size=5, use_bbd=True)
+    sb = make_batch("MID", 1234, "meanstd", 5, True, max_frames=200, max_tokens=300, pcm_capacity=1 << 17)
+    audio = synth.synth_audio(8, 80000)
+    for pos in range(0, 80000, 8192):
+        end = min(pos + 8192, 80000)
+        ora(audio[pos:end], is_final=end >= 80000, finalize_all=end >= 80000)
+        sb.push([(0, audio[pos:end], end >= 80000)])
+    got, ref = sb.hypotheses(0), ora.running_hyps
+    assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref]
+    np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=5e-3)
