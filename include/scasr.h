@@ -130,6 +130,9 @@ int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W, c
  * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it
  * sc_gemm never splits K. */
 int sc_set_workspace(void *ptr, size_t bytes);
+/* per-stream workspace (several StreamBatches running concurrently on their own
+ * streams must not share partial-sum storage); ptr == NULL unregisters */
+int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 
 /* Optional per-launch timing of sc_gemm with HIP events on the launch stream
  * (every `sample_every`-th launch; 0 disables).  sc_prof_collect synchronises

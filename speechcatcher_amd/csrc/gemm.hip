@@ -12,6 +12,8 @@
 // Row gather (a_rows) / scatter (c_rows) tables let ragged per-stream buffers
 // be consumed and produced without staging copies.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -482,13 +484,34 @@ extern "C" int sc_prof_collect2(double *ms, double *flops, double *bytes, long l
 }
 
 static int g_skinny_max_m = 64;     // SC_SKINNY_MAX_M overrides (A-B tests: the LDS-tiled kernel wins for M > 64, profiles/r01_gemm_skinny_ab.txt)
-static float *g_ws = nullptr;
-static size_t g_ws_bytes = 0;
+// split-K workspaces: one per HIP stream (independent StreamBatches run
+// concurrently on their own streams), plus a default for unregistered streams
+struct Workspace { float *ptr; size_t bytes; };
+static Workspace g_ws_default{nullptr, 0};
+static std::unordered_map<void *, Workspace> g_ws_by_stream;
+static std::mutex g_ws_mutex;
+static thread_local float *g_ws = nullptr;       // resolved per sc_gemm call
+static thread_local size_t g_ws_bytes = 0;
 
 extern "C" int sc_set_workspace(void *ptr, size_t bytes) {
-  g_ws = (float *)ptr;
-  g_ws_bytes = bytes;
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  g_ws_default = Workspace{(float *)ptr, bytes};
   return SC_OK;
+}
+
+extern "C" int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  if (ptr) g_ws_by_stream[stream] = Workspace{(float *)ptr, bytes};
+  else g_ws_by_stream.erase(stream);
+  return SC_OK;
+}
+
+static void resolve_workspace(void *stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  auto it = g_ws_by_stream.find(stream);
+  const Workspace &w = it != g_ws_by_stream.end() ? it->second : g_ws_default;
+  g_ws = w.ptr;
+  g_ws_bytes = w.bytes;
 }
 
 // Launches the main kernel.  force_part: always leave raw partial sums in the
@@ -594,6 +617,7 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   if (M == 0) return SC_OK;
   GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
+  resolve_workspace(stream);
   ProfRec rec;
   bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
   if (sample) {  // never record timing events into a stream capture
@@ -636,6 +660,7 @@ extern "C" int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const 
   if (M == 0) return SC_OK;
   GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
+  resolve_workspace(stream);
   const bool fusable = N <= 1024 && N % 4 == 0 && ld_ln % 4 == 0;
   int ksplit = 0, variant = 0;
   gemm_dispatch(g, fusable, &ksplit, &variant, st);

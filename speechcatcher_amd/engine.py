@@ -194,6 +194,8 @@ class StreamBatch:
         # all device work of this batch runs on one dedicated (non-default) HIP
         # stream, which also makes the decode step capturable as a hipGraph
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        if self.stream is not None and hasattr(backend, "bind_stream"):
+            backend.bind_stream(self.stream)
         self.st = [StreamState() for _ in range(S)]
         self.reset_all()
         self.stats = {"enc_calls": 0, "dec_steps": 0, "dec_blocks": 0}

@@ -27,6 +27,15 @@ class HipBackend:
         self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
         self._chk(self.lib.sc_set_workspace(self.workspace.data_ptr(), self.workspace.numel()), "sc_set_workspace")
 
+    def bind_stream(self, stream):
+        """Give the batch that runs on `stream` its own split-K workspace, so that
+        several batches can run concurrently on different HIP streams."""
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        self._stream_ws = getattr(self, "_stream_ws", [])
+        self._stream_ws.append(ws)
+        self._chk(self.lib.sc_set_stream_workspace(stream.cuda_stream, ws.data_ptr(), ws.numel()),
+                  "sc_set_stream_workspace")
+
     # ------------------------------------------------------------------
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
