@@ -97,55 +97,6 @@ def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
                       f"({n} steps, {dt:.1f} s wall), beam {beam}, bbd {int(bbd)}, XL dims, torch-CPU oracle"}
 
 
-def run_grouped(args, world, rank, device, dist, total_steps):
-    """G independent StreamBatches (one host thread + one HIP stream each)."""
-    import threading
-    G = args.groups
-    per = args.streams // G
-    groups = []
-    for g in range(G):
-        sb, be = build_batch(per, args.beam, bool(args.bbd), total_steps, device)
-        preload_audio(sb, total_steps, stream_offset=rank * args.streams + g * per)
-        groups.append(sb)
-
-    def work(sb, n):
-        run_steps(sb, n)
-
-    def run_all(n):
-        th = [threading.Thread(target=work, args=(sb, n)) for sb in groups]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-
-    run_all(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run_all(args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        from speechcatcher_amd.distributed import max_over_ranks
-        elapsed = max_over_ranks(elapsed, device)
-    if rank == 0:
-        audio_s = world * per * G * args.steps * CHUNK / 16000.0
-        print(json.dumps({
-            "metric": "concurrent real-time streams (audio-seconds/s), de_xl dims, 640 ms (10240-sample) chunk steps, beam 10 CTC+attention",
-            "value": round(audio_s / elapsed, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"de_streaming_transformer_xl dims, {per * G} concurrent synthetic streams/GPU in "
-                                   f"{G} independent batches (threads x HIP streams), beam {args.beam}, chunk 10240, bbd {args.bbd}",
-                       "streams_per_gpu": per * G, "groups": G, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd},
-            "roofline": None, "cpu_baseline": None}))
-    if dist is not None:
-        dist.destroy_process_group()
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,9 +105,6 @@ def main():
     ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="split the streams of one GPU into G independent batches driven by G host threads on "
-                         "G HIP streams (overlaps the latency-bound decoder kernels of different groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2,
@@ -176,8 +124,6 @@ def main():
     torch.cuda.set_device(device)
 
     total_steps = args.warmup + args.steps + args.roofline_steps
-    if args.groups > 1:
-        return run_grouped(args, world, rank, device, dist, total_steps)
     sb, be = build_batch(args.streams, args.beam, bool(args.bbd), total_steps, device)
     preload_audio(sb, total_steps, stream_offset=rank * args.streams)
 
