@@ -45,8 +45,9 @@ def build_batch(n_streams, beam, bbd, n_steps_total, device):
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
     w = PackedWeights(sd, XL, device, mean, std)
     be = HipBackend(device)
-    frames = 16 * (n_steps_total + 2) + 64
-    tokens = min(1024, 14 * (n_steps_total + 2) + 32)
+    hops = (n_steps_total + 2) * CHUNK / 10240.0       # encoder hops (16 frames each) in the window
+    frames = int(16 * hops) + 64
+    tokens = min(2048, int(14 * hops) + 32)
     sb = StreamBatch(w, be, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd),
                      max_frames=frames, max_tokens=tokens,
                      pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK)
@@ -105,11 +106,15 @@ def main():
     ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
+    ap.add_argument("--chunk", type=int, default=10240,
+                    help="samples per chunk step (10240 = 640 ms = one encoder hop; also 8192 = CLI default, 25600 = block size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the GEMM kernel")
     args = ap.parse_args()
+    global CHUNK
+    CHUNK = args.chunk
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,8 +124,14 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm.  SC_DIST_BACKEND=gloo + SC_BENCH_SINGLE_DEVICE=1 lets the
+        # multi-rank control flow be smoke-tested on a 1-GPU box (collectives on CPU tensors).
+        backend = os.environ.get("SC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     device = f"cuda:{local_rank}"
+    coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
     torch.cuda.set_device(device)
 
     total_steps = args.warmup + args.steps + args.roofline_steps
@@ -161,14 +172,14 @@ def main():
         ev_over_ms = float(be.lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the path's single collective: gather of final token ids
         from speechcatcher_amd.distributed import gather_final_hypotheses, pack_hypotheses
         hy = [sb.hypotheses(s) for s in range(args.streams)]
         ids, sc = pack_hypotheses([h[0]["yseq"] if h else [] for h in hy],
-                                  [h[0]["score"] if h else 0.0 for h in hy], 256, device)
+                                  [h[0]["score"] if h else 0.0 for h in hy], 256, coll_device)
         gathered = gather_final_hypotheses(ids, sc, args.streams)
         assert len(gathered) == world
 
@@ -239,7 +250,7 @@ def main():
             cpu = {"error": repr(e)}
 
     out = {
-        "metric": "concurrent real-time streams (audio-seconds/s), de_xl dims, 640 ms (10240-sample) chunk steps, beam 10 CTC+attention",
+        "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
