@@ -52,7 +52,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has its own
+  // L2).  Give every XCD a CONTIGUOUS range of tiles (n fastest), so the tiles
+  // that share an A row panel sit behind one L2 instead of being fetched by all
+  // eight.  Bijective for any grid size; affects speed / traffic only.
+  int tile_n, tile_m;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y;
+    const int b = blockIdx.x + gx * blockIdx.y;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    tile_n = tile % gx;
+    tile_m = tile / gx;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kq = tid & 7, lr = tid >> 3;
   const int kbeg = blockIdx.z * g.kslice;
   const int kend = (kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K;

@@ -250,7 +250,11 @@ class StreamBatch:
         if self.strict_reference:
             ns.short_pos = old.short_pos  # A13: counter survives reset()
         self.st[s] = ns
-        self._init_hyp(s)
+        if getattr(self, "stream", None) is not None:
+            with torch.cuda.stream(self.stream):   # same stream as the kernels that read it
+                self._init_hyp(s)
+        else:
+            self._init_hyp(s)
 
     def reset_all(self):
         for s in range(self.S):
