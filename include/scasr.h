@@ -221,6 +221,23 @@ int sc_ctc_gather_state(const sc_search *sb, void *stream);
 /* one full beam-search step = all of the above in order (beam_search.py:701-758) */
 int sc_decode_step(const sc_search *sb, void *stream);
 
+/* ---- Conformer building blocks (north-star components, unused by the shipped
+ * contextual-block Transformer models: SURVEY.md section 8(f) rank 3) ---------- */
+
+/* GLU -> depthwise Conv1d(ksize, same padding) -> BatchNorm1d(eval) -> Swish of
+ * ConvolutionModule.forward (model/layers/convolution.py:103-112); the two
+ * pointwise convolutions around it are sc_gemm calls.  y [B][T][2C] -> out [B][T][C]. */
+int sc_glu_dwconv_bn_swish(const float *y, int B, int T, int C, int ksize, const float *dw_w,
+                           const float *dw_b, const float *bn_g, const float *bn_b,
+                           const float *bn_mean, const float *bn_var, float bn_eps, float *out,
+                           void *stream);
+
+/* RelPositionMultiHeadedAttention.forward core (model/attention/multi_head_attention.py:
+ * 343-378, rel_shift :300-314): qkv [B*T][3d] projected q|k|v, p [T][d] = linear_pos(pos_emb),
+ * bias_u / bias_v [H][dk] -> out [B*T][d] (before linear_out).  T <= 128. */
+int sc_relpos_attention(const float *qkv, const float *p, const float *bias_u, const float *bias_v,
+                        float *out, int B, int T, int H, int d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,30 @@ class SpecBackend:
         o = torch.matmul(p, v).transpose(1, 2).reshape(nblk * R, d)
         att[:nblk * R] = o
 
+    def glu_dwconv_bn_swish(self, y, B, T, Cc, ksize, dw_w, dw_b, bn_g, bn_b, bn_mean, bn_var, eps, out):
+        """convolution.py:103-112 on channels-last data."""
+        yv = y.view(B, T, 2 * Cc).transpose(1, 2)
+        a, g = yv[:, :Cc], yv[:, Cc:]
+        z = a * torch.sigmoid(g)
+        z = F.conv1d(z, dw_w.view(Cc, 1, ksize), dw_b, padding=(ksize - 1) // 2, groups=Cc)
+        z = F.batch_norm(z, bn_mean, bn_var, bn_g, bn_b, False, 0.0, eps)
+        z = z * torch.sigmoid(z)
+        out.view(B, T, Cc).copy_(z.transpose(1, 2))
+
+    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H):
+        """multi_head_attention.py:343-375 (mask None) incl. rel_shift :300-314."""
+        d = out.shape[-1]
+        dk = d // H
+        q, k, v = qkv.view(B, T, 3, H, dk).unbind(2)
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))
+        pp = p.view(1, T, H, dk).transpose(1, 2)
+        ac = torch.matmul(q + bias_u.view(1, H, 1, dk), k.transpose(-2, -1))
+        bd = torch.matmul(q + bias_v.view(1, H, 1, dk), pp.transpose(-2, -1))
+        zp = torch.zeros((B, H, T, 1))
+        bd = torch.cat([zp, bd], dim=-1).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
+        att = torch.softmax((ac + bd) / math.sqrt(dk), dim=-1)
+        out.view(B, T, d).copy_(torch.matmul(att, v).transpose(1, 2).reshape(B, T, d))
+
     def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
         """contextual_block_encoder_layer.py:215-271 x n_layers"""
         cfg = w.cfg

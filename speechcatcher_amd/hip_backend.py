@@ -95,6 +95,15 @@ class HipBackend:
         self._chk(self.lib.sc_enc_attention(_p(qkv), _p(att), nblk, R, H, att.shape[-1], int(masked),
                                             self._stream()), "sc_enc_attention")
 
+    def glu_dwconv_bn_swish(self, y, B, T, Cc, ksize, dw_w, dw_b, bn_g, bn_b, bn_mean, bn_var, eps, out):
+        self._chk(self.lib.sc_glu_dwconv_bn_swish(_p(y), B, T, Cc, ksize, _p(dw_w), _p(dw_b), _p(bn_g), _p(bn_b),
+                                                  _p(bn_mean), _p(bn_var), eps, _p(out), self._stream()),
+                  "sc_glu_dwconv_bn_swish")
+
+    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H):
+        self._chk(self.lib.sc_relpos_attention(_p(qkv), _p(p), _p(bias_u), _p(bias_v), _p(out), B, T, H,
+                                               out.shape[-1], self._stream()), "sc_relpos_attention")
+
     def _enc_layer_table(self, w):
         # cached ON the weights object (never keyed by id(): ids are recycled)
         arr = getattr(w, "_sc_enc_layer_table", None)

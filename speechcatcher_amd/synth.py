@@ -142,3 +142,38 @@ def synth_audio(stream_id: int, n_samples: int) -> np.ndarray:
     g = torch.Generator().manual_seed(1000 + stream_id)
     x = torch.randn(n_samples, generator=g) * 0.1
     return x.clamp_(-1.0, 1.0).numpy().astype(np.float32)
+
+
+def make_conformer_state(channels: int, n_head: int, kernel_size: int = 31, seed: int = 4321):
+    """Seeded weights for the stand-alone Conformer blocks, in the reference's
+    parameter names (ConvolutionModule: model/layers/convolution.py:46-80;
+    RelPositionMultiHeadedAttention: model/attention/multi_head_attention.py:281-298)."""
+    g = torch.Generator().manual_seed(seed)
+    C, k, dk = channels, kernel_size, channels // n_head
+
+    def u(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return ((torch.rand(shape, generator=g) * 2 - 1) * b).float()
+
+    conv = OrderedDict()
+    conv["layernorm.weight"] = 1.0 + 0.1 * torch.randn(C, generator=g)
+    conv["layernorm.bias"] = 0.1 * torch.randn(C, generator=g)
+    conv["pointwise_conv1.weight"] = u((2 * C, C, 1), C)
+    conv["pointwise_conv1.bias"] = 0.05 * torch.randn(2 * C, generator=g)
+    conv["depthwise_conv.weight"] = u((C, 1, k), k)
+    conv["depthwise_conv.bias"] = 0.05 * torch.randn(C, generator=g)
+    conv["batch_norm.weight"] = 1.0 + 0.1 * torch.randn(C, generator=g)
+    conv["batch_norm.bias"] = 0.1 * torch.randn(C, generator=g)
+    conv["batch_norm.running_mean"] = 0.1 * torch.randn(C, generator=g)
+    conv["batch_norm.running_var"] = 0.5 + torch.rand(C, generator=g)
+    conv["pointwise_conv2.weight"] = u((C, C, 1), C)
+    conv["pointwise_conv2.bias"] = 0.05 * torch.randn(C, generator=g)
+    att = OrderedDict()
+    for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+        att[n + ".weight"] = u((C, C), C)
+        att[n + ".bias"] = 0.05 * torch.randn(C, generator=g)
+    att["linear_pos.weight"] = u((C, C), C)
+    att["pos_bias_u"] = 0.2 * torch.randn(n_head, dk, generator=g)
+    att["pos_bias_v"] = 0.2 * torch.randn(n_head, dk, generator=g)
+    return ({k_: v.float().contiguous() for k_, v in conv.items()},
+            {k_: v.float().contiguous() for k_, v in att.items()})
