@@ -40,12 +40,13 @@ __device__ __forceinline__ long gemm_kofs(const GemmArgs &g, int k0) {
   return k0;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
-  constexpr int BK = 32;
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
   constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
-  constexpr int AI = BM / 32, BI = BN / 32;
+  constexpr int KQ = BK / 4;            // float4 per K row of a tile
+  constexpr int RP = 256 / KQ;          // tile rows loaded per pass of the 256 threads
+  constexpr int AI = BM / RP, BI = BN / RP;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   __shared__ float As[BK * LDA_S];
   __shared__ float Bs[BK * LDB_S];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
     tile_m = tile / gx;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kq = tid & 7, lr = tid >> 3;
+  const int kq = tid % KQ, lr = tid / KQ;
   const int kbeg = blockIdx.z * g.kslice;
   const int kend = (kbeg + g.kslice < g.K) ? kbeg + g.kslice : g.K;
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   float amask[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    int m = m0 + lr + 32 * i;
+    int m = m0 + lr + RP * i;
     m = m < g.M ? m : g.M - 1;
     int row = g.a_rows ? g.a_rows[m] : m;
     amask[i] = row < 0 ? 0.f : 1.f;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   long wbase[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    int n = n0 + lr + 32 * i;
+    int n = n0 + lr + RP * i;
     wbase[i] = (long)(n < g.N ? n : g.N - 1) * g.K;
   }
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      float *p = As + (kq * 4) * LDA_S + lr + 32 * i;
+      float *p = As + (kq * 4) * LDA_S + lr + RP * i;
       p[0] = ra[i].x * amask[i];
       p[LDA_S] = ra[i].y * amask[i];
       p[2 * LDA_S] = ra[i].z * amask[i];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      float *p = Bs + (kq * 4) * LDB_S + lr + 32 * i;
+      float *p = Bs + (kq * 4) * LDB_S + lr + RP * i;
       p[0] = rb[i].x;
       p[LDB_S] = rb[i].y;
       p[2 * LDB_S] = rb[i].z;
@@ -496,6 +497,7 @@ extern "C" int sc_prof_collect2(double *ms, double *flops, double *bytes, long l
   return SC_OK;
 }
 
+static int g_bk64 = 0;               // SC_GEMM_BK=64: 64-deep K tiles for the 64x64 kernel (A/B switch)
 static int g_skinny_max_m = 64;     // SC_SKINNY_MAX_M overrides (A-B tests: the LDS-tiled kernel wins for M > 64, profiles/r01_gemm_skinny_ab.txt)
 // split-K workspaces: one per HIP stream (independent StreamBatches run
 // concurrently on their own streams), plus a default for unregistered streams
@@ -536,6 +538,7 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
     const char *e = getenv("SC_GEMM_NAIVE");
     g_force_naive = (e && e[0] == '1') ? 1 : 0;
     if (const char *m = getenv("SC_SKINNY_MAX_M")) g_skinny_max_m = atoi(m);
+    if (const char *m = getenv("SC_GEMM_BK")) g_bk64 = atoi(m) == 64;
   }
   bool aligned = (K % 32 == 0) && (g.lda % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
                  (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
@@ -611,7 +614,10 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   } else if (variant == 2) {
     gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), ksplit), 256, 0, st>>>(g);
   } else {
-    gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
+    if (g_bk64 && g.kslice % 64 == 0 && K % 64 == 0 && (g.conv_f1 == 0 || g.lda % 64 == 0))
+      gemm_mfma_kernel<64, 64, 2, 2, 64><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
+    else
+      gemm_mfma_kernel<64, 64, 2, 2><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
   }
   *ksplit_out = part ? ksplit : 0;
   *variant_out = variant;
