@@ -436,7 +436,13 @@ extern "C" int sc_logsoftmax_topk(const sc_search *sbp, void *stream) {
 // CTC prefix scan (Watanabe Alg. 2): one lane per (hypothesis, candidate),
 // sequential over encoder frames, log-domain, logzero = -1e10.
 // ---------------------------------------------------------------------------
+struct CtcChunk {
+  static constexpr int CH = 16;
+  float xc[CH], xb[CH], pn[CH], pb[CH];
+};
+
 __global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
+  constexpr int CH = CtcChunk::CH;
   const int s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP), K = sb.K, W = sb.W, V = sb.V;
@@ -449,8 +455,8 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
   const int c = sb.pre_ids[row * K + k];
   const int last = YSEQ(cur, s, h)[L - 1];
   const bool same = (c == last);
-  const float *x = sb.ctcx + (long)s * sb.TCAP * V;
-  const float *rp = CTCR(cur, s);
+  const float *__restrict__ x = sb.ctcx + (long)s * sb.TCAP * V;
+  const float *__restrict__ rp = CTCR(cur, s);
   float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
   const int WK = W * K;
   const int out_len = L - 1;
@@ -465,46 +471,75 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
   float r_b = SC_LOGZERO;
   rn[((long)(start - 1) * 2) * WK + e] = r_n;
   rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b;
-  // previous-prefix forward variables at t-1
-  float cum = 0.f;  // running blank log-prob sum for the initial (state None) hypothesis
+  // running blank log-prob sum of the initial (state None) hypothesis: sum_{tau < start} x[tau, blank]
+  float cum = 0.f;
   if (!has)
     for (int t = 0; t < start; ++t) cum += x[(long)t * V + sb.blank];
-  auto prev_at = [&](int t, float &pn, float &pb) {
-    if (has) {
-      pn = rp[((long)t * 2) * W + h];
-      pb = rp[((long)t * 2 + 1) * W + h];
-    } else {
-      pn = SC_LOGZERO;
-      pb = cum;  // caller keeps cum == sum_{tau<=t} x[tau, blank]
+
+  // The recurrence over t is sequential, but everything it READS (the CTC table
+  // column of this candidate, the blank column, the previous prefix's r) is
+  // known in advance: fetch it CH frames at a time, one chunk ahead of the
+  // arithmetic (double buffered, unconditional clamped loads), so the dependent
+  // chain only contains the log-add-exps.
+  auto fetch = [&](CtcChunk &q, int t0) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      int t = t0 + i;
+      t = t < T ? t : T - 1;
+      q.xc[i] = x[(long)t * V + c];
+      q.xb[i] = x[(long)t * V + sb.blank];
+      if (has) {  // wave-uniform
+        q.pn[i] = rp[((long)(t - 1) * 2) * W + h];
+        q.pb[i] = rp[((long)(t - 1) * 2 + 1) * W + h];
+      }
     }
   };
-  // psi accumulates logsumexp over {phi[t-1] + x[t,c]} and r[start-1][n]
-  float pm = r_n, ps = 1.f;
-  float pn, pb;
-  prev_at(start - 1, pn, pb);
-  for (int t = start; t < T; ++t) {
-    const float phi = same ? pb : lse2(pn, pb);
-    const float xc = x[(long)t * V + c], xb = x[(long)t * V + sb.blank];
-    const float nr_n = lse2(r_n, phi) + xc;
-    const float nr_b = lse2(r_n, r_b) + xb;
-    r_n = nr_n;
-    r_b = nr_b;
-    rn[((long)t * 2) * WK + e] = r_n;
-    rn[((long)t * 2 + 1) * WK + e] = r_b;
-    const float v = phi + xc;
-    if (v > pm) {
-      ps = ps * expf(pm - v) + 1.f;
-      pm = v;
-    } else {
-      ps += expf(v - pm);
+  float pm = r_n, ps = 1.f;  // psi = logsumexp over {phi[t-1] + x[t,c]} and r[start-1][n]
+  auto advance = [&](const CtcChunk &q, int t0) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int t = t0 + i;
+      if (t < T) {
+        const float pn = has ? q.pn[i] : SC_LOGZERO;
+        const float pb = has ? q.pb[i] : cum;     // r_prev[t-1]
+        const float phi = same ? pb : lse2(pn, pb);
+        const float nr_n = lse2(r_n, phi) + q.xc[i];
+        const float nr_b = lse2(r_n, r_b) + q.xb[i];
+        r_n = nr_n;
+        r_b = nr_b;
+        rn[((long)t * 2) * WK + e] = r_n;
+        rn[((long)t * 2 + 1) * WK + e] = r_b;
+        const float v = phi + q.xc[i];
+        if (v > pm) {
+          ps = ps * expf(pm - v) + 1.f;
+          pm = v;
+        } else {
+          ps += expf(v - pm);
+        }
+        if (!has) cum += q.xb[i];
+      }
     }
-    if (!has) cum += xb;
-    prev_at(t, pn, pb);
+  };
+  if (start < T) {
+    CtcChunk qa, qb;
+    int t0 = start;
+    fetch(qa, t0);
+    while (true) {
+      if (t0 + CH < T) fetch(qb, t0 + CH);
+      advance(qa, t0);
+      t0 += CH;
+      if (t0 >= T) break;
+      if (t0 + CH < T) fetch(qa, t0 + CH);
+      advance(qb, t0);
+      t0 += CH;
+      if (t0 >= T) break;
+    }
   }
   float psi = pm + logf(ps);
-  // (pn, pb) hold r_prev[T-1]: from the last loop iteration, or from
-  // prev_at(start-1) with start == T when the loop did not run.
-  const float rsum_last = lse2(pn, pb);
+  // r_prev at the last frame (cum == sum_{tau <= T-1} x[tau, blank] here)
+  const float pn_last = has ? rp[((long)(T - 1) * 2) * W + h] : SC_LOGZERO;
+  const float pb_last = has ? rp[((long)(T - 1) * 2 + 1) * W + h] : cum;
+  const float rsum_last = lse2(pn_last, pb_last);
   if (c == sb.eos) psi = rsum_last;
   if (c == sb.blank) psi = SC_LOGZERO;
   sb.psi[row * K + k] = psi;
