@@ -65,6 +65,7 @@ typedef struct sc_dec_layer {
   const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
   const float *ln2_g, *ln2_b, *wq, *bq, *wo2, *bo2;
   const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;
+  const float *wo_p, *wq_p, *wo2_p; /* sc_pack_panel_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -125,6 +126,24 @@ int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W, c
                float *C, const int32_t *c_rows, int ldc, int M, int N, int K, int flags, int conv_f1,
                const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, int ld_ln,
                void *stream);
+
+/* Row-panel form of "attention output projection + residual + LayerNorm
+ * (+ next projection)" for the decoder layer (decoder_layer.py:101-123:
+ * x = residual + self_attn(..); x = norm2(x); src_attn's linear_q,
+ * multi_head_attention.py:58-60):
+ *   X[m] += A[m] . W1^T + b1;  XN[m] = LN(X[m]) (if XN);  Q[m] = LN(X[m]) . W2^T + b2 (if W2).
+ * One workgroup owns 16 complete rows (D = 64, 128 or 256), so the LayerNorm
+ * and the second projection need no second launch.  v_mfma_f32_16x16x4_f32.
+ * A must be 16-byte aligned with lda % 4 == 0. */
+int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const float *b1, float *X, int ldx,
+                    const float *ln_g, const float *ln_b, float ln_eps, float *XN, int ldn,
+                    const float *W2p, const float *b2, float *Q, int ldq, int M, int D, void *stream);
+int sc_proj_ln_proj_supported(int D);
+/* W1p / W2p are the [D][D] Linear weights re-ordered ONCE into MFMA fragment
+ * order so that every wave load is 1 KB contiguous:
+ *   out[((((tile*(D/32) + ki)*2 + half)*64 + lane)*4 + c]
+ *       = W[tile*16 + lane%16][ki*32 + 8*(lane/16) + 4*half + c]              */
+int sc_pack_panel_weight(const float *W, int D, float *out, void *stream);
 
 /* Workspace (device memory, caller-owned) for the deterministic split-K path of
  * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it

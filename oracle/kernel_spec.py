@@ -296,6 +296,19 @@ class SpecBackend:
         self.gemm(A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, relu=relu, conv_f1=conv_f1, residual=residual)
         self.layernorm(C, c_rows, ln_out, None, M, ln_g, ln_b, eps)
 
+    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12):
+        """sc_proj_ln_proj: X += A.W1^T + b1; XN = LN(X) (optional output);
+        Q = LN(X).W2^T + b2 (optional).  W1 / W2 arrive in the fragment order of
+        sc_pack_panel_weight."""
+        from speechcatcher_amd.weights import unpack_panel_weight
+        xn = XN if XN is not None else torch.empty(M, D, dtype=torch.float32, device=X.device)
+        self.gemm_ln(A, None, lda, unpack_panel_weight(W1), b1, X, None, ldx, M, D, D, ln_g, ln_b, xn,
+                     residual=True, eps=eps)
+        if W2 is not None:
+            self.gemm(xn, None, D, unpack_panel_weight(W2), b2, Q, None, D, M, D, D)
+
+    PANEL_DIMS = (64, 128, 256)   # sc_proj_ln_proj_supported
+
     def decoder_layers(self, sb):
         """decoder_layer.py:60-132 x n_layers; leaves after_norm(x) in dxn
         (every LayerNorm but the first is fused into the GEMM producing its input)."""
@@ -308,12 +321,19 @@ class SpecBackend:
             nb = w.dec_norm_b if last else w.dec[li + 1]["ln1_b"]
             self.gemm(sb.dxn, None, d, lw["wqkv"], lw["bqkv"], sb.dqkv, None, 3 * d, n, 3 * d, d)
             self.dec_self_attn(sb, li)
-            self.gemm_ln(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d,
-                         lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True)
-            self.gemm(sb.dxn, None, d, lw["wq"], lw["bq"], sb.dq, None, d, n, d, d)
-            self.dec_cross_attn(sb, li)
-            self.gemm_ln(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d,
-                         lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True)
+            if d in self.PANEL_DIMS:
+                self.proj_ln_proj(sb.datt, d, lw["wo_p"], lw["bo"], sb.dx, d, lw["ln2_g"], lw["ln2_b"], None,
+                                  lw["wq_p"], lw["bq"], sb.dq, n, d)
+                self.dec_cross_attn(sb, li)
+                self.proj_ln_proj(sb.datt, d, lw["wo2_p"], lw["bo2"], sb.dx, d, lw["ln3_g"], lw["ln3_b"], sb.dxn,
+                                  None, None, None, n, d)
+            else:
+                self.gemm_ln(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d,
+                             lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True)
+                self.gemm(sb.dxn, None, d, lw["wq"], lw["bq"], sb.dq, None, d, n, d, d)
+                self.dec_cross_attn(sb, li)
+                self.gemm_ln(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d,
+                             lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True)
             self.gemm(sb.dxn, None, d, lw["w1"], lw["b1"], sb.dffh, None, Fd, n, Fd, d, relu=True)
             self.gemm_ln(sb.dffh, None, Fd, lw["w2"], lw["b2"], sb.dx, None, d, n, d, Fd, ng, nb, sb.dxn,
                          residual=True)

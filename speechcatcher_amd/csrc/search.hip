@@ -320,6 +320,10 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp && sbp->layers, "null");
   const sc_search &sb = *sbp;
   const int n = sb.S * sb.W, d = sb.d, F = sb.F;
+  // SC_DEC_PANEL=0 keeps the three-launch form (GEMM, reduce+LN, GEMM) for A/B runs
+  const char *pe = getenv("SC_DEC_PANEL");
+  const bool panel_env = !(pe && atoi(pe) == 0);
+  const bool panel = panel_env && sc_proj_ln_proj_supported(d);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
@@ -332,12 +336,21 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
     const float *nb = last ? sb.dec_norm_b : sb.layers[li + 1].ln1_b;
     SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wqkv, w.bqkv, sb.dqkv, nullptr, 3 * d, n, 3 * d, d, 0, 0, stream));
     SC_TRY(sc_dec_self_attn(sbp, li, stream));
-    SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
-                      w.ln2_g, w.ln2_b, sb.ln_eps, sb.dxn, d, stream));
-    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wq, w.bq, sb.dq, nullptr, d, n, d, d, 0, 0, stream));
-    SC_TRY(sc_dec_cross_attn(sbp, li, stream));
-    SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
-                      w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
+    if (panel) {
+      // out-projection + residual + norm2 + cross-attention query in one row-panel kernel
+      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo_p, w.bo, sb.dx, d, w.ln2_g, w.ln2_b, sb.ln_eps, nullptr, d,
+                             w.wq_p, w.bq, sb.dq, d, n, d, stream));
+      SC_TRY(sc_dec_cross_attn(sbp, li, stream));
+      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo2_p, w.bo2, sb.dx, d, w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d,
+                             nullptr, nullptr, nullptr, d, n, d, stream));
+    } else {
+      SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+                        w.ln2_g, w.ln2_b, sb.ln_eps, sb.dxn, d, stream));
+      SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wq, w.bq, sb.dq, nullptr, d, n, d, d, 0, 0, stream));
+      SC_TRY(sc_dec_cross_attn(sbp, li, stream));
+      SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+                        w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
+    }
     SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.w1, w.b1, sb.dffh, nullptr, F, n, F, d, SC_GEMM_RELU, 0, stream));
     // FFN2 + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
     SC_TRY(sc_gemm_ln(sb.dffh, nullptr, F, w.w2, w.b2, sb.dx, nullptr, d, n, d, F, SC_GEMM_RESIDUAL, 0,

@@ -71,6 +71,11 @@ class HipBackend:
                                       M, N, K, flags, conv_f1, _p(ln_g), _p(ln_b), eps, _p(ln_out),
                                       ln_out.shape[-1], self._stream()), "sc_gemm_ln")
 
+    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12):
+        self._chk(self.lib.sc_proj_ln_proj(_p(A), lda, _p(W1), _p(b1), _p(X), ldx, _p(ln_g), _p(ln_b), eps,
+                                           _p(XN), D, _p(W2), _p(b2), _p(Q), D, M, D, self._stream()),
+                  "sc_proj_ln_proj")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")

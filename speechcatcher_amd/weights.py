@@ -27,6 +27,23 @@ from .mel import (fft_twiddles, hann_window_periodic, melscale_fbanks_slaney,
                   positional_encoding_table)
 
 
+PANEL_DIMS = (64, 128, 256)   # feature dims of the row-panel kernel (sc_proj_ln_proj_supported)
+
+
+def pack_panel_weight(W: torch.Tensor) -> torch.Tensor:
+    """[D][D] Linear weight -> MFMA fragment order of sc_proj_ln_proj
+    (include/scasr.h: out[tile][ki][half][lane = kk*16 + r][c] =
+    W[tile*16 + r][ki*32 + 8*kk + 4*half + c]); a pure permutation."""
+    D = W.shape[0]
+    assert W.shape == (D, D) and D % 32 == 0
+    return W.reshape(D // 16, 16, D // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(D, D)
+
+
+def unpack_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
+    D = Wp.shape[0]
+    return Wp.reshape(D // 16, D // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5).contiguous().reshape(D, D)
+
+
 class PackedWeights:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
                  mean=None, std=None):
@@ -99,6 +116,9 @@ class PackedWeights:
                 w1=dev(g(p + ".feed_forward.w_1.weight")), b1=dev(g(p + ".feed_forward.w_1.bias")),
                 w2=dev(g(p + ".feed_forward.w_2.weight")), b2=dev(g(p + ".feed_forward.w_2.bias")),
             ))
+        for lw in self.dec:   # fragment-ordered copies for the row-panel kernel
+            for n in ("wo", "wq", "wo2"):
+                lw[n + "_p"] = pack_panel_weight(lw[n]) if d in PANEL_DIMS else lw[n]
         self.dec_norm_g = dev(g("decoder.after_norm.weight"))
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))

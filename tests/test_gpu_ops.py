@@ -98,6 +98,50 @@ def test_gemm_ln_fused(hip, M, N, K):
     np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=3e-4, rtol=3e-4)
 
 
+@pytest.mark.parametrize("M,D", [(10, 256), (16, 256), (1280, 256), (1275, 256), (50, 128), (23, 64), (160, 64)])
+@pytest.mark.parametrize("second", [True, False])
+def test_proj_ln_proj_row_panel(hip, M, D, second):
+    """Row-panel kernel (out-projection + residual + LayerNorm + next projection,
+    v_mfma_f32_16x16x4_f32) against gemm_ln + gemm of the spec; ragged last panel."""
+    from oracle.kernel_spec import SpecBackend
+    A, W1, b1 = _rand(M, D, seed=31), _rand(D, D, seed=32, scale=D ** -0.5), _rand(D, seed=33)
+    W2, b2 = _rand(D, D, seed=34, scale=D ** -0.5), _rand(D, seed=35)
+    g, be_ = 1 + 0.1 * _rand(D, seed=36), _rand(D, seed=37)
+    X0 = _rand(M, D, seed=38)
+    refX, refN, refQ = X0.clone(), torch.zeros(M, D), torch.zeros(M, D)
+    from speechcatcher_amd.weights import pack_panel_weight, unpack_panel_weight
+    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+    assert torch.equal(unpack_panel_weight(W1p), W1)
+    # the device-side packer of the C ABI produces the same permutation
+    dev_p = torch.empty(D, D, device="cuda")
+    assert hip.lib.sc_pack_panel_weight(W1.cuda().data_ptr(), D, dev_p.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dev_p.cpu(), W1p)
+    SpecBackend().proj_ln_proj(A, D, W1p, b1, refX, D, g, be_, refN, W2p if second else None, b2 if second else None,
+                               refQ if second else None, M, D)
+    Xg = X0.cuda()
+    Ng = torch.zeros(M + 3, D, device="cuda")   # rows past M must stay untouched
+    Qg = torch.zeros(M + 3, D, device="cuda")
+    hip.proj_ln_proj(A.cuda(), D, W1p.cuda(), b1.cuda(), Xg, D, g.cuda(), be_.cuda(), Ng if not second else None,
+                     W2p.cuda() if second else None, b2.cuda() if second else None, Qg if second else None, M, D)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Xg.cpu().numpy(), refX.numpy(), atol=2e-4, rtol=2e-4)
+    if second:
+        np.testing.assert_allclose(Qg[:M].cpu().numpy(), refQ.numpy(), atol=3e-4, rtol=3e-4)
+        assert float(Qg[M:].abs().max()) == 0.0
+    else:
+        np.testing.assert_allclose(Ng[:M].cpu().numpy(), refN.numpy(), atol=3e-4, rtol=3e-4)
+        assert float(Ng[M:].abs().max()) == 0.0
+
+
+def test_decoder_without_row_panel_kernel(hip, monkeypatch):
+    """SC_DEC_PANEL=0 keeps the GEMM / reduce+LN / GEMM form (also the path for
+    feature dims the panel kernel does not cover): same trajectories."""
+    monkeypatch.setenv("SC_DEC_PANEL", "0")
+    from test_engine_spec import run_case
+    run_case("tiny_c10240_b10_bbd0", backend=hip, device="cuda:0")
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_layernorm(hip, d):
     M = 77
@@ -140,7 +184,7 @@ def _dump(ls, name):
         json.dump(rep, f, indent=1)
 
 
-ALL_OPS = {"logmel", "conv1", "gemm", "gemm_ln", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
+ALL_OPS = {"logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
            "dec_self_attn", "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw",
            "beam_prune", "ctc_gather_state", "ctc_extend_state", "dec_embed", "copy_rows",
            "log_softmax_rows"}
