@@ -140,12 +140,281 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li
   }
 }
 
+// ---------------------------------------------------------------------------
+// decoder self-attention, shared-prefix form: one workgroup per (stream, head)
+// serves ALL hypotheses of the stream.  Hypotheses of a beam share almost all
+// of their history (measured on the XL fixture: 1.2 distinct K/V rows per
+// position for 10 hypotheses), so the kernel first compacts, per 128-position
+// chunk, the list of DISTINCT (position, slot) rows referenced through the
+// ancestor table together with the bit set of hypotheses that use each row,
+// then reads every distinct row exactly once:
+//   pass 1: DK/4 lanes per row (16 B each, full-line coalesced), partial dot
+//           products against the query of every hypothesis, scores -> LDS;
+//   softmax per hypothesis in LDS;
+//   pass 2: same row list, context accumulators per hypothesis in registers;
+//   reduce over row groups (shuffles, then LDS across the 4 waves).
+// The per-(stream, hyp, head) kernel above stays as the generic fallback
+// (beam > 16 or LDS budget exceeded).
+// ---------------------------------------------------------------------------
+// DPP lane permutations (no LDS round trip, unlike ds_bpermute-based __shfl)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#define SC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define SC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define SC_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
+#define SC_DPP_ROR4 0x124        // rotate by 4 inside each 16 lanes
+#define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
+
+// sum over the LPR (4 or 8) adjacent lanes of a row group; every lane gets the total
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<SC_DPP_XOR1>(v);
+  v += dpp_mov<SC_DPP_XOR2>(v);
+  if (LPR == 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+  return v;
+}
+
+template <int DK, int WM>
+__global__ __launch_bounds__(256) void dec_self_attn_shared_kernel(sc_search sb, int li) {
+  constexpr int LPR = DK / 4;    // lanes per K/V row
+  constexpr int NG = 256 / LPR;  // row groups per workgroup
+  constexpr int PCH = 128;       // positions per chunk
+  constexpr int UNR = 4;         // rows in flight per group
+  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row (reduced in registers)
+  constexpr int NPART = NG / GPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int head = blockIdx.x, s = blockIdx.y;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int nh = CTRL(s, SC_C_NHYP);
+  if (nh <= 0) return;
+  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  const int W = sb.W, d = sb.d, LCAP = sb.LCAP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid / LPR, cq = tid % LPR;
+  // LDS: region A = scores [W][LCAP], re-used for the partial contexts
+  // [NPART][W][DK] at the end; then rows[PCH*W], lsum[W], wtot[4]
+  const int regA = max(W * LCAP, NPART * W * DK);
+  float *sc = smem;
+  float *red = smem;
+  int *rows = (int *)(smem + regA);
+  float *lsum = (float *)(rows + PCH * W);
+  int *wtot = (int *)(lsum + W);
+
+  const float *qkv = sb.dqkv + (long)s * W * 3 * d + head * DK;  // hypothesis h at + h*3d
+  float *skv = sb.skv + ((long)s * sb.n_layers + li) * LCAP * W * 2 * d + head * DK;
+  // append this token's K|V rows at (position L-1, slot h); this launch reads
+  // them from dqkv, later steps from the cache
+  for (int e = tid; e < nh * DK; e += 256) {
+    const int h = e / DK, c = e % DK;
+    float *dst = skv + ((long)(L - 1) * W + h) * 2 * d;
+    dst[c] = qkv[(long)h * 3 * d + d + c];
+    dst[d + c] = qkv[(long)h * 3 * d + 2 * d + c];
+  }
+  // queries of all hypotheses (rows >= nh: a valid row, results never used)
+  float4 q[WM];
+#pragma unroll
+  for (int h = 0; h < WM; ++h)
+    q[h] = *reinterpret_cast<const float4 *>(qkv + (long)min(h, nh - 1) * 3 * d + 4 * cq);
+  const int *anc = ANC(cur, s);
+  const float scale = sqrtf((float)DK);
+  const int nchunk = cdiv(L, PCH);
+
+  // distinct (position, slot) rows of positions [c0, c0+PCH): entry =
+  // local position | slot << 8 | hypothesis bit set << 12.  Returns the count.
+  auto build = [&](int c0) -> int {
+    for (int e = tid; e < PCH * W; e += 256) rows[e] = 0;
+    const int p = c0 + tid;
+    const bool live = tid < PCH && p < L;
+    int sl[WM];
+#pragma unroll
+    for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? p : 0) * W + min(h, nh - 1)];
+    unsigned mask = 0;
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      if (p == L - 1) sl[h] = h;
+      if (h < nh) mask |= 1u << sl[h];
+    }
+    const int cnt = live ? __popc(mask) : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();   // also orders the zero fill before the ORs
+    const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
+    const int U = wtot[0] + wtot[1];
+    if (live) {
+#pragma unroll
+      for (int h = 0; h < WM; ++h) {
+        if (h < nh) {
+          const int rank = __popc(mask & ((1u << sl[h]) - 1u));
+          atomicOr(&rows[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
+        }
+      }
+    }
+    __syncthreads();
+    return U;
+  };
+  auto row_ptr = [&](int e, int c0, int vofs) -> const float * {
+    const int p = c0 + (e & 255), u = (e >> 8) & 15;
+    return (p == L - 1) ? qkv + (long)u * 3 * d + d + vofs : skv + ((long)p * W + u) * 2 * d + vofs;
+  };
+
+  // ---- pass 1: raw dot products q.k of every (hypothesis, position) ----
+  int U = 0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * PCH;
+    U = build(c0);
+    for (int j0 = g; j0 < U; j0 += NG * UNR) {
+      int e[UNR];
+      float4 k[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        e[i] = rows[min(j0 + i * NG, U - 1)];
+        k[i] = *reinterpret_cast<const float4 *>(row_ptr(e[i], c0, 0) + 4 * cq);
+      }
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        if (j0 + i * NG < U) {   // uniform inside a row group
+          const int p = c0 + (e[i] & 255);
+          const unsigned hm = (unsigned)e[i] >> 12;
+          float mine = 0.f;
+#pragma unroll
+          for (int h = 0; h < WM; ++h) {
+            float part = q[h].x * k[i].x;
+            part = fmaf(q[h].y, k[i].y, part);
+            part = fmaf(q[h].z, k[i].z, part);
+            part = fmaf(q[h].w, k[i].w, part);
+            part = group_sum<LPR>(part);
+            if (cq == (h % LPR)) mine = part;   // lane cq keeps hypotheses h = cq, cq + LPR, ...
+            if ((h % LPR) == LPR - 1 || h == WM - 1) {
+              const int hh = h - (h % LPR) + cq;   // the hypothesis this lane holds
+              if (hh <= h && ((hm >> hh) & 1u)) sc[(long)hh * LCAP + p] = mine;
+            }
+          }
+        }
+      }
+    }
+    if (nchunk > 1) __syncthreads();  // rows is rebuilt by the next chunk
+  }
+  __syncthreads();
+
+  // ---- softmax over the L positions of each hypothesis (scores = dot / sqrt(dk)) ----
+  for (int h = wave; h < nh; h += 4) {
+    float *row = sc + (long)h * LCAP;
+    float m = -INFINITY;
+    for (int p = lane; p < L; p += 64) {
+      const float v = row[p] / scale;
+      row[p] = v;
+      m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int p = lane; p < L; p += 64) {
+      const float ex = expf(row[p] - m);
+      row[p] = ex;
+      l += ex;
+    }
+    l = wave_sum(l);
+    if (lane == 0) lsum[h] = l;
+  }
+  __syncthreads();
+
+  // ---- pass 2: context ----
+  float4 acc[WM];
+#pragma unroll
+  for (int h = 0; h < WM; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * PCH;
+    if (nchunk > 1) U = build(c0);
+    for (int j0 = g; j0 < U; j0 += NG * UNR) {
+      int e[UNR];
+      float4 v[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        e[i] = rows[min(j0 + i * NG, U - 1)];
+        v[i] = *reinterpret_cast<const float4 *>(row_ptr(e[i], c0, d) + 4 * cq);
+      }
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        if (j0 + i * NG < U) {
+          const int p = c0 + (e[i] & 255);
+          const unsigned hm = (unsigned)e[i] >> 12;
+#pragma unroll
+          for (int h = 0; h < WM; ++h) {
+            const float w = ((hm >> h) & 1u) ? sc[(long)min(h, W - 1) * LCAP + p] : 0.f;
+            acc[h].x = fmaf(w, v[i].x, acc[h].x);
+            acc[h].y = fmaf(w, v[i].y, acc[h].y);
+            acc[h].z = fmaf(w, v[i].z, acc[h].z);
+            acc[h].w = fmaf(w, v[i].w, acc[h].w);
+          }
+        }
+      }
+    }
+    if (nchunk > 1) __syncthreads();
+  }
+  // ---- reduce over the row groups: the GPR groups of a 16-lane row in registers
+  // (rotations keep a lane's 4 dims aligned), the rest through LDS ----
+#pragma unroll
+  for (int h = 0; h < WM; ++h) {
+    if (LPR == 4) {
+      acc[h].x += dpp_mov<SC_DPP_ROR4>(acc[h].x);
+      acc[h].y += dpp_mov<SC_DPP_ROR4>(acc[h].y);
+      acc[h].z += dpp_mov<SC_DPP_ROR4>(acc[h].z);
+      acc[h].w += dpp_mov<SC_DPP_ROR4>(acc[h].w);
+    }
+    acc[h].x += dpp_mov<SC_DPP_ROR8>(acc[h].x);
+    acc[h].y += dpp_mov<SC_DPP_ROR8>(acc[h].y);
+    acc[h].z += dpp_mov<SC_DPP_ROR8>(acc[h].z);
+    acc[h].w += dpp_mov<SC_DPP_ROR8>(acc[h].w);
+  }
+  __syncthreads();  // scores are dead: region A now holds the partial contexts
+  if ((g % GPR) == 0) {
+#pragma unroll
+    for (int h = 0; h < WM; ++h)
+      if (h < nh) *reinterpret_cast<float4 *>(red + ((long)((g / GPR) * W + h)) * DK + 4 * cq) = acc[h];
+  }
+  __syncthreads();
+  for (int e = tid; e < nh * DK; e += 256) {
+    const int h = e / DK, c = e % DK;
+    float o = 0.f;
+    for (int pp = 0; pp < NPART; ++pp) o += red[((long)pp * W + h) * DK + c];
+    sb.datt[((long)s * W + h) * d + head * DK + c] = o / lsum[h];
+  }
+}
+
+static size_t self_attn_shared_lds(const sc_search &sb, int dk) {
+  const size_t a = (size_t)sb.W * sb.LCAP, b = (size_t)16 * sb.W * dk;   // NPART == 16 for dk 16 and 32
+  return ((a > b ? a : b) + (size_t)128 * sb.W + sb.W + 8) * sizeof(float);
+}
+
+template <int DK>
+static void launch_self_attn_shared(const sc_search &sb, int layer, size_t lds, hipStream_t st) {
+  const dim3 grid(sb.H, sb.S);
+  if (sb.W <= 5) dec_self_attn_shared_kernel<DK, 5><<<grid, 256, lds, st>>>(sb, layer);
+  else if (sb.W <= 10) dec_self_attn_shared_kernel<DK, 10><<<grid, 256, lds, st>>>(sb, layer);
+  else dec_self_attn_shared_kernel<DK, 16><<<grid, 256, lds, st>>>(sb, layer);
+}
+
 extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
   const int dk = sb.d / sb.H;
   const int grid = cdiv(sb.S * sb.W * sb.H, 4);
   hipStream_t st = (hipStream_t)stream;
+  const char *mode = getenv("SC_SELF_ATTN");   // test / A-B hook: "legacy"
+  const bool legacy = mode && mode[0] == 'l';
+  const size_t lds = self_attn_shared_lds(sb, dk);
+  if (!legacy && sb.W <= 16 && (dk == 32 || dk == 16) && lds <= 64 * 1024) {
+    if (dk == 32) launch_self_attn_shared<32>(sb, layer, lds, st);
+    else launch_self_attn_shared<16>(sb, layer, lds, st);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+  }
   if (dk == 32) dec_self_attn_kernel<32><<<grid, 256, 0, st>>>(sb, layer);
   else if (dk == 16) dec_self_attn_kernel<16><<<grid, 256, 0, st>>>(sb, layer);
   else { sc_set_error("sc_dec_self_attn: unsupported head dim %d", dk); return SC_ERR_ARG; }
