@@ -38,6 +38,7 @@ extern "C" {
 /* flags of sc_gemm */
 #define SC_GEMM_RELU 1
 #define SC_GEMM_RESIDUAL 2
+#define SC_GEMM_LN_AT_CROWS 8 /* sc_gemm_ln: ln_out rows follow c_rows instead of 0..M-1 */
 #define SC_GEMM_NAIVE 4 /* force the scalar reference kernel (debugging) */
 
 /* beam_prune stop flags (one int32 per stream) */
@@ -94,6 +95,14 @@ typedef struct sc_search {
   float *xpart;           /* [S*W*H*nchunk][dk+2] cross-attention partials */
   const float *embed, *pe, *dec_norm_g, *dec_norm_b, *out_w, *out_b;
   const sc_dec_layer *layers; /* HOST array [n_layers] */
+  /* Ragged-batch compaction of the dense decoder kernels (GEMMs, row panels,
+   * LayerNorm): they process the first n_rows entries of rowmap, a permutation
+   * of the S*W hypothesis rows that lists the rows of the ACTIVE streams first
+   * (streams leave the lock-step decode loop at different steps).  rowmap NULL:
+   * all S*W rows in order.  n_rows is a launch parameter (one captured graph
+   * per bucket); rowmap is re-uploaded by the host together with ctrl. */
+  const int32_t *rowmap;
+  int32_t n_rows;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -134,10 +143,12 @@ int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W, c
  *   X[m] += A[m] . W1^T + b1;  XN[m] = LN(X[m]) (if XN);  Q[m] = LN(X[m]) . W2^T + b2 (if W2).
  * One workgroup owns 16 complete rows (D = 64, 128 or 256), so the LayerNorm
  * and the second projection need no second launch.  v_mfma_f32_16x16x4_f32.
- * A must be 16-byte aligned with lda % 4 == 0. */
+ * A must be 16-byte aligned with lda % 4 == 0.  rows (optional): the M rows of
+ * A / X / XN / Q to process (NULL: rows 0..M-1). */
 int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const float *b1, float *X, int ldx,
                     const float *ln_g, const float *ln_b, float ln_eps, float *XN, int ldn,
-                    const float *W2p, const float *b2, float *Q, int ldq, int M, int D, void *stream);
+                    const float *W2p, const float *b2, float *Q, int ldq, const int32_t *rows,
+                    int M, int D, void *stream);
 int sc_proj_ln_proj_supported(int D);
 /* W1p / W2p are the [D][D] Linear weights re-ordered ONCE into MFMA fragment
  * order so that every wave load is 1 KB contiguous:

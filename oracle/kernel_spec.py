@@ -291,52 +291,57 @@ class SpecBackend:
             sb.datt[rows] = torch.matmul(p, v).transpose(1, 2).reshape(nh, d)
 
     def gemm_ln(self, A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, ln_g, ln_b, ln_out,
-                relu=False, conv_f1=0, residual=False, eps=1e-12):
-        """sc_gemm_ln: GEMM (+bias/ReLU/residual) then LayerNorm of the produced rows."""
+                relu=False, conv_f1=0, residual=False, eps=1e-12, ln_at_crows=False):
+        """sc_gemm_ln: GEMM (+bias/ReLU/residual) then LayerNorm of the produced rows
+        (ln_at_crows: ln_out rows follow c_rows, SC_GEMM_LN_AT_CROWS)."""
         self.gemm(A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, relu=relu, conv_f1=conv_f1, residual=residual)
-        self.layernorm(C, c_rows, ln_out, None, M, ln_g, ln_b, eps)
+        self.layernorm(C, c_rows, ln_out, c_rows if ln_at_crows else None, M, ln_g, ln_b, eps)
 
-    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12):
+    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12, rows=None):
         """sc_proj_ln_proj: X += A.W1^T + b1; XN = LN(X) (optional output);
         Q = LN(X).W2^T + b2 (optional).  W1 / W2 arrive in the fragment order of
         sc_pack_panel_weight."""
         from speechcatcher_amd.weights import unpack_panel_weight
-        xn = XN if XN is not None else torch.empty(M, D, dtype=torch.float32, device=X.device)
-        self.gemm_ln(A, None, lda, unpack_panel_weight(W1), b1, X, None, ldx, M, D, D, ln_g, ln_b, xn,
-                     residual=True, eps=eps)
+        xn = XN if XN is not None else torch.empty_like(X)
+        self.gemm_ln(A, rows, lda, unpack_panel_weight(W1), b1, X, rows, ldx, M, D, D, ln_g, ln_b, xn,
+                     residual=True, eps=eps, ln_at_crows=rows is not None)
         if W2 is not None:
-            self.gemm(xn, None, D, unpack_panel_weight(W2), b2, Q, None, D, M, D, D)
+            self.gemm(xn, rows, D, unpack_panel_weight(W2), b2, Q, rows, D, M, D, D)
 
     PANEL_DIMS = (64, 128, 256)   # sc_proj_ln_proj_supported
 
     def decoder_layers(self, sb):
         """decoder_layer.py:60-132 x n_layers; leaves after_norm(x) in dxn
-        (every LayerNorm but the first is fused into the GEMM producing its input)."""
+        (every LayerNorm but the first is fused into the kernel producing its
+        input).  Dense ops run over the compacted rows sb.rowmap[:n_rows_step]
+        of the active streams (scasr.h: rowmap)."""
         w, cfg = sb.w, sb.cfg
-        d, Fd, n = cfg.d_model, cfg.ffn_dim, sb.S * sb.W
-        self.layernorm(sb.dx, None, sb.dxn, None, n, w.dec[0]["ln1_g"], w.dec[0]["ln1_b"])
+        d, Fd = cfg.d_model, cfg.ffn_dim
+        n = int(sb.n_rows_step)
+        rows = sb.rowmap[:n]
+        self.layernorm(sb.dx, rows, sb.dxn, rows, n, w.dec[0]["ln1_g"], w.dec[0]["ln1_b"])
         for li, lw in enumerate(w.dec):
             last = li + 1 == len(w.dec)
             ng = w.dec_norm_g if last else w.dec[li + 1]["ln1_g"]
             nb = w.dec_norm_b if last else w.dec[li + 1]["ln1_b"]
-            self.gemm(sb.dxn, None, d, lw["wqkv"], lw["bqkv"], sb.dqkv, None, 3 * d, n, 3 * d, d)
+            self.gemm(sb.dxn, rows, d, lw["wqkv"], lw["bqkv"], sb.dqkv, rows, 3 * d, n, 3 * d, d)
             self.dec_self_attn(sb, li)
             if d in self.PANEL_DIMS:
                 self.proj_ln_proj(sb.datt, d, lw["wo_p"], lw["bo"], sb.dx, d, lw["ln2_g"], lw["ln2_b"], None,
-                                  lw["wq_p"], lw["bq"], sb.dq, n, d)
+                                  lw["wq_p"], lw["bq"], sb.dq, n, d, rows=rows)
                 self.dec_cross_attn(sb, li)
                 self.proj_ln_proj(sb.datt, d, lw["wo2_p"], lw["bo2"], sb.dx, d, lw["ln3_g"], lw["ln3_b"], sb.dxn,
-                                  None, None, None, n, d)
+                                  None, None, None, n, d, rows=rows)
             else:
-                self.gemm_ln(sb.datt, None, d, lw["wo"], lw["bo"], sb.dx, None, d, n, d, d,
-                             lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True)
-                self.gemm(sb.dxn, None, d, lw["wq"], lw["bq"], sb.dq, None, d, n, d, d)
+                self.gemm_ln(sb.datt, rows, d, lw["wo"], lw["bo"], sb.dx, rows, d, n, d, d,
+                             lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True, ln_at_crows=True)
+                self.gemm(sb.dxn, rows, d, lw["wq"], lw["bq"], sb.dq, rows, d, n, d, d)
                 self.dec_cross_attn(sb, li)
-                self.gemm_ln(sb.datt, None, d, lw["wo2"], lw["bo2"], sb.dx, None, d, n, d, d,
-                             lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True)
-            self.gemm(sb.dxn, None, d, lw["w1"], lw["b1"], sb.dffh, None, Fd, n, Fd, d, relu=True)
-            self.gemm_ln(sb.dffh, None, Fd, lw["w2"], lw["b2"], sb.dx, None, d, n, d, Fd, ng, nb, sb.dxn,
-                         residual=True)
+                self.gemm_ln(sb.datt, rows, d, lw["wo2"], lw["bo2"], sb.dx, rows, d, n, d, d,
+                             lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True, ln_at_crows=True)
+            self.gemm(sb.dxn, rows, d, lw["w1"], lw["b1"], sb.dffh, rows, Fd, n, Fd, d, relu=True)
+            self.gemm_ln(sb.dffh, rows, Fd, lw["w2"], lw["b2"], sb.dx, rows, d, n, d, Fd, ng, nb, sb.dxn,
+                         residual=True, ln_at_crows=True)
 
     def logsoftmax_topk(self, sb):
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
@@ -502,10 +507,11 @@ class SpecBackend:
         """One beam-search step for every active stream
         (beam_search.py:701-758)."""
         w, cfg = sb.w, sb.cfg
-        n, d = sb.S * sb.W, cfg.d_model
+        n, d = int(sb.n_rows_step), cfg.d_model
+        rows = sb.rowmap[:n]
         self.dec_embed(sb)
         self.decoder_layers(sb)      # leaves after_norm(x) in dxn
-        self.gemm(sb.dxn, None, d, w.out_w, w.out_b, sb.logits, None, cfg.vocab_size, n, cfg.vocab_size, d)
+        self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
         self.logsoftmax_topk(sb)
         self.ctc_prefix_scan(sb)
         self.fuse_topw(sb)

@@ -44,7 +44,8 @@ class Search(C.Structure):
                              "sc_dec", "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv",
                              "datt", "dq", "dffh", "logits", "logp", "pre_ids", "psi", "psi_eos",
                              "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
-                             "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers")]
+                             "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
+        + [("n_rows", C.c_int32)]
     )
 
 
@@ -56,7 +57,7 @@ _SIGS = {
     "sc_gemm_ln": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, vp, vp, C.c_float, vp, C.c_int, vp]),
     "sc_proj_ln_proj": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_float, vp, C.c_int,
-                                  vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+                                  vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "sc_proj_ln_proj_supported": (C.c_int, [C.c_int]),
     "sc_pack_panel_weight": (C.c_int, [vp, C.c_int, vp, vp]),
     "sc_graph_capture_begin": (C.c_int, [vp]),

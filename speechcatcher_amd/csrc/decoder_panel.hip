@@ -38,6 +38,7 @@ struct PanelArgs {
   float *XN; int ldn;
   const float *W2p, *b2;
   float *Q; int ldq;
+  const int *rows;   // optional row table
   int M;
 };
 
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(NW * 64) void proj_ln_proj_kernel(PanelArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int m0 = blockIdx.x * 16;
+  // panel row i -> buffer row (clamped for loads; stores are masked by m0 + i < M)
+  auto brow = [&](int i) -> long {
+    const int m = min(m0 + i, p.M - 1);
+    return p.rows ? p.rows[m] : m;
+  };
 
   // ---- all global loads of GEMM 1 are issued before anything waits ----
   float4 a[KI][2], b[KI][NT][2];
@@ -97,16 +103,16 @@ __global__ __launch_bounds__(NW * 64) void proj_ln_proj_kernel(PanelArgs p) {
 #pragma unroll
   for (int q = 0; q < (NV + NTH - 1) / NTH; ++q) {
     const int e = threadIdx.x + q * NTH;
-    const int row = min(m0 + e / (D / 4), p.M - 1);  // clamped loads, masked stores
-    stage[q] = *reinterpret_cast<const float4 *>(p.A + (long)row * p.lda + 4 * (e % (D / 4)));
+    stage[q] = *reinterpret_cast<const float4 *>(p.A + brow(e / (D / 4)) * p.lda + 4 * (e % (D / 4)));
   }
   // residual rows in the row-wise layout (wave -> rows, lane -> columns lane+64e)
   float res[RW][EL];
+  long xrow[RW];
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
-    const int row = min(m0 + wave * RW + rr, p.M - 1);
+    xrow[rr] = brow(wave * RW + rr);
 #pragma unroll
-    for (int e = 0; e < EL; ++e) res[rr][e] = p.X[(long)row * p.ldx + lane + 64 * e];
+    for (int e = 0; e < EL; ++e) res[rr][e] = p.X[xrow[rr] * p.ldx + lane + 64 * e];
   }
   float gam[EL], bet[EL];
 #pragma unroll
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void proj_ln_proj_kernel(PanelArgs p) {
 #pragma unroll
     for (int e = 0; e < EL; ++e) {
       x[e] = res[rr][e] + PC[i * LD + lane + 64 * e];
-      if (live) p.X[(long)(m0 + i) * p.ldx + lane + 64 * e] = x[e];
+      if (live) p.X[xrow[rr] * p.ldx + lane + 64 * e] = x[e];
       s += x[e];
     }
     const float mean = wave_sum(s) / (float)D;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void proj_ln_proj_kernel(PanelArgs p) {
       const int c = lane + 64 * e;
       const float y = (x[e] - mean) * rstd * gam[e] + bet[e];
       PA[i * LD + c] = y;
-      if (p.XN && live) p.XN[(long)(m0 + i) * p.ldn + c] = y;
+      if (p.XN && live) p.XN[xrow[rr] * p.ldn + c] = y;
     }
   }
   if (!p.W2p) return;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void proj_ln_proj_kernel(PanelArgs p) {
     const int i = wave * RW + rr;
     if (m0 + i < p.M) {
 #pragma unroll
-      for (int e = 0; e < EL; ++e) p.Q[(long)(m0 + i) * p.ldq + lane + 64 * e] = PC[i * LD + lane + 64 * e];
+      for (int e = 0; e < EL; ++e) p.Q[xrow[rr] * p.ldq + lane + 64 * e] = PC[i * LD + lane + 64 * e];
     }
   }
 }
@@ -227,7 +233,8 @@ extern "C" int sc_proj_ln_proj_supported(int D) { return D == 256 || D == 128 ||
 
 extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const float *b1, float *X, int ldx,
                                const float *ln_g, const float *ln_b, float ln_eps, float *XN, int ldn,
-                               const float *W2p, const float *b2, float *Q, int ldq, int M, int D, void *stream) {
+                               const float *W2p, const float *b2, float *Q, int ldq, const int32_t *rows,
+                               int M, int D, void *stream) {
   SC_CHECK_ARG(A && W1p && X && ln_g && ln_b, "null operand");
   SC_CHECK_ARG(M > 0, "M must be positive");
   SC_CHECK_ARG(sc_proj_ln_proj_supported(D), "feature dim must be 64, 128 or 256");
@@ -235,7 +242,7 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const 
   SC_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W1p & 15) == 0 && ((uintptr_t)W2p & 15) == 0, "16-byte alignment");
   SC_CHECK_ARG(!W2p || Q, "second projection needs an output");
   SC_CHECK_ARG(XN || W2p, "nothing to produce after the LayerNorm");
-  PanelArgs p{A, lda, W1p, b1, X, ldx, ln_g, ln_b, ln_eps, XN, ldn, W2p, b2, Q, ldq, M};
+  PanelArgs p{A, lda, W1p, b1, X, ldx, ln_g, ln_b, ln_eps, XN, ldn, W2p, b2, Q, ldq, rows, M};
   hipStream_t st = (hipStream_t)stream;
   const int grid = cdiv(M, 16);
   if (D == 256) proj_ln_proj_kernel<256, 8, 2><<<grid, 512, 0, st>>>(p);

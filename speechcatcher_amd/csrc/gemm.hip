@@ -406,7 +406,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(GemmArgs g, 
       o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
       o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
       o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-      reinterpret_cast<float4 *>(ln_out + (long)m * ld_ln)[c] = o;
+      const long lrow = (g.flags & SC_GEMM_LN_AT_CROWS) ? crow : m;
+      if (lrow >= 0) reinterpret_cast<float4 *>(ln_out + lrow * ld_ln)[c] = o;
     }
   }
 }
@@ -693,5 +694,6 @@ extern "C" int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const 
     gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
   }
   SC_CHECK_LAUNCH();
-  return sc_layernorm(C, c_rows, ldc, ln_out, nullptr, ld_ln, M, N, ln_g, ln_b, ln_eps, stream);
+  return sc_layernorm(C, c_rows, ldc, ln_out, (flags & SC_GEMM_LN_AT_CROWS) ? c_rows : nullptr, ld_ln, M, N, ln_g,
+                      ln_b, ln_eps, stream);
 }

@@ -140,22 +140,6 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li
   }
 }
 
-// ---------------------------------------------------------------------------
-// decoder self-attention, shared-prefix form: one workgroup per (stream, head)
-// serves ALL hypotheses of the stream.  Hypotheses of a beam share almost all
-// of their history (measured on the XL fixture: 1.2 distinct K/V rows per
-// position for 10 hypotheses), so the kernel first compacts, per 128-position
-// chunk, the list of DISTINCT (position, slot) rows referenced through the
-// ancestor table together with the bit set of hypotheses that use each row,
-// then reads every distinct row exactly once:
-//   pass 1: DK/4 lanes per row (16 B each, full-line coalesced), partial dot
-//           products against the query of every hypothesis, scores -> LDS;
-//   softmax per hypothesis in LDS;
-//   pass 2: same row list, context accumulators per hypothesis in registers;
-//   reduce over row groups (shuffles, then LDS across the 4 waves).
-// The per-(stream, hyp, head) kernel above stays as the generic fallback
-// (beam > 16 or LDS budget exceeded).
-// ---------------------------------------------------------------------------
 // DPP lane permutations (no LDS round trip, unlike ds_bpermute-based __shfl)
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -176,228 +160,253 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <int DK, int WM>
-__global__ __launch_bounds__(256) void dec_self_attn_shared_kernel(sc_search sb, int li) {
+// ---------------------------------------------------------------------------
+// Single-pass ("flash decoding") attention of the decoder, shared by the self-
+// and the cross-attention: one workgroup per (stream, head) serves ALL
+// hypotheses of the stream.
+//   * rows: SELF  - the DISTINCT (position, slot) K/V rows referenced through
+//                   the ancestor table (hypotheses of a beam share almost all
+//                   of their history: 1.2 distinct rows per position for 10
+//                   hypotheses on the XL fixture), compacted per 128-position
+//                   chunk into an LDS list with the bit set of hypotheses
+//                   using each row;
+//           CROSS - the T encoder frames, used by every hypothesis.
+//   * DK/4 lanes per row load 16 B each of K and of V (full-line coalesced; a
+//     per-lane row walk costs one cache-line lookup per lane and was the
+//     limiter of the per-hypothesis kernels), UNR rows in flight per group;
+//   * the group's lanes reduce the 4-dim partial dot products with DPP adds,
+//     every lane then runs the online softmax of the hypothesis in registers
+//     (running max / sum per hypothesis, its own 4 dims of the context);
+//   * partial states of the row groups are merged with DPP (inside a 16-lane
+//     row) and through LDS.
+// Scores use q/sqrt(dk) . k and exp2-based __expf: differences to the reference's
+// softmax(q.k/sqrt(dk)) are rounding-level (parity tests: 2e-4).
+// ---------------------------------------------------------------------------
+struct AttnState {
+  float m, l;
+  float4 a;
+};
+
+template <int CTRL>
+__device__ __forceinline__ void attn_merge_dpp(AttnState &st) {
+  const float pm = dpp_mov<CTRL>(st.m), pl = dpp_mov<CTRL>(st.l);
+  const float px = dpp_mov<CTRL>(st.a.x), py = dpp_mov<CTRL>(st.a.y);
+  const float pz = dpp_mov<CTRL>(st.a.z), pw = dpp_mov<CTRL>(st.a.w);
+  const float M = fmaxf(st.m, pm);
+  const float ca = (st.m == -INFINITY) ? 0.f : __expf(st.m - M);
+  const float cb = (pm == -INFINITY) ? 0.f : __expf(pm - M);
+  st.m = M;
+  st.l = st.l * ca + pl * cb;
+  st.a.x = st.a.x * ca + px * cb;
+  st.a.y = st.a.y * ca + py * cb;
+  st.a.z = st.a.z * ca + pz * cb;
+  st.a.w = st.a.w * ca + pw * cb;
+}
+
+template <int DK, int WM, bool SELF>
+__global__ __launch_bounds__(256, WM <= 10 ? 4 : 2) void dec_attn_flash_kernel(sc_search sb, int li) {
   constexpr int LPR = DK / 4;    // lanes per K/V row
   constexpr int NG = 256 / LPR;  // row groups per workgroup
-  constexpr int PCH = 128;       // positions per chunk
-  constexpr int UNR = 4;         // rows in flight per group
-  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row (reduced in registers)
+  constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
+  constexpr int UNR = WM <= 5 ? 4 : 2;  // rows in flight per group (register budget: 128 VGPRs)
+  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
   constexpr int NPART = NG / GPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int head = blockIdx.x, s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
-  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
   const int W = sb.W, d = sb.d, LCAP = sb.LCAP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tid / LPR, cq = tid % LPR;
-  // LDS: region A = scores [W][LCAP], re-used for the partial contexts
-  // [NPART][W][DK] at the end; then rows[PCH*W], lsum[W], wtot[4]
-  const int regA = max(W * LCAP, NPART * W * DK);
-  float *sc = smem;
-  float *red = smem;
-  int *rows = (int *)(smem + regA);
-  float *lsum = (float *)(rows + PCH * W);
-  int *wtot = (int *)(lsum + W);
+  // LDS: partial states red_m/red_l [NPART][W], red_a [NPART][W][DK]; rows[PCH*W]; wtot[4]
+  float *red_m = smem;
+  float *red_l = red_m + NPART * W;
+  float *red_a = red_l + NPART * W;
+  int *rows = (int *)(red_a + NPART * W * DK);
+  int *wtot = rows + (SELF ? PCH * W : 0);
+  float *qs = (float *)(wtot + 4);   // [W][DK] queries / sqrt(dk)
 
-  const float *qkv = sb.dqkv + (long)s * W * 3 * d + head * DK;  // hypothesis h at + h*3d
+  // SELF: q|k|v of the new token in dqkv (hypothesis h at + h*3d); CROSS: q in dq
+  const float *qbase = SELF ? sb.dqkv + (long)s * W * 3 * d + head * DK : sb.dq + (long)s * W * d + head * DK;
+  const int qld = SELF ? 3 * d : d;
   float *skv = sb.skv + ((long)s * sb.n_layers + li) * LCAP * W * 2 * d + head * DK;
-  // append this token's K|V rows at (position L-1, slot h); this launch reads
-  // them from dqkv, later steps from the cache
-  for (int e = tid; e < nh * DK; e += 256) {
-    const int h = e / DK, c = e % DK;
-    float *dst = skv + ((long)(L - 1) * W + h) * 2 * d;
-    dst[c] = qkv[(long)h * 3 * d + d + c];
-    dst[d + c] = qkv[(long)h * 3 * d + 2 * d + c];
+  const float *ckv = sb.ckv + ((long)s * sb.n_layers + li) * sb.TCAP * 2 * d + head * DK;
+  if (SELF) {
+    // append this token's K|V rows at (position L-1, slot h); this launch reads
+    // them from dqkv, later steps from the cache
+    for (int e = tid; e < nh * DK; e += 256) {
+      const int h = e / DK, c = e % DK;
+      float *dst = skv + ((long)(L - 1) * W + h) * 2 * d;
+      dst[c] = qbase[(long)h * 3 * d + d + c];
+      dst[d + c] = qbase[(long)h * 3 * d + 2 * d + c];
+    }
   }
-  // queries of all hypotheses (rows >= nh: a valid row, results never used)
-  float4 q[WM];
-#pragma unroll
-  for (int h = 0; h < WM; ++h)
-    q[h] = *reinterpret_cast<const float4 *>(qkv + (long)min(h, nh - 1) * 3 * d + 4 * cq);
-  const int *anc = ANC(cur, s);
+  // queries of all hypotheses, pre-divided by sqrt(dk) (rows >= nh: a valid row, never used)
   const float scale = sqrtf((float)DK);
-  const int nchunk = cdiv(L, PCH);
-
-  // distinct (position, slot) rows of positions [c0, c0+PCH): entry =
-  // local position | slot << 8 | hypothesis bit set << 12.  Returns the count.
-  auto build = [&](int c0) -> int {
-    for (int e = tid; e < PCH * W; e += 256) rows[e] = 0;
-    const int p = c0 + tid;
-    const bool live = tid < PCH && p < L;
-    int sl[WM];
-#pragma unroll
-    for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? p : 0) * W + min(h, nh - 1)];
-    unsigned mask = 0;
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      if (p == L - 1) sl[h] = h;
-      if (h < nh) mask |= 1u << sl[h];
-    }
-    const int cnt = live ? __popc(mask) : 0;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();   // also orders the zero fill before the ORs
-    const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
-    const int U = wtot[0] + wtot[1];
-    if (live) {
-#pragma unroll
-      for (int h = 0; h < WM; ++h) {
-        if (h < nh) {
-          const int rank = __popc(mask & ((1u << sl[h]) - 1u));
-          atomicOr(&rows[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
-        }
-      }
-    }
-    __syncthreads();
-    return U;
-  };
-  auto row_ptr = [&](int e, int c0, int vofs) -> const float * {
-    const int p = c0 + (e & 255), u = (e >> 8) & 15;
-    return (p == L - 1) ? qkv + (long)u * 3 * d + d + vofs : skv + ((long)p * W + u) * 2 * d + vofs;
-  };
-
-  // ---- pass 1: raw dot products q.k of every (hypothesis, position) ----
-  int U = 0;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int c0 = ch * PCH;
-    U = build(c0);
-    for (int j0 = g; j0 < U; j0 += NG * UNR) {
-      int e[UNR];
-      float4 k[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        e[i] = rows[min(j0 + i * NG, U - 1)];
-        k[i] = *reinterpret_cast<const float4 *>(row_ptr(e[i], c0, 0) + 4 * cq);
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        if (j0 + i * NG < U) {   // uniform inside a row group
-          const int p = c0 + (e[i] & 255);
-          const unsigned hm = (unsigned)e[i] >> 12;
-          float mine = 0.f;
-#pragma unroll
-          for (int h = 0; h < WM; ++h) {
-            float part = q[h].x * k[i].x;
-            part = fmaf(q[h].y, k[i].y, part);
-            part = fmaf(q[h].z, k[i].z, part);
-            part = fmaf(q[h].w, k[i].w, part);
-            part = group_sum<LPR>(part);
-            if (cq == (h % LPR)) mine = part;   // lane cq keeps hypotheses h = cq, cq + LPR, ...
-            if ((h % LPR) == LPR - 1 || h == WM - 1) {
-              const int hh = h - (h % LPR) + cq;   // the hypothesis this lane holds
-              if (hh <= h && ((hm >> hh) & 1u)) sc[(long)hh * LCAP + p] = mine;
-            }
-          }
-        }
-      }
-    }
-    if (nchunk > 1) __syncthreads();  // rows is rebuilt by the next chunk
+  // (kept in LDS, not registers: the kernel must stay under 128 VGPRs so that all
+  // S*H workgroups of a 128-stream batch are resident at once)
+  for (int e = tid; e < WM * DK; e += 256) {
+    const int h = e / DK, c = e % DK;
+    qs[e] = qbase[(long)min(h, nh - 1) * qld + c] / scale;
   }
-  __syncthreads();
-
-  // ---- softmax over the L positions of each hypothesis (scores = dot / sqrt(dk)) ----
-  for (int h = wave; h < nh; h += 4) {
-    float *row = sc + (long)h * LCAP;
-    float m = -INFINITY;
-    for (int p = lane; p < L; p += 64) {
-      const float v = row[p] / scale;
-      row[p] = v;
-      m = fmaxf(m, v);
-    }
-    m = wave_max(m);
-    float l = 0.f;
-    for (int p = lane; p < L; p += 64) {
-      const float ex = expf(row[p] - m);
-      row[p] = ex;
-      l += ex;
-    }
-    l = wave_sum(l);
-    if (lane == 0) lsum[h] = l;
-  }
-  __syncthreads();
-
-  // ---- pass 2: context ----
-  float4 acc[WM];
-#pragma unroll
-  for (int h = 0; h < WM; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int c0 = ch * PCH;
-    if (nchunk > 1) U = build(c0);
-    for (int j0 = g; j0 < U; j0 += NG * UNR) {
-      int e[UNR];
-      float4 v[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        e[i] = rows[min(j0 + i * NG, U - 1)];
-        v[i] = *reinterpret_cast<const float4 *>(row_ptr(e[i], c0, d) + 4 * cq);
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        if (j0 + i * NG < U) {
-          const int p = c0 + (e[i] & 255);
-          const unsigned hm = (unsigned)e[i] >> 12;
-#pragma unroll
-          for (int h = 0; h < WM; ++h) {
-            const float w = ((hm >> h) & 1u) ? sc[(long)min(h, W - 1) * LCAP + p] : 0.f;
-            acc[h].x = fmaf(w, v[i].x, acc[h].x);
-            acc[h].y = fmaf(w, v[i].y, acc[h].y);
-            acc[h].z = fmaf(w, v[i].z, acc[h].z);
-            acc[h].w = fmaf(w, v[i].w, acc[h].w);
-          }
-        }
-      }
-    }
-    if (nchunk > 1) __syncthreads();
-  }
-  // ---- reduce over the row groups: the GPR groups of a 16-lane row in registers
-  // (rotations keep a lane's 4 dims aligned), the rest through LDS ----
+  AttnState st[WM];
 #pragma unroll
   for (int h = 0; h < WM; ++h) {
-    if (LPR == 4) {
-      acc[h].x += dpp_mov<SC_DPP_ROR4>(acc[h].x);
-      acc[h].y += dpp_mov<SC_DPP_ROR4>(acc[h].y);
-      acc[h].z += dpp_mov<SC_DPP_ROR4>(acc[h].z);
-      acc[h].w += dpp_mov<SC_DPP_ROR4>(acc[h].w);
-    }
-    acc[h].x += dpp_mov<SC_DPP_ROR8>(acc[h].x);
-    acc[h].y += dpp_mov<SC_DPP_ROR8>(acc[h].y);
-    acc[h].z += dpp_mov<SC_DPP_ROR8>(acc[h].z);
-    acc[h].w += dpp_mov<SC_DPP_ROR8>(acc[h].w);
+    st[h].m = -INFINITY;
+    st[h].l = 0.f;
+    st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();  // scores are dead: region A now holds the partial contexts
-  if ((g % GPR) == 0) {
+
+  auto process = [&](const float4 &k, const float4 &v, unsigned hm) {
 #pragma unroll
-    for (int h = 0; h < WM; ++h)
-      if (h < nh) *reinterpret_cast<float4 *>(red + ((long)((g / GPR) * W + h)) * DK + 4 * cq) = acc[h];
+    for (int h = 0; h < WM; ++h) {
+      const float4 qh = *reinterpret_cast<const float4 *>(qs + h * DK + 4 * cq);
+      float sdot = qh.x * k.x;
+      sdot = fmaf(qh.y, k.y, sdot);
+      sdot = fmaf(qh.z, k.z, sdot);
+      sdot = fmaf(qh.w, k.w, sdot);
+      sdot = group_sum<LPR>(sdot);
+      if ((hm >> h) & 1u) {
+        if (sdot > st[h].m) {   // rescale only when the running max moves
+          const float corr = __expf(st[h].m - sdot);   // exp(-inf) = 0 on the first row
+          st[h].l *= corr;
+          st[h].a.x *= corr; st[h].a.y *= corr; st[h].a.z *= corr; st[h].a.w *= corr;
+          st[h].m = sdot;
+        }
+        const float pe = __expf(sdot - st[h].m);
+        st[h].l += pe;
+        st[h].a.x = fmaf(pe, v.x, st[h].a.x);
+        st[h].a.y = fmaf(pe, v.y, st[h].a.y);
+        st[h].a.z = fmaf(pe, v.z, st[h].a.z);
+        st[h].a.w = fmaf(pe, v.w, st[h].a.w);
+      }
+    }
+  };
+
+  if (SELF) {
+    const int *anc = ANC(cur, s);
+    const int nchunk = cdiv(L, PCH);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int c0 = ch * PCH;
+      // ---- distinct (position, slot) rows of positions [c0, c0+PCH): entry =
+      // local position | slot << 8 | hypothesis bit set << 12 ----
+      for (int e = tid; e < PCH * W; e += 256) rows[e] = 0;
+      const int p = c0 + tid;
+      const bool live = tid < PCH && p < L;
+      int sl[WM];
+#pragma unroll
+      for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? p : 0) * W + min(h, nh - 1)];
+      unsigned mask = 0;
+#pragma unroll
+      for (int h = 0; h < WM; ++h) {
+        if (p == L - 1) sl[h] = h;
+        if (h < nh) mask |= 1u << sl[h];
+      }
+      const int cnt = live ? __popc(mask) : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();   // also orders the zero fill before the ORs
+      const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
+      const int U = wtot[0] + wtot[1];
+      if (live) {
+#pragma unroll
+        for (int h = 0; h < WM; ++h) {
+          if (h < nh) {
+            const int rank = __popc(mask & ((1u << sl[h]) - 1u));
+            atomicOr(&rows[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
+          }
+        }
+      }
+      __syncthreads();
+      // ---- walk the rows ----
+      for (int j0 = g; j0 < U; j0 += NG * UNR) {
+        int e[UNR];
+        float4 k[UNR], v[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+          e[i] = rows[min(j0 + i * NG, U - 1)];
+          const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
+          const float *kp = (pp == L - 1) ? qbase + (long)u * 3 * d + d : skv + ((long)pp * W + u) * 2 * d;
+          k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
+          v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i)
+          if (j0 + i * NG < U) process(k[i], v[i], (unsigned)e[i] >> 12);   // uniform inside a row group
+      }
+      if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+    }
+  } else {
+    __syncthreads();   // qs
+    const unsigned all = (1u << nh) - 1u;
+    for (int j0 = g; j0 < T; j0 += NG * UNR) {
+      float4 k[UNR], v[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        const float *kp = ckv + (long)min(j0 + i * NG, T - 1) * 2 * d;
+        k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
+        v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
+      }
+#pragma unroll
+      for (int i = 0; i < UNR; ++i)
+        if (j0 + i * NG < T) process(k[i], v[i], all);
+    }
+  }
+
+  // ---- merge the row groups: inside a 16-lane DPP row in registers, then LDS ----
+#pragma unroll
+  for (int h = 0; h < WM; ++h) {
+    if (LPR == 4) attn_merge_dpp<SC_DPP_ROR4>(st[h]);
+    attn_merge_dpp<SC_DPP_ROR8>(st[h]);
+  }
+  if ((g % GPR) == 0) {
+    const int pp = g / GPR;
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      if (h < nh) {
+        if (cq == 0) {
+          red_m[pp * W + h] = st[h].m;
+          red_l[pp * W + h] = st[h].l;
+        }
+        *reinterpret_cast<float4 *>(red_a + ((long)(pp * W + h)) * DK + 4 * cq) = st[h].a;
+      }
+    }
   }
   __syncthreads();
   for (int e = tid; e < nh * DK; e += 256) {
     const int h = e / DK, c = e % DK;
-    float o = 0.f;
-    for (int pp = 0; pp < NPART; ++pp) o += red[((long)pp * W + h) * DK + c];
-    sb.datt[((long)s * W + h) * d + head * DK + c] = o / lsum[h];
+    float M = -INFINITY;
+    for (int pp = 0; pp < NPART; ++pp) M = fmaxf(M, red_m[pp * W + h]);
+    float num = 0.f, den = 0.f;
+    for (int pp = 0; pp < NPART; ++pp) {
+      const float mp = red_m[pp * W + h];
+      const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
+      num = fmaf(w, red_a[((long)(pp * W + h)) * DK + c], num);
+      den = fmaf(w, red_l[pp * W + h], den);
+    }
+    sb.datt[((long)s * W + h) * d + head * DK + c] = num / den;
   }
 }
 
-static size_t self_attn_shared_lds(const sc_search &sb, int dk) {
-  const size_t a = (size_t)sb.W * sb.LCAP, b = (size_t)16 * sb.W * dk;   // NPART == 16 for dk 16 and 32
-  return ((a > b ? a : b) + (size_t)128 * sb.W + sb.W + 8) * sizeof(float);
+static size_t attn_flash_lds(const sc_search &sb, int dk, bool self) {
+  const size_t npart = 16;   // NG / GPR for dk 16 and 32
+  return (npart * sb.W * (dk + 2) + (self ? (size_t)128 * sb.W : 0) + 8 + (size_t)16 * dk) * sizeof(float);
 }
 
-template <int DK>
-static void launch_self_attn_shared(const sc_search &sb, int layer, size_t lds, hipStream_t st) {
+template <int DK, bool SELF>
+static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
   const dim3 grid(sb.H, sb.S);
-  if (sb.W <= 5) dec_self_attn_shared_kernel<DK, 5><<<grid, 256, lds, st>>>(sb, layer);
-  else if (sb.W <= 10) dec_self_attn_shared_kernel<DK, 10><<<grid, 256, lds, st>>>(sb, layer);
-  else dec_self_attn_shared_kernel<DK, 16><<<grid, 256, lds, st>>>(sb, layer);
+  const size_t lds = attn_flash_lds(sb, DK, SELF);
+  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF><<<grid, 256, lds, st>>>(sb, layer);
+  else if (sb.W <= 10) dec_attn_flash_kernel<DK, 10, SELF><<<grid, 256, lds, st>>>(sb, layer);
+  else dec_attn_flash_kernel<DK, 16, SELF><<<grid, 256, lds, st>>>(sb, layer);
 }
 
 extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
@@ -408,10 +417,9 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const char *mode = getenv("SC_SELF_ATTN");   // test / A-B hook: "legacy"
   const bool legacy = mode && mode[0] == 'l';
-  const size_t lds = self_attn_shared_lds(sb, dk);
-  if (!legacy && sb.W <= 16 && (dk == 32 || dk == 16) && lds <= 64 * 1024) {
-    if (dk == 32) launch_self_attn_shared<32>(sb, layer, lds, st);
-    else launch_self_attn_shared<16>(sb, layer, lds, st);
+  if (!legacy && sb.W <= 16 && (dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024) {
+    if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
+    else launch_attn_flash<16, true>(sb, layer, st);
     SC_CHECK_LAUNCH();
     return SC_OK;
   }
@@ -561,6 +569,14 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
     if (e[0] == 's' && e[1] == 'e') seq = true;
     else if (e[0] == 's' && e[1] == 'p') seq = false;
   }
+  const char *xm = getenv("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
+  if (seq && !(xm && xm[0] == 'l') && sb.W <= 16 && (dk == 32 || dk == 16)) {
+    // one workgroup per (stream, head), single pass, coalesced K/V rows
+    if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
+    else launch_attn_flash<16, false>(sb, layer, st);
+    SC_CHECK_LAUNCH();
+    return SC_OK;
+  }
   dim3 grid(seq ? 1 : cdiv(sb.TCAP, 256), sb.H, sb.S);
   size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 4 * sb.W + sb.W * dk) * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "beam too wide for the cross-attention LDS tile");
@@ -588,7 +604,12 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
 extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp && sbp->layers, "null");
   const sc_search &sb = *sbp;
-  const int n = sb.S * sb.W, d = sb.d, F = sb.F;
+  const int d = sb.d, F = sb.F;
+  // dense kernels run over the compacted rows of the active streams (scasr.h: rowmap)
+  const int32_t *rows = sb.rowmap;
+  const int n = rows ? sb.n_rows : sb.S * sb.W;
+  SC_CHECK_ARG(n > 0 && n <= sb.S * sb.W, "n_rows out of range");
+  const int lnf = rows ? SC_GEMM_LN_AT_CROWS : 0;
   // SC_DEC_PANEL=0 keeps the three-launch form (GEMM, reduce+LN, GEMM) for A/B runs
   const char *pe = getenv("SC_DEC_PANEL");
   const bool panel_env = !(pe && atoi(pe) == 0);
@@ -596,33 +617,33 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
-  // fused into the GEMM that produces its input (sc_gemm_ln).
-  SC_TRY(sc_layernorm(sb.dx, nullptr, d, sb.dxn, nullptr, d, n, d, sb.layers[0].ln1_g, sb.layers[0].ln1_b, sb.ln_eps, stream));
+  // fused into the kernel that produces its input.
+  SC_TRY(sc_layernorm(sb.dx, rows, d, sb.dxn, rows, d, n, d, sb.layers[0].ln1_g, sb.layers[0].ln1_b, sb.ln_eps, stream));
   for (int li = 0; li < sb.n_layers; ++li) {
     const sc_dec_layer &w = sb.layers[li];
     const bool last = li + 1 == sb.n_layers;
     const float *ng = last ? sb.dec_norm_g : sb.layers[li + 1].ln1_g;
     const float *nb = last ? sb.dec_norm_b : sb.layers[li + 1].ln1_b;
-    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wqkv, w.bqkv, sb.dqkv, nullptr, 3 * d, n, 3 * d, d, 0, 0, stream));
+    SC_TRY(sc_gemm(sb.dxn, rows, d, w.wqkv, w.bqkv, sb.dqkv, rows, 3 * d, n, 3 * d, d, 0, 0, stream));
     SC_TRY(sc_dec_self_attn(sbp, li, stream));
     if (panel) {
       // out-projection + residual + norm2 + cross-attention query in one row-panel kernel
       SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo_p, w.bo, sb.dx, d, w.ln2_g, w.ln2_b, sb.ln_eps, nullptr, d,
-                             w.wq_p, w.bq, sb.dq, d, n, d, stream));
+                             w.wq_p, w.bq, sb.dq, d, rows, n, d, stream));
       SC_TRY(sc_dec_cross_attn(sbp, li, stream));
       SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo2_p, w.bo2, sb.dx, d, w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d,
-                             nullptr, nullptr, nullptr, d, n, d, stream));
+                             nullptr, nullptr, nullptr, d, rows, n, d, stream));
     } else {
-      SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo, w.bo, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo, w.bo, sb.dx, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
                         w.ln2_g, w.ln2_b, sb.ln_eps, sb.dxn, d, stream));
-      SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.wq, w.bq, sb.dq, nullptr, d, n, d, d, 0, 0, stream));
+      SC_TRY(sc_gemm(sb.dxn, rows, d, w.wq, w.bq, sb.dq, rows, d, n, d, d, 0, 0, stream));
       SC_TRY(sc_dec_cross_attn(sbp, li, stream));
-      SC_TRY(sc_gemm_ln(sb.datt, nullptr, d, w.wo2, w.bo2, sb.dx, nullptr, d, n, d, d, SC_GEMM_RESIDUAL, 0,
+      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo2, w.bo2, sb.dx, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
                         w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
     }
-    SC_TRY(sc_gemm(sb.dxn, nullptr, d, w.w1, w.b1, sb.dffh, nullptr, F, n, F, d, SC_GEMM_RELU, 0, stream));
+    SC_TRY(sc_gemm(sb.dxn, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));
     // FFN2 + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
-    SC_TRY(sc_gemm_ln(sb.dffh, nullptr, F, w.w2, w.b2, sb.dx, nullptr, d, n, d, F, SC_GEMM_RESIDUAL, 0,
+    SC_TRY(sc_gemm_ln(sb.dffh, rows, F, w.w2, w.b2, sb.dx, rows, d, n, d, F, SC_GEMM_RESIDUAL | lnf, 0,
                       ng, nb, sb.ln_eps, sb.dxn, d, stream));
   }
   return SC_OK;
@@ -994,11 +1015,11 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
-  const int n = sb.S * sb.W;
+  const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
   SC_TRY(sc_dec_embed(sbp, stream));
   SC_TRY(sc_decoder_layers(sbp, stream));  // leaves after_norm(x) in dxn
-  SC_TRY(sc_gemm(sb.dxn, nullptr, sb.d, sb.out_w, sb.out_b, sb.logits, nullptr, sb.V, n, sb.V, sb.d, 0, 0, stream));
+  SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
   SC_TRY(sc_ctc_prefix_scan(sbp, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));

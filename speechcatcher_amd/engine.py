@@ -153,12 +153,25 @@ class StreamBatch:
         self.ctc_r = z(2, S, self.TCAP, 2, W)
         self.ctc_s = z(2, S, W)
         self.ctc_rnew = z(S, self.TCAP, 2, W * K)
-        self.ctrl = z(S, 8, dtype=i32)
+        # ctrl rows and the compaction row map share one buffer: one upload per step
+        self._ctrlmap = z(S * 8 + S * W, dtype=i32)
+        self.ctrl = self._ctrlmap[: S * 8].view(S, 8)
+        self.rowmap = self._ctrlmap[S * 8:]
+        self.rowmap.copy_(torch.arange(S * W, dtype=i32))
+        self.n_rows_step = S * W
+        self._decode_prepared = False
         self.flags = z(S, dtype=i32)
         # pinned host mirrors: the per-step ctrl upload / flag read-back are the
         # only host<->device traffic of the decode loop
         pin = dev.type == "cuda"
-        self._ctrl_host = torch.zeros(S, 8, dtype=i32, pin_memory=pin)
+        self._ctrlmap_host = torch.zeros(S * 8 + S * W, dtype=i32, pin_memory=pin)
+        self._ctrl_host = self._ctrlmap_host[: S * 8].view(S, 8)
+        self._rowmap_np = self._ctrlmap_host[S * 8:].numpy()
+        self._rowmap_np[:] = np.arange(S * W, dtype=np.int32)
+        self._hyp_ofs = np.arange(W, dtype=np.int64)
+        self._stream_ids = np.arange(S, dtype=np.int64)
+        self._rowmap_identity = np.arange(S * W, dtype=np.int32)
+        self.row_bucket = max(1, S // 16)        # compaction granularity in streams
         self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
         self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
         self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
@@ -210,10 +223,23 @@ class StreamBatch:
     def _upload_ctrl(self):
         """ctrl rows -> device (async from pinned memory when on a GPU; the
         kernels that read them are ordered behind the copy on the same stream)."""
-        if self.stream is not None:
-            self.ctrl.copy_(self._ctrl_host, non_blocking=True)
+        self._ctrlmap.copy_(self._ctrlmap_host, non_blocking=self.stream is not None)
+
+    def _set_rowmap(self, active_streams: np.ndarray):
+        """Dense decoder kernels process the first n_rows_step entries of rowmap:
+        the hypothesis rows of the streams still in the step loop, rounded up to
+        a bucket of row_bucket streams (one captured graph per bucket) with rows
+        of idle streams (their activations are scratch until their next step)."""
+        S, W = self.S, self.W
+        na = int(active_streams.size)
+        nb = min(S, -(-na // self.row_bucket) * self.row_bucket)
+        if na == S:
+            self._rowmap_np[:] = self._rowmap_identity
         else:
-            self.ctrl.copy_(self._ctrl_host)
+            idle = np.setdiff1d(self._stream_ids, active_streams, assume_unique=True)
+            order = np.concatenate([active_streams, idle])
+            self._rowmap_np[:] = (order[:, None] * W + self._hyp_ofs[None, :]).reshape(-1)
+        self.n_rows_step = nb * W
 
     def _read_flags(self) -> np.ndarray:
         if self.stream is not None:
@@ -745,6 +771,13 @@ class StreamBatch:
             for li in range(Ld):
                 be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
                         self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+        if not self._decode_prepared:
+            # one-time: capture the per-bucket decode graphs while every stream is idle on the device
+            self._decode_prepared = True
+            if hasattr(be, "prepare_decode"):
+                self._ctrl_np[:] = 0
+                self._upload_ctrl()
+                be.prepare_decode(self)
         ctrl0 = self._ctrl_np0             # (every earlier use was followed by a flag read-back sync)
         ctrl0[:] = 0
         ctrl0[ids] = np.stack([np.ones(n, np.int64), cur, fin, T, L, nhyp, has, told], 1)
@@ -772,6 +805,7 @@ class StreamBatch:
             if (L[act] + 1 > self.LCAP).any():
                 raise EngineError("max_tokens exceeded")
             ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, zeros_n], 1)
+            self._set_rowmap(ids[act])
             self._upload_ctrl()
             self.stats["dec_steps"] += 1
             t_st = time.perf_counter()

@@ -65,15 +65,15 @@ class HipBackend:
                                    M, N, K, flags, conv_f1, self._stream()), "sc_gemm")
 
     def gemm_ln(self, A, a_rows, lda, W, bias, Cm, c_rows, ldc, M, N, K, ln_g, ln_b, ln_out,
-                relu=False, conv_f1=0, residual=False, eps=1e-12):
-        flags = (1 if relu else 0) | (2 if residual else 0)
+                relu=False, conv_f1=0, residual=False, eps=1e-12, ln_at_crows=False):
+        flags = (1 if relu else 0) | (2 if residual else 0) | (8 if ln_at_crows else 0)
         self._chk(self.lib.sc_gemm_ln(_p(A), _p(a_rows), lda, _p(W), _p(bias), _p(Cm), _p(c_rows), ldc,
                                       M, N, K, flags, conv_f1, _p(ln_g), _p(ln_b), eps, _p(ln_out),
                                       ln_out.shape[-1], self._stream()), "sc_gemm_ln")
 
-    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12):
+    def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12, rows=None):
         self._chk(self.lib.sc_proj_ln_proj(_p(A), lda, _p(W1), _p(b1), _p(X), ldx, _p(ln_g), _p(ln_b), eps,
-                                           _p(XN), D, _p(W2), _p(b2), _p(Q), D, M, D, self._stream()),
+                                           _p(XN), D, _p(W2), _p(b2), _p(Q), D, _p(rows), M, D, self._stream()),
                   "sc_proj_ln_proj")
 
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
@@ -177,11 +177,13 @@ class HipBackend:
         s.dec_norm_g, s.dec_norm_b = w.dec_norm_g.data_ptr(), w.dec_norm_b.data_ptr()
         s.out_w, s.out_b = w.out_w.data_ptr(), w.out_b.data_ptr()
         s.layers = C.cast(layers, C.c_void_p).value
+        s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
         sb._sc_search_struct = (s, layers)
         return s
 
     def _sb_call(self, fn, sb, *extra):
         s = self.search_struct(sb)
+        s.n_rows = int(getattr(sb, "n_rows_step", sb.S * sb.W))   # compaction bucket of this step
         self._chk(getattr(self.lib, fn)(C.addressof(s), *extra, self._stream()), fn)
 
     def ctc_extend_state(self, sb):
@@ -221,7 +223,10 @@ class HipBackend:
         if not self.use_graphs:
             self._sb_call("sc_decode_step", sb)
             return
-        g = getattr(sb, "_sc_decode_graph", None)
+        graphs = getattr(sb, "_sc_decode_graphs", None)
+        if graphs is None:
+            graphs = sb._sc_decode_graphs = {}
+        g = graphs.get(int(sb.n_rows_step))     # one graph per compaction bucket
         st = self._stream()
         if g is None:
             if st == 0:
@@ -234,10 +239,24 @@ class HipBackend:
                 out = C.c_void_p()
                 rc = self.lib.sc_graph_capture_end(st, C.byref(out))
             self._chk(rc, "sc_graph_capture_end")
-            sb._sc_decode_graph = out
-            sb._sc_decode_graph_warm = True
+            graphs[int(sb.n_rows_step)] = out
             return self._redo_after_capture(sb)
         self._chk(self.lib.sc_graph_launch(g, st), "sc_graph_launch")
+
+    def prepare_decode(self, sb):
+        """Capture the decode-step graph of every compaction bucket up front
+        (graph instantiation costs ~0.1 s per bucket; without this it would land
+        in the middle of the stream the first time a bucket size occurs).  Runs
+        dry steps: the device ctrl rows are all-inactive, so every per-stream
+        kernel exits and the dense kernels only touch scratch activations."""
+        if not self.use_graphs or self._stream() == 0:
+            return
+        keep = sb.n_rows_step
+        for nb in range(sb.row_bucket, sb.S + sb.row_bucket, sb.row_bucket):
+            sb.n_rows_step = min(nb, sb.S) * sb.W
+            if int(sb.n_rows_step) not in getattr(sb, "_sc_decode_graphs", {}):
+                self.decode_step(sb)
+        sb.n_rows_step = keep
 
     def _redo_after_capture(self, sb):
         # the warm-up launch before capture already executed this step once;

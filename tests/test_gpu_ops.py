@@ -134,6 +134,44 @@ def test_proj_ln_proj_row_panel(hip, M, D, second):
         assert float(Ng[M:].abs().max()) == 0.0
 
 
+def test_row_compaction_tables(hip):
+    """Ragged-batch compaction: the row-panel kernel and gemm_ln driven through a
+    row table touch exactly the listed rows (others keep their content)."""
+    from oracle.kernel_spec import SpecBackend
+    from speechcatcher_amd.weights import pack_panel_weight
+    M, D, n = 200, 256, 53
+    g0 = torch.Generator().manual_seed(77)
+    rows = torch.randperm(M, generator=g0)[:n].to(torch.int32)
+    A, W1, b1 = _rand(M, D, seed=41), _rand(D, D, seed=42, scale=D ** -0.5), _rand(D, seed=43)
+    W2, b2 = _rand(D, D, seed=44, scale=D ** -0.5), _rand(D, seed=45)
+    g, be_ = 1 + 0.1 * _rand(D, seed=46), _rand(D, seed=47)
+    X0, N0, Q0 = _rand(M, D, seed=48), _rand(M, D, seed=49), _rand(M, D, seed=50)
+    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+    refX, refN, refQ = X0.clone(), N0.clone(), Q0.clone()
+    spec = SpecBackend()
+    spec.proj_ln_proj(A, D, W1p, b1, refX, D, g, be_, refN, W2p, b2, refQ, n, D, rows=rows)
+    Xg, Ng, Qg = X0.cuda(), N0.cuda(), Q0.cuda()
+    hip.proj_ln_proj(A.cuda(), D, W1p.cuda(), b1.cuda(), Xg, D, g.cuda(), be_.cuda(), Ng, W2p.cuda(), b2.cuda(), Qg,
+                     n, D, rows=rows.cuda())
+    torch.cuda.synchronize()
+    for got, ref in ((Xg, refX), (Ng, refN), (Qg, refQ)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=3e-4, rtol=3e-4)
+    untouched = torch.ones(M, dtype=torch.bool)
+    untouched[rows.long()] = False
+    assert torch.equal(Xg.cpu()[untouched], X0[untouched]) and torch.equal(Qg.cpu()[untouched], Q0[untouched])
+    # gemm_ln with the LayerNorm output following c_rows (split-K reduce+LN and the unfused path)
+    for K in (256, 2048):
+        A2, W = _rand(M, K, seed=51), _rand(D, K, seed=52, scale=K ** -0.5)
+        refC, refL = X0.clone(), N0.clone()
+        spec.gemm_ln(A2, rows, K, W, b1, refC, rows, D, n, D, K, g, be_, refL, residual=True, ln_at_crows=True)
+        Cg, Lg = X0.cuda(), N0.cuda()
+        hip.gemm_ln(A2.cuda(), rows.cuda(), K, W.cuda(), b1.cuda(), Cg, rows.cuda(), D, n, D, K, g.cuda(), be_.cuda(),
+                    Lg, residual=True, ln_at_crows=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(Cg.cpu().numpy(), refC.numpy(), atol=3e-4, rtol=3e-4)
+        np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=3e-4, rtol=3e-4)
+
+
 def test_decoder_without_row_panel_kernel(hip, monkeypatch):
     """SC_DEC_PANEL=0 keeps the GEMM / reduce+LN / GEMM form (also the path for
     feature dims the panel kernel does not cover): same trajectories."""

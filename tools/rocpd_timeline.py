@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Timeline of one decode step from a rocprofv3 rocpd (.db) kernel trace: every
+kernel between two dec_embed launches with its duration and the idle gap before
+it.  Usage: python tools/rocpd_timeline.py <results.db> [which_step] [max_rows]"""
+import sqlite3
+import sys
+
+
+def main():
+    con = sqlite3.connect(sys.argv[1])
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+    max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    scol = [r[1] for r in cur.execute(f"pragma table_info({ks})")]
+    name_col = "kernel_name" if "kernel_name" in scol else "display_name"
+    rows = list(cur.execute(f"select s.{name_col}, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id "
+                            f"order by d.start"))
+    starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0]]
+    a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
+    seg = rows[a:b]
+    busy = sum(r[2] - r[1] for r in seg)
+    span = seg[-1][2] - seg[0][1]
+    print(f"decode step #{which}: {len(seg)} kernels, span {span / 1e3:.1f} us, busy {busy / 1e3:.1f} us "
+          f"({100.0 * busy / span:.1f} %)")
+    prev_end = seg[0][1]
+    agg = {}
+    for i, (name, s, e) in enumerate(seg):
+        short = name.split("(")[0].replace("void ", "")[:60]
+        if i < max_rows:
+            print(f"{(s - seg[0][1]) / 1e3:9.1f} us  gap {(s - prev_end) / 1e3:6.2f}  dur {(e - s) / 1e3:7.2f}  {short}")
+        g = agg.setdefault(short, [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += (e - s) / 1e3
+        g[2] += (s - prev_end) / 1e3
+        prev_end = e
+    print("\nper kernel over the step: calls, total dur us, total gap-before us")
+    for k, (n, dur, gap) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n:4d} {dur:9.1f} {gap:8.1f}  {k}")
+
+
+if __name__ == "__main__":
+    main()
