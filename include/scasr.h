@@ -60,6 +60,7 @@ extern "C" {
 typedef struct sc_enc_layer {
   const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
   const float *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+  const float *w1_p, *w2_p; /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -67,6 +68,7 @@ typedef struct sc_dec_layer {
   const float *ln2_g, *ln2_b, *wq, *bq, *wo2, *bo2;
   const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;
   const float *wo_p, *wq_p, *wo2_p; /* sc_pack_panel_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
+  const float *w1_p, *w2_p;         /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -150,11 +152,22 @@ int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const float *b1, 
                     const float *W2p, const float *b2, float *Q, int ldq, const int32_t *rows,
                     int M, int D, void *stream);
 int sc_proj_ln_proj_supported(int D);
-/* W1p / W2p are the [D][D] Linear weights re-ordered ONCE into MFMA fragment
- * order so that every wave load is 1 KB contiguous:
- *   out[((((tile*(D/32) + ki)*2 + half)*64 + lane)*4 + c]
+/* W1p / W2p are Linear weights [N][K] re-ordered ONCE into MFMA fragment
+ * order so that every wave load is 1 KB contiguous (N % 16 == 0, K % 32 == 0):
+ *   out[((((tile*(K/32) + ki)*2 + half)*64 + lane)*4 + c]
  *       = W[tile*16 + lane%16][ki*32 + 8*(lane/16) + 4*half + c]              */
-int sc_pack_panel_weight(const float *W, int D, float *out, void *stream);
+int sc_pack_panel_weight(const float *W, int N, int K, float *out, void *stream);
+
+/* Fused position-wise feed-forward (feed_forward.py:48-50 + the residual of the
+ * encoder / decoder layer, + the LayerNorm that follows when ln_out != NULL):
+ *   X[r] += W2 . relu(W1 . XN[r] + b1) + b2;  ln_out[r] = LN(X[r])   for r in rows[0..M)
+ * (rows NULL: r = 0..M-1; ln_out may alias XN).  The hidden activations stay in
+ * LDS; W1p [F][D] and W2p [D][F] are sc_pack_panel_weight copies.  Needs the
+ * split-K workspace (sc_set_workspace / sc_set_stream_workspace). */
+int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+              const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
+              const float *ln_b, float ln_eps, float *ln_out, void *stream);
+int sc_ffn_ln_supported(int D, int F);
 
 /* Workspace (device memory, caller-owned) for the deterministic split-K path of
  * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it

@@ -200,6 +200,7 @@ class SpecBackend:
 
     def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):
         """contextual_block_encoder_layer.py:215-271 x n_layers"""
+        from speechcatcher_amd.weights import ffn_fused_supported
         cfg = w.cfg
         d, Fd, M = cfg.d_model, cfg.ffn_dim, nblk * R
         for li, lw in enumerate(w.enc):
@@ -208,8 +209,11 @@ class SpecBackend:
             self.enc_attention(qkv, att, nblk, R, cfg.enc_heads, masked)
             self.gemm(att, None, d, lw["wo"], lw["bo"], x, None, d, M, d, d, residual=True)
             self.layernorm(x, None, xn, None, M, lw["ln2_g"], lw["ln2_b"])
-            self.gemm(xn, None, d, lw["w1"], lw["b1"], ffh, None, Fd, M, Fd, d, relu=True)
-            self.gemm(ffh, None, Fd, lw["w2"], lw["b2"], x, None, d, M, d, Fd, residual=True)
+            if ffn_fused_supported(d, Fd):
+                self.ffn_ln(xn, None, M, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], x, None, None, None)
+            else:
+                self.gemm(xn, None, d, lw["w1"], lw["b1"], ffh, None, Fd, M, Fd, d, relu=True)
+                self.gemm(ffh, None, Fd, lw["w2"], lw["b2"], x, None, d, M, d, Fd, residual=True)
             if masked:
                 self.ctx_handoff(x, R, jobs, ns, past_ctx, li)
 
@@ -308,6 +312,20 @@ class SpecBackend:
         if W2 is not None:
             self.gemm(xn, rows, D, unpack_panel_weight(W2), b2, Q, rows, D, M, D, D)
 
+    def ffn_ln(self, XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
+        """sc_ffn_ln: X[r] += W2.relu(W1.XN[r] + b1) + b2; ln_out[r] = LN(X[r]) (optional).
+        W1p / W2p arrive in the fragment order of sc_pack_panel_weight."""
+        from speechcatcher_amd.weights import unpack_panel_weight
+        W1, W2 = unpack_panel_weight(W1p), unpack_panel_weight(W2p)
+        nrow = XN.reshape(-1, D).shape[0]
+        h = torch.empty(nrow, F, dtype=torch.float32)
+        self.gemm(XN, rows, D, W1, b1, h, rows, F, M, F, D, relu=True)
+        if ln_out is not None:
+            self.gemm_ln(h, rows, F, W2, b2, X, rows, D, M, D, F, ln_g, ln_b, ln_out, residual=True, eps=eps,
+                         ln_at_crows=rows is not None)
+        else:
+            self.gemm(h, rows, F, W2, b2, X, rows, D, M, D, F, residual=True)
+
     PANEL_DIMS = (64, 128, 256)   # sc_proj_ln_proj_supported
 
     def decoder_layers(self, sb):
@@ -315,6 +333,7 @@ class SpecBackend:
         (every LayerNorm but the first is fused into the kernel producing its
         input).  Dense ops run over the compacted rows sb.rowmap[:n_rows_step]
         of the active streams (scasr.h: rowmap)."""
+        from speechcatcher_amd.weights import ffn_fused_supported
         w, cfg = sb.w, sb.cfg
         d, Fd = cfg.d_model, cfg.ffn_dim
         n = int(sb.n_rows_step)
@@ -339,9 +358,12 @@ class SpecBackend:
                 self.dec_cross_attn(sb, li)
                 self.gemm_ln(sb.datt, rows, d, lw["wo2"], lw["bo2"], sb.dx, rows, d, n, d, d,
                              lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True, ln_at_crows=True)
-            self.gemm(sb.dxn, rows, d, lw["w1"], lw["b1"], sb.dffh, rows, Fd, n, Fd, d, relu=True)
-            self.gemm_ln(sb.dffh, rows, Fd, lw["w2"], lw["b2"], sb.dx, rows, d, n, d, Fd, ng, nb, sb.dxn,
-                         residual=True, ln_at_crows=True)
+            if ffn_fused_supported(d, Fd):
+                self.ffn_ln(sb.dxn, rows, n, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], sb.dx, ng, nb, sb.dxn)
+            else:
+                self.gemm(sb.dxn, rows, d, lw["w1"], lw["b1"], sb.dffh, rows, Fd, n, Fd, d, relu=True)
+                self.gemm_ln(sb.dffh, rows, Fd, lw["w2"], lw["b2"], sb.dx, rows, d, n, d, Fd, ng, nb, sb.dxn,
+                             residual=True, ln_at_crows=True)
 
     def logsoftmax_topk(self, sb):
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:

@@ -55,15 +55,15 @@ __device__ __forceinline__ f32x4 mfma8(f32x4 acc, const float4 &a0, const float4
   return acc;
 }
 
-// W [D][D] row-major (torch Linear weight) -> fragment order
+// W [N][K] row-major (torch Linear weight) -> fragment order
 //   out[((((tile*KI + ki)*2 + half)*64 + lane)*4 + c] = W[tile*16 + lane%16][ki*32 + 8*(lane/16) + 4*half + c]
-__global__ void pack_panel_weight_kernel(const float *W, int D, float *out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= D * D) return;
-  const int KI = D / 32;
+__global__ void pack_panel_weight_kernel(const float *W, int N, int K, float *out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * K) return;
+  const int KI = K / 32;
   const int c = idx & 3, lane = (idx >> 2) & 63, half = (idx >> 8) & 1;
   const int ki = (idx >> 9) % KI, tile = (idx >> 9) / KI;
-  out[idx] = W[(long)(tile * 16 + (lane & 15)) * D + ki * 32 + 8 * (lane >> 4) + 4 * half + c];
+  out[idx] = W[(long)(tile * 16 + (lane & 15)) * K + ki * 32 + 8 * (lane >> 4) + 4 * half + c];
 }
 
 // D = feature dim, NW waves per workgroup, NT 16-column tiles per wave (NW*NT*16 == D)
@@ -252,10 +252,11 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const 
   return SC_OK;
 }
 
-extern "C" int sc_pack_panel_weight(const float *W, int D, float *out, void *stream) {
+extern "C" int sc_pack_panel_weight(const float *W, int N, int K, float *out, void *stream) {
   SC_CHECK_ARG(W && out, "null");
-  SC_CHECK_ARG(D > 0 && D % 32 == 0, "D must be a multiple of 32");
-  pack_panel_weight_kernel<<<cdiv(D * D, 256), 256, 0, (hipStream_t)stream>>>(W, D, out);
+  SC_CHECK_ARG(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "N must be a multiple of 16, K of 32");
+  const long total = (long)N * K;
+  pack_panel_weight_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, N, K, out);
   SC_CHECK_LAUNCH();
   return SC_OK;
 }

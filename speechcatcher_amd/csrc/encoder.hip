@@ -449,6 +449,8 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   SC_CHECK_ARG(L && x && xn && qkv && att && ffh, "null pointer");
   const int M = nblk * R;
   if (M <= 0) return SC_OK;
+  const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
+  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   for (int li = 0; li < n_layers; ++li) {
@@ -458,8 +460,12 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
     SC_TRY(sc_enc_attention(qkv, att, nblk, R, H, d, masked, stream));
     SC_TRY(sc_gemm(att, nullptr, d, w.wo, w.bo, x, nullptr, d, M, d, d, SC_GEMM_RESIDUAL, 0, stream));
     SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
-    SC_TRY(sc_gemm(xn, nullptr, d, w.w1, w.b1, ffh, nullptr, F, M, F, d, SC_GEMM_RELU, 0, stream));
-    SC_TRY(sc_gemm(ffh, nullptr, F, w.w2, w.b2, x, nullptr, d, M, d, F, SC_GEMM_RESIDUAL, 0, stream));
+    if (ffn_fused) {
+      SC_TRY(sc_ffn_ln(xn, nullptr, M, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
+    } else {
+      SC_TRY(sc_gemm(xn, nullptr, d, w.w1, w.b1, ffh, nullptr, F, M, F, d, SC_GEMM_RELU, 0, stream));
+      SC_TRY(sc_gemm(ffh, nullptr, F, w.w2, w.b2, x, nullptr, d, M, d, F, SC_GEMM_RESIDUAL, 0, stream));
+    }
     if (masked && ns > 0) SC_TRY(sc_ctx_handoff(x, R, jobs, ns, past_ctx, li, d, stream));
   }
 #undef SC_TRY

@@ -697,3 +697,272 @@ extern "C" int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const 
   return sc_layernorm(C, c_rows, ldc, ln_out, (flags & SC_GEMM_LN_AT_CROWS) ? c_rows : nullptr, ld_ln, M, N, ln_g,
                       ln_b, ln_eps, stream);
 }
+
+// ===========================================================================
+// Fused position-wise feed-forward:  x += W2 . relu(W1 . xn + b1) + b2  (+ LN)
+// (reference: feed_forward.py:48-50 behind the residual of encoder_layer /
+// decoder_layer / contextual_block_encoder_layer).
+//
+// One workgroup owns RT = 16*RTT rows and CPW consecutive 128-wide chunks of
+// the hidden dimension.  Per chunk:  h = relu(xn_tile . W1c^T + b1c) goes to
+// LDS, never to HBM, and is immediately contracted with W2c; the RT x D
+// partial result stays in MFMA accumulators across the CPW chunks.  Partials
+// of the F/128/CPW chunk groups land in the split-K workspace and are reduced
+// in fixed order by the same reduce(+LayerNorm) kernels as the split-K GEMM.
+//   * MFMA v_mfma_f32_16x16x4_f32; A operands (activations) from LDS with the
+//     k-permuted 32-byte-per-lane fetch, B operands (weights) straight from
+//     HBM/L2 into registers out of the fragment-packed copies of W1 / W2
+//     (sc_pack_panel_weight): every wave load is 1 KB contiguous;
+//   * 8 waves: wave w owns hidden columns [16w,16w+16) of the chunk in GEMM 1
+//     and output columns [w*D/8, (w+1)*D/8) in GEMM 2.
+// Algorithmic work per row: 4*D*F flop; HBM bytes per row ~ 2*D*4 (+ the
+// partial round trip 2*D*4*F/128/CPW).
+// ===========================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ffn_mfma8(f32x4 acc, const float4 &a0, const float4 &a1, const float4 &b0,
+                                           const float4 &b1) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+  return acc;
+}
+
+struct FfnArgs {
+  const float *XN;
+  const int *rows;
+  const float *W1p, *b1, *W2p;
+  float *part;  // [F/128/cpw][M][D]
+  int M, F, cpw;
+};
+
+template <int D, int RTT>
+__global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
+  constexpr int RT = 16 * RTT, FC = 128;
+  constexpr int KI1 = D / 32, KI2 = FC / 32, NT2 = D / 128;
+  constexpr int LDX = D + 4, LDH = FC + 4;
+  extern __shared__ __attribute__((aligned(16))) float ffn_smem[];
+  float *Xs = ffn_smem;            // [RT][LDX]  xn tile; re-used to stage the partial result
+  float *Hs = ffn_smem + RT * LDX; // [RT][LDH]  relu(h) of the current chunk
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int grp = blockIdx.x, m0 = blockIdx.y * RT;
+  const int KF = p.F / 32;  // k-blocks of W2's packed layout
+
+  // xn tile -> LDS (coalesced, rows through the optional table).  Three separate
+  // unrolled phases so that all row-index loads, then all data loads are in flight together.
+  constexpr int NV = RT * D / 4;
+  constexpr int NQ = NV / 512;
+  static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
+  {
+    long rowv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = min(m0 + (threadIdx.x + q * 512) / (D / 4), p.M - 1);
+      rowv[q] = p.rows ? p.rows[m] : m;
+    }
+    float4 stage[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      stage[q] = *reinterpret_cast<const float4 *>(p.XN + rowv[q] * D + 4 * ((threadIdx.x + q * 512) % (D / 4)));
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * 512;
+      *reinterpret_cast<float4 *>(Xs + (e / (D / 4)) * LDX + 4 * (e % (D / 4))) = stage[q];
+    }
+  }
+  f32x4 acc2[RTT][NT2];
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 bf[KI1][2];  // GEMM 1 weights of this wave's 16 hidden columns (all of K)
+  auto load_b1 = [&](int chunk) {
+    const float4 *wp = reinterpret_cast<const float4 *>(p.W1p) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
+#pragma unroll
+    for (int ki = 0; ki < KI1; ++ki) {
+      bf[ki][0] = wp[ki * 128];
+      bf[ki][1] = wp[ki * 128 + 64];
+    }
+  };
+  load_b1(grp * p.cpw);
+  __syncthreads();
+
+  for (int cc = 0; cc < p.cpw; ++cc) {
+    const int chunk = grp * p.cpw + cc;
+    const float bias = p.b1 ? p.b1[chunk * FC + wave * 16 + r] : 0.f;
+    // ---- GEMM 1: h[RT x 16] of this wave ----
+    f32x4 acc1[RTT];
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {  // A operands are fetched one step ahead of the MFMAs that use them
+      constexpr int NS = RTT * KI1;
+      const float *ab = Xs + r * LDX + 8 * kk;
+      float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        float4 n0 = a0, n1 = a1;
+        if (st + 1 < NS) {
+          const float *ap = ab + ((st + 1) % RTT) * 16 * LDX + ((st + 1) / RTT) * 32;
+          n0 = *reinterpret_cast<const float4 *>(ap);
+          n1 = *reinterpret_cast<const float4 *>(ap + 4);
+        }
+        acc1[rt] = ffn_mfma8(acc1[rt], a0, a1, bf[ki][0], bf[ki][1]);
+        a0 = n0;
+        a1 = n1;
+      }
+    }
+    // GEMM 2 weights of this chunk: in flight during the epilogue
+    float4 b2f[KI2][NT2][2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      const float4 *wp = reinterpret_cast<const float4 *>(p.W2p) +
+                         ((long)(wave * NT2 + t) * KF + chunk * KI2) * 128 + lane;
+#pragma unroll
+      for (int k = 0; k < KI2; ++k) {
+        b2f[k][t][0] = wp[k * 128];
+        b2f[k][t][1] = wp[k * 128 + 64];
+      }
+    }
+    if (cc > 0) __syncthreads();  // previous chunk's GEMM 2 is done reading Hs
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        Hs[(rt * 16 + 4 * kk + j) * LDH + wave * 16 + r] = fmaxf(acc1[rt][j] + bias, 0.f);
+    if (cc + 1 < p.cpw) load_b1(chunk + 1);  // next chunk's GEMM 1 weights, overlapped with GEMM 2
+    __syncthreads();
+    // ---- GEMM 2: partial y[RT x D/8] of this wave ----
+    {
+      constexpr int NS = RTT * KI2;
+      const float *ab = Hs + r * LDH + 8 * kk;
+      float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int k = st / RTT, rt = st % RTT;
+        float4 n0 = a0, n1 = a1;
+        if (st + 1 < NS) {
+          const float *ap = ab + ((st + 1) % RTT) * 16 * LDH + ((st + 1) / RTT) * 32;
+          n0 = *reinterpret_cast<const float4 *>(ap);
+          n1 = *reinterpret_cast<const float4 *>(ap + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[rt][t] = ffn_mfma8(acc2[rt][t], a0, a1, b2f[k][t][0], b2f[k][t][1]);
+        a0 = n0;
+        a1 = n1;
+      }
+    }
+  }
+  // ---- partial result -> LDS (row-major) -> workspace, full lines ----
+  // (Xs is free: its last readers finished before the barrier that preceded the last GEMM 2)
+#pragma unroll
+  for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] = acc2[rt][t][j];
+  __syncthreads();
+  float *dst = p.part + ((long)grp * p.M + m0) * D;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = threadIdx.x + q * 512;
+    const int i = e / (D / 4), c4 = e % (D / 4);
+    if (m0 + i < p.M)
+      *reinterpret_cast<float4 *>(dst + (long)i * D + 4 * c4) = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
+  }
+}
+
+template <int D, int RTT>
+static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
+  constexpr int RT = 16 * RTT;
+  const size_t lds = (size_t)(RT * (D + 4) + RT * (128 + 4)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<D, RTT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  ffn_fused_kernel<D, RTT><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+}
+
+template <int D>
+static void launch_ffn_rtt(const FfnArgs &p, int rtt, int ngrp, hipStream_t st) {
+  switch (rtt) {
+    case 1: launch_ffn<D, 1>(p, ngrp, st); break;
+    case 2: launch_ffn<D, 2>(p, ngrp, st); break;
+    case 3: launch_ffn<D, 3>(p, ngrp, st); break;
+    case 4: launch_ffn<D, 4>(p, ngrp, st); break;
+    default: launch_ffn<D, 5>(p, ngrp, st); break;
+  }
+}
+
+extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128) && F % 128 == 0 && F >= 128; }
+
+extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+                         const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
+                         const float *ln_b, float ln_eps, float *ln_out, void *stream) {
+  SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
+  SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
+  SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
+  SC_CHECK_ARG((((uintptr_t)XN | (uintptr_t)W1p | (uintptr_t)W2p | (uintptr_t)X) & 15) == 0, "16-byte alignment");
+  if (M <= 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  resolve_workspace(stream);
+  SC_CHECK_ARG(g_ws && g_ws_bytes >= (size_t)16 * D * sizeof(float), "sc_ffn_ln needs the split-K workspace");
+  const int nch = F / 128;
+  const long ws_rows_per_part = (long)(g_ws_bytes / sizeof(float) / D);   // rows*parts that fit
+  // rows in slabs so that the partials fit the workspace; per slab pick the
+  // tile height (16*rtt rows) and chunks per workgroup (cpw) with the fewest
+  // rounds of 256 workgroups, ties towards more partial groups (= less serial work)
+  int m_done = 0;
+  while (m_done < M) {
+    int best_rtt = 5, best_cpw = nch;
+    long slab = M - m_done;
+    double best = 1e30;
+    for (int cpw = 1; cpw <= nch; cpw *= 2) {
+      if (nch % cpw) continue;
+      const int ngrp = nch / cpw;
+      long fit = ws_rows_per_part / ngrp;
+      if (fit < 16) continue;
+      const long mm = fit < (M - m_done) ? (fit / 80) * 80 : (M - m_done);
+      if (mm <= 0) continue;
+      for (int rtt = 1; rtt <= 5; ++rtt) {
+        const long wgs = (long)ngrp * ((mm + 16 * rtt - 1) / (16 * rtt));
+        const double rounds = (double)((wgs + 255) / 256);
+        // per workgroup: fixed ~2 us + 3.4 us of MFMA per 16 rows and chunk; reduce: bytes of the partials
+        double t = rounds * (2.0 + 3.4 * rtt * cpw) + 1.5 + 2.0 * (double)mm * D * 4.0 * ngrp / 3.0e6;
+        t *= (double)(M - m_done) / (double)mm;   // slabs needed at this size
+        if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; slab = mm; }
+      }
+    }
+    SC_CHECK_ARG(best < 1e29, "workspace too small for sc_ffn_ln");
+    const int ngrp = nch / best_cpw;
+    FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
+    // without a row table the slab is addressed by offsetting the base pointers
+    const float *xn_base = rows ? XN : XN + (long)m_done * D;
+    p.XN = xn_base;
+    if (D == 256) launch_ffn_rtt<256>(p, best_rtt, ngrp, st);
+    else launch_ffn_rtt<128>(p, best_rtt, ngrp, st);
+    SC_CHECK_LAUNCH();
+    GemmArgs g{nullptr, nullptr, D, nullptr, b2, rows ? X : X + (long)m_done * D, rows ? rows + m_done : nullptr, D,
+               (int)slab, D, F, SC_GEMM_RESIDUAL | (rows ? SC_GEMM_LN_AT_CROWS : 0), 0, g_ws, 0};
+    if (ln_out) {
+      float *lo = rows ? ln_out : ln_out + (long)m_done * D;
+      gemm_splitk_reduce_ln_kernel<<<cdiv((int)slab, 4), 256, 0, st>>>(g, ngrp, ln_g, ln_b, ln_eps, lo, D);
+    } else {
+      const long n4 = (long)slab * (D / 4);
+      gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ngrp);
+    }
+    SC_CHECK_LAUNCH();
+    m_done += (int)slab;
+  }
+  return SC_OK;
+}

@@ -614,6 +614,8 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   const char *pe = getenv("SC_DEC_PANEL");
   const bool panel_env = !(pe && atoi(pe) == 0);
   const bool panel = panel_env && sc_proj_ln_proj_supported(d);
+  const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
+  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
@@ -641,10 +643,14 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
       SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo2, w.bo2, sb.dx, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
                         w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
     }
-    SC_TRY(sc_gemm(sb.dxn, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));
-    // FFN2 + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
-    SC_TRY(sc_gemm_ln(sb.dffh, rows, F, w.w2, w.b2, sb.dx, rows, d, n, d, F, SC_GEMM_RESIDUAL | lnf, 0,
-                      ng, nb, sb.ln_eps, sb.dxn, d, stream));
+    // feed-forward + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
+    if (ffn_fused) {
+      SC_TRY(sc_ffn_ln(sb.dxn, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, sb.dx, ng, nb, sb.ln_eps, sb.dxn, stream));
+    } else {
+      SC_TRY(sc_gemm(sb.dxn, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));
+      SC_TRY(sc_gemm_ln(sb.dffh, rows, F, w.w2, w.b2, sb.dx, rows, d, n, d, F, SC_GEMM_RESIDUAL | lnf, 0,
+                        ng, nb, sb.ln_eps, sb.dxn, d, stream));
+    }
   }
   return SC_OK;
 }

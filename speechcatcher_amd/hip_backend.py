@@ -24,13 +24,13 @@ class HipBackend:
         self.use_graphs = use_graphs
         self._enc_graphs = {}
         # split-K partial sums of sc_gemm live in this caller-owned workspace
-        self.workspace = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
         self._chk(self.lib.sc_set_workspace(self.workspace.data_ptr(), self.workspace.numel()), "sc_set_workspace")
 
     def bind_stream(self, stream):
         """Give the batch that runs on `stream` its own split-K workspace, so that
         several batches can run concurrently on different HIP streams."""
-        ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+        ws = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
         self._stream_ws = getattr(self, "_stream_ws", [])
         self._stream_ws.append(ws)
         self._chk(self.lib.sc_set_stream_workspace(stream.cuda_stream, ws.data_ptr(), ws.numel()),
@@ -76,6 +76,10 @@ class HipBackend:
                                            _p(XN), D, _p(W2), _p(b2), _p(Q), D, _p(rows), M, D, self._stream()),
                   "sc_proj_ln_proj")
 
+    def ffn_ln(self, XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
+        self._chk(self.lib.sc_ffn_ln(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(X),
+                                     _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")
@@ -115,7 +119,7 @@ class HipBackend:
         if arr is None:
             arr = (_abi.EncLayer * len(w.enc))()
             for i, lw in enumerate(w.enc):
-                for name in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2"):
+                for name, _ in _abi.EncLayer._fields_:
                     setattr(arr[i], name, lw[name].data_ptr())
             w._sc_enc_layer_table = arr
         return arr

@@ -31,17 +31,22 @@ PANEL_DIMS = (64, 128, 256)   # feature dims of the row-panel kernel (sc_proj_ln
 
 
 def pack_panel_weight(W: torch.Tensor) -> torch.Tensor:
-    """[D][D] Linear weight -> MFMA fragment order of sc_proj_ln_proj
+    """[N][K] Linear weight -> MFMA fragment order of sc_proj_ln_proj / sc_ffn_ln
     (include/scasr.h: out[tile][ki][half][lane = kk*16 + r][c] =
     W[tile*16 + r][ki*32 + 8*kk + 4*half + c]); a pure permutation."""
-    D = W.shape[0]
-    assert W.shape == (D, D) and D % 32 == 0
-    return W.reshape(D // 16, 16, D // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(D, D)
+    N, K = W.shape
+    assert N % 16 == 0 and K % 32 == 0
+    return W.reshape(N // 16, 16, K // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5).contiguous().reshape(N, K)
 
 
 def unpack_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
-    D = Wp.shape[0]
-    return Wp.reshape(D // 16, D // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5).contiguous().reshape(D, D)
+    N, K = Wp.shape
+    return Wp.reshape(N // 16, K // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5).contiguous().reshape(N, K)
+
+
+def ffn_fused_supported(d: int, F: int) -> bool:
+    """sc_ffn_ln_supported"""
+    return d in (128, 256) and F % 128 == 0 and F >= 128
 
 
 class PackedWeights:
@@ -119,6 +124,9 @@ class PackedWeights:
         for lw in self.dec:   # fragment-ordered copies for the row-panel kernel
             for n in ("wo", "wq", "wo2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if d in PANEL_DIMS else lw[n]
+        for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
+            for n in ("w1", "w2"):
+                lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]
         self.dec_norm_g = dev(g("decoder.after_norm.weight"))
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))

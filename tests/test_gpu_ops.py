@@ -114,7 +114,7 @@ def test_proj_ln_proj_row_panel(hip, M, D, second):
     assert torch.equal(unpack_panel_weight(W1p), W1)
     # the device-side packer of the C ABI produces the same permutation
     dev_p = torch.empty(D, D, device="cuda")
-    assert hip.lib.sc_pack_panel_weight(W1.cuda().data_ptr(), D, dev_p.data_ptr(), None) == 0
+    assert hip.lib.sc_pack_panel_weight(W1.cuda().data_ptr(), D, D, dev_p.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert torch.equal(dev_p.cpu(), W1p)
     SpecBackend().proj_ln_proj(A, D, W1p, b1, refX, D, g, be_, refN, W2p if second else None, b2 if second else None,
@@ -132,6 +132,35 @@ def test_proj_ln_proj_row_panel(hip, M, D, second):
     else:
         np.testing.assert_allclose(Ng[:M].cpu().numpy(), refN.numpy(), atol=3e-4, rtol=3e-4)
         assert float(Ng[M:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,D,F", [(10, 256, 2048), (1280, 256, 2048), (533, 256, 2048), (5376, 256, 2048),
+                                   (77, 128, 256), (200, 256, 128)])
+@pytest.mark.parametrize("with_ln", [True, False])
+def test_ffn_fused(hip, M, D, F, with_ln):
+    """Fused feed-forward (hidden activations in LDS, 16x16x4 f32 MFMA, partials reduced
+    in fixed order) against gemm + gemm_ln of the spec; with and without a row table."""
+    from oracle.kernel_spec import SpecBackend
+    from speechcatcher_amd.weights import pack_panel_weight
+    XN, X0, L0 = _rand(M + 5, D, seed=61), _rand(M + 5, D, seed=62), _rand(M + 5, D, seed=63)
+    W1, b1 = _rand(F, D, seed=64, scale=D ** -0.5), _rand(F, seed=65)
+    W2, b2 = _rand(D, F, seed=66, scale=F ** -0.5), _rand(D, seed=67)
+    g, be_ = 1 + 0.1 * _rand(D, seed=68), _rand(D, seed=69)
+    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+    dev_p = torch.empty(F, D, device="cuda")   # device-side packer, rectangular
+    assert hip.lib.sc_pack_panel_weight(W1.cuda().data_ptr(), F, D, dev_p.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dev_p.cpu(), W1p)
+    spec = SpecBackend()
+    for rows in (None, torch.randperm(M + 5, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32)):
+        refX, refL = X0.clone(), L0.clone()
+        spec.ffn_ln(XN, rows, M, D, F, W1p, b1, W2p, b2, refX, g, be_, refL if with_ln else None)
+        Xg, Lg = X0.cuda(), L0.cuda()
+        hip.ffn_ln(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, W1p.cuda(), b1.cuda(), W2p.cuda(),
+                   b2.cuda(), Xg, g.cuda(), be_.cuda(), Lg if with_ln else None)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(Xg.cpu().numpy(), refX.numpy(), atol=3e-4, rtol=3e-4)
+        np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
 def test_row_compaction_tables(hip):
