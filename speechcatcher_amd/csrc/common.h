@@ -42,8 +42,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.
+// log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.  One of the two
+// exponentials is exp(0) == 1 exactly, so only the other one is evaluated.
 __device__ __forceinline__ float lse2(float a, float b) {
-  float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
+  const float m = fmaxf(a, b);
+  return m + __logf(1.f + __expf(-fabsf(a - b)));
 }

@@ -697,7 +697,98 @@ __device__ __forceinline__ int next_pow2(int v) {
   return n;
 }
 
+// ---- wave-level bitonic primitives: one 64-bit composite per lane, no LDS, no barriers ----
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  const unsigned lo = __shfl_xor((unsigned)v, mask, 64), hi = __shfl_xor((unsigned)(v >> 32), mask, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// sorts the 64 values of a wave descending (lane i ends with rank i)
+__device__ __forceinline__ unsigned long long wave_sort64_desc(unsigned long long v, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long o = shfl_xor_u64(v, j);
+      const bool keep_max = ((lane & j) == 0) == ((lane & k) == 0);
+      v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
+    }
+  }
+  return v;
+}
+// a, b sorted descending over the lanes -> the 64 largest of the union, sorted descending
+__device__ __forceinline__ unsigned long long wave_merge64_desc(unsigned long long a, unsigned long long b, int lane) {
+  const unsigned long long br = shfl_u64(b, 63 - lane);
+  unsigned long long v = a > br ? a : br;   // bitonic sequence holding the top 64
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const unsigned long long o = shfl_xor_u64(v, j);
+    v = ((lane & j) == 0) ? (v > o ? v : o) : (v < o ? v : o);
+  }
+  return v;
+}
+
+// log-softmax + exact top-K (K <= 64, V <= 1024): every wave sorts its 4 x 64 keys
+// in registers and merges them to its top 64; wave 0 merges the four wave results.
+// Same composite keys as the full sort below, so the same ids in the same order.
 __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(sc_search sb) {
+  __shared__ float red[8];
+  __shared__ unsigned long long tops[4][64];
+  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
+  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
+  const int V = sb.V, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *x = sb.logits + (long)row * V;
+  float xv[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = wave * 256 + q * 64 + lane;
+    xv[q] = c < V ? x[c] : -INFINITY;
+    m = fmaxf(m, xv[q]);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sum += (wave * 256 + q * 64 + lane < V) ? expf(xv[q] - m) : 0.f;
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float ls = logf(sum);
+  unsigned long long key[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = wave * 256 + q * 64 + lane;
+    if (c < V) {
+      const float lp = (xv[q] - m) - ls;
+      sb.logp[(long)row * V + c] = lp;
+      key[q] = sort_key(__fmul_rn(sb.w_dec, lp), c);
+    } else {
+      key[q] = 0ull;  // below every real key
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) key[q] = wave_sort64_desc(key[q], lane);
+  const unsigned long long m0 = wave_merge64_desc(key[0], key[1], lane);
+  const unsigned long long m1 = wave_merge64_desc(key[2], key[3], lane);
+  tops[wave][lane] = wave_merge64_desc(m0, m1, lane);
+  __syncthreads();
+  if (wave == 0) {
+    const unsigned long long a = wave_merge64_desc(tops[0][lane], tops[1][lane], lane);
+    const unsigned long long b = wave_merge64_desc(tops[2][lane], tops[3][lane], lane);
+    const unsigned long long f = wave_merge64_desc(a, b, lane);
+    if (lane < sb.K) sb.pre_ids[(long)row * sb.K + lane] = sort_key_index(f);
+  }
+}
+
+// generic path (V > 1024 or K > 64): full bitonic sort in LDS
+__global__ __launch_bounds__(256) void logsoftmax_topk_sort_kernel(sc_search sb) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long comp[];
   __shared__ float red[8];
   const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
@@ -736,7 +827,10 @@ extern "C" int sc_logsoftmax_topk(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   int np = 1;
   while (np < sbp->V) np <<= 1;
-  logsoftmax_topk_kernel<<<sbp->S * sbp->W, 256, np * sizeof(unsigned long long), (hipStream_t)stream>>>(*sbp);
+  if (sbp->V <= 1024 && sbp->K <= 64)
+    logsoftmax_topk_kernel<<<sbp->S * sbp->W, 256, 0, (hipStream_t)stream>>>(*sbp);
+  else
+    logsoftmax_topk_sort_kernel<<<sbp->S * sbp->W, 256, np * sizeof(unsigned long long), (hipStream_t)stream>>>(*sbp);
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -820,10 +914,10 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
         rn[((long)t * 2 + 1) * WK + e] = r_b;
         const float v = phi + q.xc[i];
         if (v > pm) {
-          ps = ps * expf(pm - v) + 1.f;
+          ps = ps * __expf(pm - v) + 1.f;
           pm = v;
         } else {
-          ps += expf(v - pm);
+          ps += __expf(v - pm);
         }
         if (!has) cum += q.xb[i];
       }
@@ -866,13 +960,60 @@ extern "C" int sc_ctc_prefix_scan(const sc_search *sbp, void *stream) {
 // ---------------------------------------------------------------------------
 // score fusion + per-hypothesis top-W
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float sort_key_value(unsigned long long c) {
+  unsigned u = (unsigned)(c >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;   // inverse of the monotone map in sort_key
+  return __uint_as_float(u);
+}
+
 __global__ __launch_bounds__(256) void fuse_topw_kernel(sc_search sb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int need_full;
   const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
   if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
   const int V = sb.V, K = sb.K, W = sb.W, tid = threadIdx.x;
   float *comb = smem, *ctc = smem + V;
   const float s_prev = CTRL(s, SC_C_HAS) ? sb.ctc_s[((long)CTRL(s, SC_C_CUR) * sb.S + s) * W + h] : 0.f;
+  // ---- fast path: only the K pre-beam candidates and eos carry a CTC score
+  // above logzero, so the top-W of the fused scores over V is the top-W over
+  // these <= K+1 tokens whenever its W-th score beats the best score any other
+  // token can reach (w_dec * logp <= 0 plus w_ctc * (logzero - s_prev)).
+  // One wave sorts them in registers; otherwise fall through to the full sort.
+  if (K < 64 && W <= 64 && sb.w_dec >= 0.f) {
+    if (tid < 64) {
+      const int lane = tid;
+      int c = -1;
+      float ps = SC_LOGZERO;
+      if (lane < K) {
+        c = sb.pre_ids[(long)row * K + lane];
+        ps = sb.psi[(long)row * K + lane];
+      }
+      const bool eos_listed = __ballot(c == sb.eos) != 0ull;
+      if (lane == K && !eos_listed) c = sb.eos;
+      if (c == sb.eos) ps = sb.psi_eos[row];
+      if (c == sb.blank) ps = SC_LOGZERO;
+      unsigned long long key = 0ull;
+      if (c >= 0) {
+        const float cv = __fsub_rn(ps, s_prev);
+        ctc[c] = cv;
+        key = sort_key(__fadd_rn(__fmul_rn(sb.w_dec, sb.logp[(long)row * V + c]), __fmul_rn(sb.w_ctc, cv)), c);
+      }
+      key = wave_sort64_desc(key, lane);
+      const float bound = __fmul_rn(sb.w_ctc, __fsub_rn(SC_LOGZERO, s_prev));
+      const unsigned long long kw = shfl_u64(key, W - 1);
+      const bool ok = kw != 0ull && sort_key_value(kw) > bound;
+      if (lane == 0) need_full = ok ? 0 : 1;
+      if (ok && lane < W) {
+        const int i = sort_key_index(key);
+        sb.cand_tok[(long)row * W + lane] = i;
+        sb.cand_score[(long)row * W + lane] = sort_key_value(key);
+        sb.cand_ctc[(long)row * W + lane] = ctc[i];
+      }
+    }
+    __syncthreads();
+    if (!need_full) return;
+    __syncthreads();
+  }
   for (int v = tid; v < V; v += 256) ctc[v] = SC_LOGZERO;
   __syncthreads();
   for (int k = tid; k < K; k += 256) ctc[sb.pre_ids[(long)row * K + k]] = sb.psi[(long)row * K + k];
@@ -919,6 +1060,7 @@ extern "C" int sc_fuse_topw(const sc_search *sbp, void *stream) {
 __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
   extern __shared__ __attribute__((aligned(16))) double tot[];
   __shared__ int fl_any, fl_all, fl_best, fl_rep;
+  __shared__ int win_h[64], win_tok[64];   // per output rank: source hypothesis, appended token
   const int s = blockIdx.x, tid = threadIdx.x;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int W = sb.W, K = sb.K;
@@ -931,6 +1073,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
     tot[e] = sb.score[((long)cur * sb.S + s) * W + h] + (double)sb.cand_score[((long)s * W + h) * W + j];
   }
   __syncthreads();
+  // ---- rank the nh*W candidates; the winners do the O(1) bookkeeping ----
   for (int e = tid; e < n; e += 256) {
     const double te = tot[e];
     int rk = 0;
@@ -939,25 +1082,12 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
     const int h = e / W, j = e % W, i = rk;
     const long prow = (long)s * W + h;
     const int tok = sb.cand_tok[prow * W + j];
-    const int *ysrc = YSEQ(cur, s, h), *xsrc = XPOS(cur, s, h);
-    int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
-    bool rep = false;
-    for (int p = 0; p < L; ++p) {
-      const int y = ysrc[p];
-      ydst[p] = y;
-      xdst[p] = xsrc[p];
-      if (p >= 1 && y == tok) rep = true;
-    }
-    ydst[L] = tok;
-    xdst[L] = T - 1;
+    win_h[i] = h;
+    win_tok[i] = tok;
     const long oi = ((long)o * sb.S + s) * W + i, ci = ((long)cur * sb.S + s) * W + h;
     sb.score[oi] = te;
     sb.sc_dec[oi] = sb.sc_dec[ci] + (double)sb.logp[prow * sb.V + tok];
     sb.sc_ctc[oi] = sb.sc_ctc[ci] + (double)sb.cand_ctc[prow * W + j];
-    const int *asrc = ANC(cur, s);
-    int *adst = ANC(o, s);
-    for (int p = 0; p < L - 1; ++p) adst[(long)p * W + i] = asrc[(long)p * W + h];
-    adst[(long)(L - 1) * W + i] = h;
     int kk = -1;
     for (int q = 0; q < K; ++q)
       if (sb.pre_ids[prow * K + q] == tok) { kk = q; break; }
@@ -973,8 +1103,28 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
     if (is_eos) atomicOr(&fl_any, 1);
     else atomicAnd(&fl_all, 0);
     if (i == 0 && is_eos) atomicOr(&fl_best, 1);
-    if (rep && tok != sb.sos && tok != sb.eos) atomicOr(&fl_rep, 1);
   }
+  __syncthreads();
+  // ---- histories of the winners: all threads copy (rank i, position p) pairs ----
+  const int *asrc = ANC(cur, s);
+  int *adst = ANC(o, s);
+  bool rep = false;
+  for (int e = tid; e < nout * (L + 1); e += 256) {
+    const int i = e / (L + 1), p = e % (L + 1);
+    const int h = win_h[i], tok = win_tok[i];
+    int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
+    if (p < L) {
+      const int y = YSEQ(cur, s, h)[p];
+      ydst[p] = y;
+      xdst[p] = XPOS(cur, s, h)[p];
+      if (p >= 1 && y == tok && tok != sb.sos && tok != sb.eos) rep = true;
+      adst[(long)p * W + i] = (p < L - 1) ? asrc[(long)p * W + h] : h;
+    } else {
+      ydst[L] = tok;
+      xdst[L] = T - 1;
+    }
+  }
+  if (rep) atomicOr(&fl_rep, 1);
   __syncthreads();
   if (tid == 0)
     sb.flags[s] = (fl_any ? SC_F_ANY_EOS : 0) | (fl_best ? SC_F_BEST_EOS : 0) |
@@ -983,6 +1133,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
 
 extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
+  SC_CHECK_ARG(sbp->W <= 64, "beam wider than 64");
   size_t smem = (size_t)sbp->W * sbp->W * sizeof(double);
   beam_prune_kernel<<<sbp->S, 256, smem, (hipStream_t)stream>>>(*sbp);
   SC_CHECK_LAUNCH();
