@@ -35,6 +35,7 @@ from speechcatcher_amd.config import XL, SearchConfig  # noqa: E402
 
 CHUNK = 10240
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 
 
 def build_batch(n_streams, beam, bbd, n_steps_total, device):
@@ -156,20 +157,25 @@ def main():
     # Roofline leg: the SAME workload continues for a few more steps with hipGraph
     # replay switched off, so that every GEMM launch can be bracketed by HIP
     # events on its launch stream (kernels inside a graph replay cannot be).
-    ms = (C.c_double * 4)()
-    fl = (C.c_double * 4)()
-    nn = (C.c_longlong * 4)()
-    by = (C.c_double * 4)()
+    NK = 8   # scasr.h: SC_PROF_KINDS
+    ms = (C.c_double * NK)()
+    fl = (C.c_double * NK)()
+    nn = (C.c_longlong * NK)()
+    by = (C.c_double * NK)()
     ev_over_ms = 0.0
+    xattn_bytes = 0.0
     if args.roofline_steps > 0:
         be.use_graphs = False
         be.lib.sc_prof_enable(1)
+        sb.stats["xattn_rows"] = 0
         run_steps(sb, args.roofline_steps)
         torch.cuda.synchronize()
         be.lib.sc_prof_enable(0)
-        be.lib.sc_prof_collect2(ms, fl, by, nn)
+        be.lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
         be.use_graphs = True
         ev_over_ms = float(be.lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
+        # cross-attention: K|V rows of every active stream are read once per layer and step
+        xattn_bytes = float(sb.stats.get("xattn_rows", 0)) * 2 * sb.cfg.d_model * 4
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
@@ -190,42 +196,66 @@ def main():
 
     audio_s = world * args.streams * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
-    # dominant kernel of the path: the f32-MFMA GEMM (50-60 % of GPU time in the
-    # rocprofv3 summary under profiles/); report the tile variant that took most time
-    v = max(range(4), key=lambda i: ms[i])
+    # dominant kernel of the path = the kernel kind with the largest summed launch time
+    # in the roofline leg (agrees with the rocprofv3 summary under profiles/)
+    names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
+             "proj_ln_proj_kernel<256,8,2>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<32,10,self>",
+             "dec_attn_flash_kernel<32,10,cross>"]
+    net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
+    tot_ms = max(sum(net), 1e-9)
+    per_kernel = []
+    for i in range(NK):
+        if nn[i] == 0:
+            continue
+        ent = {"kernel": names[i], "launches": int(nn[i]), "avg_launch_us": round(net[i] * 1e3 / nn[i], 2),
+               "share_of_timed_kernel_time": round(net[i] / tot_ms, 4)}
+        if fl[i] > 0:
+            ent["tflops"] = round(fl[i] / (max(net[i], 1e-9) * 1e-3) / 1e12, 3)
+            ent["frac_of_f32_mfma_peak"] = round(ent["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        if i == 7 and xattn_bytes > 0:
+            ent["hbm_gbs_algorithmic"] = round(xattn_bytes / (max(net[i], 1e-9) * 1e-3) / 1e9, 1)
+            ent["frac_of_hbm_peak"] = round(ent["hbm_gbs_algorithmic"] / PEAK_HBM_GBS, 4)
+        per_kernel.append(ent)
     roof = None
-    if nn[v] > 0:
+    if any(nn[i] > 0 for i in range(NK)):
+        v = max(range(NK), key=lambda i: net[i])
         raw_us = ms[v] * 1e3 / nn[v]
-        # every sample carries one empty-event-pair of overhead; remove it
-        t_ms = max(ms[v] - nn[v] * ev_over_ms, 1e-9)
-        ach = fl[v] / (t_ms * 1e-3) / 1e12
-        allf = sum(fl[i] for i in range(1, 4))
-        allms = max(sum(ms[i] - nn[i] * ev_over_ms for i in range(1, 4)), 1e-9)
-        names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>"]
-        roof = {"bound": "mfma", "kernel": names[v],
-                "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
-                "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
-                "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
-                "flops_unit": "MFLOP (2*M*N*K per launch)",
-                "all_gemm_variants_tflops": round(allf / (allms * 1e-3) / 1e12, 3) if allms > 0 else None,
-                "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
-                                 "hipGraph replay off, HIP events around every launch"}
+        t_ms = max(net[v], 1e-9)
+        common = {"kernel": names[v], "traffic": None,
+                  "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
+                  "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
+                  "share_of_timed_kernel_time": round(net[v] / tot_ms, 4),
+                  "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
+                                   "hipGraph replay off, HIP events around every launch",
+                  "per_kernel": per_kernel}
+        if fl[v] > 0:
+            ach = fl[v] / (t_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
+                    "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 5)",
+                    "algorithmic_bytes_per_launch_avg": int(by[v] / nn[v])}
+        else:
+            bytes_v = xattn_bytes if v == 7 else 0.0
+            ach = bytes_v / (t_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "algorithmic_bytes_per_launch_avg": int(bytes_v / nn[v])}
+        roof.update(common)
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of
     # this same command (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE), committed
     # under profiles/; it cannot be collected from inside the process.
     if roof is not None and args.streams == 128 and not args.bbd:
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_s128_pmc_hbm_traffic.csv")
-        key = {"gemm_mfma_kernel<64,64>": "gemm_mfma_kernelILi64ELi64E", "gemm_mfma_kernel<128,128>": "gemm_mfma_kernelILi128ELi128E"}.get(roof["kernel"])
-        if key and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_default_pmc_hbm_traffic.csv")
+        key = roof["kernel"].split("<")[0]
+        if os.path.exists(tpath):
             for line in open(tpath).read().splitlines()[1:]:
                 cols = line.split(",")
-                if key in cols[0]:
+                if key in cols[0] and (("Lb1E" in cols[0]) == ("self" in roof["kernel"]) or "attn" not in key):
                     roof["traffic"] = int(cols[-1])
-                    roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_bench_s128_pmc_hbm_traffic.csv)"
-                    roof["algorithmic_bytes_per_launch_avg"] = int(by[v] / nn[v])
+                    roof["traffic_unit"] = ("HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE, "
+                                            "profiles/r01_bench_default_pmc_hbm_traffic.csv)")
                     break
 
     single = None

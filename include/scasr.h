@@ -182,6 +182,17 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
  * and returns, per kernel variant v (0 scalar, 1 = 32x128 tile, 2 = 128x128,
  * 3 = 64x64): summed milliseconds, summed algorithmic flops (2*M*N*K) and the
  * number of sampled launches (variant 1 = skinny register-direct kernel for M <= 64).  All three pointers are HOST arrays of 4. */
+/* kernel kinds of the per-launch timing records */
+#define SC_PROF_GEMM_NAIVE 0
+#define SC_PROF_GEMM_SKINNY 1
+#define SC_PROF_GEMM_128 2
+#define SC_PROF_GEMM_64 3
+#define SC_PROF_PROJ_LN_PROJ 4
+#define SC_PROF_FFN_FUSED 5
+#define SC_PROF_ATTN_SELF 6
+#define SC_PROF_ATTN_CROSS 7
+#define SC_PROF_KINDS 8
+int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
 /* same, plus summed ALGORITHMIC bytes (A + W read once, C written; C read too with SC_GEMM_RESIDUAL) */

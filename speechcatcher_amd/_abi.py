@@ -68,6 +68,8 @@ _SIGS = {
     "sc_graph_destroy": (C.c_int, [vp]),
     "sc_set_workspace": (C.c_int, [vp, C.c_size_t]),
     "sc_set_stream_workspace": (C.c_int, [vp, vp, C.c_size_t]),
+    "sc_prof_collect_kinds": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_longlong), C.c_int]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_collect": (C.c_int, [c_double_p, c_double_p, C.POINTER(C.c_longlong)]),
     "sc_prof_collect2": (C.c_int, [c_double_p, c_double_p, c_double_p, C.POINTER(C.c_longlong)]),

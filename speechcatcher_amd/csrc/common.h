@@ -30,6 +30,11 @@ void sc_set_error(const char *fmt, ...);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// HIP events around one kernel launch (enabled by sc_prof_enable; gemm.hip)
+struct ProfScope { bool on; hipEvent_t a, b; hipStream_t st; };
+ProfScope sc_prof_begin(hipStream_t st);
+void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
+
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -245,9 +245,15 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const 
   PanelArgs p{A, lda, W1p, b1, X, ldx, ln_g, ln_b, ln_eps, XN, ldn, W2p, b2, Q, ldq, rows, M};
   hipStream_t st = (hipStream_t)stream;
   const int grid = cdiv(M, 16);
+  ProfScope prof = sc_prof_begin(st);
   if (D == 256) proj_ln_proj_kernel<256, 8, 2><<<grid, 512, 0, st>>>(p);
   else if (D == 128) proj_ln_proj_kernel<128, 8, 1><<<grid, 512, 0, st>>>(p);
   else proj_ln_proj_kernel<64, 4, 1><<<grid, 256, 0, st>>>(p);
+  // algorithmic: 2*D*D flop per row and projection; A read, X read + written, the
+  // weights read once, XN / Q written
+  const int np = W2p ? 2 : 1;
+  sc_prof_end(prof, SC_PROF_PROJ_LN_PROJ, 2.0 * M * D * D * np,
+              4.0 * ((double)M * D * (3 + (XN ? 1 : 0) + (W2p ? 1 : 0)) + (double)np * D * D));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }

@@ -448,6 +448,25 @@ static std::vector<ProfRec> g_recs;
 static int g_prof_every = 0;
 static long long g_gemm_calls = 0;
 
+// shared by every launcher of the library (common.h): events around ONE kernel launch
+ProfScope sc_prof_begin(hipStream_t st) {
+  ProfScope p{false, nullptr, nullptr, st};
+  if (g_prof_every <= 0 || (g_gemm_calls++ % g_prof_every) != 0) return p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // never record timing events into a stream capture
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return p;
+  (void)hipEventCreate(&p.a);
+  (void)hipEventCreate(&p.b);
+  (void)hipEventRecord(p.a, st);
+  p.on = true;
+  return p;
+}
+void sc_prof_end(ProfScope &p, int kind, double flops, double bytes) {
+  if (!p.on) return;
+  (void)hipEventRecord(p.b, p.st);
+  g_recs.push_back(ProfRec{p.a, p.b, flops, bytes, kind});
+  p.on = false;
+}
+
 extern "C" int sc_prof_enable(int sample_every) {
   g_prof_every = sample_every;
   g_gemm_calls = 0;
@@ -478,14 +497,14 @@ extern "C" double sc_prof_event_overhead_ms(void *stream) {
   return (double)t[n / 2];
 }
 
-// ms[v], flops[v], n[v] for v = 0 naive, 1 = 32x128 tile, 2 = 128x128, 3 = 64x64
-extern "C" int sc_prof_collect2(double *ms, double *flops, double *bytes, long long *n) {
+// ms[v], flops[v], n[v] per kernel kind v (scasr.h: SC_PROF_*), nkinds entries
+extern "C" int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds) {
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { sc_set_error("sc_prof_collect: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
-  for (int v = 0; v < 4; ++v) { ms[v] = 0; flops[v] = 0; n[v] = 0; if (bytes) bytes[v] = 0; }
+  for (int v = 0; v < nkinds; ++v) { ms[v] = 0; flops[v] = 0; n[v] = 0; if (bytes) bytes[v] = 0; }
   for (auto &r : g_recs) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+    if (r.variant < nkinds && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
       ms[r.variant] += t;
       flops[r.variant] += r.flops;
       if (bytes) bytes[r.variant] += r.bytes;
@@ -625,6 +644,10 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   return SC_OK;
 }
 
+extern "C" int sc_prof_collect2(double *ms, double *flops, double *bytes, long long *n) {
+  return sc_prof_collect_kinds(ms, flops, bytes, n, 4);
+}
+
 extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
   return sc_prof_collect2(ms, flops, nullptr, n);
 }
@@ -638,31 +661,16 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
   resolve_workspace(stream);
-  ProfRec rec;
-  bool sample = g_prof_every > 0 && (g_gemm_calls++ % g_prof_every == 0);
-  if (sample) {  // never record timing events into a stream capture
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) sample = false;
-  }
-  if (sample) {
-    (void)hipEventCreate(&rec.a);
-    (void)hipEventCreate(&rec.b);
-    (void)hipEventRecord(rec.a, st);
-  }
+  ProfScope prof = sc_prof_begin(st);
   int ksplit = 0, variant = 0;
   gemm_dispatch(g, false, &ksplit, &variant, st);
   if (ksplit > 0) {
     const long n4 = (long)M * (N / 4);
     gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
   }
-  if (sample) {
-    rec.flops = 2.0 * M * N * K;
-    // algorithmic bytes: read A and W once, write C (read it too for the residual form)
-    rec.bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * ((flags & SC_GEMM_RESIDUAL) ? 2.0 : 1.0));
-    rec.variant = variant;
-    (void)hipEventRecord(rec.b, st);
-    g_recs.push_back(rec);
-  }
+  // algorithmic bytes: read A and W once, write C (read it too for the residual form)
+  sc_prof_end(prof, variant, 2.0 * M * N * K,
+              4.0 * ((double)M * K + (double)N * K + (double)M * N * ((flags & SC_GEMM_RESIDUAL) ? 2.0 : 1.0)));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -949,8 +957,12 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
     // without a row table the slab is addressed by offsetting the base pointers
     const float *xn_base = rows ? XN : XN + (long)m_done * D;
     p.XN = xn_base;
+    ProfScope prof = sc_prof_begin(st);
     if (D == 256) launch_ffn_rtt<256>(p, best_rtt, ngrp, st);
     else launch_ffn_rtt<128>(p, best_rtt, ngrp, st);
+    // algorithmic: 4*D*F flop per row; xn read, W1 + W2 read once, partials written
+    sc_prof_end(prof, SC_PROF_FFN_FUSED, 4.0 * (double)slab * D * F,
+                4.0 * ((double)slab * D + 2.0 * (double)D * F + (double)ngrp * slab * D));
     SC_CHECK_LAUNCH();
     GemmArgs g{nullptr, nullptr, D, nullptr, b2, rows ? X : X + (long)m_done * D, rows ? rows + m_done : nullptr, D,
                (int)slab, D, F, SC_GEMM_RESIDUAL | (rows ? SC_GEMM_LN_AT_CROWS : 0), 0, g_ws, 0};

@@ -418,8 +418,10 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
   const char *mode = getenv("SC_SELF_ATTN");   // test / A-B hook: "legacy"
   const bool legacy = mode && mode[0] == 'l';
   if (!legacy && sb.W <= 16 && (dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024) {
+    ProfScope prof = sc_prof_begin(st);
     if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
     else launch_attn_flash<16, true>(sb, layer, st);
+    sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);   // traffic depends on device-side state (L, ancestors)
     SC_CHECK_LAUNCH();
     return SC_OK;
   }
@@ -572,8 +574,10 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
   const char *xm = getenv("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
   if (seq && !(xm && xm[0] == 'l') && sb.W <= 16 && (dk == 32 || dk == 16)) {
     // one workgroup per (stream, head), single pass, coalesced K/V rows
+    ProfScope prof = sc_prof_begin(st);
     if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
     else launch_attn_flash<16, false>(sb, layer, st);
+    sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
     SC_CHECK_LAUNCH();
     return SC_OK;
   }

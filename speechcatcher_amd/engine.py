@@ -808,6 +808,8 @@ class StreamBatch:
             self._set_rowmap(ids[act])
             self._upload_ctrl()
             self.stats["dec_steps"] += 1
+            if "xattn_rows" in self.stats:   # bench.py roofline leg: K|V rows the cross-attention reads this step
+                self.stats["xattn_rows"] += int(T[act].sum()) * Ld
             t_st = time.perf_counter()
             be.decode_step(self)
             self._tick("decode_launch", t_st)
