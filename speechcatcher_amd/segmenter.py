@@ -1,0 +1,176 @@
+"""Long-recording segmentation and the file-level recognise loop on top of the
+batched engine - SURVEY.md section 8(f) rank 2.
+
+Replaces, for the native-decoder path, the reference CLI's
+``segment_speech`` + process pool over segments
+(speechcatcher/simple_endpointing.py:21-145, speechcatcher/speechcatcher.py:414-497,
+574-592): recordings longer than a minute are cut at low-energy points into
+~60 s segments, every segment is decoded as its own stream - here as PARALLEL
+streams of one ``StreamBatch`` on the GPU instead of forked CPU processes.
+
+* ``CutSearch`` restates the reference's beam search over cut points; pinned
+  against the reference class on seeded energy curves (tests/golden/segmenter.json,
+  tools/gen_golden_segmenter.py).
+* ``log_fbank_energy`` restates ``python_speech_features.logfbank`` (third-party
+  dependency of the reference, requirements.txt:10, unpinned version; absent in
+  this image) from its published algorithm: pre-emphasis 0.97, 25 ms / 10 ms
+  rectangular frames, 512-point power spectrum / NFFT, 26 triangular mel filters
+  0..fs/2, log.  PARITY UNPINNED for this function (no fixture can be generated
+  without the package); the cut search downstream of it is pinned.
+* ``plan_segments`` mirrors the chunk-aligned finalize positions of
+  speechcatcher.py:430-446; ``recognize_recording`` is the file-level loop.
+"""
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .scheduler import recognize_segments
+
+
+# ---------------------------------------------------------------------------
+# energy curve
+# ---------------------------------------------------------------------------
+def _mel_filterbank(nfilt: int, nfft: int, samplerate: int) -> np.ndarray:
+    hz2mel = lambda hz: 2595.0 * np.log10(1.0 + hz / 700.0)      # noqa: E731
+    mel2hz = lambda mel: 700.0 * (10.0 ** (mel / 2595.0) - 1.0)  # noqa: E731
+    melpoints = np.linspace(hz2mel(0.0), hz2mel(samplerate / 2.0), nfilt + 2)
+    bins = np.floor((nfft + 1) * mel2hz(melpoints) / samplerate)
+    fb = np.zeros((nfilt, nfft // 2 + 1))
+    for j in range(nfilt):
+        lo, mid, hi = int(bins[j]), int(bins[j + 1]), int(bins[j + 2])
+        for i in range(lo, mid):
+            fb[j, i] = (i - bins[j]) / (bins[j + 1] - bins[j])
+        for i in range(mid, hi):
+            fb[j, i] = (bins[j + 2] - i) / (bins[j + 2] - bins[j + 1])
+    return fb
+
+
+def log_fbank_energy(data: np.ndarray, samplerate: int = 16000, winlen: float = 0.025, winstep: float = 0.01,
+                     nfilt: int = 26, nfft: int = 512, preemph: float = 0.97) -> np.ndarray:
+    """(n_frames, nfilt) log mel filterbank energies, 100 frames per second."""
+    sig = np.asarray(data, dtype=np.float64)
+    sig = np.append(sig[0], sig[1:] - preemph * sig[:-1])
+    flen, fstep = int(round(winlen * samplerate)), int(round(winstep * samplerate))
+    n = len(sig)
+    nframes = 1 if n <= flen else 1 + int(math.ceil((1.0 * n - flen) / fstep))
+    pad = np.concatenate([sig, np.zeros((nframes - 1) * fstep + flen - n)])
+    idx = np.arange(flen)[None, :] + (np.arange(nframes) * fstep)[:, None]
+    frames = pad[idx]
+    pspec = (1.0 / nfft) * np.square(np.abs(np.fft.rfft(frames, nfft)))
+    feat = pspec @ _mel_filterbank(nfilt, nfft, samplerate).T
+    feat = np.where(feat == 0, np.finfo(float).eps, feat)
+    return np.log(feat)
+
+
+def smoothed_negative_energy(data: np.ndarray, samplerate: int = 16000) -> np.ndarray:
+    """simple_endpointing.py:81-84: summed log fbank / 10, Gaussian sigma = 20 frames, sign flipped
+    (pauses become maxima)."""
+    from scipy.ndimage import gaussian_filter1d
+    power = log_fbank_energy(data, samplerate).sum(axis=-1) / 10.0
+    return gaussian_filter1d(power, sigma=20) * -1.0
+
+
+# ---------------------------------------------------------------------------
+# cut search (simple_endpointing.py:21-79)
+# ---------------------------------------------------------------------------
+class CutSearch:
+    """Beam search over cut positions: a path is a list of cut frames; extending
+    it by a segment of j frames (min_len <= j < max_lookahead, every ``step``)
+    adds  w_len * f * (ideal - |ideal - j|) + w_energy * energy[cut]  with
+    f = w_len / ideal (the length weight enters twice, as in the reference)."""
+
+    def __init__(self, beam_size=10, ideal_segment_len=4000, max_lookahead=18000, min_len=2000, step=10,
+                 len_reward_weight=1.0, energy_weight=1.0):
+        self.beam_size, self.ideal, self.max_lookahead = beam_size, ideal_segment_len, max_lookahead
+        self.min_len, self.step = min_len, step
+        self.w_len, self.w_energy = len_reward_weight, energy_weight
+        self.factor = len_reward_weight / float(ideal_segment_len)
+
+    def search(self, energy: np.ndarray, n_frames: int) -> List[Tuple[int, int]]:
+        energy = np.asarray(energy, dtype=np.float64)
+        paths: List[Tuple[List[int], float]] = [([0], 0.0)]
+        while True:
+            worst_in_beam = paths[-1][1]
+            cand_scores, cand_src, cand_cut = [], [], []
+            expand = False
+            for pi, (cuts, score) in enumerate(paths):
+                last = cuts[-1]
+                j = np.arange(self.min_len, min(self.max_lookahead, n_frames - last - 1), self.step)
+                if j.size == 0:
+                    continue
+                length_reward = self.factor * (self.ideal - np.abs(self.ideal - j.astype(np.float64)))
+                new = score + ((self.w_len * length_reward) + (self.w_energy * energy[last + j]))
+                keep = new > score
+                if (new > worst_in_beam).any():
+                    expand = True
+                cand_scores.append(new[keep])
+                cand_cut.append(last + j[keep] + 1)
+                cand_src.append(np.full(int(keep.sum()), pi))
+            if not cand_scores or not expand:
+                break
+            sc, cut, src = np.concatenate(cand_scores), np.concatenate(cand_cut), np.concatenate(cand_src)
+            if sc.size == 0:
+                break
+            order = np.argsort(-sc, kind="stable")[: self.beam_size]   # ties keep generation order
+            paths = [(paths[int(src[o])][0] + [int(cut[o])], float(sc[o])) for o in order]
+        best = paths[0][0] if paths[0][0] != [0] else [0, n_frames]
+        return list(zip(best[:-1], best[1:]))
+
+
+def segment_speech(data: np.ndarray, samplerate: int = 16000, average_segment_length: float = 60.0,
+                   max_segment_len_sec: float = 180, beam_size: int = 10, step: int = 10,
+                   len_reward_weight: float = 12.0, energy_weight: float = 1.0) -> List[Tuple[int, int]]:
+    """simple_endpointing.py:81-145: (start, end) in 10 ms frames; no segment longer than max_segment_len_sec."""
+    energy = smoothed_negative_energy(data, samplerate)
+    search = CutSearch(beam_size=beam_size, ideal_segment_len=int(average_segment_length * 100), step=step,
+                       len_reward_weight=len_reward_weight, energy_weight=energy_weight)
+    return constrain_segments(search.search(energy, len(energy)), max_segment_len_sec)
+
+
+def constrain_segments(segments, max_segment_len_sec: float = 180) -> List[Tuple[int, int]]:
+    max_frames = int(max_segment_len_sec * 100)
+    out = []
+    for start, end in segments:
+        while end - start > max_frames:
+            out.append((start, start + max_frames))
+            start += max_frames
+        out.append((start, end))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# file-level loop (speechcatcher.py:414-497)
+# ---------------------------------------------------------------------------
+def plan_segments(n_samples: int, rate: int, segments: List[Tuple[int, int]], chunk_length: int = 8192):
+    """Chunk-aligned sample ranges of the decode segments: the reference finalises
+    at chunk index ceil((end_s * rate - chunk) / chunk) for every cut that leaves
+    at least 10 s, segment k covers chunks (i_k, i_{k+1}]  (speechcatcher.py:430-446,
+    574-586)."""
+    n_frames = (n_samples / rate) * 100.0
+    ends = [e for _, e in segments if e < n_frames - 1000.0]
+    max_i = (n_samples // chunk_length) + 1
+    idx = [-1] + [math.ceil((((f / 100.0) * rate) - chunk_length) / chunk_length) for f in ends] + [max_i]
+    ranges = []
+    for a, b in zip(idx[:-1], idx[1:]):
+        lo, hi = (a + 1) * chunk_length, min((b + 1) * chunk_length, n_samples)
+        if hi > lo:
+            ranges.append((lo, hi))
+    return ranges
+
+
+def recognize_recording(batch, raw_speech_data: np.ndarray, rate: int = 16000, chunk_length: int = 8192,
+                        token_list: Optional[List[str]] = None) -> Tuple[str, List[dict]]:
+    """int16 recording -> (text, per-segment info).  Native-decoder input scaling
+    /32768 in fp32 (speechcatcher.py:421); recordings over a minute are segmented;
+    the segments run as parallel streams of ``batch``."""
+    assert rate == 16000
+    speech = np.asarray(raw_speech_data).astype(np.float32) / 32768.0
+    segments = segment_speech(raw_speech_data, rate) if len(speech) > 60.0 * rate else []
+    ranges = plan_segments(len(speech), rate, segments, chunk_length)
+    res = recognize_segments(batch, speech, ranges, chunk_length=chunk_length, token_list=token_list)
+    info = []
+    for (lo, hi), r in zip(ranges, res):
+        info.append({"start": lo / rate, "end": hi / rate, "text": r["text"], "tokens": r["tokens"],
+                     "token_timestamps": r["token_timestamps"]})
+    return "\n\n".join(r["text"] for r in res) + "\n", info

@@ -118,6 +118,46 @@ def load_token_list(model_dir: Path) -> Optional[List[str]]:
     return None
 
 
+# ---------------------------------------------------------------------------
+# single-file model blob (offline-friendly asset path)
+# ---------------------------------------------------------------------------
+BLOB_SUFFIX = ".scasr"
+_CFG_FIELDS = ("vocab_size", "d_model", "enc_heads", "enc_layers", "dec_heads", "dec_layers", "n_fft",
+               "hop_length", "win_length")
+
+
+def save_model_blob(model_dir: Union[str, Path], out_path: Union[str, Path]) -> Path:
+    """Pack an ESPnet-layout model directory (``*.pth`` + ``config.yaml`` +
+    ``feats_stats.npz`` + ``bpe.model``: speech2text_streaming.py:76-81,100-105,
+    163-180) into ONE file that needs neither yaml, numpy archives nor
+    sentencepiece at load time: fp32 state dict, architecture, MVN statistics in
+    their original precision (float64 for the sum/count form, A11) and the token
+    list.  Loadable with ``torch.load(weights_only=True)``."""
+    model_dir, out_path = Path(model_dir), Path(out_path)
+    sd = load_state_dict(find_checkpoint(model_dir))
+    cfg = config_from_dir(model_dir, sd)
+    mean, std = load_stats(model_dir)
+    blob = {"format": 1, "config": {k: int(getattr(cfg, k)) for k in _CFG_FIELDS},
+            "state_dict": {k: v.detach().to(torch.float32).contiguous() for k, v in sd.items()
+                           if isinstance(v, torch.Tensor) and v.dtype.is_floating_point},
+            "mean": None if mean is None else torch.from_numpy(np.ascontiguousarray(mean)),
+            "std": None if std is None else torch.from_numpy(np.ascontiguousarray(std)),
+            "token_list": load_token_list(model_dir)}
+    torch.save(blob, out_path)
+    return out_path
+
+
+def load_model_blob(path: Union[str, Path]):
+    """-> (state_dict, ModelConfig, mean, std, token_list)"""
+    blob = torch.load(Path(path), map_location="cpu", weights_only=True)
+    if not isinstance(blob, dict) or blob.get("format") != 1:
+        raise ValueError(f"{path} is not a speechcatcher_amd model blob")
+    cfg = ModelConfig(**blob["config"])
+    mean = None if blob["mean"] is None else blob["mean"].numpy()
+    std = None if blob["std"] is None else blob["std"].numpy()
+    return blob["state_dict"], cfg, mean, std, blob["token_list"]
+
+
 class _BeamSearchView:
     """The attributes callers/tests touch on ``s2t.beam_search``
     (tests/test_speech2text_streaming.py:213-219)."""
@@ -206,10 +246,13 @@ class Speech2TextStreaming:
         self.use_bbd = use_bbd
         self.result_format = result_format
         from .hip_backend import HipBackend
-        sd = load_state_dict(find_checkpoint(self.model_dir))
-        self.cfg = config_from_dir(self.model_dir, sd)
-        self.mean, self.std = load_stats(self.model_dir)
-        self.token_list = load_token_list(self.model_dir)
+        if self.model_dir.is_file() and self.model_dir.suffix == BLOB_SUFFIX:
+            sd, self.cfg, self.mean, self.std, self.token_list = load_model_blob(self.model_dir)
+        else:
+            sd = load_state_dict(find_checkpoint(self.model_dir))
+            self.cfg = config_from_dir(self.model_dir, sd)
+            self.mean, self.std = load_stats(self.model_dir)
+            self.token_list = load_token_list(self.model_dir)
         self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std)
         self.model = self.weights
         self.backend = HipBackend(self.device)

@@ -177,3 +177,16 @@ def make_conformer_state(channels: int, n_head: int, kernel_size: int = 31, seed
     att["pos_bias_v"] = 0.2 * torch.randn(n_head, dk, generator=g)
     return ({k_: v.float().contiguous() for k_, v in conv.items()},
             {k_: v.float().contiguous() for k_, v in att.items()})
+
+
+def synth_energy_curve(seed: int, n_frames: int) -> np.ndarray:
+    """Seeded smoothed negative log-energy curve (100 frames/s) with speech-like
+    bursts and pauses: input of the segment cut search fixtures
+    (tools/gen_golden_segmenter.py, tests/test_segmenter.py)."""
+    from scipy.ndimage import gaussian_filter1d
+    rng = np.random.RandomState(seed)
+    raw = rng.randn(n_frames) * 2.0 + 20.0 + 6.0 * np.sin(np.arange(n_frames) / rng.uniform(150, 400))
+    for _ in range(n_frames // 900):
+        a = rng.randint(0, n_frames - 60)
+        raw[a:a + rng.randint(20, 120)] -= rng.uniform(4, 12)
+    return gaussian_filter1d(raw, sigma=20) * -1.0

@@ -147,3 +147,31 @@ def test_other_model_dimensions_spec_vs_oracle():
     got, ref = sb.hypotheses(0), ora.running_hyps
     assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref]
     np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=5e-3)
+
+
+def test_model_blob_round_trip(tmp_path):
+    """One-file model blob: same tensors, architecture and
+    MVN statistics (float64 kept for the sum/count form) as the directory."""
+    import numpy as np
+    import torch
+    from speechcatcher_amd import synth
+    from speechcatcher_amd.config import TINY
+    from speechcatcher_amd.speech2text_streaming import (config_from_dir, find_checkpoint, load_model_blob,
+                                                         load_state_dict, load_stats, save_model_blob)
+    for kind in ("meanstd", "sums"):
+        mdir = synth.write_model_dir(tmp_path / kind, TINY, seed=7, stats_kind=kind)
+        blob = save_model_blob(mdir, tmp_path / f"{kind}.scasr")
+        sd, cfg, mean, std, toks = load_model_blob(blob)
+        ref_sd = load_state_dict(find_checkpoint(mdir))
+        assert cfg == config_from_dir(mdir, ref_sd)
+        assert set(sd) == set(ref_sd) and all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+        rm, rs = load_stats(mdir)
+        assert mean.dtype == np.asarray(rm).dtype
+        np.testing.assert_array_equal(mean, rm)
+        np.testing.assert_array_equal(std, rs)
+        assert toks is None
+    with open(tmp_path / "bad.scasr", "wb") as f:
+        torch.save({"format": 99}, f)
+    import pytest
+    with pytest.raises(ValueError):
+        load_model_blob(tmp_path / "bad.scasr")

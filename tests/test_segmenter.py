@@ -1,0 +1,66 @@
+"""Segmentation: the cut search against golden vectors from
+the real reference class, the chunk-aligned segment plan, and the file-level
+loop on CPU with the spec backend."""
+import json
+
+import numpy as np
+
+from conftest import GOLDEN
+from speechcatcher_amd import synth
+from speechcatcher_amd.segmenter import (CutSearch, constrain_segments, log_fbank_energy, plan_segments,
+                                         recognize_recording, segment_speech)
+
+
+def test_cut_search_matches_reference_golden():
+    cases = json.loads((GOLDEN / "segmenter.json").read_text())["cases"]
+    assert len(cases) >= 5
+    for c in cases:
+        e = synth.synth_energy_curve(c["seed"], c["n"])
+        s = CutSearch(ideal_segment_len=int(c["average_segment_length"] * 100), **c["params"])
+        assert [list(x) for x in s.search(e, c["n"])] == c["segments"], c["seed"]
+
+
+def test_constrain_and_plan():
+    assert constrain_segments([(0, 50000), (50000, 52000)], 180) == [(0, 18000), (18000, 36000), (36000, 50000),
+                                                                     (50000, 52000)]
+    # 100 s of audio, cuts at 30 s and 95 s: the second leaves < 10 s and is dropped (speechcatcher.py:430)
+    n, rate, chunk = 1_600_000, 16000, 8192
+    r = plan_segments(n, rate, [(0, 3000), (3000, 9500), (9500, 10000)], chunk)
+    assert r[0][0] == 0 and r[-1][1] == n and len(r) == 2
+    assert all(a % chunk == 0 for a, _ in r) and r[0][1] == r[1][0]
+    i_fin = int(np.ceil((30.0 * rate - chunk) / chunk))
+    assert r[0][1] == (i_fin + 1) * chunk
+    assert plan_segments(50000, rate, [], chunk) == [(0, 50000)]
+
+
+def test_log_fbank_shape_and_silence_detection():
+    rate = 16000
+    rng = np.random.RandomState(0)
+    x = (rng.randn(rate * 4) * 3000).astype(np.int16)
+    x[rate:2 * rate] = (rng.randn(rate) * 30).astype(np.int16)      # one quiet second
+    fb = log_fbank_energy(x, rate)
+    assert fb.shape == (1 + int(np.ceil((len(x) - 400) / 160)), 26) and np.isfinite(fb).all()
+    e = fb.sum(-1)
+    assert e[110:190].mean() < e[10:90].mean() - 20      # the pause is far below the speech level
+    assert log_fbank_energy(np.zeros(100, np.int16), rate).shape == (1, 26)
+
+
+def test_recognize_recording_segments_run_as_parallel_streams():
+    from test_engine_spec import make_batch
+    rate = 16000
+    rng = np.random.RandomState(1)
+    x = (synth.synth_audio(40, 70 * rate) * 20000)
+    for t0 in (18, 41):                                   # two pauses
+        x[t0 * rate:(t0 + 2) * rate] *= 0.01
+    x = x.astype(np.int16)
+    segs = segment_speech(x, rate, average_segment_length=20.0)
+    assert len(segs) >= 2 and segs[0][0] == 0
+    sb = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=2, max_frames=2000, max_tokens=1200,
+                    pcm_capacity=1 << 21)
+    text, info = recognize_recording(sb, x, rate, chunk_length=8192)
+    assert len(info) >= 1 and info[0]["start"] == 0.0 and abs(info[-1]["end"] - 70.0) < 1e-6
+    assert all(a["end"] == b["start"] for a, b in zip(info[:-1], info[1:]))
+    assert isinstance(text, str) and text.endswith("\n")
+    for seg in info:
+        assert len(seg["tokens"]) == len(seg["token_timestamps"])
+        assert all(seg["start"] <= t <= seg["end"] + 1.0 for t in seg["token_timestamps"])
