@@ -321,10 +321,22 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
   const int n4 = g.N >> 2;
   if (idx >= (long)g.M * n4) return;
   const int m = idx / n4, n = (idx % n4) * 4;
-  float4 acc = *reinterpret_cast<const float4 *>(g.part + (long)m * g.N + n);
-  for (int z = 1; z < ksplit; ++z) {
-    const float4 p = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
-    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  // partials are fetched 8 at a time (independent loads in flight), summed in slice order
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z0 = 0; z0 < ksplit; z0 += 8) {
+    float4 p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int z = min(z0 + i, ksplit - 1);
+      p[i] = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (z0 + i < ksplit) {
+        if (z0 + i == 0) acc = p[0];
+        else { acc.x += p[i].x; acc.y += p[i].y; acc.z += p[i].z; acc.w += p[i].w; }
+      }
+    }
   }
   if (g.bias) {
     const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
@@ -360,10 +372,22 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(GemmArgs g, 
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
     if (c < nv) {
-      float4 acc = reinterpret_cast<const float4 *>(g.part + (long)m * g.N)[c];
-      for (int z = 1; z < ksplit; ++z) {
-        const float4 p = reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N)[c];
-        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+      // partials are fetched 8 at a time (independent loads in flight), summed in slice order
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z0 = 0; z0 < ksplit; z0 += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int z = min(z0 + q, ksplit - 1);
+          p[q] = reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N)[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (z0 + q < ksplit) {
+            if (z0 + q == 0) acc = p[0];
+            else { acc.x += p[q].x; acc.y += p[q].y; acc.z += p[q].z; acc.w += p[q].w; }
+          }
+        }
       }
       if (g.bias) {
         const float4 b = reinterpret_cast<const float4 *>(g.bias)[c];
@@ -945,13 +969,22 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
       for (int rtt = 1; rtt <= 5; ++rtt) {
         const long wgs = (long)ngrp * ((mm + 16 * rtt - 1) / (16 * rtt));
         const double rounds = (double)((wgs + 255) / 256);
-        // per workgroup: fixed ~2 us + 3.4 us of MFMA per 16 rows and chunk; reduce: bytes of the partials
-        double t = rounds * (2.0 + 3.4 * rtt * cpw) + 1.5 + 2.0 * (double)mm * D * 4.0 * ngrp / 3.0e6;
+        // per workgroup: fixed ~2.5 us + 4.0 us per 16 rows and chunk (measured); reduce: bytes of the partials
+        double t = rounds * (2.5 + 4.0 * rtt * cpw) + 1.5 + 2.0 * (double)mm * D * 4.0 * ngrp / 3.0e6;   // fitted: tools/ffn_sweep.py
         t *= (double)(M - m_done) / (double)mm;   // slabs needed at this size
         if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; slab = mm; }
       }
     }
     SC_CHECK_ARG(best < 1e29, "workspace too small for sc_ffn_ln");
+    if (const char *f = getenv("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
+      int r = 0, c = 0;
+      if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && nch % c == 0 &&
+          (long)(M - m_done) * (nch / c) <= ws_rows_per_part) {
+        best_rtt = r;
+        best_cpw = c;
+        slab = M - m_done;
+      }
+    }
     const int ngrp = nch / best_cpw;
     FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
     // without a row table the slab is addressed by offsetting the base pointers
