@@ -64,10 +64,16 @@ def preload_audio(sb, n_steps_total, stream_offset=0):
     torch.cuda.synchronize()
 
 
+OVERLAP = False   # --overlap: prefetch the next step's encoder stage on a second HIP stream
+
+
 def run_steps(sb, n):
+    """n chunk steps over all streams.  With OVERLAP the frontend + encoder pass of
+    step i+1 is launched on a second HIP stream before the decode loop of step i
+    (StreamBatch.push(prefetch=...)): steady-state pipelining of the same work."""
     items = [(s, CHUNK, False) for s in range(sb.S)]
     for _ in range(n):
-        sb.push(items, pcm_resident=True)
+        sb.push(items, pcm_resident=True, prefetch=items if OVERLAP else None)
 
 
 def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
@@ -113,9 +119,13 @@ def main():
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the GEMM kernel")
+    ap.add_argument("--overlap", action="store_true",
+                    help="launch the frontend + encoder of step i+1 on a second HIP stream before the decode loop of "
+                         "step i (measured slower than the serial order: DESIGN.md section 4, negative results)")
     args = ap.parse_args()
-    global CHUNK
+    global CHUNK, OVERLAP
     CHUNK = args.chunk
+    OVERLAP = bool(args.overlap)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -260,6 +270,7 @@ def main():
 
     single = None
     if not args.no_single_stream and world == 1:
+        OVERLAP = False   # latency of ONE real-time stream: the next chunk does not exist yet
         sb1, _ = build_batch(1, args.beam, bool(args.bbd), args.warmup + args.steps, device)
         preload_audio(sb1, args.warmup + args.steps)
         run_steps(sb1, args.warmup)
@@ -287,6 +298,8 @@ def main():
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
+                   "pipelining": ("encoder of chunk step i+1 on a second HIP stream overlaps the decode loop of step i"
+                                  if args.overlap else "none"),
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
         "chunk_steps_per_s": round(world * args.streams * args.steps / elapsed, 2),
         "decode_steps_per_hop": round(dec_steps / max(args.steps, 1), 2),

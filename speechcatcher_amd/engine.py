@@ -183,6 +183,10 @@ class StreamBatch:
             self._arena_host = torch.zeros(self._arena_cap, dtype=i32, pin_memory=True)
             self._arena_np = self._arena_host.numpy()
             self._arena_dev = torch.zeros(self._arena_cap, dtype=i32, device=dev)
+        self._arena_main = None      # saved main arena while the prefetch stage uses its own (push(prefetch=...))
+        self._arena_pf = None
+        self.stream_enc = None       # second HIP stream: frontend + encoder of the NEXT chunk step
+        self._prefetched = None
         self._flags_np = self._flags_host.numpy()
         n = S * W
         self.dx = z(n, d)
@@ -206,7 +210,9 @@ class StreamBatch:
 
         # all device work of this batch runs on one dedicated (non-default) HIP
         # stream, which also makes the decode step capturable as a hipGraph
-        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # (high priority: when a prefetched encoder stage runs on the second stream, the
+        # latency-bound decode kernels must not queue behind its large grids)
+        self.stream = torch.cuda.Stream(device=dev, priority=-1) if dev.type == "cuda" else None
         if self.stream is not None and hasattr(backend, "bind_stream"):
             backend.bind_stream(self.stream)
         self.st = [StreamState() for _ in range(S)]
@@ -271,6 +277,8 @@ class StreamBatch:
         (speech2text_streaming.py:252-263, beam_search.py:343-356).  Unlike
         the reference, the CTC table is dropped too (the reference keeps its
         stale scorer.impl - see DESIGN.md "Deliberate deviations")."""
+        if self._prefetched is not None:
+            raise EngineError("reset() while a prefetched chunk step is pending")
         old = self.st[s]
         ns = StreamState()
         if self.strict_reference:
@@ -334,17 +342,65 @@ class StreamBatch:
 
     # ------------------------------------------------------------------
     def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]],
-             pcm_resident: bool = False):
+             pcm_resident: bool = False, prefetch: Optional[Sequence[Tuple[int, Optional[np.ndarray], bool]]] = None):
+        """One chunk step.  ``prefetch`` (GPU only, optional): the chunk step that the
+        NEXT push() call will pass - its frontend + encoder pass is launched on a
+        second HIP stream before this step's decode loop starts, so that the encoder
+        (large MFMA-bound kernels) overlaps the latency-bound decode steps; the next
+        push() then only waits for it.  Results are identical to the serial order:
+        the decode schedule of this step sees the encoder frames of this step only."""
         if self.stream is None:
-            return self._push(chunks, pcm_resident)
-        self._arena_off = 0
+            out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
+            self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
+            return out
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None:
+            if pf["key"] != self._chunk_key(chunks, pcm_resident):
+                raise EngineError("push() does not match the chunk step announced by the previous push(prefetch=...)")
+            out, feat_new, finals = pf["out"], pf["feat_new"], pf["finals"]
+            self.stream.wait_stream(self.stream_enc)
+            self._arena_off = 0
+        else:
+            self._arena_off = 0
+            with torch.cuda.stream(self.stream):
+                out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
+        t_avail = {s: self.st[s].T_enc for s in feat_new}
+        if prefetch is not None:
+            self._launch_prefetch(prefetch, pcm_resident)
         with torch.cuda.stream(self.stream):
-            out = self._push(chunks, pcm_resident)
+            self._stage_decode(feat_new, finals, t_avail)
         self.stream.synchronize()
         return out
 
-    def _push(self, chunks, pcm_resident=False):
-        """One chunk step for the listed streams: (stream, samples, is_final).
+    @staticmethod
+    def _chunk_key(chunks, pcm_resident):
+        return tuple((int(s), int(x) if pcm_resident else int(len(x)), bool(f)) for s, x, f in chunks)
+
+    def _launch_prefetch(self, chunks, pcm_resident):
+        if any(f for _, _, f in chunks):
+            raise EngineError("prefetch is for non-final chunk steps")
+        if self.stream_enc is None:
+            self.stream_enc = torch.cuda.Stream(device=self.dev, priority=0)
+            if hasattr(self.be, "bind_stream"):
+                self.be.bind_stream(self.stream_enc)
+            self._arena_pf = {"host": torch.zeros(self._arena_cap, dtype=torch.int32, pin_memory=True),
+                              "dev": torch.zeros(self._arena_cap, dtype=torch.int32, device=self.dev)}
+        # the prefetched stage stages its job tables in its own pinned arena (the main
+        # one is recycled by the decode stage of this step and by the next push)
+        main = (self._arena_host, self._arena_np, self._arena_dev, self._arena_off)
+        self._arena_host, self._arena_dev = self._arena_pf["host"], self._arena_pf["dev"]
+        self._arena_np, self._arena_off = self._arena_host.numpy(), 0
+        try:
+            self.stream_enc.wait_stream(self.stream)   # this step's own encoder stage (if it ran on the main stream)
+            with torch.cuda.stream(self.stream_enc):
+                out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
+        finally:
+            self._arena_host, self._arena_np, self._arena_dev, self._arena_off = main
+        self._prefetched = {"key": self._chunk_key(chunks, pcm_resident), "out": out, "feat_new": feat_new,
+                            "finals": finals}
+
+    def _stage_encode(self, chunks, pcm_resident=False):
+        """Frontend + encoder of one chunk step for the listed streams: (stream, samples, is_final).
 
         ``samples`` is 1-D float PCM in +-1 (np.ndarray / torch tensor); with
         ``pcm_resident`` the samples are already in ``self.pcm`` and the
@@ -389,8 +445,8 @@ class StreamBatch:
         out = {s: (s in feat_new) for s, _, _ in chunks}
         self._tick("frontend_host", t_ph)
         if feat_new:
-            self._process_features(feat_new, finals)
-        return out
+            self._encode_features(feat_new, finals)
+        return out, feat_new, finals
 
     def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]]):
         if self.stream is None:
@@ -412,7 +468,8 @@ class StreamBatch:
             self.featbuf[r0:r0 + n].copy_(torch.as_tensor(feats, dtype=torch.float32))
             feat_new[s] = n
             finals[s] = bool(is_final)
-        self._process_features(feat_new, finals)
+        self._encode_features(feat_new, finals)
+        self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
 
     def _compact_pcm(self, s: int):
         st = self.st[s]
@@ -424,8 +481,7 @@ class StreamBatch:
     # ------------------------------------------------------------------
     # process_block: encoder + decode schedule
     # ------------------------------------------------------------------
-    def _process_features(self, feat_new: Dict[int, int], finals: Dict[int, bool]):
-        cfg = self.cfg
+    def _encode_features(self, feat_new: Dict[int, int], finals: Dict[int, bool]):
         for s in feat_new:
             st = self.st[s]
             if not st.started:
@@ -436,6 +492,14 @@ class StreamBatch:
             t_ph = time.perf_counter()
             self._encode(enc_streams, feat_new, finals)
             self._tick("encode_host", t_ph)
+
+    def _stage_decode(self, feat_new: Dict[int, int], finals: Dict[int, bool], t_avail: Dict[int, int]):
+        """Decode schedule of one chunk step.  ``t_avail[s]`` = encoder frames of
+        stream s after THIS step's encoder stage (a prefetched next step may already
+        have appended more frames to the buffer; they belong to the next call)."""
+        cfg = self.cfg
+        if not feat_new:
+            return
         # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
         pending = list(feat_new.keys())
         done_final = set()
@@ -446,10 +510,10 @@ class StreamBatch:
                 if s in done_final:
                     continue
                 cur_end = cfg.block_size - cfg.look_ahead + cfg.hop_size * st.processed_block
-                if st.T_enc > 0 and cur_end < st.T_enc:
+                if t_avail[s] > 0 and cur_end < t_avail[s]:
                     todo.append((s, cur_end, False))
-                elif finals[s] and st.T_enc > 0:
-                    todo.append((s, st.T_enc, True))
+                elif finals[s] and t_avail[s] > 0:
+                    todo.append((s, t_avail[s], True))
                     done_final.add(s)
             if not todo:
                 break
