@@ -168,6 +168,10 @@ int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const f
               const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
               const float *ln_b, float ln_eps, float *ln_out, void *stream);
 int sc_ffn_ln_supported(int D, int F);
+/* bytes of the split-K workspace registered for `stream` (0: none).  sc_decoder_layers /
+ * sc_encoder_layers use the fused FFN only when a workspace is available and fall back to
+ * two GEMMs otherwise. */
+size_t sc_workspace_bytes(void *stream);
 
 /* Workspace (device memory, caller-owned) for the deterministic split-K path of
  * sc_gemm: partial sums [ksplit][M][N] reduced in fixed order.  Without it

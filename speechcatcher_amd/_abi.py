@@ -62,6 +62,7 @@ _SIGS = {
     "sc_pack_panel_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "sc_ffn_ln": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
+    "sc_workspace_bytes": (C.c_size_t, [vp]),
     "sc_graph_capture_begin": (C.c_int, [vp]),
     "sc_graph_capture_end": (C.c_int, [vp, C.POINTER(vp)]),
     "sc_graph_launch": (C.c_int, [vp, vp]),

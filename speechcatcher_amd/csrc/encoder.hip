@@ -450,7 +450,8 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   const int M = nblk * R;
   if (M <= 0) return SC_OK;
   const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
-  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F);
+  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
+                         sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   for (int li = 0; li < n_layers; ++li) {

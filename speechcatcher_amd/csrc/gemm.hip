@@ -573,6 +573,11 @@ static void resolve_workspace(void *stream) {
   g_ws_bytes = w.bytes;
 }
 
+extern "C" size_t sc_workspace_bytes(void *stream) {
+  resolve_workspace(stream);
+  return g_ws ? g_ws_bytes : 0;
+}
+
 // Launches the main kernel.  force_part: always leave raw partial sums in the
 // workspace (ksplit >= 1) for a fused reduce epilogue.  Returns the number of
 // K slices through *ksplit_out (0: the kernel wrote the final result itself).

@@ -619,7 +619,8 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   const bool panel_env = !(pe && atoi(pe) == 0);
   const bool panel = panel_env && sc_proj_ln_proj_supported(d);
   const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
-  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F);
+  const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
+                         sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
