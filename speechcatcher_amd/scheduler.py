@@ -105,7 +105,7 @@ class StreamScheduler:
 
 def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tuple[int, int]],
                        chunk_length: int = 8192, token_list: Optional[List[str]] = None,
-                       frames_per_second: float = 24.0) -> List[dict]:
+                       frames_per_second: float = 24.0, finalize_all_last_only: bool = False) -> List[dict]:
     """Decode the (start, end) sample ranges of one recording as PARALLEL streams
     of one batch instead of the reference's process pool over segments
     (speechcatcher/speechcatcher.py:474-497, chunk loop :574-592; SURVEY 8(f)
@@ -126,7 +126,11 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
             for pos in range(0, len(seg), chunk_length):
                 end = min(pos + chunk_length, len(seg))
                 last = end >= len(seg)
-                sch.feed(sid, seg[pos:end], is_final=last, finalize_all=last)
+                # the reference CLI passes finalize_all only with the very last chunk of the
+                # recording (speechcatcher.py:586): earlier segments then return only beams that
+                # ended in <eos> (A5); the default here returns the best beam of every segment
+                fa = last and (not finalize_all_last_only or idx == len(segments) - 1)
+                sch.feed(sid, seg[pos:end], is_final=last, finalize_all=fa)
         for sid, res in sch.step().items():
             if not sch._queue[sid]:          # that was the final chunk of the session
                 idx = sid_to_seg.pop(sid)

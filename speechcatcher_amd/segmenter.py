@@ -159,18 +159,72 @@ def plan_segments(n_samples: int, rate: int, segments: List[Tuple[int, int]], ch
     return ranges
 
 
+def upper_case_first_letter(text: str) -> str:
+    """speechcatcher.py:309-312"""
+    return text[0].upper() + text[1:] if text and text[0].islower() else text
+
+
+def is_completed(text: str) -> bool:
+    """speechcatcher.py:316-317"""
+    return text.endswith((".", "?", "!"))
+
+
+def interpolate_repeating_positions(positions: List[float]) -> List[float]:
+    """speechcatcher.py:323-352: inside a run of equal positions only the last element keeps
+    the value, the others are spread linearly between the preceding value (0 before the first
+    run) and it - several tokens emitted on the same encoder frame get increasing timestamps."""
+    vals = [0.0] + [float(p) for p in positions]
+    out: List[float] = []
+    i = 0
+    while i < len(vals):
+        start = i
+        while i < len(vals) and vals[i] == vals[start]:
+            i += 1
+        end = i - 1
+        prev = 0.0 if start == 0 else vals[start - 1]
+        n = end - start + 1
+        out.extend(prev + (end - j) / n * (vals[start] - vals[start - 1]) for j in range(start, end))
+        out.append(vals[end])
+    return out[1:]
+
+
+def merge_paragraphs(segments: List[dict]) -> Tuple[str, List[dict]]:
+    """speechcatcher.py:516-572: a segment starts a new paragraph (first letter capitalised)
+    only if the previous segment's text ended a sentence; otherwise its text, tokens and
+    timestamps are appended to the open paragraph."""
+    if not segments:
+        return "\n", []
+    merged = [segments[0]["text"]]
+    info = [dict(segments[0])]
+    for prev, seg in zip(segments[:-1], segments[1:]):
+        if is_completed(prev["text"]):
+            text = upper_case_first_letter(seg["text"])
+            merged.append(text)
+            info.append(dict(seg, text=text))
+        else:
+            merged[-1] += " " + seg["text"]
+            last = info[-1]
+            last["end"] = seg["end"]
+            last["text"] += " " + seg["text"]
+            last["tokens"] = list(last["tokens"]) + list(seg["tokens"])
+            last["token_timestamps"] = list(last["token_timestamps"]) + list(seg["token_timestamps"])
+    return "\n\n".join(merged) + "\n", info
+
+
 def recognize_recording(batch, raw_speech_data: np.ndarray, rate: int = 16000, chunk_length: int = 8192,
-                        token_list: Optional[List[str]] = None) -> Tuple[str, List[dict]]:
-    """int16 recording -> (text, per-segment info).  Native-decoder input scaling
+                        token_list: Optional[List[str]] = None, reference_finalize: bool = False
+                        ) -> Tuple[str, List[dict]]:
+    """int16 recording -> (text, per-paragraph info).  Native-decoder input scaling
     /32768 in fp32 (speechcatcher.py:421); recordings over a minute are segmented;
-    the segments run as parallel streams of ``batch``."""
+    the segments run as parallel streams of ``batch``; paragraphs are merged like
+    the CLI does.  ``reference_finalize``: pass finalize_all only with the last
+    chunk of the recording, as the reference CLI does."""
     assert rate == 16000
     speech = np.asarray(raw_speech_data).astype(np.float32) / 32768.0
     segments = segment_speech(raw_speech_data, rate) if len(speech) > 60.0 * rate else []
     ranges = plan_segments(len(speech), rate, segments, chunk_length)
-    res = recognize_segments(batch, speech, ranges, chunk_length=chunk_length, token_list=token_list)
-    info = []
-    for (lo, hi), r in zip(ranges, res):
-        info.append({"start": lo / rate, "end": hi / rate, "text": r["text"], "tokens": r["tokens"],
-                     "token_timestamps": r["token_timestamps"]})
-    return "\n\n".join(r["text"] for r in res) + "\n", info
+    res = recognize_segments(batch, speech, ranges, chunk_length=chunk_length, token_list=token_list,
+                             finalize_all_last_only=reference_finalize)
+    segs = [{"start": lo / rate, "end": hi / rate, "text": r["text"], "tokens": r["tokens"],
+             "token_timestamps": r["token_timestamps"]} for (lo, hi), r in zip(ranges, res)]
+    return merge_paragraphs(segs)

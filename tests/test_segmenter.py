@@ -7,8 +7,9 @@ import numpy as np
 
 from conftest import GOLDEN
 from speechcatcher_amd import synth
-from speechcatcher_amd.segmenter import (CutSearch, constrain_segments, log_fbank_energy, plan_segments,
-                                         recognize_recording, segment_speech)
+from speechcatcher_amd.segmenter import (CutSearch, constrain_segments, interpolate_repeating_positions,
+                                         log_fbank_energy, merge_paragraphs, plan_segments, recognize_recording,
+                                         segment_speech)
 
 
 def test_cut_search_matches_reference_golden():
@@ -64,3 +65,19 @@ def test_recognize_recording_segments_run_as_parallel_streams():
     for seg in info:
         assert len(seg["tokens"]) == len(seg["token_timestamps"])
         assert all(seg["start"] <= t <= seg["end"] + 1.0 for t in seg["token_timestamps"])
+
+
+def test_paragraph_merge_and_position_interpolation():
+    segs = [{"start": 0.0, "end": 10.0, "text": "hallo welt", "tokens": ["a", "b"], "token_timestamps": [1.0, 2.0]},
+            {"start": 10.0, "end": 20.0, "text": "und weiter.", "tokens": ["c"], "token_timestamps": [11.0]},
+            {"start": 20.0, "end": 30.0, "text": "neuer satz", "tokens": ["d"], "token_timestamps": [21.0]}]
+    text, info = merge_paragraphs(segs)
+    assert text == "hallo welt und weiter.\n\nNeuer satz\n"
+    assert len(info) == 2 and info[0]["end"] == 20.0 and info[0]["tokens"] == ["a", "b", "c"]
+    assert info[0]["token_timestamps"] == [1.0, 2.0, 11.0] and info[1]["text"] == "Neuer satz"
+    assert merge_paragraphs([]) == ("\n", [])
+    # runs of equal frame positions are spread between the previous value and the run's value; like the
+    # reference (speechcatcher.py:343-348, checked against its function on random inputs when this was
+    # written) the interpolated values of a run come out in DEcreasing order before the run's last element
+    assert interpolate_repeating_positions([4, 4, 8, 8, 8, 9]) == [2.0, 4.0, 4.0 + 8 / 3, 4.0 + 4 / 3, 8.0, 9.0]
+    assert interpolate_repeating_positions([3]) == [3.0] and interpolate_repeating_positions([]) == []
