@@ -566,13 +566,18 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
   SC_CHECK_ARG(sb.xchunk == 256, "xchunk must be 256");
   const int dk = sb.d / sb.H;
   hipStream_t st = (hipStream_t)stream;
-  bool seq = sb.S * sb.H >= 192;   // enough workgroups without splitting T
+  // one workgroup per (stream, head) over all of T.  With the single-pass kernel this is
+  // also the faster form for few streams (measured: 1 / 8 / 16 streams 58.3 / 266.9 / 452.5
+  // vs 58.3 / 260.8 / 433.6 audio-s/s for the split + merge pair); the legacy kernel
+  // pair only splits T when S*H workgroups would not fill the chip.
+  const bool flash_ok = sb.W <= 16 && (dk == 32 || dk == 16);
+  bool seq = flash_ok || sb.S * sb.H >= 192;
   if (const char *e = getenv("SC_XATTN_MODE")) {   // test hook: "seq" / "split"
     if (e[0] == 's' && e[1] == 'e') seq = true;
     else if (e[0] == 's' && e[1] == 'p') seq = false;
   }
   const char *xm = getenv("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
-  if (seq && !(xm && xm[0] == 'l') && sb.W <= 16 && (dk == 32 || dk == 16)) {
+  if (seq && !(xm && xm[0] == 'l') && flash_ok) {
     // one workgroup per (stream, head), single pass, coalesced K/V rows
     ProfScope prof = sc_prof_begin(st);
     if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
