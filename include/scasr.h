@@ -67,7 +67,7 @@ typedef struct sc_dec_layer {
   const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
   const float *ln2_g, *ln2_b, *wq, *bq, *wo2, *bo2;
   const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;
-  const float *wo_p, *wq_p, *wo2_p; /* sc_pack_panel_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
+  const float *wo_p, *wq_p, *wo2_p; /* sc_pack_lane_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
   const float *w1_p, *w2_p;         /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
 } sc_dec_layer;
 
@@ -143,17 +143,20 @@ int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const float *W, c
  * x = residual + self_attn(..); x = norm2(x); src_attn's linear_q,
  * multi_head_attention.py:58-60):
  *   X[m] += A[m] . W1^T + b1;  XN[m] = LN(X[m]) (if XN);  Q[m] = LN(X[m]) . W2^T + b2 (if W2).
- * One workgroup owns 16 complete rows (D = 64, 128 or 256), so the LayerNorm
- * and the second projection need no second launch.  v_mfma_f32_16x16x4_f32.
+ * One workgroup owns 4, 8 or 16 complete rows (D = 64, 128 or 256), so the LayerNorm
+ * and the second projection need no second launch.  v_mfma_f32_4x4x1_16B_f32.
  * A must be 16-byte aligned with lda % 4 == 0.  rows (optional): the M rows of
  * A / X / XN / Q to process (NULL: rows 0..M-1). */
-int sc_proj_ln_proj(const float *A, int lda, const float *W1p, const float *b1, float *X, int ldx,
+int sc_proj_ln_proj(const float *A, int lda, const float *W1q, const float *b1, float *X, int ldx,
                     const float *ln_g, const float *ln_b, float ln_eps, float *XN, int ldn,
-                    const float *W2p, const float *b2, float *Q, int ldq, const int32_t *rows,
+                    const float *W2q, const float *b2, float *Q, int ldq, const int32_t *rows,
                     int M, int D, void *stream);
 int sc_proj_ln_proj_supported(int D);
-/* W1p / W2p are Linear weights [N][K] re-ordered ONCE into MFMA fragment
- * order so that every wave load is 1 KB contiguous (N % 16 == 0, K % 32 == 0):
+/* W1q / W2q: the [D][D] Linear weights re-ordered ONCE so that lane l of a wave reads
+ * W[64*tile + l][4*q .. 4*q+3] as one 16-byte element (N % 64 == 0, K % 4 == 0):
+ *   out[((tile*(K/4) + q)*64 + lane)*4 + c] = W[tile*64 + lane][4*q + c]            */
+int sc_pack_lane_weight(const float *W, int N, int K, float *out, void *stream);
+/* Fragment order of the 16x16x4-MFMA kernels (sc_ffn_ln; N % 16 == 0, K % 32 == 0):
  *   out[((((tile*(K/32) + ki)*2 + half)*64 + lane)*4 + c]
  *       = W[tile*16 + lane%16][ki*32 + 8*(lane/16) + 4*half + c]              */
 int sc_pack_panel_weight(const float *W, int N, int K, float *out, void *stream);

@@ -303,14 +303,14 @@ class SpecBackend:
 
     def proj_ln_proj(self, A, lda, W1, b1, X, ldx, ln_g, ln_b, XN, W2, b2, Q, M, D, eps=1e-12, rows=None):
         """sc_proj_ln_proj: X += A.W1^T + b1; XN = LN(X) (optional output);
-        Q = LN(X).W2^T + b2 (optional).  W1 / W2 arrive in the fragment order of
-        sc_pack_panel_weight."""
-        from speechcatcher_amd.weights import unpack_panel_weight
+        Q = LN(X).W2^T + b2 (optional).  W1 / W2 arrive in the lane order of
+        sc_pack_lane_weight."""
+        from speechcatcher_amd.weights import unpack_lane_weight
         xn = XN if XN is not None else torch.empty_like(X)
-        self.gemm_ln(A, rows, lda, unpack_panel_weight(W1), b1, X, rows, ldx, M, D, D, ln_g, ln_b, xn,
+        self.gemm_ln(A, rows, lda, unpack_lane_weight(W1), b1, X, rows, ldx, M, D, D, ln_g, ln_b, xn,
                      residual=True, eps=eps, ln_at_crows=rows is not None)
         if W2 is not None:
-            self.gemm(xn, rows, D, unpack_panel_weight(W2), b2, Q, rows, D, M, D, D)
+            self.gemm(xn, rows, D, unpack_lane_weight(W2), b2, Q, rows, D, M, D, D)
 
     def ffn_ln(self, XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
         """sc_ffn_ln: X[r] += W2.relu(W1.XN[r] + b1) + b2; ln_out[r] = LN(X[r]) (optional).

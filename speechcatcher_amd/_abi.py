@@ -60,6 +60,7 @@ _SIGS = {
                                   vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "sc_proj_ln_proj_supported": (C.c_int, [C.c_int]),
     "sc_pack_panel_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "sc_pack_lane_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "sc_ffn_ln": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_workspace_bytes": (C.c_size_t, [vp]),

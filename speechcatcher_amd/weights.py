@@ -44,6 +44,19 @@ def unpack_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
     return Wp.reshape(N // 16, K // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5).contiguous().reshape(N, K)
 
 
+def pack_lane_weight(W: torch.Tensor) -> torch.Tensor:
+    """[N][K] Linear weight -> lane order of sc_proj_ln_proj (include/scasr.h:
+    out[tile][q][lane][c] = W[tile*64 + lane][4*q + c]); a pure permutation."""
+    N, K = W.shape
+    assert N % 64 == 0 and K % 4 == 0
+    return W.reshape(N // 64, 64, K // 4, 4).permute(0, 2, 1, 3).contiguous().reshape(N, K)
+
+
+def unpack_lane_weight(Wq: torch.Tensor) -> torch.Tensor:
+    N, K = Wq.shape
+    return Wq.reshape(N // 64, K // 4, 64, 4).permute(0, 2, 1, 3).contiguous().reshape(N, K)
+
+
 def ffn_fused_supported(d: int, F: int) -> bool:
     """sc_ffn_ln_supported"""
     return d in (128, 256) and F % 128 == 0 and F >= 128
@@ -123,7 +136,7 @@ class PackedWeights:
             ))
         for lw in self.dec:   # fragment-ordered copies for the row-panel kernel
             for n in ("wo", "wq", "wo2"):
-                lw[n + "_p"] = pack_panel_weight(lw[n]) if d in PANEL_DIMS else lw[n]
+                lw[n + "_p"] = pack_lane_weight(lw[n]) if d in PANEL_DIMS else lw[n]
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]

@@ -98,23 +98,23 @@ def test_gemm_ln_fused(hip, M, N, K):
     np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=3e-4, rtol=3e-4)
 
 
-@pytest.mark.parametrize("M,D", [(10, 256), (16, 256), (1280, 256), (1275, 256), (50, 128), (23, 64), (160, 64)])
+@pytest.mark.parametrize("M,D", [(10, 256), (16, 256), (1280, 256), (1275, 256), (643, 256), (2101, 256), (50, 128), (23, 64), (160, 64)])
 @pytest.mark.parametrize("second", [True, False])
 def test_proj_ln_proj_row_panel(hip, M, D, second):
     """Row-panel kernel (out-projection + residual + LayerNorm + next projection,
-    v_mfma_f32_16x16x4_f32) against gemm_ln + gemm of the spec; ragged last panel."""
+    v_mfma_f32_4x4x1_16B_f32, 4/8/16-row panels) against gemm_ln + gemm of the spec; ragged last panel."""
     from oracle.kernel_spec import SpecBackend
     A, W1, b1 = _rand(M, D, seed=31), _rand(D, D, seed=32, scale=D ** -0.5), _rand(D, seed=33)
     W2, b2 = _rand(D, D, seed=34, scale=D ** -0.5), _rand(D, seed=35)
     g, be_ = 1 + 0.1 * _rand(D, seed=36), _rand(D, seed=37)
     X0 = _rand(M, D, seed=38)
     refX, refN, refQ = X0.clone(), torch.zeros(M, D), torch.zeros(M, D)
-    from speechcatcher_amd.weights import pack_panel_weight, unpack_panel_weight
-    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
-    assert torch.equal(unpack_panel_weight(W1p), W1)
+    from speechcatcher_amd.weights import pack_lane_weight, unpack_lane_weight
+    W1p, W2p = pack_lane_weight(W1), pack_lane_weight(W2)
+    assert torch.equal(unpack_lane_weight(W1p), W1)
     # the device-side packer of the C ABI produces the same permutation
     dev_p = torch.empty(D, D, device="cuda")
-    assert hip.lib.sc_pack_panel_weight(W1.cuda().data_ptr(), D, D, dev_p.data_ptr(), None) == 0
+    assert hip.lib.sc_pack_lane_weight(W1.cuda().data_ptr(), D, D, dev_p.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert torch.equal(dev_p.cpu(), W1p)
     SpecBackend().proj_ln_proj(A, D, W1p, b1, refX, D, g, be_, refN, W2p if second else None, b2 if second else None,
@@ -167,7 +167,7 @@ def test_row_compaction_tables(hip):
     """Ragged-batch compaction: the row-panel kernel and gemm_ln driven through a
     row table touch exactly the listed rows (others keep their content)."""
     from oracle.kernel_spec import SpecBackend
-    from speechcatcher_amd.weights import pack_panel_weight
+    from speechcatcher_amd.weights import pack_lane_weight as pack_panel_weight
     M, D, n = 200, 256, 53
     g0 = torch.Generator().manual_seed(77)
     rows = torch.randperm(M, generator=g0)[:n].to(torch.int32)

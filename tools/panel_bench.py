@@ -20,8 +20,8 @@ for M in rows:
     g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
     X, XN, Q = torch.zeros(M, D, device="cuda"), torch.zeros(M, D, device="cuda"), torch.zeros(M, D, device="cuda")
 
-    from speechcatcher_amd.weights import pack_panel_weight
-    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+    from speechcatcher_amd.weights import pack_lane_weight
+    W1p, W2p = pack_lane_weight(W1), pack_lane_weight(W2)
 
     def panel2():
         be.proj_ln_proj(A, D, W1p, b1, X, D, g, b, None, W2p, b2, Q, M, D)
