@@ -243,7 +243,7 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1q, const 
   SC_CHECK_ARG(XN || W2q, "nothing to produce after the LayerNorm");
   // rows per panel: the smallest that keeps the launch within one round of workgroups and
   // the weight re-streaming (every workgroup reads all of W) modest (tools/panel4_probe.py)
-  int rpp = M <= 640 ? 4 : (M <= 2048 ? 8 : 16);
+  int rpp = M <= 1024 ? 4 : (M <= 2048 ? 8 : 16);   // <= 256 workgroups (measured sweep: one round is what matters)
   if (const char *e = getenv("SC_PANEL_ROWS")) {
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) rpp = v;
