@@ -150,6 +150,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 #define SC_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
 #define SC_DPP_ROR4 0x124        // rotate by 4 inside each 16 lanes
 #define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
+#define SC_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16 lanes
 
 // sum over the LPR (4 or 8) adjacent lanes of a row group; every lane gets the total
 template <int LPR>
@@ -203,12 +204,15 @@ __device__ __forceinline__ void attn_merge_dpp(AttnState &st) {
   st.a.w = st.a.w * ca + pw * cb;
 }
 
-template <int DK, int WM, bool SELF>
-__global__ __launch_bounds__(256, WM <= 10 ? 4 : 2) void dec_attn_flash_kernel(sc_search sb, int li) {
+// UNR = K/V rows in flight per row group.  2 keeps the kernel at 128 VGPRs so that all S*H
+// workgroups of a full batch are resident at once (bandwidth-bound regime); 8 is used when
+// at most half of the streams are active (ragged-batch compaction bucket): then occupancy is
+// no issue and the kernel is bound by the number of serial HBM round trips per workgroup.
+template <int DK, int WM, bool SELF, int UNR>
+__global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_flash_kernel(sc_search sb, int li) {
   constexpr int LPR = DK / 4;    // lanes per K/V row
   constexpr int NG = 256 / LPR;  // row groups per workgroup
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
-  constexpr int UNR = WM <= 5 ? 4 : 2;  // rows in flight per group (register budget: 128 VGPRs)
   constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
   constexpr int NPART = NG / GPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -380,18 +384,34 @@ __global__ __launch_bounds__(256, WM <= 10 ? 4 : 2) void dec_attn_flash_kernel(s
     }
   }
   __syncthreads();
+  // ---- final merge.  Step 1: one thread per (hypothesis, partial): weight of the partial
+  // exp(m - max m) and the normaliser, reduced inside the 16 lanes of a hypothesis with DPP ----
+  static_assert(NPART == 16, "the final merge maps a hypothesis to one 16-lane DPP row");
+  if (tid < nh * NPART) {
+    const int h = tid / NPART, pp = tid % NPART;
+    const float mp = red_m[pp * W + h];
+    float M = mp;
+    M = fmaxf(M, dpp_mov<SC_DPP_XOR1>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_XOR2>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_HALF_MIRROR>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_ROW_MIRROR>(M));
+    const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
+    float den = w * red_l[pp * W + h];
+    den += dpp_mov<SC_DPP_XOR1>(den);
+    den += dpp_mov<SC_DPP_XOR2>(den);
+    den += dpp_mov<SC_DPP_HALF_MIRROR>(den);
+    den += dpp_mov<SC_DPP_ROW_MIRROR>(den);
+    red_m[pp * W + h] = w;            // each element is read and written by this thread only
+    if (pp == 0) red_l[h] = den;
+  }
+  __syncthreads();
+  // ---- step 2: context = sum of the weighted partial contexts / normaliser ----
   for (int e = tid; e < nh * DK; e += 256) {
     const int h = e / DK, c = e % DK;
-    float M = -INFINITY;
-    for (int pp = 0; pp < NPART; ++pp) M = fmaxf(M, red_m[pp * W + h]);
-    float num = 0.f, den = 0.f;
-    for (int pp = 0; pp < NPART; ++pp) {
-      const float mp = red_m[pp * W + h];
-      const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
-      num = fmaf(w, red_a[((long)(pp * W + h)) * DK + c], num);
-      den = fmaf(w, red_l[pp * W + h], den);
-    }
-    sb.datt[((long)s * W + h) * d + head * DK + c] = num / den;
+    float num = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < NPART; ++pp) num = fmaf(red_m[pp * W + h], red_a[((long)(pp * W + h)) * DK + c], num);
+    sb.datt[((long)s * W + h) * d + head * DK + c] = num / red_l[h];
   }
 }
 
@@ -404,9 +424,13 @@ template <int DK, bool SELF>
 static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
   const dim3 grid(sb.H, sb.S);
   const size_t lds = attn_flash_lds(sb, DK, SELF);
-  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF><<<grid, 256, lds, st>>>(sb, layer);
-  else if (sb.W <= 10) dec_attn_flash_kernel<DK, 10, SELF><<<grid, 256, lds, st>>>(sb, layer);
-  else dec_attn_flash_kernel<DK, 16, SELF><<<grid, 256, lds, st>>>(sb, layer);
+  // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
+  const bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
+  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4><<<grid, 256, lds, st>>>(sb, layer);
+  else if (sb.W <= 10) {
+    if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8><<<grid, 256, lds, st>>>(sb, layer);
+    else dec_attn_flash_kernel<DK, 10, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
+  } else dec_attn_flash_kernel<DK, 16, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
 }
 
 extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
