@@ -119,6 +119,12 @@ def main():
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the GEMM kernel")
+    ap.add_argument("--defer", type=int, default=-1,
+                    help="deferred stragglers: end a chunk step's decode loop when at most this many streams are "
+                         "still inside their block; they resume in the next step's loop (StreamBatch."
+                         "set_defer_threshold; identical per-stream results, a stream is never more than one block "
+                         "behind).  Pending blocks are flushed inside the timed region.  -1 (default): 3/8 of the "
+                         "streams (measured optimum); 0: strict lock-step, every block completes inside its chunk step.")
     ap.add_argument("--overlap", action="store_true",
                     help="launch the frontend + encoder of step i+1 on a second HIP stream before the decode loop of "
                          "step i (measured slower than the serial order: DESIGN.md section 4, negative results)")
@@ -149,7 +155,11 @@ def main():
     sb, be = build_batch(args.streams, args.beam, bool(args.bbd), total_steps, device)
     preload_audio(sb, total_steps, stream_offset=rank * args.streams)
 
+    if args.defer < 0:
+        args.defer = (3 * args.streams) // 8
+    sb.set_defer_threshold(args.defer)
     run_steps(sb, args.warmup)
+    sb.flush()
     torch.cuda.synchronize()
     if sb.timing is not None:
         sb.timing.clear()
@@ -159,6 +169,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(sb, args.steps)
+    sb.flush()                      # deferred blocks of the last steps belong to the timed work
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -298,6 +309,7 @@ def main():
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
+                   "deferred_stragglers": args.defer,
                    "pipelining": ("encoder of chunk step i+1 on a second HIP stream overlaps the decode loop of step i"
                                   if args.overlap else "none"),
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},

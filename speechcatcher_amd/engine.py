@@ -160,6 +160,13 @@ class StreamBatch:
         self.rowmap.copy_(torch.arange(S * W, dtype=i32))
         self.n_rows_step = S * W
         self._decode_prepared = False
+        # deferred stragglers (opt-in, set_defer_threshold): resumable per-stream decode-loop state
+        self.defer_threshold = 0
+        self._dq: List[List[Tuple[int, bool]]] = [[] for _ in range(S)]   # queued (T, is_final) blocks per stream
+        self._d_inblk = np.zeros(S, bool)
+        self._d = {k: np.zeros(S, np.int64) for k in ("T", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
+        self._db = {k: np.zeros(S, bool) for k in ("fin", "has", "pvalid", "live", "took", "hsp")}
+        self._T_proj = np.zeros(S, np.int64)   # encoder frames already projected to CTC / cross-K|V rows
         self.flags = z(S, dtype=i32)
         # pinned host mirrors: the per-step ctrl upload / flag read-back are the
         # only host<->device traffic of the decode loop
@@ -279,6 +286,10 @@ class StreamBatch:
         stale scorer.impl - see DESIGN.md "Deliberate deviations")."""
         if self._prefetched is not None:
             raise EngineError("reset() while a prefetched chunk step is pending")
+        if hasattr(self, "_dq"):
+            self._dq[s] = []
+            self._d_inblk[s] = False
+            self._T_proj[s] = 0
         old = self.st[s]
         ns = StreamState()
         if self.strict_reference:
@@ -499,6 +510,10 @@ class StreamBatch:
         have appended more frames to the buffer; they belong to the next call)."""
         cfg = self.cfg
         if not feat_new:
+            return
+        if self.defer_threshold > 0:
+            self._enqueue_blocks(feat_new, finals, t_avail)
+            self._decode_deferred(0 if any(finals.values()) else self.defer_threshold)
             return
         # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
         pending = list(feat_new.keys())
@@ -916,8 +931,198 @@ class StreamBatch:
             x.n_steps_total += int(nsteps[i])
 
     # ------------------------------------------------------------------
+    # deferred stragglers: the same decode schedule, but the step loop of a chunk step may stop
+    # while a few streams are still inside their block; they resume in the next chunk step's loop
+    # (together with the other streams' next blocks).  Per stream nothing changes - same blocks,
+    # same steps, same order - only WHEN its last steps of a block run.  Lock-step batches spend
+    # most of their decode iterations on a handful of stragglers (bench: 8.5 steps per stream-hop
+    # on average, ~20 per batch); with deferral the iterations per chunk step approach the average.
+    # ------------------------------------------------------------------
+    def set_defer_threshold(self, n_streams: int):
+        """Stop a chunk step's decode loop when at most ``n_streams`` streams are still inside
+        their newest block (0: run every block to completion inside its push - the default and
+        the reference's per-call semantics).  A stream never falls more than one block behind;
+        ``flush()`` / a final chunk / ``hypotheses()`` complete whatever is pending."""
+        if n_streams <= 0:
+            self.flush()
+        elif self.defer_threshold == 0:
+            for s, st in enumerate(self.st):   # rows projected so far by the run-to-completion path
+                self._T_proj[s] = st.T_ctc
+        self.defer_threshold = max(0, int(n_streams))
+
+    def flush(self):
+        """Complete every pending (deferred) block."""
+        if not (self._d_inblk.any() or any(self._dq)):
+            return
+        if self.stream is None:
+            self._decode_deferred(0)
+            return
+        with torch.cuda.stream(self.stream):
+            self._decode_deferred(0)
+        self.stream.synchronize()
+
+    def _enqueue_blocks(self, feat_new, finals, t_avail):
+        """The decode schedule of beam_search.py:590-634 as per-stream queues of (T, is_final)."""
+        cfg = self.cfg
+        for s in feat_new:
+            st, q = self.st[s], self._dq[s]
+            pb = st.processed_block + sum(1 for _, f in q if not f) + (1 if self._d_inblk[s] and not self._db["fin"][s] else 0)
+            while t_avail[s] > 0:
+                cur_end = cfg.block_size - cfg.look_ahead + cfg.hop_size * pb
+                if not cur_end < t_avail[s]:
+                    break
+                q.append((cur_end, False))
+                pb += 1
+            if finals[s] and t_avail[s] > 0:
+                q.append((t_avail[s], True))
+        # extend_scorers, encoder-side half (:403-464): CTC rows and cross-attention K|V rows of
+        # every frame a queued block will see - they depend on the encoder output only, so they
+        # are projected here for all streams at once (not when a deferred stream starts its block)
+        cfg, be, w = self.cfg, self.be, self.w
+        d, Ld = cfg.d_model, cfg.dec_layers
+        rows, kv0, lsm = [], [], []
+        for s in feat_new:
+            q = self._dq[s]
+            if not q:
+                continue
+            t_to = max(t for t, _ in q)
+            if t_to > self.TCAP:
+                raise EngineError("max_frames exceeded")
+            t_from = int(self._T_proj[s])
+            if t_to > t_from:
+                rows.append(s * self.TCAP + _AR[t_from:t_to])
+                kv0.append(s * Ld * self.TCAP + _AR[t_from:t_to])
+                if t_from == 0:   # quirk A1: only the rows of the stream's FIRST block are log-softmaxed
+                    first_T = self._d["T"][s] if self._d_inblk[s] else q[0][0]
+                    lsm.append(s * self.TCAP + _AR[0:int(first_T)])
+                self._T_proj[s] = t_to
+        if rows:
+            rows, kv0 = np.concatenate(rows), np.concatenate(kv0)
+            ar = self._itensor(rows)
+            m = int(rows.shape[0])
+            be.gemm(self.enc, ar, d, w.ctc_w, w.ctc_b, self.ctcx, ar, cfg.vocab_size, m, cfg.vocab_size, d)
+            if lsm:
+                lr = np.concatenate(lsm)
+                be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+            for li in range(Ld):
+                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
+                        self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+
+    def _decode_deferred(self, threshold: int):
+        """Resumable form of _decode_blocks over S-sized state vectors (self._d / self._db)."""
+        be, W = self.be, self.W
+        D, B, inblk = self._d, self._db, self._d_inblk
+        Ld = self.cfg.dec_layers
+        use_bbd = self.search.use_bbd
+        if not self._decode_prepared:
+            self._decode_prepared = True
+            if hasattr(be, "prepare_decode"):
+                self._ctrl_np[:] = 0
+                self._upload_ctrl()
+                be.prepare_decode(self)
+        ctrl = self._ctrl_np
+        while True:
+            # ---- A. idle streams with a queued block start it (extend_scorers, search-side half) ----
+            start = [s for s in range(self.S) if not inblk[s] and self._dq[s]]
+            if start:
+                ids = np.asarray(start, np.int64)
+                self.stats["dec_blocks"] += len(start)
+                told = np.zeros(len(start), np.int64)
+                for i, s in enumerate(start):
+                    T, fin = self._dq[s].pop(0)
+                    x = self.st[s]
+                    D["T"][s], B["fin"][s] = T, fin
+                    D["cur"][s], D["L"][s], D["nhyp"][s], B["has"][s] = x.cur, x.L, x.nhyp, x.has_ctc
+                    D["pidx"][s], B["pvalid"][s] = x.process_idx, x.prev_valid
+                    told[i] = x.T_ctc
+                    x.T_ctc = int(max(T, x.T_ctc))
+                    x.output_index = 0
+                B["live"][ids], B["took"][ids] = True, False
+                D["nhp"][ids], B["hsp"][ids] = D["nhyp"][ids], B["has"][ids]
+                D["out"][ids] = 0
+                D["nsteps"][ids] = 0
+                inblk[ids] = True
+                ctrl0 = self._ctrl_np0
+                if self.stream is not None:
+                    self.stream.synchronize()   # the pinned block-start buffer may still be in flight
+                ctrl0[:] = 0
+                ctrl0[ids] = np.stack([np.ones(len(start), np.int64), D["cur"][ids], B["fin"][ids], D["T"][ids],
+                                       D["L"][ids], D["nhyp"][ids], B["has"][ids], told], 1)
+                self.ctrl.copy_(self._ctrl_host0, non_blocking=self.stream is not None)
+                be.ctc_extend_state(self)
+            # ---- B. streams whose block ended: rewind (:827-836), back to the stream state ----
+            act = inblk & B["live"] & (D["pidx"] < self.search.max_length)
+            done = np.nonzero(inblk & ~act)[0]
+            if done.size:
+                for s in done:
+                    pidx, pvalid = int(D["pidx"][s]), bool(B["pvalid"][s])
+                    cur, L, nhyp, has = int(D["cur"][s]), int(D["L"][s]), int(D["nhyp"][s]), bool(B["has"][s])
+                    rw = pidx > 1 and pvalid
+                    if rw and B["took"][s]:
+                        cur, L, nhyp, has = 1 - cur, L - 1, int(D["nhp"][s]), bool(B["hsp"][s])
+                    if rw:
+                        pidx, pvalid = pidx - 1, False
+                    x = self.st[s]
+                    x.cur, x.L, x.nhyp, x.has_ctc = cur, L, nhyp, has
+                    x.process_idx, x.prev_valid = pidx, pvalid
+                    x.output_index = int(D["out"][s])
+                    x.n_steps_total += int(D["nsteps"][s])
+                    if not B["fin"][s]:
+                        x.processed_block += 1
+                    inblk[s] = False
+                continue   # they may have another block queued
+            if not act.any():
+                break
+            ids = np.nonzero(act)[0]
+            # ---- D. defer: few streams left, all of them on their newest block, none final ----
+            if threshold > 0 and ids.size <= threshold and not B["fin"][ids].any() and \
+                    not any(self._dq[s] for s in ids):
+                self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + int(ids.size)
+                break
+            if (D["L"][ids] + 1 > self.LCAP).any():
+                raise EngineError("max_tokens exceeded")
+            # ---- E. one decode step for the active streams (:701-821) ----
+            ctrl[:] = 0
+            n = ids.size
+            ctrl[ids] = np.stack([np.ones(n, np.int64), D["cur"][ids], B["fin"][ids], D["T"][ids], D["L"][ids],
+                                  D["nhyp"][ids], B["has"][ids], np.zeros(n, np.int64)], 1)
+            self._set_rowmap(ids)
+            self._upload_ctrl()
+            self.stats["dec_steps"] += 1
+            if "xattn_rows" in self.stats:
+                self.stats["xattn_rows"] += int(D["T"][ids].sum()) * Ld
+            t_st = time.perf_counter()
+            be.decode_step(self)
+            self._tick("decode_launch", t_st)
+            t_st = time.perf_counter()
+            f = self._read_flags()[ids]
+            self._tick("decode_wait_flags", t_st)
+            f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
+            fin = B["fin"][ids]
+            nhyp, has = D["nhyp"][ids], B["has"][ids]
+            stop_eos = f_any & (~fin | f_best)
+            stop_bbd = (~stop_eos & f_rep & ~fin) if use_bbd else np.zeros(n, bool)
+            stop_all = ~stop_eos & ~stop_bbd & f_all & fin
+            accept = ~(stop_eos | stop_bbd | stop_all)
+            take = stop_eos | stop_all | accept
+            D["out"][ids] += 1 - stop_bbd.astype(np.int64)
+            D["nsteps"][ids] += 1
+            D["nhp"][ids] = np.where(take, nhyp, D["nhp"][ids])
+            B["hsp"][ids] = np.where(take, has, B["hsp"][ids])
+            D["cur"][ids] = np.where(take, 1 - D["cur"][ids], D["cur"][ids])
+            D["L"][ids] += take
+            D["nhyp"][ids] = np.where(take, np.minimum(W, nhyp * W), nhyp)
+            B["has"][ids] = has | take
+            B["took"][ids] |= stop_eos | stop_all
+            B["live"][ids] = accept
+            B["pvalid"][ids] |= accept
+            D["pidx"][ids] += accept
+
+    # ------------------------------------------------------------------
     def hypotheses(self, s: int):
         """Live hypotheses of stream s: list of dicts (yseq, score, scores, xpos)."""
+        if self._d_inblk[s] or self._dq[s]:
+            self.flush()
         st = self.st[s]
         if not st.started:
             return []
