@@ -220,7 +220,7 @@ def main():
     # dominant kernel of the path = the kernel kind with the largest summed launch time
     # in the roofline leg (agrees with the rocprofv3 summary under profiles/)
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
-             "proj_ln_proj_kernel<256,8,2>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<32,10,self>",
+             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<32,10,self>",
              "dec_attn_flash_kernel<32,10,cross>"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
