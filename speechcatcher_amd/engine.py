@@ -162,6 +162,7 @@ class StreamBatch:
         self._decode_prepared = False
         # deferred stragglers (opt-in, set_defer_threshold): resumable per-stream decode-loop state
         self.defer_threshold = 0
+        self.defer_max_lag = 1       # blocks a deferred stream may be behind
         self._dq: List[List[Tuple[int, bool]]] = [[] for _ in range(S)]   # queued (T, is_final) blocks per stream
         self._d_inblk = np.zeros(S, bool)
         self._d = {k: np.zeros(S, np.int64) for k in ("T", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
@@ -938,11 +939,13 @@ class StreamBatch:
     # most of their decode iterations on a handful of stragglers (bench: 8.5 steps per stream-hop
     # on average, ~20 per batch); with deferral the iterations per chunk step approach the average.
     # ------------------------------------------------------------------
-    def set_defer_threshold(self, n_streams: int):
+    def set_defer_threshold(self, n_streams: int, max_lag_blocks: int = 1):
         """Stop a chunk step's decode loop when at most ``n_streams`` streams are still inside
-        their newest block (0: run every block to completion inside its push - the default and
-        the reference's per-call semantics).  A stream never falls more than one block behind;
-        ``flush()`` / a final chunk / ``hypotheses()`` complete whatever is pending."""
+        a block (0: run every block to completion inside its push - the default and the
+        reference's per-call semantics).  A stream never falls more than ``max_lag_blocks``
+        blocks (= chunk periods of result latency) behind; ``flush()`` / a final chunk /
+        ``hypotheses()`` complete whatever is pending."""
+        self.defer_max_lag = max(1, int(max_lag_blocks))
         if n_streams <= 0:
             self.flush()
         elif self.defer_threshold == 0:
@@ -1076,7 +1079,7 @@ class StreamBatch:
             ids = np.nonzero(act)[0]
             # ---- D. defer: few streams left, all of them on their newest block, none final ----
             if threshold > 0 and ids.size <= threshold and not B["fin"][ids].any() and \
-                    not any(self._dq[s] for s in ids):
+                    not any(len(self._dq[s]) >= self.defer_max_lag for s in ids):
                 self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + int(ids.size)
                 break
             if (D["L"][ids] + 1 > self.LCAP).any():
