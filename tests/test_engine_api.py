@@ -186,19 +186,19 @@ def test_deferred_stragglers_give_identical_hypotheses():
     S, chunk, steps = 6, 10240, 6
     audio = [synth.synth_audio(400 + i, chunk * steps) for i in range(S)]
 
-    def run(threshold, final_last):
+    def run(threshold, final_last, lag=1):
         sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=S, max_frames=400, max_tokens=500,
                         pcm_capacity=1 << 17)
-        sb.set_defer_threshold(threshold)
+        sb.set_defer_threshold(threshold, max_lag_blocks=lag)
         for k in range(steps):
             fin = final_last and k == steps - 1
             sb.push([(s, audio[s][k * chunk:(k + 1) * chunk], fin) for s in range(S)])
         hy = [sb.hypotheses(s) for s in range(S)]      # flushes pending blocks
         return hy, sb
 
-    for final_last in (False, True):
+    for final_last, lag in ((False, 1), (True, 1), (False, 2)):
         ref, sb0 = run(0, final_last)
-        got, sb1 = run(2, final_last)
+        got, sb1 = run(2 * lag, final_last, lag)
         assert sb1.stats.get("deferred_blocks", 0) > 0, "the test must exercise deferral"
         assert sb1.stats["dec_steps"] < sb0.stats["dec_steps"]       # fewer batch iterations for the same work
         assert [st.n_steps_total for st in sb1.st] == [st.n_steps_total for st in sb0.st]
