@@ -30,6 +30,9 @@ class ServerBusy(RuntimeError):
 class StreamScheduler:
     def __init__(self, batch: StreamBatch, token_list: Optional[List[str]] = None,
                  result_format: str = "native"):
+        # results are reported per chunk, so every block must complete inside its step: the
+        # scheduler always runs the batch in run-to-completion mode (no deferred stragglers)
+        batch.set_defer_threshold(0)
         self.batch = batch
         self.token_list = token_list
         self.result_format = result_format
