@@ -165,6 +165,7 @@ class StreamBatch:
         self.defer_max_lag = 1       # blocks a deferred stream may be behind
         self._dq: List[List[Tuple[int, bool]]] = [[] for _ in range(S)]   # queued (T, is_final) blocks per stream
         self._d_inblk = np.zeros(S, bool)
+        self._dq_len = np.zeros(S, np.int64)     # len(self._dq[s]), kept in step for vectorised tests
         self._d = {k: np.zeros(S, np.int64) for k in ("T", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
         self._db = {k: np.zeros(S, bool) for k in ("fin", "has", "pvalid", "live", "took", "hsp")}
         self._T_proj = np.zeros(S, np.int64)   # encoder frames already projected to CTC / cross-K|V rows
@@ -178,6 +179,7 @@ class StreamBatch:
         self._rowmap_np[:] = np.arange(S * W, dtype=np.int32)
         self._hyp_ofs = np.arange(W, dtype=np.int64)
         self._stream_ids = np.arange(S, dtype=np.int64)
+        self._rowmap_key = None
         self._rowmap_identity = np.arange(S * W, dtype=np.int32)
         self.row_bucket = max(1, S // 16)        # compaction granularity in streams
         self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
@@ -247,12 +249,16 @@ class StreamBatch:
         S, W = self.S, self.W
         na = int(active_streams.size)
         nb = min(S, -(-na // self.row_bucket) * self.row_bucket)
-        if na == S:
-            self._rowmap_np[:] = self._rowmap_identity
-        else:
-            idle = np.setdiff1d(self._stream_ids, active_streams, assume_unique=True)
-            order = np.concatenate([active_streams, idle])
-            self._rowmap_np[:] = (order[:, None] * W + self._hyp_ofs[None, :]).reshape(-1)
+        key = active_streams.tobytes()
+        if key != self._rowmap_key:          # the active set changes only when a stream stops / starts
+            self._rowmap_key = key
+            if na == S:
+                self._rowmap_np[:] = self._rowmap_identity
+            else:
+                m = np.ones(S, bool)
+                m[active_streams] = False
+                order = np.concatenate([active_streams, self._stream_ids[m]])
+                np.add((order * W)[:, None], self._hyp_ofs[None, :], out=self._rowmap_np.reshape(S, W), casting="unsafe")
         self.n_rows_step = nb * W
 
     def _read_flags(self) -> np.ndarray:
@@ -289,6 +295,7 @@ class StreamBatch:
             raise EngineError("reset() while a prefetched chunk step is pending")
         if hasattr(self, "_dq"):
             self._dq[s] = []
+            self._dq_len[s] = 0
             self._d_inblk[s] = False
             self._T_proj[s] = 0
         old = self.st[s]
@@ -955,7 +962,7 @@ class StreamBatch:
 
     def flush(self):
         """Complete every pending (deferred) block."""
-        if not (self._d_inblk.any() or any(self._dq)):
+        if not (self._d_inblk.any() or self._dq_len.any()):
             return
         if self.stream is None:
             self._decode_deferred(0)
@@ -978,6 +985,7 @@ class StreamBatch:
                 pb += 1
             if finals[s] and t_avail[s] > 0:
                 q.append((t_avail[s], True))
+            self._dq_len[s] = len(q)
         # extend_scorers, encoder-side half (:403-464): CTC rows and cross-attention K|V rows of
         # every frame a queued block will see - they depend on the encoder output only, so they
         # are projected here for all streams at once (not when a deferred stream starts its block)
@@ -1026,13 +1034,14 @@ class StreamBatch:
         ctrl = self._ctrl_np
         while True:
             # ---- A. idle streams with a queued block start it (extend_scorers, search-side half) ----
-            start = [s for s in range(self.S) if not inblk[s] and self._dq[s]]
-            if start:
-                ids = np.asarray(start, np.int64)
+            start = np.nonzero(~inblk & (self._dq_len > 0))[0]
+            if start.size:
+                ids = start
                 self.stats["dec_blocks"] += len(start)
                 told = np.zeros(len(start), np.int64)
                 for i, s in enumerate(start):
                     T, fin = self._dq[s].pop(0)
+                    self._dq_len[s] -= 1
                     x = self.st[s]
                     D["T"][s], B["fin"][s] = T, fin
                     D["cur"][s], D["L"][s], D["nhyp"][s], B["has"][s] = x.cur, x.L, x.nhyp, x.has_ctc
@@ -1079,16 +1088,16 @@ class StreamBatch:
             ids = np.nonzero(act)[0]
             # ---- D. defer: few streams left, all of them on their newest block, none final ----
             if threshold > 0 and ids.size <= threshold and not B["fin"][ids].any() and \
-                    not any(len(self._dq[s]) >= self.defer_max_lag for s in ids):
+                    not (self._dq_len[ids] >= self.defer_max_lag).any():
                 self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + int(ids.size)
                 break
             if (D["L"][ids] + 1 > self.LCAP).any():
                 raise EngineError("max_tokens exceeded")
             # ---- E. one decode step for the active streams (:701-821) ----
-            ctrl[:] = 0
             n = ids.size
-            ctrl[ids] = np.stack([np.ones(n, np.int64), D["cur"][ids], B["fin"][ids], D["T"][ids], D["L"][ids],
-                                  D["nhyp"][ids], B["has"][ids], np.zeros(n, np.int64)], 1)
+            ctrl[:, 0] = act
+            ctrl[:, 1], ctrl[:, 2], ctrl[:, 3], ctrl[:, 4] = D["cur"], B["fin"], D["T"], D["L"]
+            ctrl[:, 5], ctrl[:, 6], ctrl[:, 7] = D["nhyp"], B["has"], 0
             self._set_rowmap(ids)
             self._upload_ctrl()
             self.stats["dec_steps"] += 1
@@ -1124,7 +1133,7 @@ class StreamBatch:
     # ------------------------------------------------------------------
     def hypotheses(self, s: int):
         """Live hypotheses of stream s: list of dicts (yseq, score, scores, xpos)."""
-        if self._d_inblk[s] or self._dq[s]:
+        if self._d_inblk[s] or self._dq_len[s]:
             self.flush()
         st = self.st[s]
         if not st.started:
