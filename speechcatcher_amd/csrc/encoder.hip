@@ -399,13 +399,19 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float *qkv, fl
 #pragma unroll
       for (int c = 0; c < DK; ++c) sdot = fmaf(q[c], Ks[j * DK + c], sdot);
       sdot = sdot / scale;
-      float mn = fmaxf(m, sdot);
-      float corr = expf(m - mn);
-      float p = expf(sdot - mn);
-      l = l * corr + p;
+      // online softmax; the rescale by exp(m - max) is exactly 1 unless the running maximum
+      // moves, so it is only executed then (bit-identical to the unconditional form)
+      if (sdot > m) {
+        const float corr = expf(m - sdot);
+        l *= corr;
 #pragma unroll
-      for (int c = 0; c < DK; ++c) acc[c] = acc[c] * corr + p * Vs[j * DK + c];
-      m = mn;
+        for (int c = 0; c < DK; ++c) acc[c] *= corr;
+        m = sdot;
+      }
+      const float p = expf(sdot - m);
+      l += p;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) acc[c] = acc[c] + p * Vs[j * DK + c];
     }
   }
   float inv = row_masked ? 0.f : 1.0f / l;

@@ -855,9 +855,10 @@ class StreamBatch:
             if first.any():   # quirk A1: only the first block is log-softmaxed
                 lr = np.concatenate([ids[i] * self.TCAP + _AR[0:T[i]] for i in np.nonzero(first)[0]])
                 be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+            kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
             for li in range(Ld):
-                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
-                        self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
+                        kvt, 2 * d, m, 2 * d, d)
         if not self._decode_prepared:
             # one-time: capture the per-bucket decode graphs while every stream is idle on the device
             self._decode_prepared = True
@@ -1015,9 +1016,10 @@ class StreamBatch:
             if lsm:
                 lr = np.concatenate(lsm)
                 be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+            kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
             for li in range(Ld):
-                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv,
-                        self._itensor(kv0 + li * self.TCAP), 2 * d, m, 2 * d, d)
+                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
+                        kvt, 2 * d, m, 2 * d, d)
 
     def _decode_deferred(self, threshold: int):
         """Resumable form of _decode_blocks over S-sized state vectors (self._d / self._db)."""
