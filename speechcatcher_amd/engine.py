@@ -255,9 +255,9 @@ class StreamBatch:
             if na == S:
                 self._rowmap_np[:] = self._rowmap_identity
             else:
-                m = np.ones(S, bool)
-                m[active_streams] = False
-                order = np.concatenate([active_streams, self._stream_ids[m]])
+                idle = np.ones(S, bool)
+                idle[active_streams] = False
+                order = np.argsort(idle, kind="stable")      # active streams first, both parts in stream order
                 np.add((order * W)[:, None], self._hyp_ofs[None, :], out=self._rowmap_np.reshape(S, W), casting="unsafe")
         self.n_rows_step = nb * W
 
@@ -1040,16 +1040,21 @@ class StreamBatch:
             if start.size:
                 ids = start
                 self.stats["dec_blocks"] += len(start)
-                told = np.zeros(len(start), np.int64)
-                for i, s in enumerate(start):
-                    T, fin = self._dq[s].pop(0)
-                    self._dq_len[s] -= 1
-                    x = self.st[s]
-                    D["T"][s], B["fin"][s] = T, fin
-                    D["cur"][s], D["L"][s], D["nhyp"][s], B["has"][s] = x.cur, x.L, x.nhyp, x.has_ctc
-                    D["pidx"][s], B["pvalid"][s] = x.process_idx, x.prev_valid
-                    told[i] = x.T_ctc
-                    x.T_ctc = int(max(T, x.T_ctc))
+                blocks = [self._dq[s].pop(0) for s in start]
+                self._dq_len[ids] -= 1
+                xs = [self.st[s] for s in start]
+                D["T"][ids] = [b[0] for b in blocks]
+                B["fin"][ids] = [b[1] for b in blocks]
+                D["cur"][ids] = [x.cur for x in xs]
+                D["L"][ids] = [x.L for x in xs]
+                D["nhyp"][ids] = [x.nhyp for x in xs]
+                B["has"][ids] = [x.has_ctc for x in xs]
+                D["pidx"][ids] = [x.process_idx for x in xs]
+                B["pvalid"][ids] = [x.prev_valid for x in xs]
+                told = np.fromiter((x.T_ctc for x in xs), np.int64, len(xs))
+                for x, b in zip(xs, blocks):
+                    if b[0] > x.T_ctc:
+                        x.T_ctc = b[0]
                     x.output_index = 0
                 B["live"][ids], B["took"][ids] = True, False
                 D["nhp"][ids], B["hsp"][ids] = D["nhyp"][ids], B["has"][ids]
@@ -1068,69 +1073,76 @@ class StreamBatch:
             act = inblk & B["live"] & (D["pidx"] < self.search.max_length)
             done = np.nonzero(inblk & ~act)[0]
             if done.size:
-                for s in done:
-                    pidx, pvalid = int(D["pidx"][s]), bool(B["pvalid"][s])
-                    cur, L, nhyp, has = int(D["cur"][s]), int(D["L"][s]), int(D["nhyp"][s]), bool(B["has"][s])
-                    rw = pidx > 1 and pvalid
-                    if rw and B["took"][s]:
-                        cur, L, nhyp, has = 1 - cur, L - 1, int(D["nhp"][s]), bool(B["hsp"][s])
-                    if rw:
-                        pidx, pvalid = pidx - 1, False
+                # rewind, vectorised over the finished streams; one pass of attribute writes
+                pidx, pvalid = D["pidx"][done], B["pvalid"][done]
+                rw = (pidx > 1) & pvalid
+                r2 = rw & B["took"][done]
+                cur = np.where(r2, 1 - D["cur"][done], D["cur"][done]).tolist()
+                L = (D["L"][done] - r2).tolist()
+                nhyp = np.where(r2, D["nhp"][done], D["nhyp"][done]).tolist()
+                has = np.where(r2, B["hsp"][done], B["has"][done]).tolist()
+                pidx, pvalid = (pidx - rw).tolist(), (pvalid & ~rw).tolist()
+                out, nst, fin = D["out"][done].tolist(), D["nsteps"][done].tolist(), B["fin"][done].tolist()
+                for i, s in enumerate(done.tolist()):
                     x = self.st[s]
-                    x.cur, x.L, x.nhyp, x.has_ctc = cur, L, nhyp, has
-                    x.process_idx, x.prev_valid = pidx, pvalid
-                    x.output_index = int(D["out"][s])
-                    x.n_steps_total += int(D["nsteps"][s])
-                    if not B["fin"][s]:
+                    x.cur, x.L, x.nhyp, x.has_ctc = cur[i], L[i], nhyp[i], has[i]
+                    x.process_idx, x.prev_valid = pidx[i], pvalid[i]
+                    x.output_index = out[i]
+                    x.n_steps_total += nst[i]
+                    if not fin[i]:
                         x.processed_block += 1
-                    inblk[s] = False
+                inblk[done] = False
                 continue   # they may have another block queued
             if not act.any():
                 break
-            ids = np.nonzero(act)[0]
+            n_act = int(np.count_nonzero(act))
             # ---- D. defer: few streams left, all of them on their newest block, none final ----
-            if threshold > 0 and ids.size <= threshold and not B["fin"][ids].any() and \
-                    not (self._dq_len[ids] >= self.defer_max_lag).any():
-                self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + int(ids.size)
+            if threshold > 0 and n_act <= threshold and not (B["fin"] & act).any() and \
+                    not ((self._dq_len >= self.defer_max_lag) & act).any():
+                self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + n_act
                 break
-            if (D["L"][ids] + 1 > self.LCAP).any():
+            if ((D["L"] + 1 > self.LCAP) & act).any():
                 raise EngineError("max_tokens exceeded")
-            # ---- E. one decode step for the active streams (:701-821) ----
-            n = ids.size
+            # ---- E. one decode step for the active streams (:701-821); S-sized vectors, masks ----
             ctrl[:, 0] = act
             ctrl[:, 1], ctrl[:, 2], ctrl[:, 3], ctrl[:, 4] = D["cur"], B["fin"], D["T"], D["L"]
             ctrl[:, 5], ctrl[:, 6], ctrl[:, 7] = D["nhyp"], B["has"], 0
-            self._set_rowmap(ids)
+            self._set_rowmap(np.nonzero(act)[0])
             self._upload_ctrl()
             self.stats["dec_steps"] += 1
             if "xattn_rows" in self.stats:
-                self.stats["xattn_rows"] += int(D["T"][ids].sum()) * Ld
+                self.stats["xattn_rows"] += int(D["T"][act].sum()) * Ld
             t_st = time.perf_counter()
             be.decode_step(self)
             self._tick("decode_launch", t_st)
             t_st = time.perf_counter()
-            f = self._read_flags()[ids]
+            f = self._read_flags()
             self._tick("decode_wait_flags", t_st)
-            f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
-            fin = B["fin"][ids]
-            nhyp, has = D["nhyp"][ids], B["has"][ids]
-            stop_eos = f_any & (~fin | f_best)
-            stop_bbd = (~stop_eos & f_rep & ~fin) if use_bbd else np.zeros(n, bool)
-            stop_all = ~stop_eos & ~stop_bbd & f_all & fin
-            accept = ~(stop_eos | stop_bbd | stop_all)
-            take = stop_eos | stop_all | accept
-            D["out"][ids] += 1 - stop_bbd.astype(np.int64)
-            D["nsteps"][ids] += 1
-            D["nhp"][ids] = np.where(take, nhyp, D["nhp"][ids])
-            B["hsp"][ids] = np.where(take, has, B["hsp"][ids])
-            D["cur"][ids] = np.where(take, 1 - D["cur"][ids], D["cur"][ids])
-            D["L"][ids] += take
-            D["nhyp"][ids] = np.where(take, np.minimum(W, nhyp * W), nhyp)
-            B["has"][ids] = has | take
-            B["took"][ids] |= stop_eos | stop_all
-            B["live"][ids] = accept
-            B["pvalid"][ids] |= accept
-            D["pidx"][ids] += accept
+            fin, nfin = B["fin"], ~B["fin"]
+            f_any, f_best, f_all = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0
+            stop_eos = act & f_any & (nfin | f_best)
+            if use_bbd:
+                stop_bbd = act & ~stop_eos & ((f & F_REPEAT) != 0) & nfin
+                stop_all = act & ~stop_eos & ~stop_bbd & f_all & fin
+                accept = act & ~(stop_eos | stop_bbd | stop_all)
+                D["out"] -= stop_bbd
+            else:
+                stop_all = act & ~stop_eos & f_all & fin
+                accept = act & ~(stop_eos | stop_all)
+            took = stop_eos | stop_all
+            take = took | accept
+            D["out"] += act
+            D["nsteps"] += act
+            np.copyto(D["nhp"], D["nhyp"], where=take)
+            np.copyto(B["hsp"], B["has"], where=take)
+            D["cur"] ^= take                       # flip the ping-pong side
+            D["L"] += take
+            np.copyto(D["nhyp"], np.minimum(W, D["nhyp"] * W), where=take)
+            B["has"] |= take
+            B["took"] |= took
+            B["live"] &= ~act | accept
+            B["pvalid"] |= accept
+            D["pidx"] += accept
 
     # ------------------------------------------------------------------
     def hypotheses(self, s: int):
