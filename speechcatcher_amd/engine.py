@@ -520,8 +520,12 @@ class StreamBatch:
         if not feat_new:
             return
         if self.defer_threshold > 0:
+            t_ph = time.perf_counter()
             self._enqueue_blocks(feat_new, finals, t_avail)
+            self._tick("enqueue_host", t_ph)
+            t_ph = time.perf_counter()
             self._decode_deferred(0 if any(finals.values()) else self.defer_threshold)
+            self._tick("decode_total", t_ph)
             return
         # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
         pending = list(feat_new.keys())
