@@ -185,6 +185,8 @@ class StreamBatch:
         self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
         self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
         self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
+        self._ctrl0_ring = [torch.zeros(S, 8, dtype=i32, pin_memory=pin) for _ in range(6)]   # deferred path
+        self._ctrl0_ring_i = 0
         self._ctrl_np = self._ctrl_host.numpy()
         # staging arena for the per-call job / row tables
         self._arena_cap = (1 << 22) if pin else 0
@@ -1065,13 +1067,16 @@ class StreamBatch:
                 D["out"][ids] = 0
                 D["nsteps"][ids] = 0
                 inblk[ids] = True
-                ctrl0 = self._ctrl_np0
-                if self.stream is not None:
-                    self.stream.synchronize()   # the pinned block-start buffer may still be in flight
+                # block-start ctrl rows go through a small ring of pinned buffers: two starts can
+                # follow each other without a flag read-back (= stream sync) in between, and the
+                # first iteration of a chunk step is queued behind the encoder stage without waiting
+                self._ctrl0_ring_i = (self._ctrl0_ring_i + 1) % len(self._ctrl0_ring)
+                host0 = self._ctrl0_ring[self._ctrl0_ring_i]
+                ctrl0 = host0.numpy()
                 ctrl0[:] = 0
                 ctrl0[ids] = np.stack([np.ones(len(start), np.int64), D["cur"][ids], B["fin"][ids], D["T"][ids],
                                        D["L"][ids], D["nhyp"][ids], B["has"][ids], told], 1)
-                self.ctrl.copy_(self._ctrl_host0, non_blocking=self.stream is not None)
+                self.ctrl.copy_(host0, non_blocking=self.stream is not None)
                 be.ctc_extend_state(self)
             # ---- B. streams whose block ended: rewind (:827-836), back to the stream state ----
             act = inblk & B["live"] & (D["pidx"] < self.search.max_length)
