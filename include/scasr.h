@@ -69,6 +69,7 @@ typedef struct sc_dec_layer {
   const float *ln3_g, *ln3_b, *w1, *b1, *w2, *b2;
   const float *wo_p, *wq_p, *wo2_p; /* sc_pack_lane_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
   const float *w1_p, *w2_p;         /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
+  const float *wqkv_q;              /* sc_pack_lane_weight of wqkv (sc_ffn_ln_proj of the layer before) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -105,6 +106,7 @@ typedef struct sc_search {
    * per bucket); rowmap is re-uploaded by the host together with ctrl. */
   const int32_t *rowmap;
   int32_t n_rows;
+  const float *out_w_q; /* sc_pack_lane_weight of out_w (sc_ffn_ln_proj of the last layer), or NULL */
 } sc_search;
 
 const char *sc_last_error(void);
@@ -171,6 +173,17 @@ int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const f
               const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
               const float *ln_b, float ln_eps, float *ln_out, void *stream);
 int sc_ffn_ln_supported(int D, int F);
+/* The same feed-forward followed by the projection that consumes its LayerNorm - the next decoder
+ * layer's Q|K|V (decoder_layer.py:85-100 of layer l+1) or the output layer
+ * (transformer_decoder.py:243-249) - with the split-sum reduce, residual, LayerNorm and projection
+ * in ONE row-panel launch:
+ *   Xout[r] = Xin[r] + FFN(XN[r]);  ln_out[r] = LN(Xout[r]) (optional);  Q[r] = LN(Xout[r]) . Wq^T + bq
+ * Wq [N][D] in sc_pack_lane_weight order, N a multiple of D, Q leading dimension N.  Xin and Xout
+ * must be different buffers.  Needs a workspace that holds all M rows (else returns an error). */
+int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+                   const float *b1, const float *W2p, const float *b2, const float *Xin, float *Xout,
+                   const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, const float *Wq,
+                   const float *bq, float *Q, int N, void *stream);
 /* bytes of the split-K workspace registered for `stream` (0: none).  sc_decoder_layers /
  * sc_encoder_layers use the fused FFN only when a workspace is available and fall back to
  * two GEMMs otherwise. */

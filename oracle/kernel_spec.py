@@ -326,44 +326,80 @@ class SpecBackend:
         else:
             self.gemm(h, rows, F, W2, b2, X, rows, D, M, D, F, residual=True)
 
+    def ffn_ln_proj(self, XN, rows, M, D, F, W1p, b1, W2p, b2, Xin, Xout, ln_g, ln_b, Wq, bq, Q, N, eps=1e-12):
+        """sc_ffn_ln_proj: Xout[r] = Xin[r] + FFN(XN[r]); Q[r] = LN(Xout[r]) . Wq^T + bq.
+        W1p / W2p in sc_pack_panel_weight order, Wq in sc_pack_lane_weight order."""
+        from speechcatcher_amd.weights import unpack_lane_weight
+        r = torch.arange(M) if rows is None else rows[:M].to(torch.long)
+        Xout.reshape(-1, D)[r] = Xin.reshape(-1, D)[r]
+        xn = torch.empty_like(Xout)
+        self.ffn_ln(XN, rows, M, D, F, W1p, b1, W2p, b2, Xout, ln_g, ln_b, xn, eps=eps)
+        self.gemm(xn, rows, D, unpack_lane_weight(Wq), bq, Q, rows, N, M, N, D)
+
     PANEL_DIMS = (64, 128, 256)   # sc_proj_ln_proj_supported
 
-    def decoder_layers(self, sb):
-        """decoder_layer.py:60-132 x n_layers; leaves after_norm(x) in dxn
-        (every LayerNorm but the first is fused into the kernel producing its
-        input).  Dense ops run over the compacted rows sb.rowmap[:n_rows_step]
-        of the active streams (scasr.h: rowmap)."""
+    def decoder_layers(self, sb, fuse_logits=False):
+        """decoder_layer.py:60-132 x n_layers, the launch sequence of sc_decoder_layers /
+        sc_decode_step: every LayerNorm but the first is fused into the kernel producing its
+        input; dense ops run over the compacted rows sb.rowmap[:n_rows_step] of the active
+        streams.  In the chained form the FFN's reduce kernel also projects the next layer's
+        Q|K|V (or the output layer: returns True, logits written), x ping-pongs dx <-> dxn and
+        the LayerNorm before the FFN lives in dq.  Otherwise leaves after_norm(x) in dxn."""
         from speechcatcher_amd.weights import ffn_fused_supported
         w, cfg = sb.w, sb.cfg
-        d, Fd = cfg.d_model, cfg.ffn_dim
+        d, Fd, V = cfg.d_model, cfg.ffn_dim, cfg.vocab_size
         n = int(sb.n_rows_step)
         rows = sb.rowmap[:n]
-        self.layernorm(sb.dx, rows, sb.dxn, rows, n, w.dec[0]["ln1_g"], w.dec[0]["ln1_b"])
+        panel = d in self.PANEL_DIMS
+        fused = ffn_fused_supported(d, Fd)
+        chain = panel and fused
+        x, xalt = sb.dx, sb.dxn
+        ffn_in = sb.dq if chain else sb.dxn
+        ln1 = sb.dq if chain else sb.dxn
+        self.layernorm(sb.dx, rows, ln1, rows, n, w.dec[0]["ln1_g"], w.dec[0]["ln1_b"])
+        self.gemm(ln1, rows, d, w.dec[0]["wqkv"], w.dec[0]["bqkv"], sb.dqkv, rows, 3 * d, n, 3 * d, d)
         for li, lw in enumerate(w.dec):
             last = li + 1 == len(w.dec)
             ng = w.dec_norm_g if last else w.dec[li + 1]["ln1_g"]
             nb = w.dec_norm_b if last else w.dec[li + 1]["ln1_b"]
-            self.gemm(sb.dxn, rows, d, lw["wqkv"], lw["bqkv"], sb.dqkv, rows, 3 * d, n, 3 * d, d)
             self.dec_self_attn(sb, li)
-            if d in self.PANEL_DIMS:
-                self.proj_ln_proj(sb.datt, d, lw["wo_p"], lw["bo"], sb.dx, d, lw["ln2_g"], lw["ln2_b"], None,
+            if panel:
+                self.proj_ln_proj(sb.datt, d, lw["wo_p"], lw["bo"], x, d, lw["ln2_g"], lw["ln2_b"], None,
                                   lw["wq_p"], lw["bq"], sb.dq, n, d, rows=rows)
                 self.dec_cross_attn(sb, li)
-                self.proj_ln_proj(sb.datt, d, lw["wo2_p"], lw["bo2"], sb.dx, d, lw["ln3_g"], lw["ln3_b"], sb.dxn,
+                self.proj_ln_proj(sb.datt, d, lw["wo2_p"], lw["bo2"], x, d, lw["ln3_g"], lw["ln3_b"], ffn_in,
                                   None, None, None, n, d, rows=rows)
             else:
-                self.gemm_ln(sb.datt, rows, d, lw["wo"], lw["bo"], sb.dx, rows, d, n, d, d,
+                self.gemm_ln(sb.datt, rows, d, lw["wo"], lw["bo"], x, rows, d, n, d, d,
                              lw["ln2_g"], lw["ln2_b"], sb.dxn, residual=True, ln_at_crows=True)
                 self.gemm(sb.dxn, rows, d, lw["wq"], lw["bq"], sb.dq, rows, d, n, d, d)
                 self.dec_cross_attn(sb, li)
-                self.gemm_ln(sb.datt, rows, d, lw["wo2"], lw["bo2"], sb.dx, rows, d, n, d, d,
+                self.gemm_ln(sb.datt, rows, d, lw["wo2"], lw["bo2"], x, rows, d, n, d, d,
                              lw["ln3_g"], lw["ln3_b"], sb.dxn, residual=True, ln_at_crows=True)
-            if ffn_fused_supported(d, Fd):
-                self.ffn_ln(sb.dxn, rows, n, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], sb.dx, ng, nb, sb.dxn)
+            if chain and (not last or (fuse_logits and getattr(w, "out_w_q", None) is not None)):
+                if not last:
+                    nx = w.dec[li + 1]
+                    self.ffn_ln_proj(ffn_in, rows, n, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], x, xalt, ng, nb,
+                                     nx["wqkv_q"], nx["bqkv"], sb.dqkv, 3 * d)
+                else:
+                    self.ffn_ln_proj(ffn_in, rows, n, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], x, xalt, ng, nb,
+                                     w.out_w_q, w.out_b, sb.logits, V)
+                    return True
+                x, xalt = xalt, x
+                continue
+            ln_next = (sb.dxn if x is sb.dx else sb.dx) if chain else sb.dxn
+            if fused:
+                self.ffn_ln(ffn_in, rows, n, d, Fd, lw["w1_p"], lw["b1"], lw["w2_p"], lw["b2"], x, ng, nb, ln_next)
             else:
-                self.gemm(sb.dxn, rows, d, lw["w1"], lw["b1"], sb.dffh, rows, Fd, n, Fd, d, relu=True)
-                self.gemm_ln(sb.dffh, rows, Fd, lw["w2"], lw["b2"], sb.dx, rows, d, n, d, Fd, ng, nb, sb.dxn,
+                self.gemm(ffn_in, rows, d, lw["w1"], lw["b1"], sb.dffh, rows, Fd, n, Fd, d, relu=True)
+                self.gemm_ln(sb.dffh, rows, Fd, lw["w2"], lw["b2"], x, rows, d, n, d, Fd, ng, nb, ln_next,
                              residual=True, ln_at_crows=True)
+            if not last:
+                nx = w.dec[li + 1]
+                self.gemm(ln_next, rows, d, nx["wqkv"], nx["bqkv"], sb.dqkv, rows, 3 * d, n, 3 * d, d)
+            elif ln_next is not sb.dxn:
+                self.copy_rows(ln_next, rows, sb.dxn, rows, n, d)
+        return False
 
     def logsoftmax_topk(self, sb):
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
@@ -532,8 +568,8 @@ class SpecBackend:
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
         self.dec_embed(sb)
-        self.decoder_layers(sb)      # leaves after_norm(x) in dxn
-        self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
+        if not self.decoder_layers(sb, fuse_logits=True):      # logits, or after_norm(x) in dxn
+            self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
         self.logsoftmax_topk(sb)
         self.ctc_prefix_scan(sb)
         self.fuse_topw(sb)

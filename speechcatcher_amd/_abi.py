@@ -32,7 +32,7 @@ class DecLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
-                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p")]
+                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q")]
 
 
 class Search(C.Structure):
@@ -45,7 +45,7 @@ class Search(C.Structure):
                              "datt", "dq", "dffh", "logits", "logp", "pre_ids", "psi", "psi_eos",
                              "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
-        + [("n_rows", C.c_int32)]
+        + [("n_rows", C.c_int32), ("out_w_q", vp)]
     )
 
 
@@ -64,6 +64,8 @@ _SIGS = {
     "sc_ffn_ln": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_workspace_bytes": (C.c_size_t, [vp]),
+    "sc_ffn_ln_proj": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp,
+                                 vp, vp, vp, C.c_int, vp]),
     "sc_graph_capture_begin": (C.c_int, [vp]),
     "sc_graph_capture_end": (C.c_int, [vp, C.POINTER(vp)]),
     "sc_graph_launch": (C.c_int, [vp, vp]),

@@ -262,3 +262,168 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1q, const 
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
+
+// ===========================================================================
+// Reduce + LayerNorm + projection: the tail of the fused feed-forward and the
+// head of what follows it (the next layer's Q|K|V projection, or the output
+// layer) in one launch:
+//     x_out[r] = x_in[r] + sum_z part[z][m] + b2            (split sums of sc_ffn_ln)
+//     q[r]     = LayerNorm(x_out[r]) . Wq^T + bq             (N = NB * D output columns)
+// Grid (row panels, NB column blocks of D).  Every column block reduces the
+// panel's rows itself (partials are L2-resident: just written), block 0 also
+// stores x_out (and LN(x_out) if asked).  x_in and x_out MUST be different
+// buffers: sibling workgroups read x_in at unrelated times.
+// Replaces gemm_splitk_reduce_ln + a 64x64-tile GEMM: one launch instead of
+// two, and the 4x4x1 MFMA row panels (see above) for the projection.
+// ===========================================================================
+struct RedProjArgs {
+  const float *part; int npart; int part_M;
+  const float *b2;
+  const float *Xin; float *Xout;
+  const int *rows; int M;
+  const float *g, *be; float eps;
+  float *XN;
+  const float *Wq, *bq;
+  float *Q; int ldq;
+};
+
+template <int D, int RG>
+__global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
+  constexpr int R = 4 * RG, NT = D / 64, KS = 8 / NT, KW = D / KS, NL = KW / 4;
+  constexpr int LD = D + 4, EL = D / 64, RPW = (R + 7) / 8;
+  __shared__ __attribute__((aligned(16))) float PA[R * LD];
+  __shared__ __attribute__((aligned(16))) float PC[KS][R * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = wave % NT, ks = wave / NT, k0 = ks * KW;
+  const int m0 = blockIdx.x * R, nb = blockIdx.y;
+  // projection weights of this column block: in flight during the reduce + LayerNorm
+  float4 b[NL];
+  {
+    const float4 *wp = reinterpret_cast<const float4 *>(p.Wq) + ((long)(nb * NT + tile) * (D / 4) + k0 / 4) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) b[q] = wp[q * 64];
+  }
+  float gam[EL], bet[EL], bia2[EL], biaq[EL];
+#pragma unroll
+  for (int e = 0; e < EL; ++e) {
+    gam[e] = p.g[lane + 64 * e];
+    bet[e] = p.be[lane + 64 * e];
+    bia2[e] = p.b2 ? p.b2[lane + 64 * e] : 0.f;
+    biaq[e] = p.bq ? p.bq[nb * D + lane + 64 * e] : 0.f;
+  }
+  long xrow[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int i = wave + 8 * rr;
+    const int m = min(m0 + min(i, R - 1), p.M - 1);
+    xrow[rr] = p.rows ? p.rows[m] : m;
+    if (i < R) {   // wave-uniform
+      const bool live = m0 + i < p.M;
+      float x[EL];
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const int c = lane + 64 * e;
+        // partials fetched 8 at a time, summed in slice order (same order as gemm_splitk_reduce_ln_kernel)
+        float y = 0.f;
+        for (int z0 = 0; z0 < p.npart; z0 += 8) {
+          float pv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pv[q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + m) * D + c];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (z0 + q < p.npart) y = (z0 + q == 0) ? pv[0] : y + pv[q];
+        }
+        y += bia2[e];
+        x[e] = p.Xin[xrow[rr] * D + c] + y;
+        if (live && nb == 0) p.Xout[xrow[rr] * D + c] = x[e];
+        s += x[e];
+      }
+      const float mean = wave_sum(s) / (float)D;
+      float q2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const float c = x[e] - mean;
+        q2 += c * c;
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + p.eps);
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const int c = lane + 64 * e;
+        const float y = (x[e] - mean) * rstd * gam[e] + bet[e];
+        PA[i * LD + c] = y;
+        if (p.XN && live && nb == 0) p.XN[xrow[rr] * D + c] = y;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float *ap = PA + (lane & 3) * LD + k0;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      float4 a[RG];
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) a[rg] = *reinterpret_cast<const float4 *>(ap + 4 * rg * LD + 4 * q);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].x, b[q].x, acc[rg], 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].y, b[q].y, acc[rg], 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].z, b[q].z, acc[rg], 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].w, b[q].w, acc[rg], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) PC[ks][(4 * rg + r) * LD + 64 * tile + lane] = acc[rg][r];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int i = wave + 8 * rr;
+    if (i < R && m0 + i < p.M) {
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        float y = PC[0][i * LD + lane + 64 * e];
+#pragma unroll
+        for (int z = 1; z < KS; ++z) y += PC[z][i * LD + lane + 64 * e];
+        p.Q[xrow[rr] * p.ldq + nb * D + lane + 64 * e] = y + biaq[e];
+      }
+    }
+  }
+}
+
+template <int D>
+static void launch_redproj(const RedProjArgs &p, int rg, int nblocks, hipStream_t st) {
+  if (rg == 1) reduce_ln_proj_kernel<D, 1><<<dim3(cdiv(p.M, 4), nblocks), 512, 0, st>>>(p);
+  else if (rg == 2) reduce_ln_proj_kernel<D, 2><<<dim3(cdiv(p.M, 8), nblocks), 512, 0, st>>>(p);
+  else reduce_ln_proj_kernel<D, 4><<<dim3(cdiv(p.M, 16), nblocks), 512, 0, st>>>(p);
+}
+
+// internal (common.h): called by sc_ffn_ln_proj after the fused FFN kernel wrote its partial sums
+int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
+                             const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,
+                             float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st) {
+  SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N % D == 0 && N > 0, "projection width must be a multiple of D");
+  SC_CHECK_ARG(Xin != Xout, "x_in and x_out must be different buffers");
+  const int nblocks = N / D;
+  // rows per panel: keep panels * column blocks within one round of workgroups
+  int rpp = (long)cdiv(M, 4) * nblocks <= 256 ? 4 : ((long)cdiv(M, 8) * nblocks <= 256 ? 8 : 16);
+  if (const char *e = getenv("SC_PANEL_ROWS")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8 || v == 16) rpp = v;
+  }
+  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N};
+  ProfScope prof = sc_prof_begin(st);
+  if (D == 256) launch_redproj<256>(p, rpp / 4, nblocks, st);
+  else if (D == 128) launch_redproj<128>(p, rpp / 4, nblocks, st);
+  else launch_redproj<64>(p, rpp / 4, nblocks, st);
+  sc_prof_end(prof, SC_PROF_PROJ_LN_PROJ, 2.0 * M * D * N,
+              4.0 * ((double)M * D * (2 + npart) + (double)N * D + (double)M * N));
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}

@@ -943,9 +943,12 @@ static void launch_ffn_rtt(const FfnArgs &p, int rtt, int ngrp, hipStream_t st) 
 
 extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128) && F % 128 == 0 && F >= 128; }
 
-extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
-                         const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
-                         const float *ln_b, float ln_eps, float *ln_out, void *stream) {
+// Wq != nullptr: the partial sums are reduced by the reduce + LayerNorm + projection row-panel
+// kernel (decoder_panel.hip) which writes x to Xout (!= X) and the projection to Q [.., N]
+static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+                   const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
+                   const float *ln_b, float ln_eps, float *ln_out, float *Xout, const float *Wq,
+                   const float *bq, float *Q, int N, void *stream) {
   SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
   SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
   SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
@@ -981,6 +984,7 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
       }
     }
     SC_CHECK_ARG(best < 1e29, "workspace too small for sc_ffn_ln");
+    SC_CHECK_ARG(!Wq || slab == M, "workspace too small for the fused projection (rows do not fit one slab)");
     if (const char *f = getenv("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
       int r = 0, c = 0;
       if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && nch % c == 0 &&
@@ -1004,7 +1008,11 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
     SC_CHECK_LAUNCH();
     GemmArgs g{nullptr, nullptr, D, nullptr, b2, rows ? X : X + (long)m_done * D, rows ? rows + m_done : nullptr, D,
                (int)slab, D, F, SC_GEMM_RESIDUAL | (rows ? SC_GEMM_LN_AT_CROWS : 0), 0, g_ws, 0};
-    if (ln_out) {
+    if (Wq) {
+      int rc = sc_launch_reduce_ln_proj(g_ws, ngrp, (int)slab, b2, X, Xout, rows, M, D, ln_g, ln_b, ln_eps, ln_out,
+                                        Wq, bq, Q, N, st);
+      if (rc != SC_OK) return rc;
+    } else if (ln_out) {
       float *lo = rows ? ln_out : ln_out + (long)m_done * D;
       gemm_splitk_reduce_ln_kernel<<<cdiv((int)slab, 4), 256, 0, st>>>(g, ngrp, ln_g, ln_b, ln_eps, lo, D);
     } else {
@@ -1015,4 +1023,21 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
     m_done += (int)slab;
   }
   return SC_OK;
+}
+
+extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+                         const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
+                         const float *ln_b, float ln_eps, float *ln_out, void *stream) {
+  return ffn_run(XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr, nullptr, nullptr,
+                 nullptr, 0, stream);
+}
+
+extern "C" int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
+                              const float *b1, const float *W2p, const float *b2, const float *Xin, float *Xout,
+                              const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, const float *Wq,
+                              const float *bq, float *Q, int N, void *stream) {
+  SC_CHECK_ARG(Xin && Xout && Xin != Xout && Wq && Q && ln_g && ln_b, "null / aliased operand");
+  SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N > 0 && N % D == 0, "projection width must be a multiple of D");
+  return ffn_run(XN, rows, M, D, F, W1p, b1, W2p, b2, const_cast<float *>(Xin), ln_g, ln_b, ln_eps, ln_out, Xout, Wq,
+                 bq, Q, N, stream);
 }

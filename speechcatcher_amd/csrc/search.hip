@@ -634,10 +634,13 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
+// fuse_logits: the last layer's reduce kernel projects the output layer too (sb.logits is
+// written here, the after_norm rows are not stored); returns that through *logits_done.
+static int decoder_layers_impl(const sc_search *sbp, void *stream, bool fuse_logits, bool *logits_done) {
   SC_CHECK_ARG(sbp && sbp->layers, "null");
   const sc_search &sb = *sbp;
   const int d = sb.d, F = sb.F;
+  if (logits_done) *logits_done = false;
   // dense kernels run over the compacted rows of the active streams (scasr.h: rowmap)
   const int32_t *rows = sb.rowmap;
   const int n = rows ? sb.n_rows : sb.S * sb.W;
@@ -650,43 +653,79 @@ extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
   const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
   const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
                          sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
+  // the FFN's reduce kernel also projects what consumes its LayerNorm (next layer's Q|K|V, output
+  // layer): needs the row panels, the fused FFN, lane-packed weights and a workspace for all rows.
+  // x then ping-pongs between dx and dxn (the reduce kernel must not update x in place), and the
+  // LayerNorm before the FFN goes to dq (free after the cross-attention).
+  const char *qe = getenv("SC_FFN_PROJ");
+  const bool chain = !(qe && atoi(qe) == 0) && panel && ffn_fused && sb.layers[0].wqkv_q &&
+                     sc_workspace_bytes(stream) >= (size_t)(F / 128) * n * d * sizeof(float);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
+  float *x = sb.dx, *xalt = sb.dxn;
+  float *ffn_in = chain ? sb.dq : sb.dxn;
   // LN1 of layer 0 is the only stand-alone LayerNorm; every other LayerNorm is
   // fused into the kernel that produces its input.
-  SC_TRY(sc_layernorm(sb.dx, rows, d, sb.dxn, rows, d, n, d, sb.layers[0].ln1_g, sb.layers[0].ln1_b, sb.ln_eps, stream));
+  {
+    float *ln1 = chain ? sb.dq : sb.dxn;
+    SC_TRY(sc_layernorm(sb.dx, rows, d, ln1, rows, d, n, d, sb.layers[0].ln1_g, sb.layers[0].ln1_b, sb.ln_eps, stream));
+    SC_TRY(sc_gemm(ln1, rows, d, sb.layers[0].wqkv, sb.layers[0].bqkv, sb.dqkv, rows, 3 * d, n, 3 * d, d, 0, 0, stream));
+  }
   for (int li = 0; li < sb.n_layers; ++li) {
     const sc_dec_layer &w = sb.layers[li];
     const bool last = li + 1 == sb.n_layers;
     const float *ng = last ? sb.dec_norm_g : sb.layers[li + 1].ln1_g;
     const float *nb = last ? sb.dec_norm_b : sb.layers[li + 1].ln1_b;
-    SC_TRY(sc_gemm(sb.dxn, rows, d, w.wqkv, w.bqkv, sb.dqkv, rows, 3 * d, n, 3 * d, d, 0, 0, stream));
     SC_TRY(sc_dec_self_attn(sbp, li, stream));
     if (panel) {
       // out-projection + residual + norm2 + cross-attention query in one row-panel kernel
-      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo_p, w.bo, sb.dx, d, w.ln2_g, w.ln2_b, sb.ln_eps, nullptr, d,
+      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo_p, w.bo, x, d, w.ln2_g, w.ln2_b, sb.ln_eps, nullptr, d,
                              w.wq_p, w.bq, sb.dq, d, rows, n, d, stream));
       SC_TRY(sc_dec_cross_attn(sbp, li, stream));
-      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo2_p, w.bo2, sb.dx, d, w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d,
+      SC_TRY(sc_proj_ln_proj(sb.datt, d, w.wo2_p, w.bo2, x, d, w.ln3_g, w.ln3_b, sb.ln_eps, ffn_in, d,
                              nullptr, nullptr, nullptr, d, rows, n, d, stream));
     } else {
-      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo, w.bo, sb.dx, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
+      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo, w.bo, x, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
                         w.ln2_g, w.ln2_b, sb.ln_eps, sb.dxn, d, stream));
       SC_TRY(sc_gemm(sb.dxn, rows, d, w.wq, w.bq, sb.dq, rows, d, n, d, d, 0, 0, stream));
       SC_TRY(sc_dec_cross_attn(sbp, li, stream));
-      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo2, w.bo2, sb.dx, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
+      SC_TRY(sc_gemm_ln(sb.datt, rows, d, w.wo2, w.bo2, x, rows, d, n, d, d, SC_GEMM_RESIDUAL | lnf, 0,
                         w.ln3_g, w.ln3_b, sb.ln_eps, sb.dxn, d, stream));
     }
-    // feed-forward + residual, then the NEXT layer's LN1 (or the final after_norm) -> dxn
+    // feed-forward + residual, then the NEXT layer's LN1 + Q|K|V (or after_norm + output layer)
+    if (chain && (!last || (fuse_logits && sb.out_w_q && sb.V % d == 0))) {
+      if (!last) {
+        SC_TRY(sc_ffn_ln_proj(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr,
+                              sb.layers[li + 1].wqkv_q, sb.layers[li + 1].bqkv, sb.dqkv, 3 * d, stream));
+      } else {
+        SC_TRY(sc_ffn_ln_proj(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr,
+                              sb.out_w_q, sb.out_b, sb.logits, sb.V, stream));
+        if (logits_done) *logits_done = true;
+      }
+      float *t = x; x = xalt; xalt = t;
+      continue;
+    }
+    float *ln_next = chain ? (x == sb.dx ? sb.dxn : sb.dx) : sb.dxn;   // a buffer that is not x
     if (ffn_fused) {
-      SC_TRY(sc_ffn_ln(sb.dxn, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, sb.dx, ng, nb, sb.ln_eps, sb.dxn, stream));
+      SC_TRY(sc_ffn_ln(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));
     } else {
-      SC_TRY(sc_gemm(sb.dxn, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));
-      SC_TRY(sc_gemm_ln(sb.dffh, rows, F, w.w2, w.b2, sb.dx, rows, d, n, d, F, SC_GEMM_RESIDUAL | lnf, 0,
-                        ng, nb, sb.ln_eps, sb.dxn, d, stream));
+      SC_TRY(sc_gemm(ffn_in, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));
+      SC_TRY(sc_gemm_ln(sb.dffh, rows, F, w.w2, w.b2, x, rows, d, n, d, F, SC_GEMM_RESIDUAL | lnf, 0,
+                        ng, nb, sb.ln_eps, ln_next, d, stream));
+    }
+    if (!last) {
+      SC_TRY(sc_gemm(ln_next, rows, d, sb.layers[li + 1].wqkv, sb.layers[li + 1].bqkv, sb.dqkv, rows, 3 * d, n, 3 * d, d,
+                     0, 0, stream));
+    } else if (ln_next != sb.dxn) {
+      // contract of sc_decoder_layers: after_norm(x) in dxn
+      SC_TRY(sc_copy_rows(ln_next, rows, sb.dxn, rows, n, d, stream));
     }
   }
   return SC_OK;
+}
+
+extern "C" int sc_decoder_layers(const sc_search *sbp, void *stream) {
+  return decoder_layers_impl(sbp, stream, false, nullptr);   // leaves after_norm(x) in dxn
 }
 
 // ---------------------------------------------------------------------------
@@ -1209,8 +1248,10 @@ extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
   SC_TRY(sc_dec_embed(sbp, stream));
-  SC_TRY(sc_decoder_layers(sbp, stream));  // leaves after_norm(x) in dxn
-  SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
+  bool logits_done = false;
+  SC_TRY(decoder_layers_impl(sbp, stream, true, &logits_done));  // logits, or after_norm(x) in dxn
+  if (!logits_done)
+    SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
   SC_TRY(sc_ctc_prefix_scan(sbp, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));

@@ -80,6 +80,11 @@ class HipBackend:
         self._chk(self.lib.sc_ffn_ln(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(X),
                                      _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln")
 
+    def ffn_ln_proj(self, XN, rows, M, D, F, W1p, b1, W2p, b2, Xin, Xout, ln_g, ln_b, Wq, bq, Q, N, eps=1e-12):
+        self._chk(self.lib.sc_ffn_ln_proj(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(Xin),
+                                          _p(Xout), _p(ln_g), _p(ln_b), eps, None, _p(Wq), _p(bq), _p(Q), N,
+                                          self._stream()), "sc_ffn_ln_proj")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")
@@ -182,6 +187,7 @@ class HipBackend:
         s.out_w, s.out_b = w.out_w.data_ptr(), w.out_b.data_ptr()
         s.layers = C.cast(layers, C.c_void_p).value
         s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
+        s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
         sb._sc_search_struct = (s, layers)
         return s
 

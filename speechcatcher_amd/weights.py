@@ -137,6 +137,8 @@ class PackedWeights:
         for lw in self.dec:   # fragment-ordered copies for the row-panel kernel
             for n in ("wo", "wq", "wo2"):
                 lw[n + "_p"] = pack_lane_weight(lw[n]) if d in PANEL_DIMS else lw[n]
+        for lw in self.dec:              # Q|K|V in lane order: projected by the reduce kernel of the layer before
+            lw["wqkv_q"] = pack_lane_weight(lw["wqkv"]) if d in PANEL_DIMS else lw["wqkv"]
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]
@@ -144,6 +146,9 @@ class PackedWeights:
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))
         self.out_b = dev(g("decoder.output_layer.bias"))
+        # output layer in lane order (projected by the last layer's reduce kernel) when V is a multiple of d
+        self.out_w_q = (pack_lane_weight(self.out_w) if d in PANEL_DIMS and cfg.vocab_size % d == 0
+                        and ffn_fused_supported(d, cfg.ffn_dim) else None)
         self.ctc_w = dev(g("ctc.ctc_lo.weight"))
         self.ctc_b = dev(g("ctc.ctc_lo.bias"))
 

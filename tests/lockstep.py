@@ -6,7 +6,7 @@ import torch
 
 from oracle.kernel_spec import SpecBackend
 
-FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
+FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "ffn_ln_proj", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
             "ctx_handoff", "enc_attention", "ctc_extend_state", "dec_embed", "dec_self_attn",
             "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw", "beam_prune",
             "ctc_gather_state"]
@@ -60,7 +60,7 @@ class LockstepBackend(SpecBackend):
 
     # buffers each op writes: attribute names of the batch, or positional args
     OUTPUTS = {
-        "logmel": ["featbuf"], "conv1": ["c1"], "gemm": [5], "gemm_ln": [5, 13], "proj_ln_proj": [4, 8, 11], "ffn_ln": [9, 12], "copy_rows": [2], "layernorm": [2],
+        "logmel": ["featbuf"], "conv1": ["c1"], "gemm": [5], "gemm_ln": [5, 13], "proj_ln_proj": [4, 8, 11], "ffn_ln": [9, 12], "ffn_ln_proj": [10, 15], "copy_rows": [2], "layernorm": [2],
         "log_softmax_rows": [0], "block_pack": ["xblk"], "ctx_handoff": [0, 4], "enc_attention": [1],
         "ctc_extend_state": ["ctc_r"], "dec_embed": ["dx"], "dec_self_attn": ["datt", "skv"],
         "dec_cross_attn": ["datt"], "logsoftmax_topk": ["logp", "pre_ids"],

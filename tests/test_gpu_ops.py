@@ -163,6 +163,33 @@ def test_ffn_fused(hip, M, D, F, with_ln):
         np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
+@pytest.mark.parametrize("M,D,F,N", [(10, 256, 2048, 768), (1280, 256, 2048, 768), (533, 256, 2048, 1024),
+                                     (77, 128, 256, 384), (2100, 256, 2048, 768)])
+def test_ffn_ln_proj_chain(hip, M, D, F, N):
+    """Fused FFN whose reduce kernel also applies the LayerNorm and the next projection
+    (x_in / x_out ping-pong, 4x4x1-MFMA row panels, N/D column blocks), with and without a row table."""
+    from oracle.kernel_spec import SpecBackend
+    from speechcatcher_amd.weights import pack_lane_weight, pack_panel_weight
+    XN, X0 = _rand(M + 5, D, seed=71), _rand(M + 5, D, seed=72)
+    W1, b1 = _rand(F, D, seed=73, scale=D ** -0.5), _rand(F, seed=74)
+    W2, b2 = _rand(D, F, seed=75, scale=F ** -0.5), _rand(D, seed=76)
+    Wq, bq = _rand(N, D, seed=77, scale=D ** -0.5), _rand(N, seed=78)
+    g, be_ = 1 + 0.1 * _rand(D, seed=79), _rand(D, seed=80)
+    W1p, W2p, Wqq = pack_panel_weight(W1), pack_panel_weight(W2), pack_lane_weight(Wq)
+    spec = SpecBackend()
+    for rows in (None, torch.randperm(M + 5, generator=torch.Generator().manual_seed(6))[:M].to(torch.int32)):
+        refO, refQ = torch.full((M + 5, D), 7.0), torch.full((M + 5, N), 9.0)
+        spec.ffn_ln_proj(XN, rows, M, D, F, W1p, b1, W2p, b2, X0, refO, g, be_, Wqq, bq, refQ, N)
+        Og, Qg = torch.full((M + 5, D), 7.0, device="cuda"), torch.full((M + 5, N), 9.0, device="cuda")
+        Xin = X0.cuda()
+        hip.ffn_ln_proj(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, W1p.cuda(), b1.cuda(), W2p.cuda(),
+                        b2.cuda(), Xin, Og, g.cuda(), be_.cuda(), Wqq.cuda(), bq.cuda(), Qg, N)
+        torch.cuda.synchronize()
+        assert torch.equal(Xin.cpu(), X0)                        # x_in is read-only
+        np.testing.assert_allclose(Og.cpu().numpy(), refO.numpy(), atol=3e-4, rtol=3e-4)   # untouched rows keep 7.0
+        np.testing.assert_allclose(Qg.cpu().numpy(), refQ.numpy(), atol=6e-4, rtol=6e-4)
+
+
 def test_row_compaction_tables(hip):
     """Ragged-batch compaction: the row-panel kernel and gemm_ln driven through a
     row table touch exactly the listed rows (others keep their content)."""
