@@ -319,23 +319,27 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
     xrow[rr] = p.rows ? p.rows[m] : m;
     if (i < R) {   // wave-uniform
       const bool live = m0 + i < p.M;
-      float x[EL];
+      float x[EL], y[EL];
       float s = 0.f;
+      // partial sums: all EL x 16 loads of a row are issued together (one memory round trip per
+      // 16 slices), then summed in slice order (same order as gemm_splitk_reduce_ln_kernel)
+      for (int z0 = 0; z0 < p.npart; z0 += 16) {
+        float pv[EL][16];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            pv[e][q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + m) * D + lane + 64 * e];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (z0 + q < p.npart) y[e] = (z0 + q == 0) ? pv[e][0] : y[e] + pv[e][q];
+      }
 #pragma unroll
       for (int e = 0; e < EL; ++e) {
         const int c = lane + 64 * e;
-        // partials fetched 8 at a time, summed in slice order (same order as gemm_splitk_reduce_ln_kernel)
-        float y = 0.f;
-        for (int z0 = 0; z0 < p.npart; z0 += 8) {
-          float pv[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) pv[q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + m) * D + c];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (z0 + q < p.npart) y = (z0 + q == 0) ? pv[0] : y + pv[q];
-        }
-        y += bia2[e];
-        x[e] = p.Xin[xrow[rr] * D + c] + y;
+        x[e] = p.Xin[xrow[rr] * D + c] + (y[e] + bia2[e]);
         if (live && nb == 0) p.Xout[xrow[rr] * D + c] = x[e];
         s += x[e];
       }
