@@ -181,7 +181,7 @@ def main():
     # Roofline leg: the SAME workload continues for a few more steps with hipGraph
     # replay switched off, so that every GEMM launch can be bracketed by HIP
     # events on its launch stream (kernels inside a graph replay cannot be).
-    NK = 8   # scasr.h: SC_PROF_KINDS
+    NK = 9   # scasr.h: SC_PROF_KINDS
     ms = (C.c_double * NK)()
     fl = (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
@@ -224,7 +224,7 @@ def main():
     # in the roofline leg (agrees with the rocprofv3 summary under profiles/)
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
              "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<32,10,self>",
-             "dec_attn_flash_kernel<32,10,cross>"]
+             "dec_attn_flash_kernel<32,10,cross>", "rowtile_proj_kernel<256,*>"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
     per_kernel = []

@@ -61,6 +61,7 @@ typedef struct sc_enc_layer {
   const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;
   const float *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
   const float *w1_p, *w2_p; /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
+  const float *wqkv_p, *wo_p; /* sc_pack_panel_weight of wqkv, wo (used when sc_rowtile_proj_supported(d, d)) */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -173,6 +174,17 @@ int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int F, const f
               const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
               const float *ln_b, float ln_eps, float *ln_out, void *stream);
 int sc_ffn_ln_supported(int D, int F);
+/* Row-tile projection with the LayerNorms around it folded in (K = D):
+ *   C[r] = LN(A[r]; ln_g, ln_b) . W^T + bias            (ln_g NULL: A[r] as is)
+ *   R != NULL or LN2 != NULL (needs N == D):  C[r] += R[r];  LN2[r] = LN(C[r]; g2, b2)
+ * the encoder layer's q|k|v Linear behind norm1 (multi_head_attention.py:63-90,
+ * contextual_block_encoder_layer.py:190-215) and its attention output Linear + residual
+ * followed by norm2 (:216-240), one launch each.  W [N][D] in sc_pack_panel_weight order,
+ * N a multiple of 128, D in {128, 256}; R may be C.  LN2 has leading dimension D. */
+int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                    float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
+                    int ldc, const float *g2, const float *b2, float *LN2, void *stream);
+int sc_rowtile_proj_supported(int D, int N);
 /* The same feed-forward followed by the projection that consumes its LayerNorm - the next decoder
  * layer's Q|K|V (decoder_layer.py:85-100 of layer l+1) or the output layer
  * (transformer_decoder.py:243-249) - with the split-sum reduce, residual, LayerNorm and projection
@@ -211,7 +223,8 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_FFN_FUSED 5
 #define SC_PROF_ATTN_SELF 6
 #define SC_PROF_ATTN_CROSS 7
-#define SC_PROF_KINDS 8
+#define SC_PROF_ROWTILE_PROJ 8
+#define SC_PROF_KINDS 9
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);

@@ -326,6 +326,23 @@ class SpecBackend:
         else:
             self.gemm(h, rows, F, W2, b2, X, rows, D, M, D, F, residual=True)
 
+    def rowtile_proj(self, A, M, D, Wp, bias, N, C_out, ln_g=None, ln_b=None, R=None, g2=None, b2=None, LN2=None,
+                     eps=1e-12):
+        """sc_rowtile_proj: C = [LN](A) . W^T + bias [+ R] [-> LN2]; W in sc_pack_panel_weight order
+        (norm1 + q|k|v Linear, output Linear + residual + norm2 of contextual_block_encoder_layer.py:190-240)."""
+        from speechcatcher_amd.weights import unpack_panel_weight
+        a = A.reshape(-1, A.shape[-1])[:M, :D].to(torch.float32)
+        if ln_g is not None:
+            a = torch.nn.functional.layer_norm(a, (D,), ln_g, ln_b, eps)
+        c = a @ unpack_panel_weight(Wp).t()
+        if bias is not None:
+            c = c + bias
+        if R is not None:
+            c = c + R.reshape(-1, R.shape[-1])[:M, :N]
+        C_out.reshape(-1, C_out.shape[-1])[:M, :N] = c
+        if LN2 is not None:
+            LN2.reshape(-1, D)[:M] = torch.nn.functional.layer_norm(c, (D,), g2, b2, eps)
+
     def ffn_ln_proj(self, XN, rows, M, D, F, W1p, b1, W2p, b2, Xin, Xout, ln_g, ln_b, Wq, bq, Q, N, eps=1e-12):
         """sc_ffn_ln_proj: Xout[r] = Xin[r] + FFN(XN[r]); Q[r] = LN(Xout[r]) . Wq^T + bq.
         W1p / W2p in sc_pack_panel_weight order, Wq in sc_pack_lane_weight order."""

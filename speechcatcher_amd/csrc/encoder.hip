@@ -458,15 +458,30 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
   const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
                          sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
+  // row-tile projections with the norms folded in (faster at every batch size: tools/rowtile_bench.py);
+  // SC_ENC_ROWTILE=0: LayerNorm + GEMM launches instead (A/B switch)
+  const char *re = getenv("SC_ENC_ROWTILE");
+  const bool rowtile_ok = sc_rowtile_proj_supported(d, d) && !(re && atoi(re) == 0);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   for (int li = 0; li < n_layers; ++li) {
     const sc_enc_layer &w = L[li];
-    SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln1_g, w.ln1_b, eps, stream));
-    SC_TRY(sc_gemm(xn, nullptr, d, w.wqkv, w.bqkv, qkv, nullptr, 3 * d, M, 3 * d, d, 0, 0, stream));
+    const bool rowtile = rowtile_ok && w.wqkv_p && w.wo_p;
+    if (rowtile) {  // norm1 + q|k|v Linear in one launch
+      SC_TRY(sc_rowtile_proj(x, d, M, d, w.ln1_g, w.ln1_b, eps, w.wqkv_p, w.bqkv, 3 * d, nullptr, qkv, 3 * d,
+                             nullptr, nullptr, nullptr, stream));
+    } else {
+      SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln1_g, w.ln1_b, eps, stream));
+      SC_TRY(sc_gemm(xn, nullptr, d, w.wqkv, w.bqkv, qkv, nullptr, 3 * d, M, 3 * d, d, 0, 0, stream));
+    }
     SC_TRY(sc_enc_attention(qkv, att, nblk, R, H, d, masked, stream));
-    SC_TRY(sc_gemm(att, nullptr, d, w.wo, w.bo, x, nullptr, d, M, d, d, SC_GEMM_RESIDUAL, 0, stream));
-    SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
+    if (rowtile) {  // output Linear + residual + norm2 in one launch
+      SC_TRY(sc_rowtile_proj(att, d, M, d, nullptr, nullptr, eps, w.wo_p, w.bo, d, x, x, d, w.ln2_g, w.ln2_b, xn,
+                             stream));
+    } else {
+      SC_TRY(sc_gemm(att, nullptr, d, w.wo, w.bo, x, nullptr, d, M, d, d, SC_GEMM_RESIDUAL, 0, stream));
+      SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
+    }
     if (ffn_fused) {
       SC_TRY(sc_ffn_ln(xn, nullptr, M, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
     } else {

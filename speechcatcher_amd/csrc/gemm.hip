@@ -941,6 +941,233 @@ static void launch_ffn_rtt(const FfnArgs &p, int rtt, int ngrp, hipStream_t st) 
   }
 }
 
+// ===========================================================================
+// Row-tile projection:  C = [LN](A) . W^T + b  [+ R]  [-> LN2]      (K = D)
+// The attention projections of an encoder layer (multi_head_attention.py:63-90
+// q/k/v Linear behind norm1, and the output Linear + residual followed by
+// norm2, contextual_block_encoder_layer.py:178-271) on the machinery of the
+// fused FFN's first GEMM: a workgroup owns RT = 16*RTT complete input rows
+// (K = D, so the LayerNorm in front of the projection is a prologue on the LDS
+// tile) and streams fragment-packed weights (sc_pack_panel_weight) straight
+// into registers.
+//   FULL = false: N a multiple of 128; grid.x = N/128/cpw groups of column
+//                 chunks, result staged per chunk through LDS -> full lines;
+//   FULL = true : N == D; the workgroup produces whole output rows, adds the
+//                 residual and (optionally) LayerNorms them into LN2.
+// Algorithmic work per row: 2*D*N flop; bytes per row 4*(D + N) (+ 2*4*D FULL).
+// ===========================================================================
+struct RowProjArgs {
+  const float *A;
+  int lda;
+  const float *ln_g, *ln_b;  // LayerNorm of the input rows (nullptr: none)
+  const float *Wp, *bias;
+  const float *R;  // FULL: residual rows [M][ldc] (may be C itself)
+  float *C;
+  int ldc;
+  const float *g2, *b2;  // FULL: LayerNorm of the result rows -> LN2 [M][D]
+  float *LN2;
+  float eps;
+  int M, N, cpw;
+};
+
+template <int D>
+__device__ __forceinline__ float4 rowtile_ln(const float4 v, bool act, const float *g, const float *b, float eps,
+                                             int lane) {
+  float s = act ? (v.x + v.y) + (v.z + v.w) : 0.f;
+  const float mean = wave_sum(s) / (float)D;
+  const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, e = v.w - mean;
+  const float q = act ? (a * a + bb * bb) + (c * c + e * e) : 0.f;
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float4 o = v;
+  if (act) {
+    const float4 gm = reinterpret_cast<const float4 *>(g)[lane];
+    const float4 bt = reinterpret_cast<const float4 *>(b)[lane];
+    o = make_float4(a * rstd * gm.x + bt.x, bb * rstd * gm.y + bt.y, c * rstd * gm.z + bt.z, e * rstd * gm.w + bt.w);
+  }
+  return o;
+}
+
+template <int D, int RTT, bool FULL>
+__global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
+  constexpr int RT = 16 * RTT, FC = 128, KI1 = D / 32;
+  constexpr int LDX = D + 4, LDO = FULL ? D + 4 : FC + 4;
+  extern __shared__ __attribute__((aligned(16))) float rowtile_smem[];
+  float *Xs = rowtile_smem;             // [RT][LDX] (normalised) input rows
+  float *Os = rowtile_smem + RT * LDX;  // [RT][LDO] result staging
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int grp = blockIdx.x, m0 = blockIdx.y * RT;
+  const int nch = FULL ? D / FC : p.cpw, ch0 = FULL ? 0 : grp * p.cpw;
+
+  float4 bf[KI1][2];
+  auto load_b = [&](int chunk) {
+    const float4 *wp = reinterpret_cast<const float4 *>(p.Wp) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
+#pragma unroll
+    for (int ki = 0; ki < KI1; ++ki) {
+      bf[ki][0] = wp[ki * 128];
+      bf[ki][1] = wp[ki * 128 + 64];
+    }
+  };
+  load_b(ch0);
+  constexpr int NV = RT * D / 4, NQ = NV / 512;
+  static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
+  {
+    float4 stage[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * 512;
+      const int m = min(m0 + e / (D / 4), p.M - 1);
+      stage[q] = *reinterpret_cast<const float4 *>(p.A + (long)m * p.lda + 4 * (e % (D / 4)));
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * 512;
+      *reinterpret_cast<float4 *>(Xs + (e / (D / 4)) * LDX + 4 * (e % (D / 4))) = stage[q];
+    }
+  }
+  __syncthreads();
+  if (p.ln_g) {  // wave w normalises rows w, w+8, ... in place
+    const bool act = lane < D / 4;
+    for (int i = wave; i < RT; i += 8) {
+      float4 *row = reinterpret_cast<float4 *>(Xs + i * LDX);
+      const float4 v = act ? row[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 o = rowtile_ln<D>(v, act, p.ln_g, p.ln_b, p.eps, lane);
+      if (act) row[lane] = o;
+    }
+    __syncthreads();
+  }
+  for (int cc = 0; cc < nch; ++cc) {
+    const int chunk = ch0 + cc;
+    const float bias = p.bias ? p.bias[chunk * FC + wave * 16 + r] : 0.f;
+    f32x4 acc[RTT];
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int NS = RTT * KI1;
+      const float *ab = Xs + r * LDX + 8 * kk;
+      float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        float4 n0 = a0, n1 = a1;
+        if (st + 1 < NS) {
+          const float *ap = ab + ((st + 1) % RTT) * 16 * LDX + ((st + 1) / RTT) * 32;
+          n0 = *reinterpret_cast<const float4 *>(ap);
+          n1 = *reinterpret_cast<const float4 *>(ap + 4);
+        }
+        acc[rt] = ffn_mfma8(acc[rt], a0, a1, bf[ki][0], bf[ki][1]);
+        a0 = n0;
+        a1 = n1;
+      }
+    }
+    if (cc + 1 < nch) load_b(chunk + 1);  // next chunk's weights, in flight during the staging
+    if (!FULL && cc > 0) __syncthreads();  // the previous chunk's stores out of Os are done
+    const int ocol = (FULL ? chunk * FC : 0) + wave * 16 + r;
+#pragma unroll
+    for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Os[(rt * 16 + 4 * kk + j) * LDO + ocol] = acc[rt][j] + bias;
+    if (!FULL) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < RT * (FC / 4); e += 512) {
+        const int i = e / (FC / 4), c4 = e % (FC / 4);
+        if (m0 + i < p.M)
+          *reinterpret_cast<float4 *>(p.C + (long)(m0 + i) * p.ldc + chunk * FC + 4 * c4) =
+              *reinterpret_cast<const float4 *>(Os + i * LDO + 4 * c4);
+      }
+    }
+  }
+  if (FULL) {
+    __syncthreads();
+    const bool act = lane < D / 4;
+    for (int i = wave; i < RT; i += 8) {
+      const int m = m0 + i;
+      if (m >= p.M) break;  // uniform per wave
+      float4 v = act ? reinterpret_cast<const float4 *>(Os + i * LDO)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (act) {
+        if (p.R) {
+          const float4 rr = reinterpret_cast<const float4 *>(p.R + (long)m * p.ldc)[lane];
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        reinterpret_cast<float4 *>(p.C + (long)m * p.ldc)[lane] = v;
+      }
+      if (p.LN2) {
+        const float4 o = rowtile_ln<D>(v, act, p.g2, p.b2, p.eps, lane);
+        if (act) reinterpret_cast<float4 *>(p.LN2 + (long)m * D)[lane] = o;
+      }
+    }
+  }
+}
+
+template <int D, int RTT, bool FULL>
+static void launch_rowtile(const RowProjArgs &p, int ngrp, hipStream_t st) {
+  constexpr int RT = 16 * RTT;
+  const size_t lds = (size_t)(RT * (D + 4) + RT * ((FULL ? D : 128) + 4)) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_proj_kernel<D, RTT, FULL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  rowtile_proj_kernel<D, RTT, FULL><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+}
+
+template <int D, bool FULL>
+static void launch_rowtile_rtt(const RowProjArgs &p, int rtt, int ngrp, hipStream_t st) {
+  switch (rtt) {
+    case 1: launch_rowtile<D, 1, FULL>(p, ngrp, st); break;
+    case 2: launch_rowtile<D, 2, FULL>(p, ngrp, st); break;
+    case 3: launch_rowtile<D, 3, FULL>(p, ngrp, st); break;
+    default: launch_rowtile<D, 4, FULL>(p, ngrp, st); break;
+  }
+}
+
+extern "C" int sc_rowtile_proj_supported(int D, int N) {
+  return (D == 256 || D == 128) && N % 128 == 0 && N >= 128;
+}
+
+extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                               float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
+                               int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
+  SC_CHECK_ARG(A && Wp && C, "null pointer");
+  SC_CHECK_ARG(sc_rowtile_proj_supported(D, N), "unsupported dimensions");
+  SC_CHECK_ARG((!ln_g) == (!ln_b) && (!LN2 || (g2 && b2)), "LayerNorm parameters missing");
+  const bool full = R || LN2;
+  SC_CHECK_ARG(!full || N == D, "residual / output LayerNorm need N == D");
+  SC_CHECK_ARG(lda % 4 == 0 && ldc % 4 == 0 && lda >= D && ldc >= N, "leading dimensions");
+  SC_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wp | (uintptr_t)C | (uintptr_t)R | (uintptr_t)LN2) & 15) == 0,
+               "16-byte alignment");
+  if (M <= 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = N / 128;
+  // tile height and chunks per workgroup with the fewest rounds of 256 workgroups
+  // (per workgroup: ~3 us fixed + 2 us per 16 rows and 128-column chunk, as measured for the FFN kernel)
+  int best_rtt = 1, best_cpw = full ? nch : 1;
+  double best = 1e30;
+  for (int cpw = full ? nch : 1; cpw <= nch; ++cpw) {
+    if (nch % cpw) continue;
+    for (int rtt = 1; rtt <= 4; ++rtt) {
+      const long wgs = (long)(nch / cpw) * cdiv(M, 16 * rtt);
+      const double t = (double)((wgs + 255) / 256) * (3.0 + 2.0 * rtt * cpw);
+      if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; }
+    }
+  }
+  RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw};
+  ProfScope prof = sc_prof_begin(st);
+  const int ngrp = full ? 1 : nch / best_cpw;
+  if (D == 256) {
+    if (full) launch_rowtile_rtt<256, true>(p, best_rtt, ngrp, st);
+    else launch_rowtile_rtt<256, false>(p, best_rtt, ngrp, st);
+  } else {
+    if (full) launch_rowtile_rtt<128, true>(p, best_rtt, ngrp, st);
+    else launch_rowtile_rtt<128, false>(p, best_rtt, ngrp, st);
+  }
+  sc_prof_end(prof, SC_PROF_ROWTILE_PROJ, 2.0 * (double)M * D * N,
+              4.0 * ((double)M * (D + N) + (double)D * N + (full ? 2.0 * M * D : 0.0)));
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
 extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128) && F % 128 == 0 && F >= 128; }
 
 // Wq != nullptr: the partial sums are reduced by the reduce + LayerNorm + projection row-panel

@@ -85,6 +85,13 @@ class HipBackend:
                                           _p(Xout), _p(ln_g), _p(ln_b), eps, None, _p(Wq), _p(bq), _p(Q), N,
                                           self._stream()), "sc_ffn_ln_proj")
 
+    def rowtile_proj(self, A, M, D, Wp, bias, N, C_out, ln_g=None, ln_b=None, R=None, g2=None, b2=None, LN2=None,
+                     eps=1e-12):
+        """C = [LN](A) . W^T + bias [+ R] [-> LN2]  (include/scasr.h: sc_rowtile_proj)"""
+        self._chk(self.lib.sc_rowtile_proj(_p(A), A.shape[-1], M, D, _p(ln_g), _p(ln_b), eps, _p(Wp), _p(bias), N,
+                                           _p(R), _p(C_out), C_out.shape[-1], _p(g2), _p(b2), _p(LN2),
+                                           self._stream()), "sc_rowtile_proj")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")

@@ -62,6 +62,11 @@ def ffn_fused_supported(d: int, F: int) -> bool:
     return d in (128, 256) and F % 128 == 0 and F >= 128
 
 
+def rowtile_proj_supported(d: int, N: int) -> bool:
+    """sc_rowtile_proj_supported"""
+    return d in (128, 256) and N % 128 == 0 and N >= 128
+
+
 class PackedWeights:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
                  mean=None, std=None):
@@ -139,6 +144,9 @@ class PackedWeights:
                 lw[n + "_p"] = pack_lane_weight(lw[n]) if d in PANEL_DIMS else lw[n]
         for lw in self.dec:              # Q|K|V in lane order: projected by the reduce kernel of the layer before
             lw["wqkv_q"] = pack_lane_weight(lw["wqkv"]) if d in PANEL_DIMS else lw["wqkv"]
+        for lw in self.enc:              # encoder attention projections for the row-tile kernel (sc_rowtile_proj)
+            for n in ("wqkv", "wo"):
+                lw[n + "_p"] = pack_panel_weight(lw[n]) if rowtile_proj_supported(d, d) else lw[n]
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]

@@ -163,6 +163,41 @@ def test_ffn_fused(hip, M, D, F, with_ln):
         np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
+@pytest.mark.parametrize("M,D", [(42, 256), (5376, 256), (1000, 256), (333, 128)])
+def test_rowtile_proj(hip, M, D):
+    """Encoder attention projections with the LayerNorms folded in (row tiles in LDS, 16x16x4 f32 MFMA,
+    fragment-packed weights): norm1 + q|k|v Linear, and output Linear + residual (in place) + norm2."""
+    from oracle.kernel_spec import SpecBackend
+    from speechcatcher_amd.weights import pack_panel_weight
+    N = 3 * D
+    X, ATT = _rand(M, D, seed=91), _rand(M, D, seed=92)
+    Wqkv, bqkv = _rand(N, D, seed=93, scale=D ** -0.5), _rand(N, seed=94)
+    Wo, bo = _rand(D, D, seed=95, scale=D ** -0.5), _rand(D, seed=96)
+    g1, b1, g2, b2 = 1 + 0.1 * _rand(D, seed=97), _rand(D, seed=98), 1 + 0.1 * _rand(D, seed=99), _rand(D, seed=100)
+    Wqp, Wop = pack_panel_weight(Wqkv), pack_panel_weight(Wo)
+    spec = SpecBackend()
+    refQ = torch.full((M + 3, N), 5.0)
+    spec.rowtile_proj(X, M, D, Wqp, bqkv, N, refQ, ln_g=g1, ln_b=b1)
+    Qg = torch.full((M + 3, N), 5.0, device="cuda")
+    hip.rowtile_proj(X.cuda(), M, D, Wqp.cuda(), bqkv.cuda(), N, Qg, ln_g=g1.cuda(), ln_b=b1.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Qg.cpu().numpy(), refQ.numpy(), atol=3e-4, rtol=3e-4)   # rows >= M untouched (5.0)
+    # without the input LayerNorm, plain projection
+    refP, Pg = torch.zeros(M, N), torch.zeros(M, N, device="cuda")
+    spec.rowtile_proj(X, M, D, Wqp, None, N, refP)
+    hip.rowtile_proj(X.cuda(), M, D, Wqp.cuda(), None, N, Pg)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Pg.cpu().numpy(), refP.numpy(), atol=3e-4, rtol=3e-4)
+    # output Linear + residual in place + LayerNorm of the result
+    refX, refL = X.clone(), torch.full((M + 3, D), 2.0)
+    spec.rowtile_proj(ATT, M, D, Wop, bo, D, refX, R=X, g2=g2, b2=b2, LN2=refL)
+    Xg, Lg = X.cuda(), torch.full((M + 3, D), 2.0, device="cuda")
+    hip.rowtile_proj(ATT.cuda(), M, D, Wop.cuda(), bo.cuda(), D, Xg, R=Xg, g2=g2.cuda(), b2=b2.cuda(), LN2=Lg)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Xg.cpu().numpy(), refX.numpy(), atol=3e-4, rtol=3e-4)
+    np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
+
+
 @pytest.mark.parametrize("M,D,F,N", [(10, 256, 2048, 768), (1280, 256, 2048, 768), (533, 256, 2048, 1024),
                                      (77, 128, 256, 384), (2100, 256, 2048, 768)])
 def test_ffn_ln_proj_chain(hip, M, D, F, N):
@@ -315,3 +350,50 @@ def test_every_kernel_lockstep_xl(hip):
     _dump(ls, "lockstep_xl")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
+
+
+def test_encoder_layers_rowtile(hip, monkeypatch):
+    """sc_encoder_layers with the row-tile projections (norm1 + q|k|v, output Linear + residual + norm2 in one
+    launch each) and with the LayerNorm + GEMM launches they replace, both against the spec encoder."""
+    from oracle.kernel_spec import SpecBackend
+    from test_engine_spec import make_batch
+    js, _ = load_case("xl_c10240_b10_bbd0")
+    meta = js["meta"]
+    caps = dict(max_frames=64, max_tokens=20, pcm_capacity=1 << 16)
+    spec = SpecBackend()
+    sb_cpu = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], backend=spec, **caps)
+    sb_gpu = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], backend=hip,
+                        device="cuda:0", **caps)
+    cfg = sb_cpu.cfg
+    # 6 of the 30 layers and inputs at the scale of x*sqrt(d) + PE: deep stacks of random layers amplify
+    # rounding differences of ANY two implementations (the end-to-end cases pin the full depth)
+    sb_cpu.w.enc, sb_gpu.w.enc = sb_cpu.w.enc[:6], sb_gpu.w.enc[:6]
+    d, F, nl = cfg.d_model, cfg.ffn_dim, 6
+    ns, nbk, R = 4, 4, 42
+    nblk, M = ns * nbk, ns * nbk * 42
+    x0 = 8.0 * _rand(M, d, seed=301)
+    jobs = torch.tensor([[s * nbk, nbk, s * nl, s % 2] for s in range(ns)], dtype=torch.int32)
+    ctx0 = _rand(ns * nl, d, seed=302)
+
+    def run(be, w, dev):
+        x, ctx = x0.clone().to(dev), ctx0.clone().to(dev)   # .to('cpu') alone would alias the inputs
+        xn, att = torch.zeros(M, d, device=dev), torch.zeros(M, d, device=dev)
+        qkv, ffh = torch.zeros(M, 3 * d, device=dev), torch.zeros(M, F, device=dev)
+        be.encoder_layers(w, x, nblk, R, True, jobs.to(dev), ns, ctx, xn, qkv, att, ffh)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        return x.cpu(), ctx.cpu()
+
+    ref_x, ref_ctx = run(spec, sb_cpu.w, "cpu")
+    graphs, hip.use_graphs = hip.use_graphs, False   # the switch is read when the launches are issued
+    try:
+        outs = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SC_ENC_ROWTILE", mode)
+            outs[mode] = run(hip, sb_gpu.w, "cuda:0")
+    finally:
+        hip.use_graphs = graphs
+    scale = float(ref_x.abs().max())
+    for mode, (gx, gctx) in outs.items():
+        assert float((gx - ref_x).abs().max()) <= 1e-3 * max(scale, 1.0), mode
+        assert float((gctx - ref_ctx).abs().max()) <= 1e-3 * max(scale, 1.0), mode
