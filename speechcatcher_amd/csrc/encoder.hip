@@ -422,6 +422,97 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float *qkv, fl
         make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
 }
 
+// ---------------------------------------------------------------------------
+// The same attention with the keys of a (block, head) split over the 4 waves of
+// a workgroup (key j -> wave j mod 4): K/V/Q of the head are staged once per
+// workgroup, every wave runs the online softmax over its quarter of the keys and
+// the four partial states (max, sum, weighted V) are merged in fixed order.  One
+// wave per unit leaves a single wave per SIMD with nothing to hide its LDS and
+// exp latency behind; this form runs 4 waves per SIMD on a quarter of the chain.
+// ---------------------------------------------------------------------------
+template <int DK>
+__global__ __launch_bounds__(256) void enc_attention_split_kernel(const float *qkv, float *att, int nblk,
+                                                                  int R, int H, int d, int masked) {
+  constexpr int LQ = DK + 1, LM = DK + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ks = smem, *Vs = smem + 64 * DK, *Qs = smem + 2 * 64 * DK;  // [64][DK], [64][DK], [64][LQ]
+  float *Ms = smem;                                                  // [4][64][LM], aliases the above after a barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.x / H, head = blockIdx.x % H;
+  const float *base = qkv + (long)blk * R * 3 * d + head * DK;
+  for (int e = threadIdx.x; e < R * (DK / 4); e += 256) {
+    const int r = e / (DK / 4), c4 = e % (DK / 4);
+    const float *row = base + (long)r * 3 * d;
+    const float4 q4 = reinterpret_cast<const float4 *>(row)[c4];
+    reinterpret_cast<float4 *>(Ks)[r * (DK / 4) + c4] = reinterpret_cast<const float4 *>(row + d)[c4];
+    reinterpret_cast<float4 *>(Vs)[r * (DK / 4) + c4] = reinterpret_cast<const float4 *>(row + 2 * d)[c4];
+    float *qd = Qs + r * LQ + 4 * c4;
+    qd[0] = q4.x; qd[1] = q4.y; qd[2] = q4.z; qd[3] = q4.w;
+  }
+  __syncthreads();
+  float acc[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const bool live = lane < R && !(masked && lane == 0);
+  if (live) {
+    float q[DK];
+#pragma unroll
+    for (int c = 0; c < DK; ++c) q[c] = Qs[lane * LQ + c];
+    const float scale = sqrtf((float)DK);
+    const int nkeys = masked ? R - 1 : R;
+    for (int j = wave; j < nkeys; j += 4) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) sdot = fmaf(q[c], Ks[j * DK + c], sdot);
+      sdot = sdot / scale;
+      if (sdot > m) {
+        const float corr = expf(m - sdot);
+        l *= corr;
+#pragma unroll
+        for (int c = 0; c < DK; ++c) acc[c] *= corr;
+        m = sdot;
+      }
+      const float p = expf(sdot - m);
+      l += p;
+#pragma unroll
+      for (int c = 0; c < DK; ++c) acc[c] = acc[c] + p * Vs[j * DK + c];
+    }
+  }
+  __syncthreads();  // every wave is done with K / V / Q: the region becomes the merge buffer
+  {
+    float *ms = Ms + (wave * 64 + lane) * LM;
+    ms[0] = m;
+    ms[1] = l;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) ms[2 + c] = acc[c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * (DK / 4); e += 256) {
+    const int r = e / (DK / 4), c4 = e % (DK / 4);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(masked && r == 0)) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mx = fmaxf(mx, Ms[(w * 64 + r) * LM]);
+      float lt = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float *ms = Ms + (w * 64 + r) * LM;
+        const float f = expf(ms[0] - mx);  // 0 for a wave without keys (max = -inf)
+        lt += ms[1] * f;
+        o.x += ms[2 + 4 * c4] * f;
+        o.y += ms[3 + 4 * c4] * f;
+        o.z += ms[4 + 4 * c4] * f;
+        o.w += ms[5 + 4 * c4] * f;
+      }
+      const float inv = 1.0f / lt;
+      o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+    }
+    reinterpret_cast<float4 *>(att + ((long)blk * R + r) * d + head * DK)[c4] = o;
+  }
+}
+
 extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, int H, int d,
                                 int masked, void *stream) {
   SC_CHECK_ARG(qkv && att, "null pointer");
@@ -431,7 +522,15 @@ extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, i
   const int dk = d / H;
   const int grid = cdiv(nblk * H, 4);
   hipStream_t st = (hipStream_t)stream;
-  if (dk == 32) {
+  const char *sp = getenv("SC_ENC_ATTN");   // =wave: one wave per (block, head) (A/B switch)
+  const bool split = !(sp && !strcmp(sp, "wave"));
+  if (dk == 32 && split) {   // LDS: the merge buffer [4][64][dk+2] (>= the K + V + Q staging it aliases)
+    enc_attention_split_kernel<32><<<nblk * H, 256, 4 * 64 * (32 + 2) * sizeof(float), st>>>(qkv, att, nblk, R, H, d,
+                                                                                            masked);
+  } else if (dk == 16 && split) {
+    enc_attention_split_kernel<16><<<nblk * H, 256, 4 * 64 * (16 + 2) * sizeof(float), st>>>(qkv, att, nblk, R, H, d,
+                                                                                            masked);
+  } else if (dk == 32) {
     enc_attention_kernel<32><<<grid, 256, 4 * 2 * 64 * 32 * sizeof(float), st>>>(qkv, att, nblk, R, H, d, masked);
   } else if (dk == 16) {
     enc_attention_kernel<16><<<grid, 256, 4 * 2 * 64 * 16 * sizeof(float), st>>>(qkv, att, nblk, R, H, d, masked);

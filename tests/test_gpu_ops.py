@@ -163,6 +163,28 @@ def test_ffn_fused(hip, M, D, F, with_ln):
         np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
+@pytest.mark.parametrize("H,dk,R,nblk,masked", [(8, 32, 42, 5, True), (8, 32, 42, 130, True), (8, 32, 7, 3, False),
+                                                (8, 32, 1, 2, False), (8, 32, 2, 2, True), (8, 32, 64, 2, False),
+                                                (4, 16, 42, 3, True), (4, 64, 42, 3, True)])
+@pytest.mark.parametrize("kernel", ["split", "wave"])
+def test_enc_attention(hip, monkeypatch, H, dk, R, nblk, masked, kernel):
+    """Encoder block attention (multi_head_attention.py:92-133 with the mask of
+    contextual_block_transformer_encoder.py:524-528): the 4-waves-per-(block, head) kernel with the keys split
+    over the waves, and the one-wave-per-unit kernel it replaced (still used for d_k = 64)."""
+    from oracle.kernel_spec import SpecBackend
+    monkeypatch.setenv("SC_ENC_ATTN", kernel)
+    d = H * dk
+    qkv = _rand(nblk * R, 3 * d, seed=201)
+    qkv[:, :d] *= 3.0   # peaked softmax rows as well
+    ref = torch.zeros(nblk * R, d)
+    SpecBackend().enc_attention(qkv, ref, nblk, R, H, masked)
+    out = torch.full((nblk * R + 2, d), 3.0, device="cuda")
+    hip.enc_attention(qkv.cuda(), out, nblk, R, H, masked)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[:nblk * R].cpu().numpy(), ref.numpy(), atol=5e-5, rtol=5e-5)
+    assert float(out[nblk * R:].min()) == 3.0 and float(out[nblk * R:].max()) == 3.0
+
+
 @pytest.mark.parametrize("M,D", [(42, 256), (5376, 256), (1000, 256), (333, 128)])
 def test_rowtile_proj(hip, M, D):
     """Encoder attention projections with the LayerNorms folded in (row tiles in LDS, 16x16x4 f32 MFMA,

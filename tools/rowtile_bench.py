@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark: row-tile projections of the encoder layer (sc_rowtile_proj: norm1 + q|k|v Linear, output
 Linear + residual + norm2) against the LayerNorm + GEMM launches they replace.
+Also: the encoder block attention with the keys of a (block, head) split over 4 waves against one wave per unit.
 Usage (GPU box): python tools/rowtile_bench.py [rows ...]"""
 import sys
 import os
@@ -45,3 +46,12 @@ for M in rows:
     for name, fn, nmul in cases:
         us = timeit(fn)
         print(f"M={M:6d} {name:26s} {us:8.1f} us  {2.0 * M * D * D * nmul / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+for nblk in (1, 2, 16, 64, 128, 256):
+    R, H = 42, 8
+    QKV, ATT = torch.randn(nblk * R, 3 * D, device="cuda"), torch.zeros(nblk * R, D, device="cuda")
+    for mode in ("split", "wave"):
+        os.environ["SC_ENC_ATTN"] = mode
+        us = timeit(lambda: be.enc_attention(QKV, ATT, nblk, R, H, True))
+        print(f"enc_attention nblk={nblk:4d} {mode:6s} {us:8.1f} us", flush=True)
