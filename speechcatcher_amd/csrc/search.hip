@@ -208,7 +208,11 @@ __device__ __forceinline__ void attn_merge_dpp(AttnState &st) {
 // workgroups of a full batch are resident at once (bandwidth-bound regime); 8 is used when
 // at most half of the streams are active (ragged-batch compaction bucket): then occupancy is
 // no issue and the kernel is bound by the number of serial HBM round trips per workgroup.
-template <int DK, int WM, bool SELF, int UNR>
+// PRE (self-attention, LCAP <= 4*128 positions): the row lists of ALL position chunks are built before
+// the first row is walked - into the LDS region that later holds the partial states - so that the
+// 60 registers of running softmax state are not live across the list build (the interleaved form
+// spills 15 VGPRs per thread = 15 MB of scratch writes per launch at 128 streams).
+template <int DK, int WM, bool SELF, int UNR, bool PRE = false>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_flash_kernel(sc_search sb, int li) {
   constexpr int LPR = DK / 4;    // lanes per K/V row
   constexpr int NG = 256 / LPR;  // row groups per workgroup
@@ -228,9 +232,12 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
   float *red_m = smem;
   float *red_l = red_m + NPART * W;
   float *red_a = red_l + NPART * W;
-  int *rows = (int *)(red_a + NPART * W * DK);
-  int *wtot = rows + (SELF ? PCH * W : 0);
-  float *qs = (float *)(wtot + 4);   // [W][DK] queries / sqrt(dk)
+  constexpr int NPRE = 4;   // chunks of a PRE launch (host: LCAP <= NPRE * PCH)
+  const int red_floats = NPART * W * (DK + 2);
+  int *rows = PRE ? (int *)smem : (int *)(red_a + NPART * W * DK);   // PRE: aliases the partial states
+  int *wtot = (int *)smem + (PRE ? max(red_floats, NPRE * PCH * W) : red_floats + (SELF ? PCH * W : 0));
+  int *ucnt = wtot + 4;              // PRE: distinct rows per chunk
+  float *qs = (float *)(wtot + 8);   // [W][DK] queries / sqrt(dk)
 
   // SELF: q|k|v of the new token in dqkv (hypothesis h at + h*3d); CROSS: q in dq
   const float *qbase = SELF ? sb.dqkv + (long)s * W * 3 * d + head * DK : sb.dq + (long)s * W * d + head * DK;
@@ -256,11 +263,13 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
     qs[e] = qbase[(long)min(h, nh - 1) * qld + c] / scale;
   }
   AttnState st[WM];
+  if (!(SELF && PRE)) {
 #pragma unroll
-  for (int h = 0; h < WM; ++h) {
-    st[h].m = -INFINITY;
-    st[h].l = 0.f;
-    st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < WM; ++h) {
+      st[h].m = -INFINITY;
+      st[h].l = 0.f;
+      st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 
   auto process = [&](const float4 &k, const float4 &v, unsigned hm) {
@@ -292,11 +301,10 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
   if (SELF) {
     const int *anc = ANC(cur, s);
     const int nchunk = cdiv(L, PCH);
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int c0 = ch * PCH;
-      // ---- distinct (position, slot) rows of positions [c0, c0+PCH): entry =
-      // local position | slot << 8 | hypothesis bit set << 12 ----
-      for (int e = tid; e < PCH * W; e += 256) rows[e] = 0;
+    // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
+    // entry = local position | slot << 8 | hypothesis bit set << 12
+    auto build = [&](int *rw, int c0) -> int {
+      for (int e = tid; e < PCH * W; e += 256) rw[e] = 0;
       const int p = c0 + tid;
       const bool live = tid < PCH && p < L;
       int sl[WM];
@@ -324,18 +332,20 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
         for (int h = 0; h < WM; ++h) {
           if (h < nh) {
             const int rank = __popc(mask & ((1u << sl[h]) - 1u));
-            atomicOr(&rows[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
+            atomicOr(&rw[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
           }
         }
       }
-      __syncthreads();
-      // ---- walk the rows ----
+      __syncthreads();   // list complete; wtot may be rewritten
+      return U;
+    };
+    auto walk = [&](const int *rw, int U, int c0) {
       for (int j0 = g; j0 < U; j0 += NG * UNR) {
         int e[UNR];
         float4 k[UNR], v[UNR];
 #pragma unroll
         for (int i = 0; i < UNR; ++i) {
-          e[i] = rows[min(j0 + i * NG, U - 1)];
+          e[i] = rw[min(j0 + i * NG, U - 1)];
           const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
           const float *kp = (pp == L - 1) ? qbase + (long)u * 3 * d + d : skv + ((long)pp * W + u) * 2 * d;
           k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
@@ -345,7 +355,27 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
         for (int i = 0; i < UNR; ++i)
           if (j0 + i * NG < U) process(k[i], v[i], (unsigned)e[i] >> 12);   // uniform inside a row group
       }
-      if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+    };
+    if (PRE) {
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int U = build(rows + ch * PCH * W, ch * PCH);
+        if (tid == 0) ucnt[ch] = U;
+      }
+      __syncthreads();   // ucnt
+#pragma unroll
+      for (int h = 0; h < WM; ++h) {
+        st[h].m = -INFINITY;
+        st[h].l = 0.f;
+        st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int ch = 0; ch < nchunk; ++ch) walk(rows + ch * PCH * W, ucnt[ch], ch * PCH);
+      __syncthreads();   // the lists are dead: their LDS becomes the partial states
+    } else {
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int U = build(rows, ch * PCH);
+        walk(rows, U, ch * PCH);
+        if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+      }
     }
   } else {
     __syncthreads();   // qs
@@ -425,11 +455,17 @@ static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
   const dim3 grid(sb.H, sb.S);
   const size_t lds = attn_flash_lds(sb, DK, SELF);
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
-  const bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
+  bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
+  if (const char *fd = getenv("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
   if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4><<<grid, 256, lds, st>>>(sb, layer);
   else if (sb.W <= 10) {
     if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8><<<grid, 256, lds, st>>>(sb, layer);
-    else dec_attn_flash_kernel<DK, 10, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
+    else if (SELF && sb.LCAP <= 4 * 128 && !getenv("SC_SELF_ATTN_NOPRE")) {
+      // all row lists first, aliased with the partial states (see the kernel's PRE note)
+      const size_t red = (size_t)16 * sb.W * (DK + 2), lists = (size_t)4 * 128 * sb.W;
+      const size_t lds_pre = ((red > lists ? red : lists) + 8 + (size_t)16 * DK) * sizeof(float);
+      dec_attn_flash_kernel<DK, 10, SELF, 2, true><<<grid, 256, lds_pre, st>>>(sb, layer);
+    } else dec_attn_flash_kernel<DK, 10, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
   } else dec_attn_flash_kernel<DK, 16, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
 }
 

@@ -419,3 +419,22 @@ def test_encoder_layers_rowtile(hip, monkeypatch):
     for mode, (gx, gctx) in outs.items():
         assert float((gx - ref_x).abs().max()) <= 1e-3 * max(scale, 1.0), mode
         assert float((gctx - ref_ctx).abs().max()) <= 1e-3 * max(scale, 1.0), mode
+
+
+@pytest.mark.parametrize("nopre", [False, True])
+def test_attention_full_batch_variants_lockstep(hip, monkeypatch, nopre):
+    """The attention kernels of FULL batches (2 K/V rows in flight at <= 128 VGPRs; self-attention with all
+    row lists built up front, or interleaved with the walk) are picked by batch size; force them on the
+    single-stream fixtures so that every launch is compared with its spec on identical inputs."""
+    monkeypatch.setenv("SC_ATTN_DEEP", "0")
+    if nopre:
+        monkeypatch.setenv("SC_SELF_ATTN_NOPRE", "1")
+    ls = _lockstep_run(hip, "tiny_c10240_b10_bbd0")
+    assert ls.calls.get("dec_self_attn", 0) > 0 and ls.calls.get("dec_cross_attn", 0) > 0
+    assert not ls.failures, ls.failures[:10]
+    assert not ls.int_mismatch, ls.int_mismatch[:10]
+    if not nopre:   # XL head size (d_k = 32) for the default variant
+        ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=4, atol=5e-4, rtol=5e-4)
+        assert ls.calls.get("dec_self_attn", 0) > 0
+        assert not ls.failures, ls.failures[:10]
+        assert not ls.int_mismatch, ls.int_mismatch[:10]
