@@ -42,3 +42,33 @@ def test_product_path_fails_loudly_without_gpu():
     from speechcatcher_amd.hip_backend import HipBackend
     with pytest.raises(_abi.ScasrError):
         HipBackend("cuda:0")
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    """include/scasr.h must be consumable by a C host (no C++ / torch types), and the ctypes mirrors of its
+    structs (speechcatcher_amd/_abi.py) must have the C compiler's size and field offsets."""
+    import ctypes
+    import shutil
+    import subprocess
+    from speechcatcher_amd import _abi
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    structs = {"sc_enc_layer": _abi.EncLayer, "sc_dec_layer": _abi.DecLayer, "sc_search": _abi.Search}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "scasr.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True,
+                                                       text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
