@@ -72,3 +72,41 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of scasr.h against the ctypes signature bound for it: parameter count, and the
+    class of every parameter (pointer / integer / float / double) - a drifted binding would pass garbage."""
+    import ctypes
+    from speechcatcher_amd import _abi
+    text = re.sub(r"/\*.*?\*/", " ", (ROOT / "include" / "scasr.h").read_text(), flags=re.S)
+    protos = re.findall(r"\b(?:int|double|size_t|const char \*)\s*(sc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text)
+    assert len(protos) == len(_abi.EXPORTED_SYMBOLS)
+
+    def c_class(param):
+        param = param.strip()
+        if "*" in param:
+            return "ptr"
+        base = param.rsplit(" ", 1)[0] if " " in param else param
+        if "float" in base:
+            return "float"
+        if "double" in base:
+            return "double"
+        return "int"
+
+    def ct_class(t):
+        if t in (ctypes.c_float,):
+            return "float"
+        if t in (ctypes.c_double,):
+            return "double"
+        if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_int32, ctypes.c_uint):
+            return "int"
+        return "ptr"
+
+    for name, params in protos:
+        params = params.strip()
+        plist = [] if params in ("", "void") else [p for p in params.split(",")]
+        _, argtypes = _abi._SIGS[name]
+        assert len(plist) == len(argtypes), f"{name}: header has {len(plist)} parameters, binding {len(argtypes)}"
+        for i, (p, t) in enumerate(zip(plist, argtypes)):
+            assert c_class(p) == ct_class(t), f"{name} parameter {i}: '{p.strip()}' bound as {t}"
