@@ -1140,16 +1140,26 @@ extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const floa
   if (M <= 0) return SC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int nch = N / 128;
-  // tile height and chunks per workgroup with the fewest rounds of 256 workgroups
-  // (per workgroup: ~3 us fixed + 2 us per 16 rows and 128-column chunk, as measured for the FFN kernel)
+  // tile height (16*rtt rows) and column chunks per workgroup (cpw) by a cost model fitted to
+  // tools/rowtile_sweep.py: a workgroup takes 4.3 + 1.0*rtt + 2.1*rtt*cpw us (+8 % for rtt = 4, whose 100 KB of LDS
+  // leave it alone on its CU); tiles up to rtt = 3 fit two workgroups per CU, which then take 1.75x as long each
   int best_rtt = 1, best_cpw = full ? nch : 1;
   double best = 1e30;
   for (int cpw = full ? nch : 1; cpw <= nch; ++cpw) {
     if (nch % cpw) continue;
     for (int rtt = 1; rtt <= 4; ++rtt) {
       const long wgs = (long)(nch / cpw) * cdiv(M, 16 * rtt);
-      const double t = (double)((wgs + 255) / 256) * (3.0 + 2.0 * rtt * cpw);
+      const int conc = (rtt <= 3 && wgs > 256) ? 2 : 1;
+      const double t_wg = (4.3 + 1.0 * rtt + 2.1 * rtt * cpw) * (rtt == 4 ? 1.08 : 1.0);
+      const double t = (double)((wgs + 256 * conc - 1) / (256 * conc)) * t_wg * (conc == 2 ? 1.75 : 1.0);
       if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; }
+    }
+  }
+  if (const char *f = getenv("SC_ROWTILE_FORCE")) {   // tools/rowtile_bench.py sweep: "rtt,cpw"
+    int r = 0, c = 0;
+    if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 4 && c >= 1 && nch % c == 0) {
+      best_rtt = r;
+      if (!full) best_cpw = c;
     }
   }
   RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw};
