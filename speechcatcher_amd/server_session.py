@@ -204,4 +204,48 @@ class ServerLoop:
         return transcription
 
 
-__all__ = ["Endpointer", "ServerLoop", "ServerBusy", "vosk_partial", "vosk_result", "scale_server_pcm"]
+class StepPacer:
+    """WHEN to run the next batched step.  The reference answers every message with its own model call as it
+    arrives (``recognize_ws``, speechcatcher_server.py:376-380); a batch needs a policy instead: run a step as
+    soon as every connected session has a message waiting (a full batch), or when the oldest waiting message has
+    waited ``max_wait_s`` (latency bound for the clients that did send), whichever comes first.  The transport
+    calls ``submit`` for every received message and ``poll`` from its event loop."""
+
+    def __init__(self, loop: ServerLoop, max_wait_s: float = 0.05, clock=None):
+        import time
+        self.loop = loop
+        self.max_wait_s = max_wait_s
+        self.clock = clock or time.monotonic
+        self._stamps: Dict[int, Deque[float]] = {}
+
+    def submit(self, sid: int, message: Message):
+        self._stamps.setdefault(sid, deque()).append(self.clock())
+        self.loop.submit(sid, message)
+
+    def due(self) -> bool:
+        sessions = self.loop.sessions
+        waiting = [sid for sid, ses in sessions.items() if ses.inbox]
+        if not waiting:
+            return False
+        if len(waiting) == len(sessions):
+            return True
+        oldest = min(self._stamps[sid][0] for sid in waiting if self._stamps.get(sid))
+        return self.clock() - oldest >= self.max_wait_s
+
+    def poll(self) -> Optional[Dict[int, List[Union[str, dict]]]]:
+        """Runs one batched step if one is due and returns its replies (None otherwise)."""
+        if not self.due():
+            return None
+        replies = self.loop.step()
+        for sid in list(self._stamps):
+            ses = self.loop.sessions.get(sid)
+            if ses is None:                       # disconnected meanwhile
+                del self._stamps[sid]
+                continue
+            st = self._stamps[sid]
+            while len(st) > len(ses.inbox):       # messages the step consumed
+                st.popleft()
+        return replies
+
+
+__all__ = ["Endpointer", "ServerLoop", "StepPacer", "ServerBusy", "vosk_partial", "vosk_result", "scale_server_pcm"]

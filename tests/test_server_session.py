@@ -106,3 +106,40 @@ def test_vosk_result_format():
     assert r["text"] == "hallo welt"
     assert [w["word"] for w in r["result"]] == [" hal", "lo", " welt"]
     assert r["result"][2]["start"] == pytest.approx(30 / 24.0)
+
+
+def test_step_pacer_full_batch_or_deadline():
+    """Pacing of batched steps: immediately when every connected client has a message waiting, otherwise when
+    the oldest waiting message reaches the latency bound; the replies are those of the plain loop."""
+    from speechcatcher_amd.server_session import StepPacer
+    sb = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=3, max_frames=400, max_tokens=300,
+                    pcm_capacity=1 << 18)
+    loop = ServerLoop(StreamScheduler(sb, None, result_format="espnet"))
+    now = [100.0]
+    pacer = StepPacer(loop, max_wait_s=0.05, clock=lambda: now[0])
+    a, b = loop.connect(), loop.connect()
+    assert not pacer.due() and pacer.poll() is None           # nothing waiting
+    pacer.submit(a, _pcm16(5, 10240))
+    assert not pacer.due()                                    # b has sent nothing and a has not waited long
+    now[0] += 0.049
+    assert pacer.poll() is None
+    now[0] += 0.002                                           # a's chunk reaches the latency bound
+    rep = pacer.poll()
+    assert rep is not None and set(rep) == {a}
+    assert not pacer.due()
+    pacer.submit(a, _pcm16(5, 10240))
+    pacer.submit(a, _pcm16(5, 10240))                         # a runs ahead: two chunks queued
+    now[0] += 0.01
+    pacer.submit(b, _pcm16(6, 10240))
+    assert pacer.due()                                        # full batch: every client has a message
+    rep = pacer.poll()
+    assert set(rep) == {a, b}
+    assert not pacer.due()                                    # a's second chunk waits; b has nothing
+    now[0] += 0.045                                           # ... but it has been waiting since before the step
+    assert pacer.due()
+    rep = pacer.poll()
+    assert set(rep) == {a} and not loop.pending()
+    loop.disconnect(b)
+    pacer.submit(a, _pcm16(5, 10240))
+    assert pacer.due()                                        # the only client left: a full batch of one
+    assert set(pacer.poll()) == {a}
