@@ -14,7 +14,6 @@ hypothesis buffers) follows DESIGN.md.  Only tests/ may import this module.
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -9,7 +9,6 @@ The library is built in-tree (speechcatcher_amd/libscasr.so) by
 missing - there is no CPU fallback in the product path.
 """
 import ctypes as C
-import os
 import subprocess
 from pathlib import Path
 

@@ -18,13 +18,13 @@ exact buffering arithmetic restated here.
 import math
 import os
 import time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
-from .config import ModelConfig, SearchConfig
+from .config import SearchConfig
 from .weights import PackedWeights
 
 # flags returned by the beam_prune kernel

@@ -17,7 +17,7 @@ the built HIP library raises.
 """
 import logging
 from pathlib import Path
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Union
 
 import numpy as np
 import torch

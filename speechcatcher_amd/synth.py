@@ -11,7 +11,7 @@ speechcatcher/model/checkpoint_loader.py:134-149, names identical to ESPnet).
 """
 from collections import OrderedDict
 from pathlib import Path
-from typing import Dict, Tuple
+from typing import Dict
 
 import numpy as np
 import torch

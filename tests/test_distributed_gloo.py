@@ -5,7 +5,6 @@ per-stream output."""
 import os
 import socket
 
-import pytest
 import torch
 import torch.multiprocessing as mp
 

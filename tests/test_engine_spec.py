@@ -7,7 +7,6 @@ import json
 
 import numpy as np
 import pytest
-import torch
 
 from conftest import GOLDEN, load_case
 from speechcatcher_amd import synth

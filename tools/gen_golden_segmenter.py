@@ -15,7 +15,6 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tools" / "ref_shim"))
 sys.path.insert(0, "/root/reference/speechcatcher")
 
-import numpy as np  # noqa: E402
 from speechcatcher_amd.synth import synth_energy_curve  # noqa: E402
 
 import simple_endpointing as ref  # noqa: E402

@@ -8,9 +8,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import torch
-
 from speechcatcher_amd import synth
 from speechcatcher_amd.config import MICRO, SearchConfig
 from speechcatcher_amd.engine import StreamBatch
