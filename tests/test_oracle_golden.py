@@ -149,14 +149,17 @@ def test_reset_quirk_matches_reference():
     assert [r[2] for r in js["final"]] == [g[0] for g in res]
 
 
+XL_CASES = ["xl_c10240_b10_bbd0", "xl_c10240_b10_bbd1", "xl_c25600_b10_bbd0", "xl_c8192_b10_bbd1"]
+
+
 @pytest.mark.slow
-@pytest.mark.parametrize("bbd", [0, 1])
-def test_xl_trajectories(bbd):
-    js, npz = load_case(f"xl_c10240_b10_bbd{bbd}")
+@pytest.mark.parametrize("name", XL_CASES)
+def test_xl_trajectories(name):
+    js, npz = load_case(name)
     meta = js["meta"]
     model = oracle_model("XL", meta["seed"], meta["stats"])
-    audio = synth.synth_audio(0, meta["n_samples"])
-    s, feats, encs, calls = run_oracle_stream(model, audio, 10240, 10, bool(bbd))
+    audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
+    s, feats, encs, calls = run_oracle_stream(model, audio, meta["chunk"], meta["beam"], bool(meta["bbd"]))
     _check_blocks(s.trace, js["blocks"], score_tol=2e-2)
     if npz is not None:
         np.testing.assert_allclose(np.concatenate(encs, 0), npz["enc"], atol=1e-3, rtol=0)

@@ -279,5 +279,27 @@ def main():
     print("done ->", OUT)
 
 
+def xl_extra():
+    """XL dims at the other two chunk sizes of SURVEY 8(d) (trajectories only: ids / positions / scores):
+    25 600-sample calls (2-3 encoder blocks and decode blocks per call) without BBD, and the CLI's 8 192 with BBD.
+    ``python tools/gen_golden.py --xl-extra`` writes just these two."""
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tmp = Path(tempfile.mkdtemp(prefix="golden_"))
+    xl_dir = synth.write_model_dir(tmp / "xl", XL, seed=1234, stats_kind="meanstd")
+    for chunk, bbd, stream in ((25600, False, 3), (8192, True, 4)):
+        audio = synth.synth_audio(stream, 16000 * 8)
+        s2t, rec, calls = run_stream(xl_dir, audio, chunk, 10, bbd)
+        name = f"xl_c{chunk}_b10_bbd{int(bbd)}"
+        meta = {"model": "XL", "seed": 1234, "stats": "meanstd", "audio_stream": stream,
+                "n_samples": len(audio), "chunk": chunk, "beam": 10, "bbd": bbd}
+        save_case(name, meta, rec, calls, with_tensors=False)
+        print(name, "blocks", len(rec.blocks))
+
+
 if __name__ == "__main__":
-    main()
+    if "--xl-extra" in sys.argv[1:]:
+        xl_extra()
+    else:
+        main()
