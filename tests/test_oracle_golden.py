@@ -149,7 +149,8 @@ def test_reset_quirk_matches_reference():
     assert [r[2] for r in js["final"]] == [g[0] for g in res]
 
 
-XL_CASES = ["xl_c10240_b10_bbd0", "xl_c10240_b10_bbd1", "xl_c25600_b10_bbd0", "xl_c8192_b10_bbd1"]
+XL_CASES = ["xl_c10240_b10_bbd0", "xl_c10240_b10_bbd1", "xl_c25600_b10_bbd0", "xl_c8192_b10_bbd1",
+            "xl_c8192_b5_bbd1", "xl_c10240_b1_bbd0"]
 
 
 @pytest.mark.slow

@@ -282,18 +282,24 @@ def main():
 def xl_extra():
     """XL dims at the other two chunk sizes of SURVEY 8(d) (trajectories only: ids / positions / scores):
     25 600-sample calls (2-3 encoder blocks and decode blocks per call) without BBD, and the CLI's 8 192 with BBD.
-    ``python tools/gen_golden.py --xl-extra`` writes just these two."""
+    plus the reference CLI's default search (beam 5, BBD on, 8 192) and greedy search.
+    ``python tools/gen_golden.py --xl-extra [case names]`` writes just these."""
     OUT.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     tmp = Path(tempfile.mkdtemp(prefix="golden_"))
     xl_dir = synth.write_model_dir(tmp / "xl", XL, seed=1234, stats_kind="meanstd")
-    for chunk, bbd, stream in ((25600, False, 3), (8192, True, 4)):
+    only = [a for a in sys.argv[1:] if a.startswith("xl_")]
+    for chunk, beam, bbd, stream in ((25600, 10, False, 3), (8192, 10, True, 4),
+                                     (8192, 5, True, 5),      # the reference CLI's defaults: -b 5, BBD on, 8192
+                                     (10240, 1, False, 6)):   # greedy
+        name = f"xl_c{chunk}_b{beam}_bbd{int(bbd)}"
+        if only and name not in only:
+            continue
         audio = synth.synth_audio(stream, 16000 * 8)
-        s2t, rec, calls = run_stream(xl_dir, audio, chunk, 10, bbd)
-        name = f"xl_c{chunk}_b10_bbd{int(bbd)}"
+        s2t, rec, calls = run_stream(xl_dir, audio, chunk, beam, bbd)
         meta = {"model": "XL", "seed": 1234, "stats": "meanstd", "audio_stream": stream,
-                "n_samples": len(audio), "chunk": chunk, "beam": 10, "bbd": bbd}
+                "n_samples": len(audio), "chunk": chunk, "beam": beam, "bbd": bbd}
         save_case(name, meta, rec, calls, with_tensors=False)
         print(name, "blocks", len(rec.blocks))
 
