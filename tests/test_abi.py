@@ -110,3 +110,34 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert len(plist) == len(argtypes), f"{name}: header has {len(plist)} parameters, binding {len(argtypes)}"
         for i, (p, t) in enumerate(zip(plist, argtypes)):
             assert c_class(p) == ct_class(t), f"{name} parameter {i}: '{p.strip()}' bound as {t}"
+
+
+def test_oracle_is_only_used_as_the_checker():
+    """The product never routes through the oracle: no module of the package imports it (neither do the tools that
+    run on the GPU box), bench.py only inside its cpu_baseline leg and __graft_entry__ only inside smoke()."""
+    import ast
+
+    def oracle_imports(path):
+        """-> names of the enclosing top-level functions (None = module level) of every oracle import"""
+        tree = ast.parse(path.read_text())
+        found = []
+
+        def visit(node, owner):
+            for child in ast.iter_child_nodes(node):
+                o = child.name if owner is None and isinstance(child, (ast.FunctionDef, ast.ClassDef)) else owner
+                if isinstance(child, ast.ImportFrom) and (child.module or "").split(".")[0] == "oracle":
+                    found.append(owner)
+                elif isinstance(child, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in child.names):
+                    found.append(owner)
+                visit(child, o)
+
+        visit(tree, None)
+        return found
+
+    for path in sorted((ROOT / "speechcatcher_amd").rglob("*.py")):
+        assert oracle_imports(path) == [], f"{path.relative_to(ROOT)} imports the oracle"
+    assert set(oracle_imports(ROOT / "bench.py")) == {"cpu_baseline"}
+    assert set(oracle_imports(ROOT / "__graft_entry__.py")) == {"smoke"}
+    # the product's only compute backend is the HIP library: no torch arithmetic fallback in the engine
+    engine_src = (ROOT / "speechcatcher_amd" / "engine.py").read_text()
+    assert "SpecBackend" not in engine_src
