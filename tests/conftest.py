@@ -1,4 +1,5 @@
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -15,6 +16,11 @@ GOLDEN = ROOT / "tests" / "golden"
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    # The oracle / kernel-spec legs of the parity tests are torch-CPU code with small
+    # operands: on the GPU box's 128 host threads the intra-op pool makes them several
+    # times SLOWER than on 8 (bench.py's cpu_baseline measured the same).
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 def load_case(name):
