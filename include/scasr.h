@@ -55,7 +55,12 @@ extern "C" {
 #define SC_C_L 4    /* tokens per live hypothesis, incl. sos */
 #define SC_C_NHYP 5 /* live hypotheses (1 or W) */
 #define SC_C_HAS 6  /* live hypotheses carry a CTC state */
-#define SC_C_TOLD 7 /* rows the CTC states covered before this block */
+#define SC_C_TOLD 7 /* sc_ctc_extend_state: rows the CTC states covered before this block */
+/* decode-step launches (sc_ctc_prefix_scan, sc_ctc_gather_state): rows of the CTC table and of the
+ * forward variables, when that differs from SC_C_T (0: same).  The reference never clears
+ * CTCPrefixScorer.impl on reset() (scorers.py:342-350): the next utterance on the same object is
+ * scored over the stale table until its own frames outgrow it, while attention sees SC_C_T frames. */
+#define SC_C_TCTC 7
 
 typedef struct sc_enc_layer {
   const float *ln1_g, *ln1_b, *wqkv, *bqkv, *wo, *bo;

@@ -446,9 +446,10 @@ class SpecBackend:
         ctrl = sb.ctrl.cpu().numpy()
         X = sb.ctcx.view(sb.S, sb.TCAP, V)
         for s in range(sb.S):
-            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            act, cur, fin, T, L, nh, has, tctc = [int(v) for v in ctrl[s]]
             if not act:
                 continue
+            T = tctc if tctc > 0 else T      # scasr.h SC_C_TCTC: stale-table quirk after reset()
             x = X[s, :T]
             xb = x[:, cfg.blank_id]
             ids = sb.pre_ids[s * W:s * W + nh].to(torch.long)        # (nh, K)
@@ -568,9 +569,10 @@ class SpecBackend:
         W, K = sb.W, sb.K
         ctrl = sb.ctrl.cpu().numpy()
         for s in range(sb.S):
-            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            act, cur, fin, T, L, nh, has, tctc = [int(v) for v in ctrl[s]]
             if not act:
                 continue
+            T = tctc if tctc > 0 else T
             o = 1 - cur
             nout = min(W, nh * W)
             for i in range(nout):

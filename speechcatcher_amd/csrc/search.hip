@@ -5,6 +5,8 @@
 #include "common.h"
 
 #define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
+// rows of the CTC table / forward variables seen by a decode step (scasr.h: SC_C_TCTC)
+#define SC_CTC_T(s) (CTRL(s, SC_C_TCTC) > 0 ? CTRL(s, SC_C_TCTC) : CTRL(s, SC_C_T))
 
 // per-index helpers for the ping-pong buffers
 #define YSEQ(pp, s, h) (sb.yseq + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= nh * K) return;
   const int h = e / K, k = e % K;
-  const int T = CTRL(s, SC_C_T), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  const int T = SC_CTC_T(s), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
   const bool has = CTRL(s, SC_C_HAS);
   const long row = (long)s * W + h;
   const int c = sb.pre_ids[row * K + k];
@@ -1253,7 +1255,7 @@ extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
 __global__ void ctc_gather_state_kernel(sc_search sb) {
   const int s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
-  const int W = sb.W, K = sb.K, T = CTRL(s, SC_C_T), nh = CTRL(s, SC_C_NHYP);
+  const int W = sb.W, K = sb.K, T = SC_CTC_T(s), nh = CTRL(s, SC_C_NHYP);
   const int nout = nh * W < W ? nh * W : W;
   const int o = 1 - CTRL(s, SC_C_CUR);
   float *dst = CTCR(o, s);

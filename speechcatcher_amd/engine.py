@@ -15,6 +15,7 @@ to launch.  It replaces, for S streams at once:
 (paths relative to /root/reference).  SURVEY.md Appendix D/E describe the
 exact buffering arithmetic restated here.
 """
+import copy
 import math
 import os
 import time
@@ -31,10 +32,22 @@ from .weights import PackedWeights
 F_ANY_EOS, F_BEST_EOS, F_ALL_EOS, F_REPEAT = 1, 2, 4, 8
 # ctrl columns (int32 [S, 8])
 C_ACTIVE, C_CUR, C_FINAL, C_T, C_L, C_NHYP, C_HAS, C_TOLD = range(8)
+C_TCTC = 7   # decode-step rows: length of the CTC table / states (include/scasr.h)
 
 
 class EngineError(RuntimeError):
     pass
+
+
+class StreamFault(Exception):
+    """Internal carrier: planning of ONE stream failed with ``exc`` (an EngineError for a
+    capacity limit, or the RuntimeError the reference itself dies with - A3).  push()
+    restores every stream's state and either re-raises ``exc`` (default) or isolates the
+    stream (``isolate_faults``)."""
+
+    def __init__(self, stream: int, exc: Exception):
+        super().__init__(f"stream {stream}: {exc}")
+        self.stream, self.exc = int(stream), exc
 
 
 _AR = np.arange(1 << 16, dtype=np.int64)
@@ -85,7 +98,8 @@ class StreamState:
     L: int = 1                    # tokens per live hypothesis (incl. sos)
     nhyp: int = 1
     has_ctc: bool = False         # live hypotheses carry a CTC state
-    T_ctc: int = 0                # rows in the CTC table / cross-KV cache
+    T_ctc: int = 0                # rows in the CTC table (strict_reference: survives reset(), see StreamBatch.reset)
+    T_kv: int = 0                 # encoder frames already projected to cross-attention K|V rows
     output_index: int = 0
     n_steps_total: int = 0
 
@@ -106,6 +120,8 @@ class StreamBatch:
         self.K = K = min(search.pre_beam, cfg.vocab_size)
         if W > K:
             raise EngineError("beam_size must not exceed the pre-beam size (40)")
+        if hasattr(backend, "check_supported"):
+            backend.check_supported(cfg, W)
         self.TCAP, self.LCAP, self.PCAP = max_frames, max_tokens, pcm_capacity
         self.strict_reference = strict_reference
         dev = weights.device
@@ -115,6 +131,7 @@ class StreamBatch:
         z = lambda *shape, dtype=f32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
 
         # ---- frontend / encoder buffers
+        self.max_chunk_samples = max_chunk_samples
         self.max_feat_new = 2 + max_chunk_samples // cfg.hop_length + 8
         self.FCAP = self.max_feat_new + 16
         self.UCAP = cfg.block_size + self.FCAP // 4 + 8
@@ -160,15 +177,17 @@ class StreamBatch:
         self.rowmap.copy_(torch.arange(S * W, dtype=i32))
         self.n_rows_step = S * W
         self._decode_prepared = False
+        self._isolate, self._faults = False, {}
         # deferred stragglers (opt-in, set_defer_threshold): resumable per-stream decode-loop state
         self.defer_threshold = 0
         self.defer_max_lag = 1       # blocks a deferred stream may be behind
         self._dq: List[List[Tuple[int, bool]]] = [[] for _ in range(S)]   # queued (T, is_final) blocks per stream
         self._d_inblk = np.zeros(S, bool)
         self._dq_len = np.zeros(S, np.int64)     # len(self._dq[s]), kept in step for vectorised tests
-        self._d = {k: np.zeros(S, np.int64) for k in ("T", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
+        self._d = {k: np.zeros(S, np.int64) for k in ("T", "Tc", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
         self._db = {k: np.zeros(S, bool) for k in ("fin", "has", "pvalid", "live", "took", "hsp")}
-        self._T_proj = np.zeros(S, np.int64)   # encoder frames already projected to CTC / cross-K|V rows
+        self._T_proj = np.zeros(S, np.int64)   # rows of the CTC table written so far (deferred path)
+        self._T_projkv = np.zeros(S, np.int64)  # encoder frames already projected to cross-K|V rows (deferred path)
         self.flags = z(S, dtype=i32)
         # pinned host mirrors: the per-step ctrl upload / flag read-back are the
         # only host<->device traffic of the decode loop
@@ -290,20 +309,29 @@ class StreamBatch:
 
     def reset(self, s: int):
         """Speech2TextStreaming.reset + BlockwiseSynchronousBeamSearch.reset
-        (speech2text_streaming.py:252-263, beam_search.py:343-356).  Unlike
-        the reference, the CTC table is dropped too (the reference keeps its
-        stale scorer.impl - see DESIGN.md "Deliberate deviations")."""
+        (speech2text_streaming.py:252-263, beam_search.py:343-356).
+
+        ``strict_reference`` (default) reproduces what the reference leaves behind:
+        CTCPrefixScorer.impl is never cleared (scorers.py:342-350), so the next
+        utterance on this stream is scored over the STALE CTC table - its rows
+        [0, T_old) keep the previous utterance's posteriors and the table only
+        grows once the new utterance has more than T_old frames (fixture
+        tests/golden/tiny_reset.json) - and the StreamPositionalEncoding counter of
+        the short-segment path keeps counting (A13).  With strict_reference=False
+        the stream restarts from a clean state."""
         if self._prefetched is not None:
             raise EngineError("reset() while a prefetched chunk step is pending")
-        if hasattr(self, "_dq"):
-            self._dq[s] = []
-            self._dq_len[s] = 0
-            self._d_inblk[s] = False
-            self._T_proj[s] = 0
         old = self.st[s]
         ns = StreamState()
         if self.strict_reference:
             ns.short_pos = old.short_pos  # A13: counter survives reset()
+            ns.T_ctc = old.T_ctc          # stale CTC table (rows stay in self.ctcx)
+        if hasattr(self, "_dq"):
+            self._dq[s] = []
+            self._dq_len[s] = 0
+            self._d_inblk[s] = False
+            self._T_proj[s] = max(int(self._T_proj[s]), old.T_ctc) if self.strict_reference else 0
+            self._T_projkv[s] = 0
         self.st[s] = ns
         if getattr(self, "stream", None) is not None:
             with torch.cuda.stream(self.stream):   # same stream as the kernels that read it
@@ -363,17 +391,26 @@ class StreamBatch:
 
     # ------------------------------------------------------------------
     def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]],
-             pcm_resident: bool = False, prefetch: Optional[Sequence[Tuple[int, Optional[np.ndarray], bool]]] = None):
+             pcm_resident: bool = False, prefetch: Optional[Sequence[Tuple[int, Optional[np.ndarray], bool]]] = None,
+             isolate_faults: bool = False):
         """One chunk step.  ``prefetch`` (GPU only, optional): the chunk step that the
         NEXT push() call will pass - its frontend + encoder pass is launched on a
         second HIP stream before this step's decode loop starts, so that the encoder
         (large MFMA-bound kernels) overlaps the latency-bound decode steps; the next
         push() then only waits for it.  Results are identical to the serial order:
-        the decode schedule of this step sees the encoder frames of this step only."""
+        the decode schedule of this step sees the encoder frames of this step only.
+
+        Returns {stream: has_output}.  A stream whose chunk cannot be processed (capacity limit;
+        a final chunk with fewer than 7 feature frames, on which the reference raises too - A3)
+        raises its exception with every stream's state as it was before the call; with
+        ``isolate_faults`` that stream alone is reset and its entry in the result is the exception
+        object - the reference's "one failing websocket does not disturb the others"
+        (speechcatcher_server.py:359-397, one model instance per client)."""
+        self._isolate, self._faults = bool(isolate_faults), {}
         if self.stream is None:
-            out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
+            out, feat_new, finals = self._stage_encode_safe(chunks, pcm_resident)
             self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
-            return out
+            return self._finish_faults(out)
         pf, self._prefetched = self._prefetched, None
         if pf is not None:
             if pf["key"] != self._chunk_key(chunks, pcm_resident):
@@ -384,14 +421,54 @@ class StreamBatch:
         else:
             self._arena_off = 0
             with torch.cuda.stream(self.stream):
-                out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
+                out, feat_new, finals = self._stage_encode_safe(chunks, pcm_resident)
         t_avail = {s: self.st[s].T_enc for s in feat_new}
         if prefetch is not None:
             self._launch_prefetch(prefetch, pcm_resident)
         with torch.cuda.stream(self.stream):
             self._stage_decode(feat_new, finals, t_avail)
         self.stream.synchronize()
+        return self._finish_faults(out)
+
+    def _finish_faults(self, out):
+        """isolate_faults: a stream that failed (capacity limit, or an input the reference itself
+        dies on) is reset and reports its exception in place of the has-output flag; every other
+        stream of the step is unaffected."""
+        for s, exc in self._faults.items():
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    self.reset(s)
+            else:
+                self.reset(s)
+            out[s] = exc
+        self._faults = {}
         return out
+
+    def _stage_encode_safe(self, chunks, pcm_resident):
+        """_stage_encode with per-stream fault handling.  All planning of a chunk step is pure host
+        integer work that runs BEFORE the first launch that changes device state, so a failure is
+        undone by restoring the host mirrors: every stream is back in the state it had before the
+        call.  Then the fault is either raised (default) or the offending stream is dropped from
+        the step (``isolate_faults``) and the step is planned again for the others."""
+        chunks = list(chunks)
+        while True:
+            for s, samples, _fin in chunks:   # compaction moves device data: settle it before the snapshot
+                n_new = int(samples) if pcm_resident else int(len(samples))
+                st = self.st[s]
+                if st.pcm_end + n_new > self.PCAP:
+                    self._compact_pcm(s)
+            snap = {s: copy.copy(self.st[s]) for s, _, _ in chunks}
+            try:
+                return self._stage_encode(chunks, pcm_resident)
+            except StreamFault as f:
+                for s, st in snap.items():
+                    self.st[s] = st
+                if not self._isolate:
+                    raise f.exc
+                self._faults[f.stream] = f.exc
+                chunks = [c for c in chunks if c[0] != f.stream]
+                if not chunks:
+                    return {}, {}, {}
 
     @staticmethod
     def _chunk_key(chunks, pcm_resident):
@@ -440,9 +517,8 @@ class StreamBatch:
             finals[s] = bool(is_final)
             n_new = int(samples) if pcm_resident else int(len(samples))
             if st.pcm_end + n_new > self.PCAP:
-                self._compact_pcm(s)
-                if st.pcm_end + n_new > self.PCAP:
-                    raise EngineError("pcm buffer capacity exceeded")
+                raise StreamFault(s, EngineError(
+                    f"pcm buffer capacity exceeded (pcm_capacity={self.PCAP} samples per stream)"))
             if not pcm_resident and n_new > 0:
                 t = torch.as_tensor(samples, dtype=torch.float32)
                 self.pcm[s, st.pcm_end: st.pcm_end + n_new].copy_(t, non_blocking=False)
@@ -452,7 +528,9 @@ class StreamBatch:
                 continue
             seg_start, seg_len, eff_len, lo, n = plan
             if n > self.max_feat_new:
-                raise EngineError("chunk produces more feature frames than max_chunk_samples allows")
+                raise StreamFault(s, EngineError(
+                    f"a call of {n_new} samples produces {n} feature frames; this batch was built for at most "
+                    f"{self.max_feat_new} (max_chunk_samples={self.max_chunk_samples})"))
             # encoder buffer_before_downsampling lives at rows [0, nfeat) of the
             # live ping-pong half; new frames are appended behind it.
             nbuf = st.nfeat if st.enc_started else 0
@@ -469,28 +547,58 @@ class StreamBatch:
             self._encode_features(feat_new, finals)
         return out, feat_new, finals
 
-    def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]]):
+    def push_features(self, items: Sequence[Tuple[int, torch.Tensor, bool]], isolate_faults: bool = False):
+        self._isolate, self._faults = bool(isolate_faults), {}
         if self.stream is None:
-            return self._push_features(items)
+            return self._finish_faults(self._push_features(items))
         self._arena_off = 0
         with torch.cuda.stream(self.stream):
-            self._push_features(items)
+            out = self._push_features(items)
         self.stream.synchronize()
+        return self._finish_faults(out)
 
     def _push_features(self, items):
         """2-D (T, n_mels) already-normalised features (the reference's 2-D /
-        3-D input path, speech2text_streaming.py:438-449)."""
-        feat_new, finals = {}, {}
-        for s, feats, is_final in items:
-            st = self.st[s]
-            n = feats.shape[0]
-            nbuf = st.nfeat if st.enc_started else 0
-            r0 = (st.fpp * self.S + s) * self.FCAP + nbuf
-            self.featbuf[r0:r0 + n].copy_(torch.as_tensor(feats, dtype=torch.float32))
-            feat_new[s] = n
-            finals[s] = bool(is_final)
-        self._encode_features(feat_new, finals)
+        3-D input path, speech2text_streaming.py:438-449).  Capacity is checked for
+        every item BEFORE anything is copied: a feature matrix must fit the stream's
+        slot of the feature buffer (rows held + new <= FCAP, new <= max_feat_new - the
+        conv scratch is sized for that), else rows would spill into the next stream's slot."""
+        items = list(items)
+        while True:
+            snap = {s: copy.copy(self.st[s]) for s, _, _ in items}
+            try:
+                feat_new, finals = {}, {}
+                for s, feats, is_final in items:
+                    st = self.st[s]
+                    n = int(feats.shape[0])
+                    nbuf = st.nfeat if st.enc_started else 0
+                    if feats.ndim != 2 or feats.shape[1] != self.cfg.n_mels:
+                        raise StreamFault(s, EngineError(f"features must be (T, {self.cfg.n_mels})"))
+                    if n > self.max_feat_new or nbuf + n > self.FCAP:
+                        raise StreamFault(s, EngineError(
+                            f"{n} feature frames in one call (+{nbuf} buffered) exceed this batch's capacity of "
+                            f"{self.max_feat_new} new frames per call (max_chunk_samples={self.max_chunk_samples})"))
+                for s, feats, is_final in items:
+                    st = self.st[s]
+                    n = int(feats.shape[0])
+                    nbuf = st.nfeat if st.enc_started else 0
+                    r0 = (st.fpp * self.S + s) * self.FCAP + nbuf
+                    self.featbuf[r0:r0 + n].copy_(torch.as_tensor(feats, dtype=torch.float32))   # appended rows only
+                    feat_new[s] = n
+                    finals[s] = bool(is_final)
+                self._encode_features(feat_new, finals)
+                break
+            except StreamFault as f:
+                for s, st in snap.items():
+                    self.st[s] = st
+                if not self._isolate:
+                    raise f.exc
+                self._faults[f.stream] = f.exc
+                items = [it for it in items if it[0] != f.stream]
+                if not items:
+                    return {}
         self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
+        return {s: True for s in feat_new}
 
     def _compact_pcm(self, s: int):
         st = self.st[s]
@@ -653,9 +761,9 @@ class StreamBatch:
                 t_use, keep = Tf, 0
                 if Tf < 7:
                     # the reference dies inside Conv2d with RuntimeError (A3)
-                    raise RuntimeError(
+                    raise StreamFault(s, RuntimeError(
                         "Calculated padded input size per channel is smaller than the 3x3 "
-                        f"subsampling kernel (stream {s}: {Tf} feature frames in a final chunk)")
+                        f"subsampling kernel (stream {s}: {Tf} feature frames in a final chunk)"))
             else:
                 n_s = Tf // sub - 1
                 if n_s < 2:
@@ -678,7 +786,7 @@ class StreamBatch:
             nsub = st.nsub if st.has_sub else 0
             ubase = (st.upp * S + s) * self.UCAP
             if nsub + t2 > self.UCAP:
-                raise EngineError("subsampled-frame buffer capacity exceeded")
+                raise StreamFault(s, EngineError("subsampled-frame buffer capacity exceeded"))
             lin_dst.append(ubase + nsub + _ar(t2))
             per[s] = (t2, nsub, ubase)
         if not conv_jobs:
@@ -701,6 +809,8 @@ class StreamBatch:
             if fin:
                 nb = math.ceil(float(U - offset - cfg.look_ahead) / float(cfg.hop_size))
                 if st.n_blocks == 0 and U <= cfg.block_size:
+                    if st.T_enc + U > self.TCAP:
+                        raise StreamFault(s, EngineError(f"encoder-frame capacity exceeded (max_frames={self.TCAP})"))
                     short_jobs.append((s, ubase, U))
                     continue
             else:
@@ -742,7 +852,7 @@ class StreamBatch:
                     clen = cfg.hop_size
                 src[cur_hop:cur_hop + clen] = (b0 + i) * R + 1 + offset + _ar(clen)
             if st.T_enc + y_len > self.TCAP:
-                raise EngineError("encoder-frame capacity (max_frames) exceeded")
+                raise StreamFault(s, EngineError(f"encoder-frame capacity exceeded (max_frames={self.TCAP})"))
             emit_src.append(src)
             emit_dst.append(s * self.TCAP + st.T_enc + _ar(y_len))
             st.T_enc += y_len
@@ -817,8 +927,6 @@ class StreamBatch:
         be.block_pack(w, self.subbuf, self._itensor(job), 1, U, self.xblk)
         be.encoder_layers(w, self.xblk, 1, U, False, None, 0, self.past_ctx,
                           self.ws_xn, self.ws_qkv, self.ws_att, self.ws_ffh)
-        if st.T_enc + U > self.TCAP:
-            raise EngineError("encoder-frame capacity (max_frames) exceeded")
         dst = s * self.TCAP + st.T_enc + _ar(U)
         be.layernorm(self.xblk, self._itensor(_ar(U)), self.enc, self._itensor(dst), U,
                      w.enc_norm_g, w.enc_norm_b)
@@ -847,13 +955,18 @@ class StreamBatch:
         pidx = np.fromiter((x.process_idx for x in sts), dtype=np.int64, count=n)
         pvalid = np.fromiter((x.prev_valid for x in sts), dtype=bool, count=n)
         told = np.fromiter((x.T_ctc for x in sts), dtype=np.int64, count=n)
+        tkv = np.fromiter((x.T_kv for x in sts), dtype=np.int64, count=n)
         if (T > self.TCAP).any():
             raise EngineError("max_frames exceeded")
+        # CTC table length after this block: the table never shrinks (a stale table left by reset()
+        # stays longer than the new utterance until the utterance outgrows it, scorers.py:342-350)
+        Ttab = np.maximum(T, told)
         # ---- extend_scorers (:403-464): CTC rows, cross-attention K/V rows, r states
         grow = T > told
+        same_rows = bool((told == tkv).all())
+        ar = None
         if grow.any():
             rows = np.concatenate([ids[i] * self.TCAP + _AR[told[i]:T[i]] for i in np.nonzero(grow)[0]])
-            kv0 = np.concatenate([ids[i] * Ld * self.TCAP + _AR[told[i]:T[i]] for i in np.nonzero(grow)[0]])
             first = grow & (told == 0)
             ar = self._itensor(rows)
             m = int(rows.shape[0])
@@ -861,6 +974,14 @@ class StreamBatch:
             if first.any():   # quirk A1: only the first block is log-softmaxed
                 lr = np.concatenate([ids[i] * self.TCAP + _AR[0:T[i]] for i in np.nonzero(first)[0]])
                 be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+        growkv = T > tkv
+        if growkv.any():
+            gi = np.nonzero(growkv)[0]
+            kv0 = np.concatenate([ids[i] * Ld * self.TCAP + _AR[tkv[i]:T[i]] for i in gi])
+            if not same_rows or ar is None:
+                rows = np.concatenate([ids[i] * self.TCAP + _AR[tkv[i]:T[i]] for i in gi])
+                ar = self._itensor(rows)
+            m = int(kv0.shape[0])
             kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
             for li in range(Ld):
                 be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
@@ -874,13 +995,14 @@ class StreamBatch:
                 be.prepare_decode(self)
         ctrl0 = self._ctrl_np0             # (every earlier use was followed by a flag read-back sync)
         ctrl0[:] = 0
-        ctrl0[ids] = np.stack([np.ones(n, np.int64), cur, fin, T, L, nhyp, has, told], 1)
+        ctrl0[ids] = np.stack([np.ones(n, np.int64), cur, fin, Ttab, L, nhyp, has, told], 1)
         self.ctrl.copy_(self._ctrl_host0, non_blocking=self.stream is not None)
         be.ctc_extend_state(self)
         ctrl = self._ctrl_np
         ctrl[:] = 0
         for i, x in enumerate(sts):
-            x.T_ctc = int(max(T[i], told[i]))
+            x.T_ctc = int(Ttab[i])
+            x.T_kv = int(max(T[i], tkv[i]))
             x.output_index = 0
         # ---- step loop (:701-821)
         live = np.ones(n, bool)
@@ -890,15 +1012,22 @@ class StreamBatch:
         out_idx = np.zeros(n, np.int64)
         nsteps = np.zeros(n, np.int64)
         use_bbd = self.search.use_bbd
-        zeros_n = np.zeros(n, np.int64)
         while True:
             act = live & (pidx < self.search.max_length)
             live &= act
             if not act.any():
                 break
-            if (L[act] + 1 > self.LCAP).any():
-                raise EngineError("max_tokens exceeded")
-            ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, zeros_n], 1)
+            over = act & (L + 1 > self.LCAP)
+            if over.any():
+                if not self._isolate:
+                    raise EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
+                for i in np.nonzero(over)[0]:   # isolate: the stream leaves the loop here and is reset by push()
+                    self._faults[int(ids[i])] = EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
+                live &= ~over
+                act = act & ~over
+                if not act.any():
+                    break
+            ctrl[ids] = np.stack([act, cur, fin, T, L, nhyp, has, Ttab], 1)
             self._set_rowmap(ids[act])
             self._upload_ctrl()
             self.stats["dec_steps"] += 1
@@ -965,6 +1094,7 @@ class StreamBatch:
         elif self.defer_threshold == 0:
             for s, st in enumerate(self.st):   # rows projected so far by the run-to-completion path
                 self._T_proj[s] = st.T_ctc
+                self._T_projkv[s] = st.T_kv
         self.defer_threshold = max(0, int(n_streams))
 
     def flush(self):
@@ -998,7 +1128,8 @@ class StreamBatch:
         # are projected here for all streams at once (not when a deferred stream starts its block)
         cfg, be, w = self.cfg, self.be, self.w
         d, Ld = cfg.d_model, cfg.dec_layers
-        rows, kv0, lsm = [], [], []
+        rows, krows, kv0, lsm = [], [], [], []
+        same_rows = True
         for s in feat_new:
             q = self._dq[s]
             if not q:
@@ -1006,22 +1137,32 @@ class StreamBatch:
             t_to = max(t for t, _ in q)
             if t_to > self.TCAP:
                 raise EngineError("max_frames exceeded")
-            t_from = int(self._T_proj[s])
+            t_from, k_from = int(self._T_proj[s]), int(self._T_projkv[s])
+            same_rows &= t_from == k_from
             if t_to > t_from:
                 rows.append(s * self.TCAP + _AR[t_from:t_to])
-                kv0.append(s * Ld * self.TCAP + _AR[t_from:t_to])
                 if t_from == 0:   # quirk A1: only the rows of the stream's FIRST block are log-softmaxed
                     first_T = self._d["T"][s] if self._d_inblk[s] else q[0][0]
                     lsm.append(s * self.TCAP + _AR[0:int(first_T)])
                 self._T_proj[s] = t_to
+            if t_to > k_from:
+                krows.append(s * self.TCAP + _AR[k_from:t_to])
+                kv0.append(s * Ld * self.TCAP + _AR[k_from:t_to])
+                self._T_projkv[s] = t_to
+        ar = None
         if rows:
-            rows, kv0 = np.concatenate(rows), np.concatenate(kv0)
+            rows = np.concatenate(rows)
             ar = self._itensor(rows)
             m = int(rows.shape[0])
             be.gemm(self.enc, ar, d, w.ctc_w, w.ctc_b, self.ctcx, ar, cfg.vocab_size, m, cfg.vocab_size, d)
             if lsm:
                 lr = np.concatenate(lsm)
                 be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
+        if kv0:
+            kv0 = np.concatenate(kv0)
+            if not same_rows or ar is None:
+                ar = self._itensor(np.concatenate(krows))
+            m = int(kv0.shape[0])
             kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
             for li in range(Ld):
                 be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
@@ -1058,9 +1199,12 @@ class StreamBatch:
                 D["pidx"][ids] = [x.process_idx for x in xs]
                 B["pvalid"][ids] = [x.prev_valid for x in xs]
                 told = np.fromiter((x.T_ctc for x in xs), np.int64, len(xs))
+                D["Tc"][ids] = np.maximum(D["T"][ids], told)      # the CTC table never shrinks (stale table after reset())
                 for x, b in zip(xs, blocks):
                     if b[0] > x.T_ctc:
                         x.T_ctc = b[0]
+                    if b[0] > x.T_kv:
+                        x.T_kv = b[0]
                     x.output_index = 0
                 B["live"][ids], B["took"][ids] = True, False
                 D["nhp"][ids], B["hsp"][ids] = D["nhyp"][ids], B["has"][ids]
@@ -1074,7 +1218,7 @@ class StreamBatch:
                 host0 = self._ctrl0_ring[self._ctrl0_ring_i]
                 ctrl0 = host0.numpy()
                 ctrl0[:] = 0
-                ctrl0[ids] = np.stack([np.ones(len(start), np.int64), D["cur"][ids], B["fin"][ids], D["T"][ids],
+                ctrl0[ids] = np.stack([np.ones(len(start), np.int64), D["cur"][ids], B["fin"][ids], D["Tc"][ids],
                                        D["L"][ids], D["nhyp"][ids], B["has"][ids], told], 1)
                 self.ctrl.copy_(host0, non_blocking=self.stream is not None)
                 be.ctc_extend_state(self)
@@ -1110,12 +1254,18 @@ class StreamBatch:
                     not ((self._dq_len >= self.defer_max_lag) & act).any():
                 self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + n_act
                 break
-            if ((D["L"] + 1 > self.LCAP) & act).any():
-                raise EngineError("max_tokens exceeded")
+            over = (D["L"] + 1 > self.LCAP) & act
+            if over.any():
+                if not self._isolate:
+                    raise EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
+                for i in np.nonzero(over)[0]:
+                    self._faults[int(i)] = EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
+                B["live"] &= ~over
+                continue
             # ---- E. one decode step for the active streams (:701-821); S-sized vectors, masks ----
             ctrl[:, 0] = act
             ctrl[:, 1], ctrl[:, 2], ctrl[:, 3], ctrl[:, 4] = D["cur"], B["fin"], D["T"], D["L"]
-            ctrl[:, 5], ctrl[:, 6], ctrl[:, 7] = D["nhyp"], B["has"], 0
+            ctrl[:, 5], ctrl[:, 6], ctrl[:, 7] = D["nhyp"], B["has"], D["Tc"]
             self._set_rowmap(np.nonzero(act)[0])
             self._upload_ctrl()
             self.stats["dec_steps"] += 1

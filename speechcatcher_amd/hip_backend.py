@@ -36,6 +36,22 @@ class HipBackend:
         self._chk(self.lib.sc_set_stream_workspace(stream.cuda_stream, ws.data_ptr(), ws.numel()),
                   "sc_set_stream_workspace")
 
+    def check_supported(self, cfg, beam_size):
+        """Reject, at construction time, model dimensions the decode kernels have no instantiation for
+        (the first decode step would otherwise fail in the middle of a stream)."""
+        dk = cfg.d_model // cfg.dec_heads
+        if cfg.d_model % cfg.dec_heads or dk not in (16, 32):
+            raise _abi.ScasrError(
+                f"decoder head dim {dk} (d_model {cfg.d_model} / {cfg.dec_heads} heads) is not supported: the HIP "
+                "decoder attention kernels are instantiated for head dims 16 and 32 (csrc/search.hip)")
+        ek = cfg.d_model // cfg.enc_heads
+        if cfg.d_model % cfg.enc_heads or ek not in (16, 32, 64):
+            raise _abi.ScasrError(f"encoder head dim {ek} is not supported (16, 32 or 64)")
+        if beam_size > 16:
+            raise _abi.ScasrError(f"beam size {beam_size} > 16 is not supported by the decoder attention kernels")
+        if cfg.d_model % 32:
+            raise _abi.ScasrError("d_model must be a multiple of 32 (sc_gemm K tiles)")
+
     # ------------------------------------------------------------------
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream

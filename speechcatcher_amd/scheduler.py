@@ -29,7 +29,13 @@ class ServerBusy(RuntimeError):
 
 class StreamScheduler:
     def __init__(self, batch: StreamBatch, token_list: Optional[List[str]] = None,
-                 result_format: str = "native"):
+                 result_format: str = "native", reset_after_final: bool = True, reset_on_open: bool = True):
+        """``reset_after_final`` / ``reset_on_open`` (default True): a finalised utterance and a newly opened
+        session start from a reset stream - what the reference CLI does (speechcatcher.py:618-619).  The
+        reference SERVER does neither (speechcatcher_server.py:270,364-397: no reset after is_final=True, models
+        go back to the pool as they are); ``ServerLoop(strict_reference=True)`` switches both off to reproduce
+        that.  What reset() itself leaves behind is the batch's ``strict_reference`` (StreamBatch.reset)."""
+        self.reset_after_final, self.reset_on_open = reset_after_final, reset_on_open
         # results are reported per chunk, so every block must complete inside its step: the
         # scheduler always runs the batch in run-to-completion mode (no deferred stragglers)
         batch.set_defer_threshold(0)
@@ -46,7 +52,8 @@ class StreamScheduler:
         if not self._free:
             raise ServerBusy("Server busy: all stream slots are in use")
         slot = self._free.popleft()
-        self.batch.reset(slot)
+        if self.reset_on_open:
+            self.batch.reset(slot)
         sid = self._next_sid
         self._next_sid += 1
         self._slot_of[sid] = slot
@@ -56,7 +63,8 @@ class StreamScheduler:
     def close(self, sid: int):
         slot = self._slot_of.pop(sid)
         self._queue.pop(sid)
-        self.batch.reset(slot)
+        if self.reset_on_open:
+            self.batch.reset(slot)
         self._free.append(slot)
 
     @property
@@ -76,7 +84,13 @@ class StreamScheduler:
         (at most one chunk per session: per-stream order is preserved).
         Returns {session: results} in the reference's tuple format; a final
         chunk resets the slot's stream state afterwards, like the reference
-        callers do (speechcatcher.py:618-619)."""
+        callers do (speechcatcher.py:618-619).
+
+        Fault isolation: a session whose chunk cannot be processed (capacity limit, or an input
+        the reference itself raises on, e.g. a final chunk of <7 feature frames) gets the
+        EXCEPTION OBJECT as its result and its stream is reset; the other sessions of the step
+        are decoded as if it had not been there (in the reference an exception ends only that
+        client's handler: every client owns a model instance)."""
         items, meta = [], {}
         for sid, q in self._queue.items():
             if q:
@@ -86,15 +100,18 @@ class StreamScheduler:
                 meta[sid] = (slot, fin, fa)
         if not items:
             return {}
-        has = self.batch.push(items)
+        has = self.batch.push(items, isolate_faults=True)
         out = {}
         for sid, (slot, fin, fa) in meta.items():
+            if isinstance(has[slot], Exception):
+                out[sid] = has[slot]          # the engine has reset the stream
+                continue
             if not has[slot]:
                 out[sid] = []
             else:
                 out[sid] = hyps_to_results(self.batch.hypotheses(slot), fin, fa, self.token_list,
                                            self.result_format)
-            if fin:
+            if fin and self.reset_after_final:
                 self.batch.reset(slot)
         return out
 
@@ -102,7 +119,10 @@ class StreamScheduler:
         """Run steps until every queue is empty; returns the LAST result of each session."""
         last: Dict[int, list] = {}
         while self.pending():
-            last.update(self.step())
+            for sid, res in self.step().items():
+                if isinstance(res, Exception):
+                    raise res
+                last[sid] = res
         return last
 
 
@@ -135,6 +155,8 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
                 fa = last and (not finalize_all_last_only or idx == len(segments) - 1)
                 sch.feed(sid, seg[pos:end], is_final=last, finalize_all=fa)
         for sid, res in sch.step().items():
+            if isinstance(res, Exception):
+                raise res
             if not sch._queue[sid]:          # that was the final chunk of the session
                 idx = sid_to_seg.pop(sid)
                 start_s = segments[idx][0] / 16000.0

@@ -211,20 +211,32 @@ def merge_paragraphs(segments: List[dict]) -> Tuple[str, List[dict]]:
     return "\n\n".join(merged) + "\n", info
 
 
-def recognize_recording(batch, raw_speech_data: np.ndarray, rate: int = 16000, chunk_length: int = 8192,
-                        token_list: Optional[List[str]] = None, reference_finalize: bool = False
-                        ) -> Tuple[str, List[dict]]:
-    """int16 recording -> (text, per-paragraph info).  Native-decoder input scaling
-    /32768 in fp32 (speechcatcher.py:421); recordings over a minute are segmented;
-    the segments run as parallel streams of ``batch``; paragraphs are merged like
-    the CLI does.  ``reference_finalize``: pass finalize_all only with the last
-    chunk of the recording, as the reference CLI does."""
+def recognize_recording_segments(batch, raw_speech_data: np.ndarray, rate: int = 16000, chunk_length: int = 8192,
+                                 token_list: Optional[List[str]] = None, reference_finalize: bool = False,
+                                 average_segment_length: float = 60.0):
+    """The segment loop of ``recognize`` (speechcatcher.py:414-497): int16 recording -> chunk-aligned sample
+    ranges and the raw per-segment results of ``recognize_segments`` (before paragraph merging)."""
     assert rate == 16000
     speech = np.asarray(raw_speech_data).astype(np.float32) / 32768.0
-    segments = segment_speech(raw_speech_data, rate) if len(speech) > 60.0 * rate else []
+    segments = (segment_speech(raw_speech_data, rate, average_segment_length=average_segment_length)
+                if len(speech) > 60.0 * rate else [])
     ranges = plan_segments(len(speech), rate, segments, chunk_length)
     res = recognize_segments(batch, speech, ranges, chunk_length=chunk_length, token_list=token_list,
                              finalize_all_last_only=reference_finalize)
+    return ranges, res
+
+
+def recognize_recording(batch, raw_speech_data: np.ndarray, rate: int = 16000, chunk_length: int = 8192,
+                        token_list: Optional[List[str]] = None, reference_finalize: bool = False,
+                        average_segment_length: float = 60.0) -> Tuple[str, List[dict]]:
+    """int16 recording -> (text, per-paragraph info).  Native-decoder input scaling
+    /32768 in fp32 (speechcatcher.py:421); recordings over a minute are segmented;
+    the segments run as parallel streams of ``batch`` (one slot = the reference CLI with one worker:
+    serial segments on one model); paragraphs are merged like the CLI does.
+    ``reference_finalize``: pass finalize_all only with the last chunk of the recording, as the
+    reference CLI does."""
+    ranges, res = recognize_recording_segments(batch, raw_speech_data, rate, chunk_length, token_list,
+                                               reference_finalize, average_segment_length)
     segs = [{"start": lo / rate, "end": hi / rate, "text": r["text"], "tokens": r["tokens"],
              "token_timestamps": r["token_timestamps"]} for (lo, hi), r in zip(ranges, res)]
     return merge_paragraphs(segs)

@@ -15,10 +15,12 @@ Differences to the reference, on purpose:
 * token timestamps of final Vosk results are real (encoder frame of the token
   / 24 s, the CLI's convention speechcatcher.py:48) instead of the placeholder
   ``idx * 0.1`` (speechcatcher_server.py:309-311);
-* after a finalised utterance the stream starts from a clean state (the native
-  decoder of the reference keeps its finished state after ``is_final=True`` - the
-  espnet decoder it replaced reset itself - so the reference server goes on
-  decoding into a finalised stream);
+* after a finalised utterance, and for every new connection, the stream is reset
+  (the native decoder of the reference keeps its finished state after
+  ``is_final=True`` - the espnet decoder it replaced reset itself - so the reference
+  server goes on decoding into a finalised stream, and a model returned to the pool
+  hands its hypotheses to the next client).  ``ServerLoop(strict_reference=True)``
+  switches this off and reproduces the reference server call for call;
 * only 16 kHz s16le / int16 input (what Vosk clients send); other container
   formats need the transport to transcode first.
 """
@@ -101,8 +103,12 @@ class ServerLoop:
     """Sessions of all connected clients over one ``StreamScheduler``."""
 
     def __init__(self, scheduler: StreamScheduler, vosk_output_format: bool = False,
-                 finalize_update_iters: int = 6, max_partial_iters: int = 42):
+                 finalize_update_iters: int = 6, max_partial_iters: int = 42, strict_reference: bool = False):
+        """``strict_reference``: no stream reset after a finalised utterance nor between clients, exactly like
+        ``recognize_ws`` / ``process_audio_chunk`` (speechcatcher_server.py:270,359-397); the default resets."""
         assert scheduler.result_format == "espnet", "sessions need token positions: result_format='espnet'"
+        if strict_reference:
+            scheduler.reset_after_final = scheduler.reset_on_open = False
         self.sch = scheduler
         self.vosk = vosk_output_format
         self.fui, self.mpi = finalize_update_iters, max_partial_iters
@@ -128,15 +134,28 @@ class ServerLoop:
     def step(self) -> Dict[int, List[Union[str, dict]]]:
         """Feeds at most one audio chunk per session into the batch (the
         endpointing decision of chunk k needs the result of chunk k-1), runs one
-        batched chunk step and returns the replies per session, in order."""
+        batched chunk step and returns the replies per session, in order.  An Exception instance
+        among a session's replies means: that client's message could not be processed (its stream
+        has been reset) - close that connection; no other session is affected."""
         replies: Dict[int, List[Union[str, dict]]] = {}
         for ses in self.sessions.values():
             while ses.inbox and ses.in_flight is None:
-                immediate = self._start(ses, ses.inbox.popleft())
+                try:
+                    immediate = self._start(ses, ses.inbox.popleft())
+                except (TypeError, NotImplementedError, ValueError) as exc:
+                    replies.setdefault(ses.sid, []).append(exc)     # this client only
+                    continue
                 if immediate is not None:
                     replies.setdefault(ses.sid, []).append(self._reply(ses, immediate))
         for sid, results in self.sch.step().items():
             ses = self.sessions[sid]
+            if isinstance(results, Exception):
+                # the client's handler dies with the exception in the reference (recognize_ws has no except for
+                # it): the transport closes this connection; every other session is untouched
+                ses.in_flight = None
+                ses.endpointer.n_best_lens = []
+                replies.setdefault(sid, []).append(results)
+                continue
             replies.setdefault(sid, []).append(self._reply(ses, self._finish(ses, results)))
         return replies
 

@@ -223,7 +223,9 @@ def hyps_to_results(hyps, is_final, finalize_all, token_list, fmt="native"):
             # (text, token, token_int, token_pos, hyp): asr_inference_streaming.py:364
             res.append((text, toks, ids, pos, h))
         else:
-            res.append((text, toks, ids))
+            # A17: the reference builds token_ids with a list comprehension over a LongTensor, so the
+            # native 3-tuples carry 0-dim torch.LongTensors, not ints (speech2text_streaming.py:498,518,537)
+            res.append((text, toks, [torch.tensor(t, dtype=torch.long) for t in ids]))
     return res
 
 
@@ -231,7 +233,11 @@ class Speech2TextStreaming:
     def __init__(self, model_dir: Union[str, Path], beam_size: int = 5, ctc_weight: float = 0.3,
                  device: str = "cuda", dtype: str = "float32", use_bbd: bool = False,
                  max_frames: int = 4800, max_tokens: int = 1024, result_format: str = "native",
-                 _shared=None):
+                 max_chunk_samples: int = 480000, strict_reference: bool = True, _shared=None):
+        """``max_chunk_samples``: longest single call (the reference accepts any length per call and its frame
+        arithmetic depends on the call boundaries, so a long call cannot be split internally; the scratch for one
+        call is sized from this: 30 s by default, ~80 MB).  ``strict_reference``: reset() behaves like the
+        reference's (stale CTC table, A13 counter: StreamBatch.reset); False gives a clean stream."""
         self.model_dir = Path(model_dir)
         self.beam_size = beam_size
         self.ctc_weight = ctc_weight
@@ -258,7 +264,9 @@ class Speech2TextStreaming:
         self.backend = HipBackend(self.device)
         self.batch = StreamBatch(self.weights, self.backend, 1,
                                  SearchConfig(beam_size=beam_size, ctc_weight=ctc_weight, use_bbd=use_bbd),
-                                 max_frames=max_frames, max_tokens=max_tokens)
+                                 max_frames=max_frames, max_tokens=max_tokens,
+                                 pcm_capacity=max(1 << 20, 2 * max_chunk_samples),
+                                 max_chunk_samples=max_chunk_samples, strict_reference=strict_reference)
         self.stream = 0
         self.win_length = self.cfg.win_length
         self.hop_length = self.cfg.hop_length

@@ -156,3 +156,83 @@ def test_engine_uniform_batch_fast_path():
             if call["n_blocks"]:
                 for s in range(4):
                     check_against_blocks(sb, s, js["blocks"][nblk - 1])
+
+
+def run_reset_quirk(backend=None, device="cpu", defer=0, score_tol=2e-3):
+    """Two utterances on ONE stream with reset() in between, exactly like
+    tools/gen_golden.py recorded the real reference (tests/golden/tiny_reset.json):
+    under strict_reference the second utterance is scored over the first one's
+    stale CTC table (scorers.py:342-350 never clears impl)."""
+    js = json.loads((GOLDEN / "tiny_reset.json").read_text())
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, backend=backend, device=device, max_frames=256,
+                    max_tokens=200, pcm_capacity=1 << 17)
+    if defer:
+        sb.set_defer_threshold(defer)
+    nblk = 0
+    for sid, n in ((5, 40000), (6, 50000)):
+        a = synth.synth_audio(sid, n)
+        sb.reset(0)
+        pos = 0
+        while pos < n:
+            end = min(pos + 10240, n)
+            b0 = sb.stats["dec_blocks"]
+            sb.push([(0, a[pos:end], end >= n)])
+            pos = end
+            sb.flush()
+            nblk += sb.stats["dec_blocks"] - b0
+            if sb.stats["dec_blocks"] > b0:
+                check_against_blocks(sb, 0, js["blocks"][nblk - 1], score_tol)
+    assert nblk == len(js["blocks"])
+    return sb, js
+
+
+@pytest.mark.parametrize("defer", [0, 1])
+def test_engine_reset_keeps_stale_ctc_table_like_the_reference(defer):
+    sb, js = run_reset_quirk(defer=defer)
+    assert sb.st[0].T_ctc >= sb.st[0].T_kv
+
+
+def test_engine_clean_reset_when_not_strict():
+    """strict_reference=False: reset() gives a clean stream - the second utterance equals
+    the same utterance on a fresh batch."""
+    a = synth.synth_audio(6, 50000)
+
+    def run(sb):
+        for pos in range(0, len(a), 10240):
+            end = min(pos + 10240, len(a))
+            sb.push([(0, a[pos:end], end >= len(a))])
+        return sb.hypotheses(0)
+
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, max_frames=256, max_tokens=200, pcm_capacity=1 << 17,
+                    strict_reference=False)
+    b = synth.synth_audio(5, 40000)
+    for pos in range(0, len(b), 10240):
+        sb.push([(0, b[pos:pos + 10240], pos + 10240 >= len(b))])
+    sb.reset(0)
+    got = run(sb)
+    ref = run(make_batch("TINY", 1234, "meanstd", 5, False, max_frames=256, max_tokens=200, pcm_capacity=1 << 17))
+    assert [h["yseq"] for h in got] == [h["yseq"] for h in ref]
+    assert all(abs(x["score"] - y["score"]) < 1e-9 for x, y in zip(got, ref))
+
+
+def run_after_final(bbd, backend=None, device="cpu", score_tol=2e-3):
+    """Calls continuing after is_final=True with no reset (what the reference server does,
+    speechcatcher_server.py:270) against the fixture recorded from the real reference."""
+    js = json.loads((GOLDEN / f"tiny_after_final_bbd{bbd}.json").read_text())
+    sb = make_batch("TINY", 1234, "meanstd", 3, bool(bbd), backend=backend, device=device, max_frames=256,
+                    max_tokens=200, pcm_capacity=1 << 17)
+    a = synth.synth_audio(5, 10240 * 10)
+    nblk = 0
+    for i, call in enumerate(js["calls"]):
+        sb.push([(0, a[i * 10240:(i + 1) * 10240], call["is_final"])])
+        nblk += call["n_blocks"]
+        assert sb.st[0].T_enc == call["enc_buffer_len"], i
+        assert sb.st[0].processed_block == call["processed_block"], i
+        if call["n_blocks"]:
+            check_against_blocks(sb, 0, js["blocks"][nblk - 1], score_tol)
+    return sb
+
+
+@pytest.mark.parametrize("bbd", [0, 1])
+def test_engine_calls_after_final_without_reset(bbd):
+    run_after_final(bbd)

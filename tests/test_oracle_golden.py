@@ -164,3 +164,19 @@ def test_xl_trajectories(name):
     _check_blocks(s.trace, js["blocks"], score_tol=2e-2)
     if npz is not None:
         np.testing.assert_allclose(np.concatenate(encs, 0), npz["enc"], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("bbd", [0, 1])
+def test_calls_after_final_without_reset_match_reference(bbd):
+    """The reference server never resets its model (speechcatcher_server.py:270): the stream goes on
+    after is_final=True.  Fixture recorded from the real reference (tools/gen_golden.py --after-final)."""
+    from oracle.ref_port import RefPortStreaming
+    js = json.loads((GOLDEN / f"tiny_after_final_bbd{bbd}.json").read_text())
+    s = RefPortStreaming(oracle_model("TINY", 1234, "meanstd"), beam_size=3, use_bbd=bool(bbd))
+    s.trace = []
+    a = synth.synth_audio(5, 10240 * 10)
+    for i, call in enumerate(js["calls"]):
+        res = s(a[i * 10240:(i + 1) * 10240], is_final=call["is_final"])
+        assert [r[2] for r in call["results"]] == [g[0] for g in res], i
+        assert (s.encoder_buffer.shape[1] if s.encoder_buffer is not None else 0) == call["enc_buffer_len"]
+    _check_blocks(s.trace, js["blocks"], score_tol=5e-2)

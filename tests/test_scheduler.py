@@ -9,11 +9,11 @@ from speechcatcher_amd.scheduler import ServerBusy, StreamScheduler
 from test_engine_spec import make_batch
 
 
-def test_sessions_batched_with_different_chunking_match_reference():
+def run_sessions_different_chunking(backend=None, device="cpu"):
     cases = {"a": ("tiny_c8192_b10_bbd0", 8192), "b": ("tiny_c10240_b10_bbd0", 10240),
              "c": ("tiny_c25600_b10_bbd0", 25600)}
-    sb = make_batch("TINY", 1234, "meanstd", 10, False, n_streams=3, max_frames=256, max_tokens=160,
-                    pcm_capacity=1 << 18)
+    sb = make_batch("TINY", 1234, "meanstd", 10, False, n_streams=3, backend=backend, device=device, max_frames=256,
+                    max_tokens=160, pcm_capacity=1 << 18)
     sch = StreamScheduler(sb)
     js = {k: load_case(v[0])[0] for k, v in cases.items()}
     audio = synth.synth_audio(0, js["a"]["meta"]["n_samples"])
@@ -41,16 +41,21 @@ def test_sessions_batched_with_different_chunking_match_reference():
     assert sch.batch.st[sch._slot_of[s2]].T_enc == 0 and sch.n_active == 3
 
 
+def test_sessions_batched_with_different_chunking_match_reference():
+    run_sessions_different_chunking()
+
+
 def test_recognize_segments_in_parallel_equals_one_by_one():
     """Segments of one recording decoded as parallel streams (2 slots for 3
     segments: one slot is recycled) give the same tokens as decoding each
-    segment alone; timestamps = segment start + frame position / 24."""
+    segment alone; timestamps = segment start + frame position / 24.
+    strict_reference=False: a recycled slot starts clean."""
     import numpy as np
     from speechcatcher_amd.scheduler import recognize_segments
     speech = synth.synth_audio(21, 70000)
     segs = [(0, 30000), (30000, 52000), (52000, 70000)]
     sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=2, max_frames=128, max_tokens=300,
-                    pcm_capacity=1 << 16)
+                    pcm_capacity=1 << 16, strict_reference=False)
     res = recognize_segments(sb, speech, segs, chunk_length=8192)
     assert len(res) == 3
     for (a, b), r in zip(segs, res):
@@ -66,3 +71,31 @@ def test_recognize_segments_in_parallel_equals_one_by_one():
         assert len(r["token_timestamps"]) == len(ids)
         assert all(t >= a / 16000.0 for t in r["token_timestamps"])
         assert np.all(np.diff(r["token_timestamps"]) >= 0)
+
+
+def run_segments_serial_strict(backend=None, device="cpu"):
+    """The reference CLI with one worker (speechcatcher.py:474-479: segments decoded serially on ONE
+    Speech2TextStreaming with reset() after every final chunk, :618-619) = one stream slot under
+    strict_reference: every segment after the first is scored over the previous segments' stale CTC
+    table.  Checked against the oracle doing exactly that (reference_reset_quirk)."""
+    from helpers import oracle_model
+    from oracle.ref_port import RefPortStreaming
+    from speechcatcher_amd.scheduler import recognize_segments
+    speech = synth.synth_audio(21, 70000)
+    segs = [(0, 30000), (30000, 52000), (52000, 70000)]
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, backend=backend, device=device, max_frames=128,
+                    max_tokens=300, pcm_capacity=1 << 16)
+    res = recognize_segments(sb, speech, segs, chunk_length=8192)
+    ora = RefPortStreaming(oracle_model("TINY", 1234, "meanstd"), beam_size=5, reference_reset_quirk=True)
+    for (a, b), r in zip(segs, res):
+        seg = speech[a:b]
+        for pos in range(0, len(seg), 8192):
+            end = min(pos + 8192, len(seg))
+            out = ora(seg[pos:end], is_final=end >= len(seg), finalize_all=end >= len(seg))
+        ora.reset()
+        assert r["token_ids"] == [t for t in out[0][0]], (a, b)
+    return res
+
+
+def test_recognize_segments_serial_strict_equals_reference_cli_semantics():
+    run_segments_serial_strict()

@@ -46,25 +46,56 @@ def test_log_fbank_shape_and_silence_detection():
     assert log_fbank_energy(np.zeros(100, np.int16), rate).shape == (1, 26)
 
 
-def test_recognize_recording_segments_run_as_parallel_streams():
+def run_recording(n_slots, seconds=70, backend=None, device="cpu", check_oracle=False):
+    """File loop: int16 recording -> segments -> streams -> text + per-segment token timestamps.
+    check_oracle (n_slots == 1): the reference CLI with one worker decodes the segments serially on ONE
+    model with reset() after every final chunk (speechcatcher.py:474-479,618-619) - token ids per segment
+    must equal the oracle doing exactly that (stale CTC table after reset included)."""
     from test_engine_spec import make_batch
+    from speechcatcher_amd.segmenter import recognize_recording_segments
     rate = 16000
-    rng = np.random.RandomState(1)
-    x = (synth.synth_audio(40, 70 * rate) * 20000)
+    x = (synth.synth_audio(40, seconds * rate) * 20000)
     for t0 in (18, 41):                                   # two pauses
-        x[t0 * rate:(t0 + 2) * rate] *= 0.01
+        if (t0 + 2) * rate < len(x):
+            x[t0 * rate:(t0 + 2) * rate] *= 0.01
     x = x.astype(np.int16)
     segs = segment_speech(x, rate, average_segment_length=20.0)
     assert len(segs) >= 2 and segs[0][0] == 0
-    sb = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=2, max_frames=2000, max_tokens=1200,
-                    pcm_capacity=1 << 21)
-    text, info = recognize_recording(sb, x, rate, chunk_length=8192)
-    assert len(info) >= 1 and info[0]["start"] == 0.0 and abs(info[-1]["end"] - 70.0) < 1e-6
+    sb = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=n_slots, backend=backend, device=device,
+                    max_frames=2000, max_tokens=1200, pcm_capacity=1 << 21)
+    if check_oracle:
+        from helpers import oracle_model
+        from oracle.ref_port import RefPortStreaming
+        ranges, res = recognize_recording_segments(sb, x, rate, chunk_length=8192, average_segment_length=20.0)
+        assert len(ranges) >= 2
+        ora = RefPortStreaming(oracle_model("TINY", 1234, "meanstd"), beam_size=3, use_bbd=True,
+                               reference_reset_quirk=True)
+        got = []
+        for (a, b) in ranges:
+            seg = x[a:b].astype(np.float32) / 32768.0           # CLI input scaling (speechcatcher.py:421)
+            for pos in range(0, len(seg), 8192):
+                end = min(pos + 8192, len(seg))
+                out = ora(seg[pos:end], is_final=end >= len(seg), finalize_all=end >= len(seg))
+            ora.reset()
+            got.append([int(t) for t in out[0][0]] if out else [])
+        assert [r["token_ids"] for r in res] == got
+        return None, res
+    text, info = recognize_recording(sb, x, rate, chunk_length=8192, average_segment_length=20.0)
+    assert len(info) >= 1 and info[0]["start"] == 0.0 and abs(info[-1]["end"] - float(seconds)) < 1e-6
     assert all(a["end"] == b["start"] for a, b in zip(info[:-1], info[1:]))
     assert isinstance(text, str) and text.endswith("\n")
     for seg in info:
         assert len(seg["tokens"]) == len(seg["token_timestamps"])
         assert all(seg["start"] <= t <= seg["end"] + 1.0 for t in seg["token_timestamps"])
+    return text, info
+
+
+def test_recognize_recording_segments_run_as_parallel_streams():
+    run_recording(2, seconds=70)
+
+
+def test_recognize_recording_serial_equals_reference_cli_semantics():
+    run_recording(1, seconds=64, check_oracle=True)
 
 
 def test_paragraph_merge_and_position_interpolation():

@@ -54,13 +54,12 @@ def _pcm16(stream_id, n):
     return np.clip(np.round(synth.synth_audio(stream_id, n) * 32767.0), -32768, 32767).astype(np.int16)
 
 
-@pytest.mark.parametrize("vosk", [False, True])
-def test_sessions_batched_equal_private_oracle_sessions(vosk):
+def run_sessions_vs_oracle(vosk, backend=None, device="cpu"):
     from helpers import oracle_model
     from oracle.ref_port import RefPortStreaming, RefServerSession
     fui, mpi, beam = 2, 5, 3
-    sb = make_batch("TINY", 1234, "meanstd", beam, True, n_streams=2, max_frames=400, max_tokens=300,
-                    pcm_capacity=1 << 18)
+    sb = make_batch("TINY", 1234, "meanstd", beam, True, n_streams=2, backend=backend, device=device, max_frames=400,
+                    max_tokens=300, pcm_capacity=1 << 18)
     loop = ServerLoop(StreamScheduler(sb, None, result_format="espnet"), vosk_output_format=vosk,
                       finalize_update_iters=fui, max_partial_iters=mpi)
     model = oracle_model("TINY", 1234, "meanstd")
@@ -82,7 +81,7 @@ def test_sessions_batched_equal_private_oracle_sessions(vosk):
         for sid, reps in loop.step().items():
             got[inv[sid]].extend(reps)
     for c, msgs in plans.items():
-        ref = RefServerSession(RefPortStreaming(model, beam_size=beam, use_bbd=True), finalize_update_iters=fui,
+        ref = RefServerSession(RefPortStreaming(model, beam_size=beam, use_bbd=True, reference_reset_quirk=True), finalize_update_iters=fui,
                                max_partial_iters=mpi, vosk_output_format=vosk)
         want = [ref.reply(m) for m in msgs]
         assert len(got[c]) == len(want)
@@ -99,6 +98,11 @@ def test_sessions_batched_equal_private_oracle_sessions(vosk):
         assert n_final >= 1, "the plan must exercise at least one finalised utterance"
     loop.disconnect(sids[0])
     assert loop.connect() is not None   # the slot is free again
+
+
+@pytest.mark.parametrize("vosk", [False, True])
+def test_sessions_batched_equal_private_oracle_sessions(vosk):
+    run_sessions_vs_oracle(vosk)
 
 
 def test_vosk_result_format():
@@ -143,3 +147,69 @@ def test_step_pacer_full_batch_or_deadline():
     pacer.submit(a, _pcm16(5, 10240))
     assert pacer.due()                                        # the only client left: a full batch of one
     assert set(pacer.poll()) == {a}
+
+
+def test_failing_client_does_not_wedge_the_others():
+    """Client B sends 50 samples, then eof: the final chunk has < 7 feature frames and the reference
+    raises inside Conv2d (A3) - for that client only.  Client A's chunks of the same batched steps are
+    decoded as if B had not been there, and A is not left 'in flight'."""
+    sb = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=2, max_frames=400, max_tokens=300,
+                    pcm_capacity=1 << 18)
+    loop = ServerLoop(StreamScheduler(sb, None, result_format="espnet"), vosk_output_format=True)
+    a, b = loop.connect(), loop.connect()
+    chunks = [_pcm16(5, 10240) for _ in range(5)]
+    for c in chunks:
+        loop.submit(a, c)
+    loop.submit(b, _pcm16(6, 50))
+    loop.submit(b, '{"eof" : 1}')
+    got = {a: [], b: []}
+    while loop.pending():
+        for sid, reps in loop.step().items():
+            got[sid].extend(reps)
+    assert any(isinstance(r, RuntimeError) for r in got[b])
+    assert loop.sessions[a].in_flight is None and loop.sessions[b].in_flight is None
+    # A alone on a fresh loop gives the same replies
+    sb2 = make_batch("TINY", 1234, "meanstd", 3, True, n_streams=1, max_frames=400, max_tokens=300,
+                     pcm_capacity=1 << 18)
+    solo = ServerLoop(StreamScheduler(sb2, None, result_format="espnet"), vosk_output_format=True)
+    a2 = solo.connect()
+    for c in chunks:
+        solo.submit(a2, c)
+    want = []
+    while solo.pending():
+        for _sid, reps in solo.step().items():
+            want.extend(reps)
+    assert got[a] == want and len(want) == 5
+    # B's slot is usable again
+    loop.submit(b, _pcm16(6, 10240))
+    assert not isinstance(loop.step()[b][0], Exception)
+
+
+def run_strict_server(backend=None, device="cpu"):
+    """ServerLoop(strict_reference=True): like the reference server, nothing resets the model after a
+    finalised utterance (speechcatcher_server.py:270 - the native decoder keeps decoding into the
+    finished stream).  Replies equal a private oracle session that never resets either."""
+    from helpers import oracle_model
+    from oracle.ref_port import RefPortStreaming, RefServerSession
+    fui, mpi, beam = 2, 5, 3
+    sb = make_batch("TINY", 1234, "meanstd", beam, True, n_streams=1, backend=backend, device=device, max_frames=400,
+                    max_tokens=300, pcm_capacity=1 << 18)
+    loop = ServerLoop(StreamScheduler(sb, None, result_format="espnet"), finalize_update_iters=fui,
+                      max_partial_iters=mpi, strict_reference=True)
+    sid = loop.connect()
+    msgs = [_pcm16(5, 10240) for _ in range(9)]
+    for m in msgs:
+        loop.submit(sid, m)
+    got = []
+    while loop.pending():
+        for _sid, reps in loop.step().items():
+            got.extend(reps)
+    ref = RefServerSession(RefPortStreaming(oracle_model("TINY", 1234, "meanstd"), beam_size=beam, use_bbd=True),
+                           finalize_update_iters=fui, max_partial_iters=mpi, reset_after_final=False)
+    want = [ref.reply(m) for m in msgs]
+    assert got == want
+    assert any(isinstance(w, str) and w.endswith(chr(10)) for w in want)
+
+
+def test_strict_reference_server_never_resets():
+    run_strict_server()

@@ -279,6 +279,32 @@ def main():
     print("done ->", OUT)
 
 
+def after_final():
+    """The reference SERVER never resets its model: calls go on after is_final=True
+    (speechcatcher_server.py:270).  ``python tools/gen_golden.py --after-final`` records a stream whose
+    4th and 8th of 10 calls are final, no reset() in between: per-call results and block trajectories."""
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tmp = Path(tempfile.mkdtemp(prefix="golden_"))
+    tiny_dir = synth.write_model_dir(tmp / "tiny", TINY, seed=1234, stats_kind="meanstd")
+    for bbd in (True, False):
+        s2t = Speech2TextStreaming(tiny_dir, beam_size=3, ctc_weight=0.3, device="cpu", use_bbd=bbd)
+        rec = Recorder(s2t)
+        a = synth.synth_audio(5, 10240 * 10)
+        calls = []
+        for i in range(10):
+            fin = i in (3, 7)
+            nb0 = len(rec.blocks)
+            res = s2t(a[i * 10240:(i + 1) * 10240], is_final=fin)
+            calls.append({"is_final": fin, "n_blocks": len(rec.blocks) - nb0, "results": results_to_json(res),
+                          "enc_buffer_len": int(s2t.beam_search.encoder_buffer.shape[1])
+                          if s2t.beam_search.encoder_buffer is not None else 0,
+                          "processed_block": int(s2t.beam_search.processed_block)})
+        (OUT / f"tiny_after_final_bbd{int(bbd)}.json").write_text(json.dumps({"blocks": rec.blocks, "calls": calls}))
+        print("after_final bbd", bbd, "blocks", len(rec.blocks), [len(c["results"]) for c in calls])
+
+
 def xl_extra():
     """XL dims at the other two chunk sizes of SURVEY 8(d) (trajectories only: ids / positions / scores):
     25 600-sample calls (2-3 encoder blocks and decode blocks per call) without BBD, and the CLI's 8 192 with BBD.
@@ -307,5 +333,7 @@ def xl_extra():
 if __name__ == "__main__":
     if "--xl-extra" in sys.argv[1:]:
         xl_extra()
+    elif "--after-final" in sys.argv[1:]:
+        after_final()
     else:
         main()
