@@ -76,6 +76,7 @@ typedef struct sc_dec_layer {
   const float *wo_p, *wq_p, *wo2_p; /* sc_pack_lane_weight of wo, wq, wo2 (used when sc_proj_ln_proj_supported(d)) */
   const float *w1_p, *w2_p;         /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
   const float *wqkv_q;              /* sc_pack_lane_weight of wqkv (sc_ffn_ln_proj of the layer before) */
+  const float *wqkv_pp, *wq_pp, *wo_pp, *wo2_pp; /* sc_pack_panel_weight of wqkv, wq, wo, wo2 (sc_dec_layer_self / _cross), or NULL */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -113,6 +114,10 @@ typedef struct sc_search {
   const int32_t *rowmap;
   int32_t n_rows;
   const float *out_w_q; /* sc_pack_lane_weight of out_w (sc_ffn_ln_proj of the last layer), or NULL */
+  /* head-parallel decoder layers (sc_dec_layer_*): per-head partial products of the two attention output
+   * projections [S*W][H][d] and the feed-forward partial sums [max_ffn_part][S*W][d]; NULL: not used */
+  float *ph1, *ph2, *ffn_part;
+  int32_t max_ffn_part;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -312,6 +317,31 @@ int sc_beam_prune(const sc_search *sb, void *stream);
 int sc_ctc_gather_state(const sc_search *sb, void *stream);
 /* one full beam-search step = all of the above in order (beam_search.py:701-758) */
 int sc_decode_step(const sc_search *sb, void *stream);
+
+/* ---- head-parallel decoder layers: 3 launches per layer (decoder_layer.py:80-132) --------------------
+ * The residual stream x ping-pongs between two [S*W][d] buffers (x_in != x_out in every call): sibling
+ * workgroups read x_in while the owner of a row writes x_out.  Grid (stream, head) for the two attention
+ * launches; every workgroup sums the producer's partial products itself (fixed order) and recomputes the
+ * LayerNorm of its stream's W rows, so neither the LayerNorms nor the attention output projections need
+ * launches of their own.  d in {128, 256}, head dim in {16, 32}, W <= 16, sc_ffn_ln_supported(d, F). */
+int sc_dec_layer_fused_supported(int d, int H, int W, int F);
+/* A: x = x_in + b2[layer-1] + sum_z ffn_part[z][row]  (layer 0: embed*sqrt(d)+PE, transformer_decoder.py:231;
+ * x_in / ffn_part unused) -> x_out; q|k|v = norm1(x) . Wqkv^T + b of every head; K|V row appended to the
+ * cache; self-attention through the ancestor table (decoder_layer.py:85-101); ph1 = per-head partial of
+ * self_attn.linear_out. */
+int sc_dec_layer_self(const sc_search *sb, int layer, const float *x_in, float *x_out, const float *ffn_part,
+                      int n_ffn_part, void *stream);
+/* B: x = x_in + bo + sum_h ph1 -> x_out; q = norm2(x) . Wq^T + bq; cross-attention over the stream's shared
+ * encoder K|V (decoder_layer.py:106-115); ph2 = per-head partial of src_attn.linear_out. */
+int sc_dec_layer_cross(const sc_search *sb, int layer, const float *x_in, float *x_out, void *stream);
+/* C: x = x_in + bo2 + sum_h ph2 -> x_out; feed-forward of norm3(x) (decoder_layer.py:117-123,
+ * feed_forward.py:48-50) as partial sums ffn_part[z][row], z < *n_part (HOST out; <= max_part). */
+int sc_dec_layer_ffn(const sc_search *sb, int layer, const float *x_in, float *x_out, float *ffn_part,
+                     int max_part, int *n_part /*HOST*/, void *stream);
+/* tail: x = x_in + b2[last] + sum_z ffn_part -> x_out; logits = after_norm(x) . out_w^T + out_b
+ * (transformer_decoder.py:243-249); needs sb->out_w_q. */
+int sc_dec_output_logits(const sc_search *sb, const float *x_in, float *x_out, const float *ffn_part,
+                         int n_ffn_part, void *stream);
 
 /* ---- Conformer building blocks (north-star components, unused by the shipped
  * contextual-block Transformer models: SURVEY.md section 8(f) rank 3) ---------- */

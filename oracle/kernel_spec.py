@@ -30,6 +30,8 @@ def _rows(t2d, rows):
 
 
 class SpecBackend:
+    fused_layers = True    # decode_step(): head-parallel layer ops when the batch has their buffers
+
     name = "spec"
 
     # ------------------------------------------------------------------
@@ -417,6 +419,104 @@ class SpecBackend:
                 self.copy_rows(ln_next, rows, sb.dxn, rows, n, d)
         return False
 
+    # ------------------------------------------------------------------
+    # head-parallel decoder layers (csrc/decoder_layer.hip, include/scasr.h sc_dec_layer_*): the same
+    # arithmetic as decoder_layers() above, cut into three ops per layer.  x ping-pongs xin -> xout.
+    # ------------------------------------------------------------------
+    def _active_rows(self, sb):
+        ctrl = sb.ctrl.cpu().numpy()
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if act and nh > 0:
+                yield s, cur, T, L, nh
+
+    def _head_partials(self, ctx, wo, H, nh):
+        """ph[w, h, :] = ctx[w, h*dk:(h+1)*dk] . wo[:, h*dk:(h+1)*dk]^T; rows >= nh are zero"""
+        Wn, d = ctx.shape
+        dk = d // H
+        ph = torch.zeros(Wn, H, d)
+        for h in range(H):
+            ph[:nh, h] = ctx[:nh, h * dk:(h + 1) * dk] @ wo[:, h * dk:(h + 1) * dk].t()
+        return ph
+
+    def dec_layer_self(self, sb, li, xin, xout, npart):
+        """sc_dec_layer_self: x (embedding for layer 0, else residual + feed-forward partial sums + b2 of the
+        layer before) -> xout; norm1, q|k|v, K|V append, self-attention (decoder_layer.py:85-101); ph1 = the
+        per-head partial products of self_attn.linear_out."""
+        w, cfg = sb.w, sb.cfg
+        d, H, W = cfg.d_model, cfg.dec_heads, sb.W
+        lw = w.dec[li]
+        sq = math.sqrt(d)
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            if li == 0:
+                hyp = torch.clamp(torch.arange(W), max=nh - 1)
+                tok = sb.yseq[cur, s, hyp, L - 1].to(torch.long)
+                x = w.embed[tok] * sq + w.pe[L - 1]
+            else:
+                y = sb.ffn_part[0, rows].clone()
+                for z in range(1, npart):
+                    y = y + sb.ffn_part[z, rows]
+                x = xin[rows] + (y + w.dec[li - 1]["b2"])
+            xout[rows] = x
+            xn = torch.nn.functional.layer_norm(x, (d,), lw["ln1_g"], lw["ln1_b"], cfg.ln_eps)
+            sb.dqkv[rows] = xn @ lw["wqkv"].t() + lw["bqkv"]
+        self.dec_self_attn(sb, li)     # dqkv -> K|V rows appended to skv, context of rows < nh in datt
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            sb.ph1[rows] = self._head_partials(sb.datt[rows], lw["wo"], H, nh)
+
+    def dec_layer_cross(self, sb, li, xin, xout):
+        """sc_dec_layer_cross: x = xin + bo + sum_h ph1 -> xout; norm2, q, cross-attention
+        (decoder_layer.py:101-115); ph2 = per-head partial products of src_attn.linear_out."""
+        w, cfg = sb.w, sb.cfg
+        d, H, W = cfg.d_model, cfg.dec_heads, sb.W
+        lw = w.dec[li]
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            y = sb.ph1[rows, 0].clone()
+            for h in range(1, H):
+                y = y + sb.ph1[rows, h]
+            x = xin[rows] + (y + lw["bo"])
+            xout[rows] = x
+            xn = torch.nn.functional.layer_norm(x, (d,), lw["ln2_g"], lw["ln2_b"], cfg.ln_eps)
+            sb.dq[rows] = xn @ lw["wq"].t() + lw["bq"]
+        self.dec_cross_attn(sb, li)
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            sb.ph2[rows] = self._head_partials(sb.datt[rows], lw["wo2"], H, nh)
+
+    def dec_layer_ffn(self, sb, li, xin, xout):
+        """sc_dec_layer_ffn over the compacted rows: x = xin + bo2 + sum_h ph2 -> xout; feed-forward of norm3(x)
+        (decoder_layer.py:117-123) as partial sums - the spec writes ONE partial sum (returns 1)."""
+        w, cfg = sb.w, sb.cfg
+        d, H = cfg.d_model, cfg.dec_heads
+        lw = w.dec[li]
+        r = sb.rowmap[:int(sb.n_rows_step)].to(torch.long)
+        y = sb.ph2[r, 0].clone()
+        for h in range(1, H):
+            y = y + sb.ph2[r, h]
+        x = xin[r] + (y + lw["bo2"])
+        xout[r] = x
+        xn = torch.nn.functional.layer_norm(x, (d,), lw["ln3_g"], lw["ln3_b"], cfg.ln_eps)
+        hid = torch.relu(xn @ lw["w1"].t() + lw["b1"])
+        sb.ffn_part[0, r] = hid @ lw["w2"].t()
+        return 1
+
+    def dec_output_logits(self, sb, xin, xout, npart):
+        """sc_dec_output_logits: residual + feed-forward partial sums + b2 -> xout; after_norm, output layer
+        (transformer_decoder.py:243-249)."""
+        w, cfg = sb.w, sb.cfg
+        d = cfg.d_model
+        r = sb.rowmap[:int(sb.n_rows_step)].to(torch.long)
+        y = sb.ffn_part[0, r].clone()
+        for z in range(1, npart):
+            y = y + sb.ffn_part[z, r]
+        x = xin[r] + (y + w.dec[-1]["b2"])
+        xout[r] = x
+        xn = torch.nn.functional.layer_norm(x, (d,), w.dec_norm_g, w.dec_norm_b, cfg.ln_eps)
+        sb.logits[r] = xn @ w.out_w.t() + w.out_b
+
     def logsoftmax_topk(self, sb):
         """transformer_decoder.py:249 + pre-beam beam_search.py:150-154:
         logp = log_softmax(logits); ids = top-K of fl(w_dec * logp), descending,
@@ -585,9 +685,19 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
-        self.dec_embed(sb)
-        if not self.decoder_layers(sb, fuse_logits=True):      # logits, or after_norm(x) in dxn
-            self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
+        if getattr(sb, "ph1", None) is not None and self.fused_layers:
+            # head-parallel layer kernels, 3 ops per layer (sc_decode_step takes this path for the same models)
+            xa, xb, npart = sb.dx, sb.dxn, 0
+            for li in range(len(w.dec)):
+                self.dec_layer_self(sb, li, xa, xb, npart)
+                self.dec_layer_cross(sb, li, xb, xa)
+                npart = self.dec_layer_ffn(sb, li, xa, xb)
+                xa, xb = xb, xa
+            self.dec_output_logits(sb, xa, xb, npart)
+        else:
+            self.dec_embed(sb)
+            if not self.decoder_layers(sb, fuse_logits=True):      # logits, or after_norm(x) in dxn
+                self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
         self.logsoftmax_topk(sb)
         self.ctc_prefix_scan(sb)
         self.fuse_topw(sb)

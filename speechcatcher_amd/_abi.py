@@ -32,7 +32,7 @@ class DecLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
-                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q")]
+                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp")]
 
 
 class Search(C.Structure):
@@ -45,7 +45,8 @@ class Search(C.Structure):
                              "datt", "dq", "dffh", "logits", "logp", "pre_ids", "psi", "psi_eos",
                              "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
-        + [("n_rows", C.c_int32), ("out_w_q", vp)]
+        + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
+           ("max_ffn_part", C.c_int32)]
     )
 
 
@@ -106,6 +107,11 @@ _SIGS = {
     "sc_beam_prune": (C.c_int, [vp, vp]),
     "sc_ctc_gather_state": (C.c_int, [vp, vp]),
     "sc_decode_step": (C.c_int, [vp, vp]),
+    "sc_dec_layer_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sc_dec_layer_self": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
+    "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

@@ -38,7 +38,8 @@ void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,
-                             float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st);
+                             float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st,
+                             int by_row = 0);
 
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
 __device__ __forceinline__ float wave_max(float v) {

@@ -1,0 +1,590 @@
+// Head-parallel decoder layer kernels of libscasr (gfx950): three launches per decoder
+// layer instead of six.
+//
+//   A  sc_dec_layer_self   grid (stream, head)
+//        x   = x_in + b2' + sum of the previous layer's feed-forward partial sums   (layer 0: embed*sqrt(d) + PE)
+//        q|k|v(head) = LayerNorm1(x) . Wqkv[head slices]^T + b      (f32 MFMA 16x16x4, K split over the 4 waves)
+//        ctx(head)   = self-attention over the ancestor-indexed K/V cache + the new row (single pass, online softmax)
+//        ph1[row][head][:] = ctx(head) . Wo[:, head slice]^T         (split-K over heads of the output projection)
+//   B  sc_dec_layer_cross  grid (stream, head)
+//        x'  = x + bo + sum_heads ph1;   q(head) = LayerNorm2(x') . Wq[head slice]^T + bq
+//        ctx(head) = cross-attention over the stream's shared encoder K|V;   ph2 = ctx(head) . Wo2[:, head slice]^T
+//   C  sc_dec_layer_ffn    (gemm.hip: ffn_fused_kernel<.., PRO>)  x'' = x' + bo2 + sum_heads ph2, LayerNorm3, FFN partials
+//
+// reference semantics: speechcatcher/model/decoder/decoder_layer.py:80-132 (pre-LN layer with caches),
+// model/attention/multi_head_attention.py:63-133, transformer_decoder.py:231 (embedding).
+//
+// Why this shape on MI355X: the decode step is a chain of ~90 dependent launches of 7-11 us each when few
+// streams are active (profiles/r02_*timeline*), so launches are what to remove.  A LayerNorm needs complete
+// rows and an output projection needs all heads, which used to force a launch boundary after every attention.
+// Here every (stream, head) workgroup REDUCES THE PRODUCER'S PARTIAL SUMS ITSELF (W <= 16 rows x d: 10 KB per
+// partial, L2-resident - blockIdx.x is the stream, so the H workgroups of a stream share an XCD and its L2)
+// and recomputes the cheap row-local LayerNorm redundantly, while the expensive parts - weight streaming,
+// K/V streaming, MFMA work - are split across heads without redundancy: Wqkv / Wq by output columns of the
+// head, Wo / Wo2 by the head's K slice (their partial products are summed by the next kernel's prologue in
+// fixed head order: deterministic).  No cross-workgroup hand-off inside a launch (an agent-scope release /
+// acquire costs an L2 write-back + invalidate on this part); the kernel boundary is the only barrier.
+#include "common.h"
+#include "attn.h"
+
+#define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
+#define YSEQ(pp, s, h) (sb.yseq + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
+#define ANC(pp, s) (sb.anc + ((long)(pp) * sb.S + (s)) * sb.LCAP * sb.W)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 dl_mfma8(f32x4 acc, const float4 &a0, const float4 &a1, const float4 &b0,
+                                          const float4 &b1) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
+  return acc;
+}
+
+struct DecLayerArgs {
+  sc_search sb;
+  int li;
+  const float *xin;  // residual stream before this kernel [S*W][d]
+  float *xout;       // ... after its prologue (!= xin: sibling workgroups read xin at unrelated times)
+  // prologue:  x[row] = xin[row] + (sum_{z < npart} part[z*zs + row*rs + :] + pbias)
+  const float *part;
+  int npart;
+  long zs, rs;
+  const float *pbias;
+  const float *ln_g, *ln_b;
+  const float *wp, *bp;  // projection behind the LayerNorm: sc_pack_panel_weight copy of Wqkv [3d][d] / Wq [d][d], bias
+  const float *wop;      // output projection [d][d] (self: linear_out of self_attn, cross: of src_attn), panel-packed
+  float *ph;             // [S*W][H][d] partial output projection of every head
+};
+
+// LDS floats of one workgroup (host and device use the same formula)
+__host__ __device__ static inline int dl_region_floats(int D, int DK, int W, bool self, bool pre) {
+  const int nt = (self ? 3 : 1) * (DK / 16);
+  const int xn = 16 * (D + 4);
+  const int ps = 4 * 16 * (nt * 16 + 4);
+  const int red = 16 * W * (DK + 2);
+  const int lists = self ? (pre ? 4 * 128 * W : 128 * W) : 0;
+  const int attn = (pre ? (red > lists ? red : lists) : red + lists) + 8;
+  const int outp = 16 * 36 + 16 * (D + 4);
+  int r = xn > ps ? xn : ps;
+  r = r > outp ? r : outp;
+  return r > attn ? r : attn;
+}
+__host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, bool pre) {
+  return dl_region_floats(D, DK, W, self, pre) + WM * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
+}
+
+template <int D, int DK, int WM, bool SELF, int UNR, bool PRE, bool FIRST>
+__global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
+  constexpr int LPR = DK / 4;    // lanes per K/V row
+  constexpr int NG = 256 / LPR;  // row groups per workgroup
+  constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
+  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
+  constexpr int NPART = NG / GPR;
+  constexpr int NPRE = 4;
+  constexpr int EL = D / 64, LDX = D + 4, KI = D / 32, KPW = KI / 4;
+  constexpr int NTQ = DK / 16, NT = (SELF ? 3 : 1) * NTQ, LDP = NT * 16 + 4;
+  static_assert(KI % 4 == 0 && NPART == 16, "d_model must be a multiple of 128, head dim 16 or 32");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const sc_search &sb = p.sb;
+  // grid.x runs over the compaction bucket: the k-th stream of rowmap's active-first order (scasr.h: rowmap)
+  const int s = sb.rowmap ? sb.rowmap[blockIdx.x * sb.W] / sb.W : blockIdx.x;
+  const int head = blockIdx.y;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int nh = CTRL(s, SC_C_NHYP);
+  if (nh <= 0) return;
+  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
+  const int W = sb.W, LCAP = sb.LCAP, H = sb.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *region = smem;
+  float *qs = smem + dl_region_floats(D, DK, W, SELF, PRE);  // [WM][DK] queries / sqrt(dk)
+  float *kvn = qs + WM * DK;                                 // SELF: [WM][2*DK] k|v of the new token
+  float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
+
+  // ------------------------------------------------------------------ L2 warm-up of this head's weight slices
+  // One dword per 128-B line of the projection fragments and of the output-projection fragments, issued before
+  // anything else: when few streams are active the weights come from the Infinity Cache / HBM (0.4-0.9 us per
+  // dependent miss); the loads that feed the MFMAs later then hit L2.  The values only keep the loads alive.
+  float touch = 0.f;
+  {
+    constexpr int NW = (SELF ? 3 : 1);
+    const int ofs = tid * 32;   // floats: 128 B per thread, 32 KB per workgroup and instruction
+#pragma unroll
+    for (int wh = 0; wh < NW; ++wh) {
+      const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
+      if (ofs < NTQ * KI * 512) touch += base[ofs];
+    }
+    // output projection: D/16 tiles, k-block (head*DK)/32, 2 KB each
+    constexpr int TPW = D / 16 * 16;   // lines: 16 per tile
+    if (tid < TPW) touch += p.wop[((long)((tid >> 4) * KI + (head * DK) / 32) * 2) * 256 + (tid & 15) * 32];
+  }
+
+  // ------------------------------------------------------------------ prologue: x rows, LayerNorm -> Xn
+  // element-parallel: every thread owns float4 pieces of the W x D tile and sums the producer's partial sums for
+  // them with ALL loads of a batch in flight at once (one memory round trip per ZB partial sums); the row-wise
+  // LayerNorm then runs on the LDS tile.
+  {
+    float *Xn = region;  // [16][LDX], rows >= W zero
+    constexpr int C4 = D / 4, QT = 16 * C4 / 256;           // float4 pieces per row; pieces per thread (16 rows)
+    constexpr int QN = (WM * C4 + 255) / 256;               // ... of the rows that can be live (W <= WM)
+    constexpr int ZB = (UNR >= 8) ? 8 : 4;          // partial sums per batch (register budget of the variant)
+    float4 xv[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+      xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < W) {
+        if (FIRST) {
+          // embed*sqrt(d) + PE of the newest token (transformer_decoder.py:231); rows >= nh repeat row nh-1
+          const int tok = YSEQ(cur, s, min(i, nh - 1))[L - 1];
+          const float sq = sqrtf((float)D);
+          const float4 ev = *reinterpret_cast<const float4 *>(sb.embed + (long)tok * D + 4 * c4);
+          const float4 pe = *reinterpret_cast<const float4 *>(sb.pe + (long)(L - 1) * D + 4 * c4);
+          xv[q] = make_float4(ev.x * sq + pe.x, ev.y * sq + pe.y, ev.z * sq + pe.z, ev.w * sq + pe.w);
+        }
+      }
+    }
+    if (!FIRST) {
+      float4 yv[QN];
+      for (int z0 = 0; z0 < p.npart; z0 += ZB) {
+        float4 pv[QN][ZB];
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int e = tid + 256 * q, i = min(e / C4, W - 1), c4 = e % C4;
+          const long row = (long)s * W + i;
+#pragma unroll
+          for (int z = 0; z < ZB; ++z)
+            pv[q][z] = *reinterpret_cast<const float4 *>(p.part + (long)min(z0 + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+#pragma unroll
+          for (int z = 0; z < ZB; ++z)
+            if (z0 + z < p.npart) {
+              if (z0 + z == 0) yv[q] = pv[q][0];
+              else {
+                yv[q].x += pv[q][z].x; yv[q].y += pv[q][z].y; yv[q].z += pv[q][z].z; yv[q].w += pv[q][z].w;
+              }
+            }
+      }
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+        if (i < W) {
+          const long row = (long)s * W + i;
+          const float4 xi = *reinterpret_cast<const float4 *>(p.xin + row * D + 4 * c4);
+          float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.pbias) pb = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
+          xv[q] = make_float4(xi.x + (yv[q].x + pb.x), xi.y + (yv[q].y + pb.y), xi.z + (yv[q].z + pb.z),
+                              xi.w + (yv[q].w + pb.w));
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                   // rows >= W: zeros
+      if (q < QN) v = xv[q];
+      *reinterpret_cast<float4 *>(Xn + i * LDX + 4 * c4) = v;
+      if (head == 0 && i < W) *reinterpret_cast<float4 *>(p.xout + ((long)s * W + i) * D + 4 * c4) = v;
+    }
+    if (touch == 123456.789f) Xn[0] = touch;   // never true: keeps the warm-up loads (they have returned by now:
+    __syncthreads();                           // loads return in order and the partial sums were waited for)
+    for (int i = wave; i < W; i += 4) {   // LayerNorm in place, one wave per row
+      float x[EL];
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        x[e] = Xn[i * LDX + lane + 64 * e];
+        sum += x[e];
+      }
+      const float mean = wave_sum(sum) / (float)D;
+      float q2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const float c = x[e] - mean;
+        q2 += c * c;
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + sb.ln_eps);
+#pragma unroll
+      for (int e = 0; e < EL; ++e)
+        Xn[i * LDX + lane + 64 * e] = (x[e] - mean) * rstd * p.ln_g[lane + 64 * e] + p.ln_b[lane + 64 * e];
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ projection of the head's columns
+  // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
+  // straight from the fragment-packed weights (1 KB contiguous per wave load)
+  {
+    const float *Xn = region;
+    const int r = lane & 15, kk = lane >> 4;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < KPW; ++kq) {
+      const int ki = wave * KPW + kq;
+      const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
+      const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+      float4 b0[NT], b1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
+        const float4 *wq = reinterpret_cast<const float4 *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
+        b0[t] = wq[0];
+        b1[t] = wq[64];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = dl_mfma8(acc[t], a0, a1, b0[t], b1[t]);
+    }
+    __syncthreads();  // every wave is done reading Xn: the region becomes the partial products
+    float *Ps = region;  // [4][16][LDP]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + 4 * kk + j) * LDP + t * 16 + r] = acc[t][j];
+  }
+  __syncthreads();
+  float *skv = sb.skv + ((long)s * sb.n_layers + p.li) * LCAP * W * 2 * D + head * DK;
+  {
+    const float *Ps = region;
+    const float scale = sqrtf((float)DK);
+    for (int e = tid; e < WM * NT * 16; e += 256) {
+      const int w = e / (NT * 16), n = e % (NT * 16);
+      const int which = n / DK, c = n % DK;
+      float v = 0.f;
+      if (w < W) {
+        v = Ps[(0 * 16 + w) * LDP + n];
+        v += Ps[(1 * 16 + w) * LDP + n];
+        v += Ps[(2 * 16 + w) * LDP + n];
+        v += Ps[(3 * 16 + w) * LDP + n];
+        v += p.bp[which * D + head * DK + c];
+      }
+      if (which == 0) {
+        qs[w * DK + c] = v / scale;
+      } else if (SELF) {
+        kvn[w * 2 * DK + (which - 1) * DK + c] = v;
+        // append this token's K|V row at (position L-1, slot w); later steps read it from the cache
+        if (w < nh) skv[((long)(L - 1) * W + w) * 2 * D + (which - 1) * D + c] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ attention of this head (all hypotheses)
+  const int g = tid / LPR, cq = tid % LPR;
+  float *red_m = region;
+  float *red_l = red_m + NPART * W;
+  float *red_a = red_l + NPART * W;
+  const int red_floats = NPART * W * (DK + 2);
+  int *rows = PRE ? (int *)region : (int *)(red_a + NPART * W * DK);  // PRE: aliases the partial states
+  int *wtot = (int *)region + (PRE ? max(red_floats, NPRE * PCH * W) : red_floats + (SELF ? PCH * W : 0));
+  int *ucnt = wtot + 4;
+  const float *ckv = sb.ckv + ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
+
+  AttnState st[WM];
+  if (!(SELF && PRE)) {
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      st[h].m = -INFINITY;
+      st[h].l = 0.f;
+      st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  auto process = [&](const float4 &k, const float4 &v, unsigned hm) {
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      const float4 qh = *reinterpret_cast<const float4 *>(qs + h * DK + 4 * cq);
+      float sdot = qh.x * k.x;
+      sdot = fmaf(qh.y, k.y, sdot);
+      sdot = fmaf(qh.z, k.z, sdot);
+      sdot = fmaf(qh.w, k.w, sdot);
+      sdot = group_sum<LPR>(sdot);
+      if ((hm >> h) & 1u) {
+        if (sdot > st[h].m) {  // rescale only when the running max moves
+          const float corr = __expf(st[h].m - sdot);  // exp(-inf) = 0 on the first row
+          st[h].l *= corr;
+          st[h].a.x *= corr; st[h].a.y *= corr; st[h].a.z *= corr; st[h].a.w *= corr;
+          st[h].m = sdot;
+        }
+        const float pe = __expf(sdot - st[h].m);
+        st[h].l += pe;
+        st[h].a.x = fmaf(pe, v.x, st[h].a.x);
+        st[h].a.y = fmaf(pe, v.y, st[h].a.y);
+        st[h].a.z = fmaf(pe, v.z, st[h].a.z);
+        st[h].a.w = fmaf(pe, v.w, st[h].a.w);
+      }
+    }
+  };
+
+  if (SELF) {
+    const int *anc = ANC(cur, s);
+    const int Lc = L - 1;  // cached positions; the new token's rows come from LDS afterwards
+    const int nchunk = cdiv(Lc, PCH);
+    // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
+    // entry = local position | slot << 8 | hypothesis bit set << 12
+    auto build = [&](int *rw, int c0) -> int {
+      for (int e = tid; e < PCH * W; e += 256) rw[e] = 0;
+      const int pp = c0 + tid;
+      const bool live = tid < PCH && pp < Lc;
+      int sl[WM];
+#pragma unroll
+      for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
+      unsigned mask = 0;
+#pragma unroll
+      for (int h = 0; h < WM; ++h)
+        if (h < nh) mask |= 1u << sl[h];
+      const int cnt = live ? __popc(mask) : 0;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();  // also orders the zero fill before the ORs
+      const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
+      const int U = wtot[0] + wtot[1];
+      if (live) {
+#pragma unroll
+        for (int h = 0; h < WM; ++h) {
+          if (h < nh) {
+            const int rank = __popc(mask & ((1u << sl[h]) - 1u));
+            atomicOr(&rw[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
+          }
+        }
+      }
+      __syncthreads();  // list complete; wtot may be rewritten
+      return U;
+    };
+    auto walk = [&](const int *rw, int U, int c0) {
+      for (int j0 = g; j0 < U; j0 += NG * UNR) {
+        int e[UNR];
+        float4 k[UNR], v[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+          e[i] = rw[min(j0 + i * NG, U - 1)];
+          const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
+          const float *kp = skv + ((long)pp * W + u) * 2 * D;
+          k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
+          v[i] = *reinterpret_cast<const float4 *>(kp + D + 4 * cq);
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i)
+          if (j0 + i * NG < U) process(k[i], v[i], (unsigned)e[i] >> 12);  // uniform inside a row group
+      }
+    };
+    if (PRE) {
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int U = build(rows + ch * PCH * W, ch * PCH);
+        if (tid == 0) ucnt[ch] = U;
+      }
+      __syncthreads();  // ucnt
+#pragma unroll
+      for (int h = 0; h < WM; ++h) {
+        st[h].m = -INFINITY;
+        st[h].l = 0.f;
+        st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int ch = 0; ch < nchunk; ++ch) walk(rows + ch * PCH * W, ucnt[ch], ch * PCH);
+    } else {
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const int U = build(rows, ch * PCH);
+        walk(rows, U, ch * PCH);
+        if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+      }
+    }
+    // the new token: hypothesis h attends to its own row (slot h at position L-1) only
+    if (g < nh) {
+      const float4 k = *reinterpret_cast<const float4 *>(kvn + g * 2 * DK + 4 * cq);
+      const float4 v = *reinterpret_cast<const float4 *>(kvn + g * 2 * DK + DK + 4 * cq);
+      process(k, v, 1u << g);
+    }
+    __syncthreads();  // the lists are dead: their LDS becomes the partial states
+  } else {
+    const unsigned all = (1u << nh) - 1u;
+    for (int j0 = g; j0 < T; j0 += NG * UNR) {
+      float4 k[UNR], v[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        const float *kp = ckv + (long)min(j0 + i * NG, T - 1) * 2 * D;
+        k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
+        v[i] = *reinterpret_cast<const float4 *>(kp + D + 4 * cq);
+      }
+#pragma unroll
+      for (int i = 0; i < UNR; ++i)
+        if (j0 + i * NG < T) process(k[i], v[i], all);
+    }
+    __syncthreads();  // Ps (read by the q reduce above) is dead before the partial states are written
+  }
+
+  // ---- merge the row groups: inside a 16-lane DPP row in registers, then LDS ----
+#pragma unroll
+  for (int h = 0; h < WM; ++h) {
+    if (LPR == 4) attn_merge_dpp<SC_DPP_ROR4>(st[h]);
+    attn_merge_dpp<SC_DPP_ROR8>(st[h]);
+  }
+  if ((g % GPR) == 0) {
+    const int pp = g / GPR;
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      if (h < nh) {
+        if (cq == 0) {
+          red_m[pp * W + h] = st[h].m;
+          red_l[pp * W + h] = st[h].l;
+        }
+        *reinterpret_cast<float4 *>(red_a + ((long)(pp * W + h)) * DK + 4 * cq) = st[h].a;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nh * NPART) {
+    const int h = tid / NPART, pp = tid % NPART;
+    const float mp = red_m[pp * W + h];
+    float M = mp;
+    M = fmaxf(M, dpp_mov<SC_DPP_XOR1>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_XOR2>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_HALF_MIRROR>(M));
+    M = fmaxf(M, dpp_mov<SC_DPP_ROW_MIRROR>(M));
+    const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
+    float den = w * red_l[pp * W + h];
+    den += dpp_mov<SC_DPP_XOR1>(den);
+    den += dpp_mov<SC_DPP_XOR2>(den);
+    den += dpp_mov<SC_DPP_HALF_MIRROR>(den);
+    den += dpp_mov<SC_DPP_ROW_MIRROR>(den);
+    red_m[pp * W + h] = w;  // each element is read and written by this thread only
+    if (pp == 0) red_l[h] = den;
+  }
+  __syncthreads();
+  for (int e = tid; e < WM * DK; e += 256) {
+    const int h = e / DK, c = e % DK;
+    float o = 0.f;  // rows >= nh: zero context (their partial products stay finite)
+    if (h < nh) {
+      float num = 0.f;
+#pragma unroll
+      for (int pp = 0; pp < NPART; ++pp) num = fmaf(red_m[pp * W + h], red_a[((long)(pp * W + h)) * DK + c], num);
+      o = num / red_l[h];
+    }
+    ctx[e] = o;
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ this head's share of the output projection
+  // ph[row][head][n] = sum_c ctx[w][c] * Wo[n][head*DK + c]: f32 MFMA over the k-block of 32 input columns that
+  // holds this head's DK columns (the columns of a neighbouring head in the same block meet zeros of the A tile);
+  // B operands from the fragment-packed copy of Wo, result staged through LDS for full-line stores.
+  {
+    constexpr int LDA = 36, NTO = D / 16, TW = NTO / 4, LDO = D + 4;
+    float *As = region;              // [16][LDA]
+    float *Os = region + 16 * LDA;   // [16][LDO]
+    const int kb = (head * DK) / 32, koff = (head * DK) % 32;
+    for (int e = tid; e < 16 * 32; e += 256) {
+      const int w = e / 32, c = e % 32;
+      As[w * LDA + c] = (w < WM && c >= koff && c < koff + DK) ? ctx[w * DK + c - koff] : 0.f;
+    }
+    const int r = lane & 15, kk = lane >> 4;
+    float4 b0[TW], b1[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
+      b0[t] = wq[0];
+      b1[t] = wq[64];
+    }
+    __syncthreads();
+    const float *ab = As + r * LDA + 8 * kk;
+    const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      f32x4 acc = dl_mfma8(f32x4{0.f, 0.f, 0.f, 0.f}, a0, a1, b0[t], b1[t]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = acc[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < W * (D / 4); e += 256) {
+      const int w = e / (D / 4), c4 = e % (D / 4);
+      *reinterpret_cast<float4 *>(p.ph + (((long)s * W + w) * H + head) * D + 4 * c4) =
+          *reinterpret_cast<const float4 *>(Os + w * LDO + 4 * c4);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int DK, bool SELF, bool FIRST>
+static int launch_dec_layer(const DecLayerArgs &p, hipStream_t st) {
+  const sc_search &sb = p.sb;
+  const dim3 grid(sb.rowmap ? sb.n_rows / sb.W : sb.S, sb.H);   // streams of the compaction bucket only
+  // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
+  bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
+  if (const char *fd = getenv("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
+  const bool pre_ok = !getenv("SC_SELF_ATTN_NOPRE");                    // tests: row lists interleaved with the walk
+  auto lds = [&](int wm, bool pre) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF, pre) * sizeof(float); };
+  if (sb.W <= 5) {
+    dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST><<<grid, 256, lds(5, false), st>>>(p);
+  } else if (sb.W <= 10) {
+    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, false, FIRST><<<grid, 256, lds(10, false), st>>>(p);
+    else if (SELF && sb.LCAP <= 4 * 128 && pre_ok)
+      dec_layer_attn_kernel<D, DK, 10, SELF, 2, SELF, FIRST><<<grid, 256, lds(10, true), st>>>(p);
+    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, false, FIRST><<<grid, 256, lds(10, false), st>>>(p);
+  } else {
+    dec_layer_attn_kernel<D, DK, 16, SELF, 2, false, FIRST><<<grid, 256, lds(16, false), st>>>(p);
+  }
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+template <bool SELF, bool FIRST>
+static int launch_dec_layer_dims(const DecLayerArgs &p, hipStream_t st) {
+  const int d = p.sb.d, dk = p.sb.d / p.sb.H;
+  if (d == 256 && dk == 32) return launch_dec_layer<256, 32, SELF, FIRST>(p, st);
+  if (d == 256 && dk == 16) return launch_dec_layer<256, 16, SELF, FIRST>(p, st);
+  if (d == 128 && dk == 32) return launch_dec_layer<128, 32, SELF, FIRST>(p, st);
+  if (d == 128 && dk == 16) return launch_dec_layer<128, 16, SELF, FIRST>(p, st);
+  sc_set_error("sc_dec_layer_*: unsupported dimensions d=%d head dim %d", d, dk);
+  return SC_ERR_ARG;
+}
+
+extern "C" int sc_dec_layer_fused_supported(int d, int H, int W, int F) {
+  if (H <= 0 || d % H) return 0;
+  const int dk = d / H;
+  return (d == 256 || d == 128) && (dk == 32 || dk == 16) && W >= 1 && W <= 16 && sc_ffn_ln_supported(d, F);
+}
+
+extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *xin, float *xout, const float *ffn_part,
+                                 int n_ffn_part, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xout && sbp->ph1, "null");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(layer >= 0 && layer < sb.n_layers, "layer out of range");
+  SC_CHECK_ARG(sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F), "unsupported dimensions");
+  SC_CHECK_ARG(layer == 0 || (xin && xin != xout && ffn_part && n_ffn_part > 0), "x_in / partial sums missing");
+  const sc_dec_layer &w = sb.layers[layer];
+  SC_CHECK_ARG(w.wqkv_pp && w.wo_pp, "panel-packed Wqkv / Wo missing");
+  DecLayerArgs p{sb, layer, xin, xout, ffn_part, n_ffn_part, (long)sb.S * sb.W * sb.d, (long)sb.d,
+                 layer > 0 ? sb.layers[layer - 1].b2 : nullptr, w.ln1_g, w.ln1_b, w.wqkv_pp, w.bqkv, w.wo_pp, sb.ph1};
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof = sc_prof_begin(st);
+  const int rc = layer == 0 ? launch_dec_layer_dims<true, true>(p, st) : launch_dec_layer_dims<true, false>(p, st);
+  sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);  // traffic depends on device-side state (L, ancestors)
+  return rc;
+}
+
+extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *xin, float *xout, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xin && xout && xin != xout && sbp->ph1 && sbp->ph2, "null / aliased");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(layer >= 0 && layer < sb.n_layers, "layer out of range");
+  SC_CHECK_ARG(sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F), "unsupported dimensions");
+  const sc_dec_layer &w = sb.layers[layer];
+  SC_CHECK_ARG(w.wq_pp && w.wo2_pp, "panel-packed Wq / Wo2 missing");
+  DecLayerArgs p{sb, layer, xin, xout, sb.ph1, sb.H, (long)sb.d, (long)sb.H * sb.d, w.bo, w.ln2_g, w.ln2_b,
+                 w.wq_pp, w.bq, w.wo2_pp, sb.ph2};
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof = sc_prof_begin(st);
+  const int rc = launch_dec_layer_dims<false, false>(p, st);
+  sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
+  return rc;
+}

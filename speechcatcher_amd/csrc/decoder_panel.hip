@@ -285,6 +285,7 @@ struct RedProjArgs {
   float *XN;
   const float *Wq, *bq;
   float *Q; int ldq;
+  int by_row;   // partial sums indexed by row id (xrow) instead of by position m (sc_dec_layer_ffn)
 };
 
 template <int D, int RG>
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
         for (int e = 0; e < EL; ++e)
 #pragma unroll
           for (int q = 0; q < 16; ++q)
-            pv[e][q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + m) * D + lane + 64 * e];
+            pv[e][q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + (p.by_row ? xrow[rr] : (long)m)) * D + lane + 64 * e];
 #pragma unroll
         for (int e = 0; e < EL; ++e)
 #pragma unroll
@@ -411,7 +412,8 @@ static void launch_redproj(const RedProjArgs &p, int rg, int nblocks, hipStream_
 // internal (common.h): called by sc_ffn_ln_proj after the fused FFN kernel wrote its partial sums
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,
-                             float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st) {
+                             float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st,
+                             int by_row) {
   SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N % D == 0 && N > 0, "projection width must be a multiple of D");
   SC_CHECK_ARG(Xin != Xout, "x_in and x_out must be different buffers");
   const int nblocks = N / D;
@@ -421,7 +423,7 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) rpp = v;
   }
-  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N};
+  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N, by_row};
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_redproj<256>(p, rpp / 4, nblocks, st);
   else if (D == 128) launch_redproj<128>(p, rpp / 4, nblocks, st);
@@ -430,4 +432,17 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
               4.0 * ((double)M * D * (2 + npart) + (double)N * D + (double)M * N));
   SC_CHECK_LAUNCH();
   return SC_OK;
+}
+
+// Tail of the head-parallel decoder (decoder_layer.hip): sum of the last layer's feed-forward partial sums
+// (by row id) + b2 + residual, after_norm, output layer -> sb->logits (transformer_decoder.py:243-249).
+extern "C" int sc_dec_output_logits(const sc_search *sbp, const float *xin, float *xout, const float *ffn_part,
+                                    int n_ffn_part, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xin && xout && xin != xout && ffn_part && n_ffn_part > 0, "null / aliased");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(sb.out_w_q && sb.V % sb.d == 0, "needs the lane-packed output layer (V a multiple of d)");
+  const int M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
+  return sc_launch_reduce_ln_proj(ffn_part, n_ffn_part, sb.S * sb.W, sb.layers[sb.n_layers - 1].b2, xin, xout,
+                                  sb.rowmap, M, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, nullptr, sb.out_w_q,
+                                  sb.out_b, sb.logits, sb.V, (hipStream_t)stream, 1);
 }

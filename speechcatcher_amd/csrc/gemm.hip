@@ -776,9 +776,20 @@ struct FfnArgs {
   const float *W1p, *b1, *W2p;
   float *part;  // [F/128/cpw][M][D]
   int M, F, cpw;
+  // PRO (decoder layer, sc_dec_layer_ffn): the row tile is computed instead of loaded -
+  //   x[row] = Xin[row] + (sum_{h < nph} PH[(row*nph + h)*D + :] + pbias);  tile = LayerNorm(x; g, b)
+  // workgroups of chunk group 0 store x to Xout (!= Xin); the partial sums are stored by ROW ID
+  // ([grp][part_rows][D]) so that a per-stream consumer finds them without the compaction map
+  const float *PH;
+  int nph;
+  const float *pbias, *Xin;
+  float *Xout;
+  const float *g, *b;
+  float eps;
+  int part_rows;
 };
 
-template <int D, int RTT>
+template <int D, int RTT, bool PRO = false>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int RT = 16 * RTT, FC = 128;
   constexpr int KI1 = D / 32, KI2 = FC / 32, NT2 = D / 128;
@@ -786,6 +797,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float ffn_smem[];
   float *Xs = ffn_smem;            // [RT][LDX]  xn tile; re-used to stage the partial result
   float *Hs = ffn_smem + RT * LDX; // [RT][LDH]  relu(h) of the current chunk
+  int *rowid = reinterpret_cast<int *>(ffn_smem + RT * LDX + RT * LDH);   // PRO: [RT] row ids of the tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int grp = blockIdx.x, m0 = blockIdx.y * RT;
@@ -796,7 +808,55 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int NV = RT * D / 4;
   constexpr int NQ = NV / 512;
   static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
-  {
+  if (PRO) {
+    // one wave per row: sum of the producer's per-head partial products (fixed head order), residual,
+    // LayerNorm - recomputed by every chunk group of the row tile (cheap, L2-resident) so that the
+    // attention output projection needs no launch of its own
+    constexpr int EL = D / 64;
+    float gam[EL], bet[EL], pb[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      gam[e] = p.g[lane + 64 * e];
+      bet[e] = p.b[lane + 64 * e];
+      pb[e] = p.pbias ? p.pbias[lane + 64 * e] : 0.f;
+    }
+    for (int i = wave; i < RT; i += 8) {
+      const int m = min(m0 + i, p.M - 1);
+      const long row = p.rows ? p.rows[m] : m;
+      if (lane == 0) rowid[i] = (int)row;
+      float x[EL], y[EL];
+      for (int z0 = 0; z0 < p.nph; z0 += 8) {
+        float pv[EL][8];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            pv[e][q] = p.PH[(row * p.nph + min(z0 + q, p.nph - 1)) * D + lane + 64 * e];
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (z0 + q < p.nph) y[e] = (z0 + q == 0) ? pv[e][0] : y[e] + pv[e][q];
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        x[e] = p.Xin[row * D + lane + 64 * e] + (y[e] + pb[e]);
+        if (grp == 0 && m0 + i < p.M) p.Xout[row * D + lane + 64 * e] = x[e];
+        sum += x[e];
+      }
+      const float mean = wave_sum(sum) / (float)D;
+      float q2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) {
+        const float c = x[e] - mean;
+        q2 += c * c;
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + p.eps);
+#pragma unroll
+      for (int e = 0; e < EL; ++e) Xs[i * LDX + lane + 64 * e] = (x[e] - mean) * rstd * gam[e] + bet[e];
+    }
+  } else {
     long rowv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -912,32 +972,34 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   for (int q = 0; q < NQ; ++q) {
     const int e = threadIdx.x + q * 512;
     const int i = e / (D / 4), c4 = e % (D / 4);
-    if (m0 + i < p.M)
-      *reinterpret_cast<float4 *>(dst + (long)i * D + 4 * c4) = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
+    if (m0 + i < p.M) {
+      float *o = PRO ? p.part + ((long)grp * p.part_rows + rowid[i]) * D : dst + (long)i * D;
+      *reinterpret_cast<float4 *>(o + 4 * c4) = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
+    }
   }
 }
 
-template <int D, int RTT>
+template <int D, int RTT, bool PRO = false>
 static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
   constexpr int RT = 16 * RTT;
-  const size_t lds = (size_t)(RT * (D + 4) + RT * (128 + 4)) * sizeof(float);
+  const size_t lds = (size_t)(RT * (D + 4) + RT * (128 + 4) + (PRO ? RT : 0)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<D, RTT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<D, RTT, PRO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  ffn_fused_kernel<D, RTT><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+  ffn_fused_kernel<D, RTT, PRO><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
 }
 
-template <int D>
+template <int D, bool PRO = false>
 static void launch_ffn_rtt(const FfnArgs &p, int rtt, int ngrp, hipStream_t st) {
   switch (rtt) {
-    case 1: launch_ffn<D, 1>(p, ngrp, st); break;
-    case 2: launch_ffn<D, 2>(p, ngrp, st); break;
-    case 3: launch_ffn<D, 3>(p, ngrp, st); break;
-    case 4: launch_ffn<D, 4>(p, ngrp, st); break;
-    default: launch_ffn<D, 5>(p, ngrp, st); break;
+    case 1: launch_ffn<D, 1, PRO>(p, ngrp, st); break;
+    case 2: launch_ffn<D, 2, PRO>(p, ngrp, st); break;
+    case 3: launch_ffn<D, 3, PRO>(p, ngrp, st); break;
+    case 4: launch_ffn<D, 4, PRO>(p, ngrp, st); break;
+    default: launch_ffn<D, 5, PRO>(p, ngrp, st); break;
   }
 }
 
@@ -1277,4 +1339,52 @@ extern "C" int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D
   SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N > 0 && N % D == 0, "projection width must be a multiple of D");
   return ffn_run(XN, rows, M, D, F, W1p, b1, W2p, b2, const_cast<float *>(Xin), ln_g, ln_b, ln_eps, ln_out, Xout, Wq,
                  bq, Q, N, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Decoder layer, launch C of the head-parallel form (decoder_layer.hip): the feed-forward of layer `layer` with the
+// cross-attention output projection folded into its prologue -
+//   x'' = xin + bo2 + sum_heads ph2[row][h];  xout = x'';  partial sums of W2 . relu(W1 . LayerNorm3(x'') + b1)
+// per chunk group into ffn_part[grp][S*W][d] (by row id).  The consumer (sc_dec_layer_self of the next layer or
+// sc_dec_output_logits) adds b2 and the residual.  *n_part (HOST) receives the number of chunk groups.
+extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xin, float *xout, float *ffn_part,
+                                int max_part, int *n_part, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xin && xout && xin != xout && ffn_part && n_part && sbp->ph2, "null / aliased");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(layer >= 0 && layer < sb.n_layers, "layer out of range");
+  const int D = sb.d, F = sb.F;
+  SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
+  const sc_dec_layer &w = sb.layers[layer];
+  const int32_t *rows = sb.rowmap;
+  const int M = rows ? sb.n_rows : sb.S * sb.W;
+  SC_CHECK_ARG(M > 0 && M <= sb.S * sb.W && max_part >= 1, "n_rows / max_part out of range");
+  const int nch = F / 128;
+  // tile height (16*rtt rows) and chunks per workgroup (cpw): fewest rounds of 256 workgroups, ties towards
+  // more partial groups - the model fitted for sc_ffn_ln (tools/ffn_sweep.py)
+  int best_rtt = 5, best_cpw = nch;
+  double best = 1e30;
+  for (int cpw = 1; cpw <= nch; cpw *= 2) {
+    if (nch % cpw || nch / cpw > max_part) continue;
+    const int ngrp = nch / cpw;
+    for (int rtt = 1; rtt <= 5; ++rtt) {
+      const long wgs = (long)ngrp * ((M + 16 * rtt - 1) / (16 * rtt));
+      const double rounds = (double)((wgs + 255) / 256);
+      const double t = rounds * (2.5 + 4.0 * rtt * cpw) + 1.5 + 2.0 * (double)M * D * 4.0 * ngrp / 3.0e6;
+      if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; }
+    }
+  }
+  SC_CHECK_ARG(best < 1e29, "max_part too small");
+  const int ngrp = nch / best_cpw;
+  FfnArgs p{nullptr, rows, w.w1_p, w.b1, w.w2_p, ffn_part, M, F, best_cpw,
+            sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W};
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof = sc_prof_begin(st);
+  if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);
+  else launch_ffn_rtt<128, true>(p, best_rtt, ngrp, st);
+  // algorithmic: 4*D*F flop per row; x + H head partials read, W1 + W2 read once, x and the partials written
+  sc_prof_end(prof, SC_PROF_FFN_FUSED, 4.0 * (double)M * D * F,
+              4.0 * ((double)M * D * (2 + sb.H) + 2.0 * (double)D * F + (double)ngrp * M * D));
+  SC_CHECK_LAUNCH();
+  *n_part = ngrp;
+  return SC_OK;
 }

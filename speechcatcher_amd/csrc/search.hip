@@ -3,6 +3,7 @@
 // Every kernel is batched over S streams x W hypotheses and masked by the
 // per-stream ctrl rows (see scasr.h), so one launch serves all streams.
 #include "common.h"
+#include "attn.h"
 
 #define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
 // rows of the CTC table / forward variables seen by a decode step (scasr.h: SC_C_TCTC)
@@ -142,27 +143,6 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li
   }
 }
 
-// DPP lane permutations (no LDS round trip, unlike ds_bpermute-based __shfl)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-#define SC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
-#define SC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
-#define SC_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
-#define SC_DPP_ROR4 0x124        // rotate by 4 inside each 16 lanes
-#define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
-#define SC_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16 lanes
-
-// sum over the LPR (4 or 8) adjacent lanes of a row group; every lane gets the total
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-  v += dpp_mov<SC_DPP_XOR1>(v);
-  v += dpp_mov<SC_DPP_XOR2>(v);
-  if (LPR == 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
-  return v;
-}
-
 // ---------------------------------------------------------------------------
 // Single-pass ("flash decoding") attention of the decoder, shared by the self-
 // and the cross-attention: one workgroup per (stream, head) serves ALL
@@ -185,27 +165,6 @@ __device__ __forceinline__ float group_sum(float v) {
 // Scores use q/sqrt(dk) . k and exp2-based __expf: differences to the reference's
 // softmax(q.k/sqrt(dk)) are rounding-level (parity tests: 2e-4).
 // ---------------------------------------------------------------------------
-struct AttnState {
-  float m, l;
-  float4 a;
-};
-
-template <int CTRL>
-__device__ __forceinline__ void attn_merge_dpp(AttnState &st) {
-  const float pm = dpp_mov<CTRL>(st.m), pl = dpp_mov<CTRL>(st.l);
-  const float px = dpp_mov<CTRL>(st.a.x), py = dpp_mov<CTRL>(st.a.y);
-  const float pz = dpp_mov<CTRL>(st.a.z), pw = dpp_mov<CTRL>(st.a.w);
-  const float M = fmaxf(st.m, pm);
-  const float ca = (st.m == -INFINITY) ? 0.f : __expf(st.m - M);
-  const float cb = (pm == -INFINITY) ? 0.f : __expf(pm - M);
-  st.m = M;
-  st.l = st.l * ca + pl * cb;
-  st.a.x = st.a.x * ca + px * cb;
-  st.a.y = st.a.y * ca + py * cb;
-  st.a.z = st.a.z * ca + pz * cb;
-  st.a.w = st.a.w * ca + pw * cb;
-}
-
 // UNR = K/V rows in flight per row group.  2 keeps the kernel at 128 VGPRs so that all S*H
 // workgroups of a full batch are resident at once (bandwidth-bound regime); 8 is used when
 // at most half of the streams are active (ragged-batch compaction bucket): then occupancy is
@@ -222,7 +181,8 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
   constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
   constexpr int NPART = NG / GPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int head = blockIdx.x, s = blockIdx.y;
+  // grid.y runs over the compaction bucket: the k-th stream of rowmap's active-first order (scasr.h: rowmap)
+  const int head = blockIdx.x, s = sb.rowmap ? sb.rowmap[blockIdx.y * sb.W] / sb.W : blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
@@ -454,7 +414,7 @@ static size_t attn_flash_lds(const sc_search &sb, int dk, bool self) {
 
 template <int DK, bool SELF>
 static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
-  const dim3 grid(sb.H, sb.S);
+  const dim3 grid(sb.H, sb.rowmap ? sb.n_rows / sb.W : sb.S);   // streams of the compaction bucket only
   const size_t lds = attn_flash_lds(sb, DK, SELF);
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
@@ -1280,16 +1240,45 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 }
 
 // ---------------------------------------------------------------------------
+// The head-parallel layer kernels (decoder_layer.hip: 3 launches per layer) are used for compaction buckets of at
+// most SC_FUSED_MAX_ROWS hypothesis rows.  They win where the step is a chain of latency-bound launches (few
+// active streams: 45 vs 51 us per layer at 8 streams); at large buckets every (stream, head) workgroup re-reading
+// all partial sums of its stream costs more fabric traffic than the launches it saves, and the six-launch form
+// (row panels + stand-alone attention) is faster (profiles/r02_fused_threshold_sweep.txt: strict lock-step
+// 28.9 / 28.1 / 29.0 ms per chunk step with the limit at 0 / 640 / 1280 rows).
+#define SC_FUSED_MAX_ROWS 640
+static bool dec_fused_ok(const sc_search &sb) {
+  if (const char *e = getenv("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
+    return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;
+  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > SC_FUSED_MAX_ROWS) return false;
+  return sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.ph2 && sb.ffn_part &&
+         sb.max_ffn_part >= 1 && sb.out_w_q && sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp &&
+         sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
+}
+
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
+  if (dec_fused_ok(sb)) {
+    // 3 launches per layer; x ping-pongs dx <-> dxn
+    float *xa = sb.dx, *xb = sb.dxn;
+    int npart = 0;
+    for (int li = 0; li < sb.n_layers; ++li) {
+      SC_TRY(sc_dec_layer_self(sbp, li, xa, xb, sb.ffn_part, npart, stream));
+      SC_TRY(sc_dec_layer_cross(sbp, li, xb, xa, stream));
+      SC_TRY(sc_dec_layer_ffn(sbp, li, xa, xb, sb.ffn_part, sb.max_ffn_part, &npart, stream));
+      float *t = xa; xa = xb; xb = t;
+    }
+    SC_TRY(sc_dec_output_logits(sbp, xa, xb, sb.ffn_part, npart, stream));
+  } else {
   SC_TRY(sc_dec_embed(sbp, stream));
   bool logits_done = false;
   SC_TRY(decoder_layers_impl(sbp, stream, true, &logits_done));  // logits, or after_norm(x) in dxn
   if (!logits_done)
     SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
+  }
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
   SC_TRY(sc_ctc_prefix_scan(sbp, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));

@@ -235,6 +235,15 @@ class StreamBatch:
         self.cand_tok = z(n, W, dtype=i32)
         self.cand_ctc = z(n, W)
         self.sel = z(S, W, 2, dtype=i32)
+        # head-parallel decoder layers (csrc/decoder_layer.hip): per-head partial products of the two attention
+        # output projections and the feed-forward partial sums (by row id)
+        from .weights import dec_layer_fused_supported
+        if dec_layer_fused_supported(cfg, W):
+            self.ph1 = z(n, cfg.dec_heads, d)
+            self.ph2 = z(n, cfg.dec_heads, d)
+            self.ffn_part = z(F // 128, n, d)
+        else:
+            self.ph1 = self.ph2 = self.ffn_part = None
         self.xchunk = 256
         nch = (self.TCAP + self.xchunk - 1) // self.xchunk
         self.xpart = z(n * cfg.dec_heads * nch, (d // cfg.dec_heads) + 2)

@@ -194,7 +194,7 @@ class HipBackend:
         layers = (_abi.DecLayer * len(w.dec))()
         for i, lw in enumerate(w.dec):
             for name, _ in _abi.DecLayer._fields_:
-                setattr(layers[i], name, lw[name].data_ptr())
+                setattr(layers[i], name, lw[name].data_ptr() if name in lw else None)
         s = _abi.Search()
         s.S, s.W, s.K, s.V, s.d, s.H, s.F = sb.S, sb.W, sb.K, cfg.vocab_size, cfg.d_model, cfg.dec_heads, cfg.ffn_dim
         s.n_layers, s.TCAP, s.LCAP, s.xchunk = cfg.dec_layers, sb.TCAP, sb.LCAP, sb.xchunk
@@ -211,6 +211,9 @@ class HipBackend:
         s.layers = C.cast(layers, C.c_void_p).value
         s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
         s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
+        if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)
+            s.ph1, s.ph2, s.ffn_part = sb.ph1.data_ptr(), sb.ph2.data_ptr(), sb.ffn_part.data_ptr()
+            s.max_ffn_part = sb.ffn_part.shape[0]
         sb._sc_search_struct = (s, layers)
         return s
 
@@ -233,6 +236,22 @@ class HipBackend:
 
     def decoder_layers(self, sb):
         self._sb_call("sc_decoder_layers", sb)
+
+    # head-parallel decoder layers: 3 launches per layer (csrc/decoder_layer.hip)
+    def dec_layer_self(self, sb, li, xin, xout, npart):
+        self._sb_call("sc_dec_layer_self", sb, li, _p(xin), _p(xout), _p(sb.ffn_part), int(npart))
+
+    def dec_layer_cross(self, sb, li, xin, xout):
+        self._sb_call("sc_dec_layer_cross", sb, li, _p(xin), _p(xout))
+
+    def dec_layer_ffn(self, sb, li, xin, xout):
+        n = C.c_int(0)
+        self._sb_call("sc_dec_layer_ffn", sb, li, _p(xin), _p(xout), _p(sb.ffn_part), int(sb.ffn_part.shape[0]),
+                      C.byref(n))
+        return int(n.value)
+
+    def dec_output_logits(self, sb, xin, xout, npart):
+        self._sb_call("sc_dec_output_logits", sb, _p(xin), _p(xout), _p(sb.ffn_part), int(npart))
 
     def logsoftmax_topk(self, sb):
         self._sb_call("sc_logsoftmax_topk", sb)

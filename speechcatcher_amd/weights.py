@@ -62,6 +62,13 @@ def ffn_fused_supported(d: int, F: int) -> bool:
     return d in (128, 256) and F % 128 == 0 and F >= 128
 
 
+def dec_layer_fused_supported(cfg, W: int) -> bool:
+    """sc_dec_layer_fused_supported + the output layer condition of sc_decode_step (V a multiple of d)"""
+    d, H = cfg.d_model, cfg.dec_heads
+    return (d in (128, 256) and d % H == 0 and d // H in (16, 32) and 1 <= W <= 16
+            and ffn_fused_supported(d, cfg.ffn_dim) and cfg.vocab_size % d == 0)
+
+
 def rowtile_proj_supported(d: int, N: int) -> bool:
     """sc_rowtile_proj_supported"""
     return d in (128, 256) and N % 128 == 0 and N >= 128
@@ -144,6 +151,12 @@ class PackedWeights:
                 lw[n + "_p"] = pack_lane_weight(lw[n]) if d in PANEL_DIMS else lw[n]
         for lw in self.dec:              # Q|K|V in lane order: projected by the reduce kernel of the layer before
             lw["wqkv_q"] = pack_lane_weight(lw["wqkv"]) if d in PANEL_DIMS else lw["wqkv"]
+        for lw in self.dec:              # Q|K|V and the cross-attention query projection in MFMA-fragment order:
+            if d in (128, 256):          # head-parallel decoder layers (sc_dec_layer_self / _cross)
+                lw["wqkv_pp"] = pack_panel_weight(lw["wqkv"])
+                lw["wq_pp"] = pack_panel_weight(lw["wq"])
+                lw["wo_pp"] = pack_panel_weight(lw["wo"])
+                lw["wo2_pp"] = pack_panel_weight(lw["wo2"])
         for lw in self.enc:              # encoder attention projections for the row-tile kernel (sc_rowtile_proj)
             for n in ("wqkv", "wo"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if rowtile_proj_supported(d, d) else lw[n]

@@ -9,7 +9,7 @@ from oracle.kernel_spec import SpecBackend
 FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "ffn_ln_proj", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
             "ctx_handoff", "enc_attention", "ctc_extend_state", "dec_embed", "dec_self_attn",
             "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw", "beam_prune",
-            "ctc_gather_state"]
+            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits"]
 
 
 class LockstepBackend(SpecBackend):
@@ -68,11 +68,18 @@ class LockstepBackend(SpecBackend):
         "fuse_topw": ["cand_tok", "cand_score", "cand_ctc"],
         "beam_prune": ["yseq", "xpos", "score", "sc_dec", "sc_ctc", "anc", "ctc_s", "sel", "flags"],
         "ctc_gather_state": ["ctc_r"],
+        # head-parallel decoder layers: (sb, li, xin, xout[, npart]) / (sb, xin, xout, npart)
+        "dec_layer_self": [3, "skv", "ph1"], "dec_layer_cross": [3, "ph2"], "dec_layer_ffn": [3, "ffn_part"],
+        "dec_output_logits": [2, "logits"],
     }
     FULL_SYNC = ("logmel", "ctc_extend_state", "dec_embed")
 
     def _compare_one(self, op, name, c, g):
         g = g.cpu()
+        if name == "ffn_part":
+            # the kernel splits the feed-forward over chunk groups, the spec writes one partial sum:
+            # what the consumer reads is the sum over the slots
+            c, g = c.sum(0), g.sum(0)
         if name == "pre_ids":
             # the pre-beam is a SET of candidates; fp32 exp/log differences of
             # ~1e-6 may swap near-tied neighbours.  Compare as sets and accept
@@ -115,7 +122,7 @@ class LockstepBackend(SpecBackend):
         for a, g in zip(args, gargs):   # job tables the host wrote since the last full sync
             if isinstance(a, torch.Tensor) and a.dtype == torch.int32 and a.data_ptr() in self._cpu_ptr:
                 g.copy_(a)
-        getattr(self.hip, op)(*gargs, **gkw)
+        ret = getattr(self.hip, op)(*gargs, **gkw)
         torch.cuda.synchronize()
         self._in_spec = True
         try:
@@ -135,6 +142,7 @@ class LockstepBackend(SpecBackend):
             g.copy_(c)   # keep the mirror identical to the CPU state: no error propagation
         self.report[op] = max(self.report.get(op, 0.0), worst)
         self.calls[op] = self.calls.get(op, 0) + 1
+        return ret    # dec_layer_ffn: the number of partial-sum slots the HIP kernel wrote
 
 
 def _make(op):

@@ -366,10 +366,16 @@ def test_engine_with_sequential_cross_attention(hip, monkeypatch):
     run_case("tiny_c25600_b10_bbd0", backend=hip, device="cuda:0")
 
 
-def test_every_kernel_lockstep_xl(hip):
-    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance."""
+@pytest.mark.parametrize("layers", ["head_parallel", "six_launch"])
+def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
+    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; both forms of the
+    decoder layer (3 launches per layer: small compaction buckets; 6 launches: large ones)."""
+    from lockstep import LockstepBackend
+    monkeypatch.setenv("SC_DEC_FUSED", "1" if layers == "head_parallel" else "0")
+    monkeypatch.setattr(LockstepBackend, "fused_layers", layers == "head_parallel")
     ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
-    _dump(ls, "lockstep_xl")
+    _dump(ls, "lockstep_xl" + ("" if layers == "head_parallel" else "_six_launch"))
+    assert ("dec_layer_self" in ls.calls) == (layers == "head_parallel")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
@@ -433,6 +439,9 @@ def test_attention_full_batch_variants_lockstep(hip, monkeypatch, nopre):
         ls = _lockstep_run(hip, "tiny_c10240_b10_bbd0")
     else:       # XL dims (d_k = 32), first decode blocks
         ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
-    assert ls.calls.get("dec_self_attn", 0) > 0 and ls.calls.get("dec_cross_attn", 0) > 0
+    if nopre:
+        assert ls.calls.get("dec_self_attn", 0) > 0 and ls.calls.get("dec_cross_attn", 0) > 0
+    else:   # XL dims run the head-parallel layer kernels (attention fused with the projections around it)
+        assert ls.calls.get("dec_layer_self", 0) > 0 and ls.calls.get("dec_layer_cross", 0) > 0
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]

@@ -18,7 +18,11 @@ def main():
     name_col = "kernel_name" if "kernel_name" in scol else "display_name"
     rows = list(cur.execute(f"select s.{name_col}, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id "
                             f"order by d.start"))
-    starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0]]
+    # a decode step starts with dec_embed (six-launch layers) or with the FIRST variant of the head-parallel
+    # self-attention layer kernel (last template argument true)
+    starts = [i for i, r in enumerate(rows)
+              if "dec_embed" in r[0] or ("dec_layer_attn_kernel" in r[0] and "ELb1EEv12DecLayerArgs" in r[0])
+              or ("dec_layer_attn_kernel" in r[0] and r[0].rstrip(">").endswith("true"))]
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
     seg = rows[a:b]
     busy = sum(r[2] - r[1] for r in seg)
