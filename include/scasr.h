@@ -34,6 +34,8 @@ extern "C" {
 #define SC_OK 0
 #define SC_ERR_ARG (-1)
 #define SC_ERR_LAUNCH (-2)
+#define SC_ERR_CAPACITY (-3) /* sc_push, per stream: a capacity limit of the batch (frames, tokens, pcm, chunk length) */
+#define SC_ERR_INPUT (-4)    /* sc_push, per stream: an input the reference itself raises on */
 
 /* flags of sc_gemm */
 #define SC_GEMM_RELU 1
@@ -359,6 +361,85 @@ int sc_glu_dwconv_bn_swish(const float *y, int B, int T, int C, int ksize, const
  * bias_u / bias_v [H][dk] -> out [B*T][d] (before linear_out).  T <= 128. */
 int sc_relpos_attention(const float *qkv, const float *p, const float *bias_u, const float *bias_v,
                         float *out, int B, int T, int H, int d, void *stream);
+
+/* ==== stream-level API: the decoder as a C library ==========================================
+ * What a reference maintainer binds instead of Speech2TextStreaming's torch modules:
+ *   engine  = one weight replica on one GPU            (load_model, speechcatcher.py:126-227)
+ *   streams = S independent recognitions sharing it    (S x Speech2TextStreaming, speech2text_streaming.py:43-263)
+ *   sc_push = Speech2TextStreaming.__call__ for the listed streams, batched   (:402-539)
+ * The library owns all device memory of these objects.  Handles are not thread-safe: one host thread and
+ * one HIP stream per sc_streams.  Functions return SC_OK / a negative code and never throw. */
+typedef struct sc_config {
+  int32_t d_model, enc_heads, enc_layers, dec_heads, dec_layers, ffn_dim, vocab_size;
+  int32_t n_mels, n_fft, win_length, hop_length, sample_rate;
+  int32_t block_size, hop_size, look_ahead, subsample, conv_freq1, conv_freq2;
+  int32_t blank_id, sos_id, eos_id, pe_max_len;
+  int32_t mvn_mode; /* 0: no global MVN, 1: fp32 statistics, 2: fp64 statistics */
+  float ln_eps;
+} sc_config;
+
+typedef struct sc_named_tensor {
+  const char *name; /* PackedWeights names: "window", "conv2_w", "enc.3.wqkv_p", "dec.0.wkv", ... */
+  const void *data; /* DEVICE pointer, borrowed for the lifetime of the engine */
+  int64_t numel;
+  int32_t dtype; /* 0 = f32, 1 = f64 (mean64 / std64) */
+} sc_named_tensor;
+
+typedef struct sc_stream_options {
+  int32_t n_streams, beam_size;
+  float ctc_weight;          /* 0.3 (speechcatcher.py:221) */
+  int32_t use_bbd;           /* block boundary detection (beam_search.py:771-790) */
+  int32_t max_frames;        /* encoder frames per utterance (capacity) */
+  int32_t max_tokens;        /* tokens per hypothesis incl. sos (capacity) */
+  int32_t pcm_capacity;      /* samples buffered per stream (0: 1 << 20) */
+  int32_t max_chunk_samples; /* longest single call (0: 32768) */
+  int32_t strict_reference;  /* reset() leaves the stale CTC table / PE counter like the reference (scorers.py:342-350) */
+} sc_stream_options;
+
+typedef struct sc_stream_info_t {
+  int32_t enc_frames, processed_block, process_idx, n_hyp, hyp_len, pcm_buffered, frontend_started;
+  int64_t decode_steps;
+} sc_stream_info_t;
+
+typedef struct sc_engine sc_engine;
+typedef struct sc_streams sc_streams;
+
+/* weights already on the device, in the layout of speechcatcher_amd.weights.PackedWeights (Python host) */
+int sc_engine_create(const sc_config *cfg, const sc_named_tensor *tensors, int n_tensors, int device, sc_engine **out);
+/* ... or from a packed model file written by PackedWeights.save_packed (C / C++ hosts: no Python, no torch) */
+int sc_engine_load(const char *packed_model_path, int device, sc_engine **out);
+int sc_engine_config(const sc_engine *engine, sc_config *out);
+void sc_engine_destroy(sc_engine *engine);
+
+int sc_streams_create(sc_engine *engine, const sc_stream_options *options, sc_streams **out);
+void sc_streams_destroy(sc_streams *streams);
+/* One chunk step for n streams: stream_ids[i] gets n_samples[i] float samples in +-1 from pcm[i] (HOST; NULL =
+ * already resident in the device PCM buffer, see sc_streams_pcm) with is_final[i].  Runs frontend -> encoder ->
+ * every decode block that became ready (run to completion).  status[i] (HOST out, may be NULL): 1 output, 0 the
+ * reference's early `return []`, SC_ERR_CAPACITY / SC_ERR_INPUT: this stream failed and was reset, the others
+ * are unaffected. */
+int sc_push(sc_streams *streams, const int *stream_ids, const float *const *pcm, const int *n_samples,
+            const uint8_t *is_final, int n, int *status);
+/* the same for 2-D (T, n_mels) already-normalised feature matrices (speech2text_streaming.py:438-449) */
+int sc_push_features(sc_streams *streams, const int *stream_ids, const float *const *feats, const int *n_frames,
+                     const uint8_t *is_final, int n, int *status);
+/* live hypotheses, best first (BeamState.hypotheses: yseq, xpos, score, scores{decoder, ctc}; hypothesis.py).
+ * Returns how many were written (<= nbest) or a negative code. */
+int sc_get_hyps(sc_streams *streams, int stream, int nbest, int max_len, int32_t *ids, int32_t *xpos, int *lens,
+                double *scores, double *score_dec, double *score_ctc);
+/* Speech2TextStreaming.reset (speech2text_streaming.py:252-263) */
+int sc_reset(sc_streams *streams, int stream);
+int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
+int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
+/* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
+void *sc_streams_hip_stream(sc_streams *streams);
+float *sc_streams_pcm(sc_streams *streams, long *capacity);
+/* host <-> device copies: write samples into a stream's device PCM ring; read back the samples buffered by the
+ * frontend (frontend_states["waveform_buffer"], speech2text_streaming.py:300-338) and the encoder output so far
+ * (beam_search.encoder_buffer).  The read functions return the number of samples / frames. */
+int sc_streams_write_pcm(sc_streams *streams, int stream, long offset, const float *host, long n);
+long sc_streams_read_pcm_buffer(sc_streams *streams, int stream, float *host, long max_n);
+int sc_streams_read_enc(sc_streams *streams, int stream, float *host, int max_frames);
 
 #ifdef __cplusplus
 }

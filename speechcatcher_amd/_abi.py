@@ -50,6 +50,29 @@ class Search(C.Structure):
     )
 
 
+class Config(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("d_model", "enc_heads", "enc_layers", "dec_heads", "dec_layers", "ffn_dim",
+                                           "vocab_size", "n_mels", "n_fft", "win_length", "hop_length", "sample_rate",
+                                           "block_size", "hop_size", "look_ahead", "subsample", "conv_freq1",
+                                           "conv_freq2", "blank_id", "sos_id", "eos_id", "pe_max_len", "mvn_mode")]
+                + [("ln_eps", C.c_float)])
+
+
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("numel", C.c_int64), ("dtype", C.c_int32)]
+
+
+class StreamOptions(C.Structure):
+    _fields_ = [("n_streams", C.c_int32), ("beam_size", C.c_int32), ("ctc_weight", C.c_float), ("use_bbd", C.c_int32),
+                ("max_frames", C.c_int32), ("max_tokens", C.c_int32), ("pcm_capacity", C.c_int32),
+                ("max_chunk_samples", C.c_int32), ("strict_reference", C.c_int32)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("enc_frames", "processed_block", "process_idx", "n_hyp", "hyp_len",
+                                           "pcm_buffered", "frontend_started")] + [("decode_steps", C.c_int64)])
+
+
 _SIGS = {
     "sc_last_error": (C.c_char_p, []),
     "sc_version": (C.c_int, []),
@@ -112,6 +135,25 @@ _SIGS = {
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    # stream-level API
+    "sc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(NamedTensor), C.c_int, C.c_int, C.POINTER(vp)]),
+    "sc_engine_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "sc_engine_config": (C.c_int, [vp, C.POINTER(Config)]),
+    "sc_engine_destroy": (None, [vp]),
+    "sc_streams_create": (C.c_int, [vp, C.POINTER(StreamOptions), C.POINTER(vp)]),
+    "sc_streams_destroy": (None, [vp]),
+    "sc_push": (C.c_int, [vp, c_int_p, C.POINTER(vp), c_int_p, C.POINTER(C.c_uint8), C.c_int, c_int_p]),
+    "sc_push_features": (C.c_int, [vp, c_int_p, C.POINTER(vp), c_int_p, C.POINTER(C.c_uint8), C.c_int, c_int_p]),
+    "sc_get_hyps": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p,
+                              c_double_p]),
+    "sc_reset": (C.c_int, [vp, C.c_int]),
+    "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),
+    "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "sc_streams_hip_stream": (vp, [vp]),
+    "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),
+    "sc_streams_write_pcm": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_long]),
+    "sc_streams_read_pcm_buffer": (C.c_long, [vp, C.c_int, vp, C.c_long]),
+    "sc_streams_read_enc": (C.c_int, [vp, C.c_int, vp, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

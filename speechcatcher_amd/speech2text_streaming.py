@@ -24,7 +24,7 @@ import torch
 
 from . import _abi
 from .config import ModelConfig, SearchConfig
-from .engine import StreamBatch
+from .engine import EngineError
 from .weights import PackedWeights
 
 logger = logging.getLogger(__name__)
@@ -175,11 +175,8 @@ class _BeamSearchView:
 
     @property
     def encoder_buffer(self):
-        b, s = self._o.batch, self._o.stream
-        T = b.st[s].T_enc
-        if T == 0:
-            return None
-        return b.enc[s * b.TCAP: s * b.TCAP + T].unsqueeze(0)
+        enc = self._o.batch.encoder_buffer(self._o.stream)
+        return None if enc is None else torch.from_numpy(enc).unsqueeze(0)
 
     def reset(self):
         self._o.batch.reset(self._o.stream)
@@ -251,7 +248,6 @@ class Speech2TextStreaming:
         self.dtype = torch.float32
         self.use_bbd = use_bbd
         self.result_format = result_format
-        from .hip_backend import HipBackend
         if self.model_dir.is_file() and self.model_dir.suffix == BLOB_SUFFIX:
             sd, self.cfg, self.mean, self.std, self.token_list = load_model_blob(self.model_dir)
         else:
@@ -261,12 +257,17 @@ class Speech2TextStreaming:
             self.token_list = load_token_list(self.model_dir)
         self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std)
         self.model = self.weights
-        self.backend = HipBackend(self.device)
-        self.batch = StreamBatch(self.weights, self.backend, 1,
-                                 SearchConfig(beam_size=beam_size, ctc_weight=ctc_weight, use_bbd=use_bbd),
-                                 max_frames=max_frames, max_tokens=max_tokens,
-                                 pcm_capacity=max(1 << 20, 2 * max_chunk_samples),
-                                 max_chunk_samples=max_chunk_samples, strict_reference=strict_reference)
+        # the decoder itself: the C++ engine behind the stream-level C ABI (csrc/streams.hip); raises without
+        # the built library or without a GPU - there is no fallback
+        from .native import NativeStreamBatch
+        try:
+            self.batch = NativeStreamBatch(self.weights, 1,
+                                           SearchConfig(beam_size=beam_size, ctc_weight=ctc_weight, use_bbd=use_bbd),
+                                           max_frames=max_frames, max_tokens=max_tokens,
+                                           pcm_capacity=max(1 << 20, 2 * max_chunk_samples),
+                                           max_chunk_samples=max_chunk_samples, strict_reference=strict_reference)
+        except EngineError as e:
+            raise _abi.ScasrError(str(e)) from e
         self.stream = 0
         self.win_length = self.cfg.win_length
         self.hop_length = self.cfg.hop_length
@@ -281,11 +282,9 @@ class Speech2TextStreaming:
 
     @property
     def frontend_states(self):
-        st = self.batch.st[self.stream]
-        if not st.fe_started:
+        if not self.batch.st[self.stream].fe_started:
             return None
-        buf = self.batch.pcm[self.stream, st.pcm_start:st.pcm_end]
-        return {"waveform_buffer": buf}
+        return {"waveform_buffer": torch.from_numpy(self.batch.waveform_buffer(self.stream))}
 
     def __call__(self, speech, is_final: bool = False, finalize_all: bool = False,
                  always_assemble_hyps: bool = False):

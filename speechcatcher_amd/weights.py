@@ -173,6 +173,50 @@ class PackedWeights:
         self.ctc_w = dev(g("ctc.ctc_lo.weight"))
         self.ctc_b = dev(g("ctc.ctc_lo.bias"))
 
+    # ---- the flat, named view the stream-level C ABI takes (include/scasr.h: sc_engine_create / sc_engine_load)
+    _TOP = ("window", "mel_fb", "twiddle", "pe", "mean64", "std64", "conv1_w", "conv1_b", "conv2_w", "conv2_b",
+            "sub_out_w", "sub_out_b", "enc_norm_g", "enc_norm_b", "embed", "dec_norm_g", "dec_norm_b", "out_w", "out_b",
+            "out_w_q", "ctc_w", "ctc_b")
+
+    def named_tensors(self):
+        """[(name, tensor)]: "window", ..., "enc.{i}.{field}", "dec.{i}.{field}" (fields = the dict keys above)."""
+        out = [(n, getattr(self, n)) for n in self._TOP if getattr(self, n, None) is not None]
+        for pre, layers in (("enc", self.enc), ("dec", self.dec)):
+            for i, lw in enumerate(layers):
+                out.extend((f"{pre}.{i}.{k}", v) for k, v in lw.items())
+        return out
+
+    def mvn_mode(self) -> int:
+        return 0 if not self.has_mvn else (2 if self.mvn_is_f64 else 1)
+
+    def save_packed(self, path):
+        """Packed model file for hosts without Python / torch (sc_engine_load): 'SCPK1', sc_config, named tensors in
+        the layouts above (weights already permuted / fragment-packed; fp32, MVN statistics fp64)."""
+        import struct
+        from ._abi import Config
+        import ctypes as C
+        cfg = self.cfg
+        c = Config()
+        for n, _ in Config._fields_:
+            if n == "mvn_mode":
+                c.mvn_mode = self.mvn_mode()
+            else:
+                setattr(c, n, getattr(cfg, n))
+        ts = self.named_tensors()
+        with open(path, "wb") as f:
+            f.write(b"SCPK1\0\0\0")
+            f.write(struct.pack("<i", C.sizeof(Config)))
+            f.write(bytes(c))
+            f.write(struct.pack("<i", len(ts)))
+            for name, t in ts:
+                nb = name.encode()
+                a = t.detach().cpu().contiguous().numpy()
+                f.write(struct.pack("<i", len(nb)))
+                f.write(nb)
+                f.write(struct.pack("<iq", 1 if a.dtype == np.float64 else 0, a.size))
+                f.write(a.astype(np.float64 if a.dtype == np.float64 else np.float32).tobytes())
+        return path
+
     def n_bytes(self, part="all") -> int:
         def tot(ds):
             return sum(t.numel() * t.element_size() for dct in ds for t in dct.values())

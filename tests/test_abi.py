@@ -54,7 +54,9 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no C compiler")
-    structs = {"sc_enc_layer": _abi.EncLayer, "sc_dec_layer": _abi.DecLayer, "sc_search": _abi.Search}
+    structs = {"sc_enc_layer": _abi.EncLayer, "sc_dec_layer": _abi.DecLayer, "sc_search": _abi.Search,
+               "sc_config": _abi.Config, "sc_named_tensor": _abi.NamedTensor, "sc_stream_options": _abi.StreamOptions,
+               "sc_stream_info_t": _abi.StreamInfo}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "scasr.h"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
@@ -80,7 +82,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     import ctypes
     from speechcatcher_amd import _abi
     text = re.sub(r"/\*.*?\*/", " ", (ROOT / "include" / "scasr.h").read_text(), flags=re.S)
-    protos = re.findall(r"\b(?:int|double|size_t|const char \*)\s*(sc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text)
+    protos = re.findall(r"\b(?:int|long|void|double|size_t|const char \*|void \*|float \*)\s*(sc_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text)
     assert len(protos) == len(_abi.EXPORTED_SYMBOLS)
 
     def c_class(param):
@@ -99,7 +101,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
             return "float"
         if t in (ctypes.c_double,):
             return "double"
-        if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_int32, ctypes.c_uint):
+        if t in (ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong, ctypes.c_int32, ctypes.c_uint, ctypes.c_long):
             return "int"
         return "ptr"
 

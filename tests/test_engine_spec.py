@@ -18,12 +18,17 @@ CFGS = {"TINY": TINY, "XL": XL}
 
 
 def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", **kw):
+    """backend: None = the torch spec backend (CPU), a HipBackend = the Python engine over the HIP kernels,
+    "native" = the C++ engine behind the stream-level C ABI (speechcatcher_amd.native)."""
     from oracle.kernel_spec import SpecBackend
     cfg = CFGS[cfg_name]
     sd = synth.make_state_dict(cfg, seed)
     mean, std = synth.stats_to_mean_std(synth.make_stats(cfg, kind=stats))
-    w = PackedWeights(sd, cfg, device, mean, std)
     sc = SearchConfig(beam_size=beam, use_bbd=bbd)
+    if isinstance(backend, str) and backend == "native":
+        from speechcatcher_amd.native import NativeStreamBatch
+        return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std), n_streams, sc, **kw)
+    w = PackedWeights(sd, cfg, device, mean, std)
     return StreamBatch(w, backend or SpecBackend(), n_streams, sc, **kw)
 
 

@@ -1,0 +1,216 @@
+"""The C++ engine behind the stream-level C ABI (csrc/streams.hip: sc_engine_* / sc_streams_* / sc_push /
+sc_get_hyps / sc_reset) against the fixtures of the real reference, the oracle sessions, and a plain C host
+program that links libscasr.so - no Python in the decode loop."""
+import json
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_case
+from speechcatcher_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TINY_CASES = [f"tiny_c{c}_b{b}_bbd{d}" for c in (8192, 10240) for b in (1, 10) for d in (0, 1)] + ["tiny_c25600_b10_bbd0"]
+XL_CASES = ["xl_c10240_b10_bbd0", "xl_c10240_b10_bbd1", "xl_c25600_b10_bbd0", "xl_c8192_b10_bbd1", "xl_c8192_b5_bbd1",
+            "xl_c10240_b1_bbd0"]
+
+
+@pytest.mark.parametrize("name", TINY_CASES + ["tiny_stats64_b5"])
+def test_native_engine_matches_reference_tiny(name):
+    from test_engine_spec import run_case
+    sb, js, npz = run_case(name, backend="native")
+    if npz is not None:
+        enc = sb.encoder_buffer(0)
+        np.testing.assert_allclose(enc, npz["enc"][:enc.shape[0]], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("name", XL_CASES)
+def test_native_engine_matches_reference_xl(name):
+    from test_engine_spec import run_case
+    run_case(name, backend="native", score_tol=5e-3)
+
+
+def test_native_short_utterances_and_the_reference_exception():
+    from test_engine_spec import make_batch, check_against_blocks
+    js = json.loads((GOLDEN / "tiny_short.json").read_text())
+    for n in (3000, 9000, 20000):
+        sb = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", max_frames=128, max_tokens=600,
+                        pcm_capacity=1 << 16)
+        sb.push([(0, synth.synth_audio(3, n), True)])
+        check_against_blocks(sb, 0, js[str(n)]["blocks"][-1])
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", max_frames=128, max_tokens=64,
+                    pcm_capacity=1 << 16)
+    with pytest.raises(RuntimeError):           # final chunk with < 7 feature frames: the reference dies in Conv2d (A3)
+        sb.push([(0, synth.synth_audio(3, 700), True)])
+    assert sb.st[0].T_enc == 0                  # ... and the stream is usable again
+    sb.push([(0, synth.synth_audio(3, 9000), True)])
+    check_against_blocks(sb, 0, js["9000"]["blocks"][-1])
+
+
+def test_native_reset_quirk_and_calls_after_final():
+    from test_engine_spec import run_after_final, run_reset_quirk
+    run_reset_quirk(backend="native", score_tol=5e-3)
+    for bbd in (0, 1):
+        run_after_final(bbd, backend="native", score_tol=5e-3)
+
+
+def test_native_capacity_faults_are_isolated():
+    from speechcatcher_amd.engine import EngineError
+    from test_engine_spec import make_batch
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=2, backend="native", max_frames=40, max_tokens=160,
+                    pcm_capacity=1 << 18)
+    a, b = synth.synth_audio(0, 80000), synth.synth_audio(1, 80000)
+    ref = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, backend="native", max_frames=400, max_tokens=160,
+                     pcm_capacity=1 << 18)
+    failed = False
+    for pos in range(0, 30720, 10240):
+        out = sb.push([(0, a[pos:pos + 10240], False), (1, b[pos:pos + 10240], False)], isolate_faults=True)
+        ref.push([(0, b[pos:pos + 10240], False)])
+        assert not isinstance(out[1], Exception)
+    # stream 0 gets a chunk that is too long for the batch: it alone fails, stream 1 is decoded normally
+    out = sb.push([(0, a[:40000], False), (1, b[30720:40960], False)], isolate_faults=True)
+    ref.push([(0, b[30720:40960], False)])
+    assert isinstance(out[0], EngineError) and out[1] is True
+    assert [h["yseq"] for h in sb.hypotheses(1)] == [h["yseq"] for h in ref.hypotheses(0)]
+    with pytest.raises(EngineError):
+        sb.push([(0, a[:40000], False)])
+
+
+def test_native_batch_of_distinct_streams_equals_one_by_one():
+    """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
+    head-parallel and six-launch layer forms by bucket size) = every stream alone."""
+    from test_engine_spec import make_batch
+    S, chunk, beam = 32, 10240, 5
+    lens = [chunk * (2 + (i * 7) % 5) + (i * 1234) % 4000 for i in range(S)]
+    audio = [synth.synth_audio(100 + i, n) for i, n in enumerate(lens)]
+
+    def run(streams):
+        sb = make_batch("TINY", 1234, "meanstd", beam, False, n_streams=len(streams), backend="native",
+                        max_frames=400, max_tokens=500, pcm_capacity=1 << 17)
+        pos = 0
+        while True:
+            items = []
+            for slot, i in enumerate(streams):
+                if pos < lens[i]:
+                    end = min(pos + chunk, lens[i])
+                    items.append((slot, audio[i][pos:end], end >= lens[i]))
+            if not items:
+                break
+            sb.push(items)
+            pos += chunk
+        return [sb.hypotheses(slot) for slot in range(len(streams))]
+
+    batch = run(list(range(S)))
+    for i in range(0, S, 3):
+        solo = run([i])
+        assert len(solo[0]) == len(batch[i]) > 0
+        for x, y in zip(solo[0], batch[i]):
+            assert x["yseq"] == y["yseq"] and x["xpos"] == y["xpos"], i
+            assert abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(x["score"])), i
+
+
+def test_native_xl_batch_equals_python_engine():
+    """XL dims, 12 streams: the C++ engine and the Python engine (same kernels) end with identical hypotheses."""
+    from speechcatcher_amd.hip_backend import HipBackend
+    from test_engine_spec import make_batch
+    S, chunk, beam, n = 12, 10240, 10, 6
+    audio = [synth.synth_audio(300 + i, chunk * n) for i in range(S)]
+
+    def run(backend, device):
+        sb = make_batch("XL", 1234, "meanstd", beam, False, n_streams=S, backend=backend, device=device, max_frames=200,
+                        max_tokens=600, pcm_capacity=1 << 17)
+        for k in range(n):
+            last = k == n - 1
+            sb.push([(s, audio[s][k * chunk:(k + 1) * chunk], last) for s in range(S) if not last or s % 2 == 0])
+        return [sb.hypotheses(s) for s in range(S)]
+
+    nat = run("native", "cuda:0")
+    py = run(HipBackend("cuda:0"), "cuda:0")
+    for s in range(S):
+        assert [h["yseq"] for h in nat[s]] == [h["yseq"] for h in py[s]], s
+        assert all(abs(x["score"] - y["score"]) < 1e-6 for x, y in zip(nat[s], py[s])), s
+
+
+@pytest.mark.parametrize("vosk", [False, True])
+def test_native_server_sessions_equal_private_oracle_sessions(vosk):
+    from test_server_session import run_sessions_vs_oracle
+    run_sessions_vs_oracle(vosk, backend="native")
+
+
+def test_native_scheduler_and_segment_loop():
+    from test_scheduler import run_segments_serial_strict, run_sessions_different_chunking
+    run_sessions_different_chunking(backend="native")
+    run_segments_serial_strict(backend="native")
+
+
+C_HOST = r"""
+/* A plain C host of libscasr: packed model file + raw f32 PCM -> token ids of the best hypotheses, one line per
+ * call that produced a decode block.  No Python, no torch. */
+#include <stdio.h>
+#include <stdlib.h>
+#include "scasr.h"
+int main(int argc, char **argv) {
+  if (argc < 6) return 2;
+  const int chunk = atoi(argv[3]), beam = atoi(argv[4]), bbd = atoi(argv[5]);
+  sc_engine *eng = NULL; sc_streams *st = NULL;
+  if (sc_engine_load(argv[1], 0, &eng) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+  sc_stream_options o = {1, beam, 0.3f, bbd, 256, 200, 1 << 18, 32768, 1};
+  if (sc_streams_create(eng, &o, &st) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+  FILE *f = fopen(argv[2], "rb"); if (!f) return 1;
+  fseek(f, 0, SEEK_END); long n = ftell(f) / 4; fseek(f, 0, SEEK_SET);
+  float *pcm = (float *)malloc(n * 4);
+  if (fread(pcm, 4, n, f) != (size_t)n) return 1;
+  fclose(f);
+  static int32_t ids[16 * 200]; int lens[16]; double sc[16];
+  for (long pos = 0; pos < n; pos += chunk) {
+    int sid = 0, cnt = (int)(pos + chunk < n ? chunk : n - pos), status = 0;
+    uint8_t fin = pos + chunk >= n;
+    const float *p = pcm + pos;
+    if (sc_push(st, &sid, &p, &cnt, &fin, 1, &status) != SC_OK || status < 0) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+    sc_stream_info_t info; sc_stream_info(st, 0, &info);
+    int nh = sc_get_hyps(st, 0, beam, 200, ids, NULL, lens, sc, NULL, NULL);
+    printf("%d %d %d", status, info.enc_frames, info.processed_block);
+    for (int h = 0; h < nh; ++h) { printf(" |"); for (int i = 0; i < lens[h]; ++i) printf(" %d", ids[h * 200 + i]); }
+    printf("\n");
+  }
+  sc_streams_destroy(st); sc_engine_destroy(eng); free(pcm);
+  return 0;
+}
+"""
+
+
+def test_c_host_program_reproduces_the_reference_fixture(tmp_path):
+    """gcc-compiled C program + libscasr.so: tiny_c10240_b10_bbd0 call by call (encoder frames, processed blocks,
+    token ids of every live hypothesis)."""
+    from speechcatcher_amd.config import TINY
+    from speechcatcher_amd.weights import PackedWeights
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    js, _ = load_case("tiny_c10240_b10_bbd0")
+    meta = js["meta"]
+    sd = synth.make_state_dict(TINY, meta["seed"])
+    mean, std = synth.stats_to_mean_std(synth.make_stats(TINY, kind=meta["stats"]))
+    PackedWeights(sd, TINY, "cpu", mean, std).save_packed(tmp_path / "tiny.scpk")
+    synth.synth_audio(meta["audio_stream"], meta["n_samples"]).astype("<f4").tofile(tmp_path / "audio.f32")
+    (tmp_path / "host.c").write_text(C_HOST)
+    libdir = ROOT / "speechcatcher_amd"
+    subprocess.run([gcc, "-std=c99", "-O1", "-I", str(ROOT / "include"), str(tmp_path / "host.c"), "-L", str(libdir),
+                    "-lscasr", f"-Wl,-rpath,{libdir}", "-o", str(tmp_path / "host")], check=True)
+    res = subprocess.run([str(tmp_path / "host"), str(tmp_path / "tiny.scpk"), str(tmp_path / "audio.f32"),
+                          str(meta["chunk"]), str(meta["beam"]), str(int(meta["bbd"]))], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert len(lines) == len(js["calls"])
+    nblk = 0
+    for line, call in zip(lines, js["calls"]):
+        head, *hyps = line.split(" |")
+        status, enc_frames, pblock = [int(x) for x in head.split()]
+        assert enc_frames == call["enc_buffer_len"] and pblock == call["processed_block"]
+        nblk += call["n_blocks"]
+        if call["n_blocks"]:
+            got = sorted(tuple(int(t) for t in h.split()) for h in hyps)
+            assert got == sorted(tuple(y) for y in js["blocks"][nblk - 1]["yseq"])
