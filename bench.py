@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the streaming-ASR hot path on MI355X.
 
-One "step" = one chunk step (10 240 samples = 640 ms of 16 kHz audio) of the
-whole path - log-mel frontend, Conv2d subsampling, contextual-block encoder,
-blockwise-synchronous beam search (decoder + CTC prefix scorer) - for EVERY
-stream of the batch (S streams per GPU, default 128 = BASELINE.json
-configs[2]; `--streams 1` gives configs[1]).  Weights: de_streaming_
-transformer_xl dimensions, seeded synthetic (no checkpoints offline); audio:
-seeded Gaussian noise, already resident in HBM when the timed region starts.
+One "step" = one chunk step (10 240 samples = 640 ms of 16 kHz audio) of the whole path - log-mel frontend,
+Conv2d subsampling, contextual-block encoder, blockwise-synchronous beam search (decoder + CTC prefix scorer) - for
+EVERY stream of the batch (S streams per GPU, default 128 = BASELINE.json configs[2]; `--streams 1` gives
+configs[1]), run to completion inside the step: every stream's result is available when its call returns, exactly
+like the reference's per-call semantics (STRICT lock-step).  The step runs on the C++ engine behind the stream-level
+C ABI (sc_push; csrc/streams.hip) - the product path of Speech2TextStreaming and of the scheduler.
+Weights: de_streaming_transformer_xl dimensions, seeded synthetic (no checkpoints offline); audio: seeded Gaussian
+noise, already resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 20 --warmup 6
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
-Prints ONE JSON line (rank 0).  value = whole-job audio-seconds processed per
-wall-clock second = number of concurrent real-time streams the job sustains.
+Prints ONE JSON line (rank 0).  value = whole-job audio-seconds processed per wall-clock second = number of
+concurrent real-time streams the job sustains.  Extra keys: `deferred` (the opt-in deferred-stragglers mode of the
+Python engine: results of some streams one chunk period late - NOT the headline), `roofline`, `cpu_baseline`,
+`single_stream`, `whole_step`.
 """
 import argparse
 import ctypes as C
@@ -35,23 +38,37 @@ from speechcatcher_amd.config import XL, SearchConfig  # noqa: E402
 CHUNK = 10240
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
+# algorithmic work of one stream-hop (10 240 samples of one stream)
+GFLOP_ENCODER_SIDE_PER_HOP = 3.83
+GFLOP_PER_DECODE_STEP = 0.437  # at beam 10
 
 
-def build_batch(n_streams, beam, bbd, n_steps_total, device):
-    from speechcatcher_amd.engine import StreamBatch
-    from speechcatcher_amd.hip_backend import HipBackend
+def capacities(n_steps_total):
+    hops = (n_steps_total + 2) * CHUNK / 10240.0       # encoder hops (16 frames each) in the window
+    return int(16 * hops) + 64, min(2048, int(14 * hops) + 32)
+
+
+def make_weights(device):
     from speechcatcher_amd.weights import PackedWeights
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    w = PackedWeights(sd, XL, device, mean, std)
-    be = HipBackend(device)
-    hops = (n_steps_total + 2) * CHUNK / 10240.0       # encoder hops (16 frames each) in the window
-    frames = int(16 * hops) + 64
-    tokens = min(2048, int(14 * hops) + 32)
-    sb = StreamBatch(w, be, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd),
-                     max_frames=frames, max_tokens=tokens,
-                     pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK)
-    return sb, be
+    return PackedWeights(sd, XL, device, mean, std)
+
+
+def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None):
+    from speechcatcher_amd.native import NativeStreamBatch
+    frames, tokens = capacities(n_steps_total)
+    return NativeStreamBatch(w, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
+                             max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
+                             engine=engine)
+
+
+def build_python_engine(w, n_streams, beam, bbd, n_steps_total, device):
+    from speechcatcher_amd.engine import StreamBatch
+    from speechcatcher_amd.hip_backend import HipBackend
+    frames, tokens = capacities(n_steps_total)
+    return StreamBatch(w, HipBackend(device), n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
+                       max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK)
 
 
 def preload_audio(sb, n_steps_total, stream_offset=0):
@@ -59,36 +76,55 @@ def preload_audio(sb, n_steps_total, stream_offset=0):
     n = CHUNK * n_steps_total
     for s in range(sb.S):
         a = synth.synth_audio(stream_offset + s, n)
-        sb.pcm[s, :n].copy_(torch.from_numpy(a))
+        if hasattr(sb, "write_pcm"):
+            sb.write_pcm(s, 0, a)
+        else:
+            sb.pcm[s, :n].copy_(torch.from_numpy(a))
     torch.cuda.synchronize()
 
 
-OVERLAP = False   # --overlap: prefetch the next step's encoder stage on a second HIP stream
-
-
 def run_steps(sb, n):
-    """n chunk steps over all streams.  With OVERLAP the frontend + encoder pass of
-    step i+1 is launched on a second HIP stream before the decode loop of step i
-    (StreamBatch.push(prefetch=...)): steady-state pipelining of the same work."""
     items = [(s, CHUNK, False) for s in range(sb.S)]
     for _ in range(n):
-        sb.push(items, pcm_resident=True, prefetch=items if OVERLAP else None)
+        sb.push(items, pcm_resident=True)
 
 
-def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
-    """The oracle (port of the reference path) timed on this box's host cores."""
+def timed(sb, warmup, steps, dist=None):
+    run_steps(sb, warmup)
+    sb.flush()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    steps0 = sum(st.n_steps_total for st in sb.st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(sb, steps)
+    sb.flush()                      # (deferred mode: pending blocks of the last steps belong to the timed work)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(sb.S)
+    return elapsed, dec_steps / max(steps, 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (restatement of the reference path, validated against the reference's fixtures) timed on
+# this box's host cores.  Three legs: one process with 1 and with 8 intra-op threads (the best
+# single-process setting measured for the reference), and N independent single-thread
+# processes - the reference's own concurrency model (one process / model copy per worker or client:
+# speechcatcher.py:482,787, speechcatcher_server.py:331-357).
+def cpu_baseline_worker(args):
+    threads, budget_s, beam, bbd, warm_calls, max_steps, stream_id = args
+    import torch as th
+    th.set_num_threads(threads)
     from oracle.ref_port import RefPortModel, RefPortStreaming
     from speechcatcher_amd.mel import melscale_fbanks_slaney
-    # 8 intra-op threads: the best single-process setting measured for the
-    # reference (BASELINE.md section 2); torch's default of one thread per host
-    # core (128 on the GPU box) is slower on these small ops.
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    mel = melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000)
-    model = RefPortModel(sd, XL, mel, mean, std)
+    model = RefPortModel(sd, XL, melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000), mean, std)
     s = RefPortStreaming(model, beam_size=beam, ctc_weight=0.3, use_bbd=bbd)
-    audio = synth.synth_audio(0, CHUNK * (warm_calls + max_steps))
+    audio = synth.synth_audio(stream_id, CHUNK * (warm_calls + max_steps))
     for i in range(warm_calls):
         s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
     t0 = time.perf_counter()
@@ -97,11 +133,30 @@ def cpu_baseline(budget_s=20.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
         i = warm_calls + n
         s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
         n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n * CHUNK / 16000.0 / dt, 4), "unit": "audio_s/s",
-            "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 stream, chunk steps {warm_calls}..{warm_calls + n - 1} of stream 0 "
-                      f"({n} steps, {dt:.1f} s wall), beam {beam}, bbd {int(bbd)}, XL dims, torch-CPU oracle"}
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    hop_s = CHUNK / 16000.0
+    legs = []
+    ctx = mp.get_context("spawn")       # fresh interpreters: never fork a process that has initialised the GPU
+    for threads, procs in ((8, 1), (1, 1), (1, min(16, ncpu))):
+        threads = min(threads, ncpu)
+        with ctx.Pool(procs) as pool:
+            res = pool.map(cpu_baseline_worker, [(threads, budget_s, beam, bbd, warm_calls, max_steps, k) for k in range(procs)])
+        rate = sum(n * hop_s / dt for n, dt in res)
+        legs.append({"processes": procs, "threads_per_process": threads, "audio_s_per_s": round(rate, 4),
+                     "steps": [n for n, _ in res][:4], "wall_s": round(max(dt for _, dt in res), 1)})
+    best = legs[0]
+    return {"value": best["audio_s_per_s"], "unit": "audio_s/s", "cores": best["threads_per_process"], "kind": "port",
+            "sample": f"1 stream, chunk steps {warm_calls}.. of stream 0 ({best['steps'][0]} steps, {best['wall_s']} s wall), "
+                      f"beam {beam}, bbd {int(bbd)}, XL dims, torch-CPU oracle (oracle/ref_port.py), 8 intra-op threads",
+            "host_cores": ncpu, "torch": torch.__version__, "legs": legs,
+            "streams_per_node_on_cpu": {"value": legs[2]["audio_s_per_s"], "processes": legs[2]["processes"],
+                                        "note": "N independent single-thread processes (the reference's concurrency "
+                                                "model), aggregate audio-seconds per second"}}
 
 
 def main():
@@ -116,89 +171,80 @@ def main():
                     help="samples per chunk step (10240 = 640 ms = one encoder hop; also 8192 = CLI default, 25600 = block size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
+    ap.add_argument("--no-deferred", action="store_true", help="skip the extra deferred-stragglers measurement")
     ap.add_argument("--roofline-steps", type=int, default=2,
-                    help="extra (untimed for `value`) steps with per-launch HIP-event timing of the GEMM kernel")
+                    help="extra (untimed for `value`) steps with per-launch HIP-event timing of the hot kernels")
+    ap.add_argument("--engine", choices=["native", "python"], default="native",
+                    help="native: C++ engine behind sc_push (product path); python: engine.StreamBatch over the same kernels")
     ap.add_argument("--defer", type=int, default=-1,
-                    help="deferred stragglers: end a chunk step's decode loop when at most this many streams are "
-                         "still inside their block; they resume in the next step's loop (StreamBatch."
-                         "set_defer_threshold; identical per-stream results, a stream is never more than one block "
-                         "behind).  Pending blocks are flushed inside the timed region.  -1 (default): 3/8 of the "
-                         "streams (measured optimum); 0: strict lock-step, every block completes inside its chunk step.")
-    ap.add_argument("--defer-lag", type=int, default=1,
-                    help="blocks (chunk periods) a deferred stream may be behind (1: results at most one chunk "
-                         "period late; 2 measured +10 %% throughput with threshold 80)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="launch the frontend + encoder of step i+1 on a second HIP stream before the decode loop of "
-                         "step i (measured slower than the serial order: DESIGN.md section 4, negative results)")
+                    help="threshold of the EXTRA deferred-stragglers run (Python engine): end a chunk step's decode loop "
+                         "when at most this many streams are still inside their block; -1: 3/8 of the streams")
+    ap.add_argument("--defer-lag", type=int, default=1)
     args = ap.parse_args()
-    global CHUNK, OVERLAP
+    global CHUNK
     CHUNK = args.chunk
-    OVERLAP = bool(args.overlap)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1":    # multi-rank control flow on a 1-GPU box (tests)
+        local_rank = 0
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)          # BEFORE init_process_group: RCCL binds the rank to this device
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" IS RCCL on ROCm.  SC_DIST_BACKEND=gloo + SC_BENCH_SINGLE_DEVICE=1 lets the
-        # multi-rank control flow be smoke-tested on a 1-GPU box (collectives on CPU tensors).
+        # "nccl" IS RCCL on ROCm.  SC_DIST_BACKEND=gloo + SC_BENCH_SINGLE_DEVICE=1 lets the multi-rank control flow
+        # be smoke-tested on a 1-GPU box (collectives on CPU tensors).
         backend = os.environ.get("SC_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    device = f"cuda:{local_rank}"
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
-    torch.cuda.set_device(device)
 
     total_steps = args.warmup + args.steps + args.roofline_steps
-    sb, be = build_batch(args.streams, args.beam, bool(args.bbd), total_steps, device)
+    w = make_weights(device)
+    if args.engine == "native":
+        sb = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
+        lib = sb.lib
+    else:
+        sb = build_python_engine(w, args.streams, args.beam, bool(args.bbd), total_steps, device)
+        sb.set_defer_threshold(0)
+        lib = sb.be.lib
     preload_audio(sb, total_steps, stream_offset=rank * args.streams)
+    elapsed, dec_steps_per_hop = timed(sb, args.warmup, args.steps, dist)
 
-    if args.defer < 0:
-        args.defer = (3 * args.streams) // 8
-    sb.set_defer_threshold(args.defer, args.defer_lag)
-    run_steps(sb, args.warmup)
-    sb.flush()
-    torch.cuda.synchronize()
-    if sb.timing is not None:
-        sb.timing.clear()
-    if dist is not None:
-        dist.barrier()
-    steps0 = sum(st.n_steps_total for st in sb.st)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(sb, args.steps)
-    sb.flush()                      # deferred blocks of the last steps belong to the timed work
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(args.streams)
-    # Roofline leg: the SAME workload continues for a few more steps with hipGraph
-    # replay switched off, so that every GEMM launch can be bracketed by HIP
-    # events on its launch stream (kernels inside a graph replay cannot be).
+    # Roofline leg: the SAME workload continues for a few more steps with hipGraph replay switched off, so that
+    # every launch of the hot kernels can be bracketed by HIP events on its launch stream.
     NK = 9   # scasr.h: SC_PROF_KINDS
-    ms = (C.c_double * NK)()
-    fl = (C.c_double * NK)()
+    ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
-    by = (C.c_double * NK)()
-    ev_over_ms = 0.0
-    xattn_bytes = 0.0
+    ev_over_ms, xattn_bytes = 0.0, 0.0
     if args.roofline_steps > 0:
-        be.use_graphs = False
-        be.lib.sc_prof_enable(1)
-        sb.stats["xattn_rows"] = 0
+        if args.engine == "native":
+            sb.set_graphs(False)
+            sb.take_xattn_rows()
+        else:
+            sb.be.use_graphs = False
+            sb.stats["xattn_rows"] = 0
+        lib.sc_prof_enable(1)
         run_steps(sb, args.roofline_steps)
         torch.cuda.synchronize()
-        be.lib.sc_prof_enable(0)
-        be.lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
-        be.use_graphs = True
-        ev_over_ms = float(be.lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
+        lib.sc_prof_enable(0)
+        lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
+        if args.engine == "native":
+            sb.set_graphs(True)
+            rows = sb.take_xattn_rows()
+            ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.hip_stream))
+        else:
+            sb.be.use_graphs = True
+            rows = sb.stats.get("xattn_rows", 0)
+            ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
         # cross-attention: K|V rows of every active stream are read once per layer and step
-        xattn_bytes = float(sb.stats.get("xattn_rows", 0)) * 2 * sb.cfg.d_model * 4
+        xattn_bytes = float(rows) * 2 * XL.d_model * 4
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
@@ -219,11 +265,10 @@ def main():
 
     audio_s = world * args.streams * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
-    # dominant kernel of the path = the kernel kind with the largest summed launch time
-    # in the roofline leg (agrees with the rocprofv3 summary under profiles/)
+    # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
-             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<32,10,self>",
-             "dec_attn_flash_kernel<32,10,cross>", "rowtile_proj_kernel<256,*>"]
+             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "decoder self-attention (dec_attn_flash / dec_layer_attn<self>)",
+             "decoder cross-attention (dec_attn_flash / dec_layer_attn<cross>)", "rowtile_proj_kernel<256,*>"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
     per_kernel = []
@@ -244,6 +289,9 @@ def main():
         v = max(range(NK), key=lambda i: net[i])
         raw_us = ms[v] * 1e3 / nn[v]
         t_ms = max(net[v], 1e-9)
+        # traffic: HBM bytes per launch need rocprofv3 --pmc passes of this command (a process cannot read the
+        # counters of its own kernels); they are committed under profiles/ with the bench sha they belong to and
+        # are NOT copied into this line - null here means "not measured by this run".
         common = {"kernel": names[v], "traffic": None,
                   "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
                   "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
@@ -256,7 +304,7 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
-                    "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 5)",
+                    "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 4)",
                     "algorithmic_bytes_per_launch_avg": int(by[v] / nn[v])}
         else:
             bytes_v = xattn_bytes if v == 7 else 0.0
@@ -266,35 +314,42 @@ def main():
                     "algorithmic_bytes_per_launch_avg": int(bytes_v / nn[v])}
         roof.update(common)
 
-    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of
-    # this same command (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE), committed
-    # under profiles/; it cannot be collected from inside the process.
-    if roof is not None and args.streams == 128 and not args.bbd:
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_default_pmc_hbm_traffic.csv")
-        key = roof["kernel"].split("<")[0]
-        if os.path.exists(tpath):
-            for line in open(tpath).read().splitlines()[1:]:
-                cols = line.split(",")
-                if key in cols[0] and (("Lb1E" in cols[0]) == ("self" in roof["kernel"]) or "attn" not in key):
-                    roof["traffic"] = int(cols[-1])
-                    roof["traffic_unit"] = ("HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE*2 + WRITE_SIZE, "
-                                            "profiles/r01_bench_default_pmc_hbm_traffic.csv)")
-                    break
+    # whole chunk step against the matrix-core peak: algorithmic FLOPs of SURVEY 8(d) / wall time
+    gflop_step = args.streams * (GFLOP_ENCODER_SIDE_PER_HOP * CHUNK / 10240.0 + GFLOP_PER_DECODE_STEP * args.beam / 10.0
+                                 * dec_steps_per_hop)
+    ms_step = elapsed / args.steps * 1e3
+    whole = {"algorithmic_gflop_per_step": round(gflop_step, 1),
+             "achieved_tflops_whole_step": round(gflop_step / ms_step, 2),
+             "frac_of_f32_mfma_peak": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 4),
+             "note": "128 x (3.83 + 0.437 x decode steps per hop) GFLOP per chunk step (SURVEY 8(d)) / ms_per_step; the step "
+                     "is latency-bound by ~50 dependent launches per decode iteration, not by FLOPs"}
+
+    deferred = None
+    if not args.no_deferred and world == 1:
+        # the opt-in deferred-stragglers mode (Python engine): identical per-stream results, but up to `threshold`
+        # streams get theirs one chunk period late.  Reported for information, never as `value`.
+        thr = (3 * args.streams) // 8 if args.defer < 0 else args.defer
+        if thr > 0:
+            del sb
+            sbd = build_python_engine(w, args.streams, args.beam, bool(args.bbd), args.warmup + args.steps, device)
+            preload_audio(sbd, args.warmup + args.steps)
+            sbd.set_defer_threshold(thr, args.defer_lag)
+            e2, _ = timed(sbd, args.warmup, args.steps)
+            deferred = {"value": round(args.streams * args.steps * CHUNK / 16000.0 / e2, 2), "unit": "audio_s/s",
+                        "ms_per_step": round(e2 / args.steps * 1e3, 3), "threshold_streams": thr,
+                        "max_lag_blocks": args.defer_lag, "engine": "python (engine.StreamBatch)",
+                        "note": "NOT the headline: results of up to `threshold_streams` streams arrive one chunk period late"}
+            del sbd
 
     single = None
     if not args.no_single_stream and world == 1:
-        OVERLAP = False   # latency of ONE real-time stream: the next chunk does not exist yet
-        sb1, _ = build_batch(1, args.beam, bool(args.bbd), args.warmup + args.steps, device)
+        sb1 = build_native(w, 1, args.beam, bool(args.bbd), args.warmup + args.steps)
         preload_audio(sb1, args.warmup + args.steps)
-        run_steps(sb1, args.warmup)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(sb1, args.steps)
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
+        e1, _ = timed(sb1, args.warmup, args.steps)
         hop_s = CHUNK / 16000.0
         single = {"ms_per_hop": round(e1 / args.steps * 1e3, 3), "rtf": round(e1 / (args.steps * hop_s), 5),
                   "x_realtime": round(args.steps * hop_s / e1, 1)}
+        del sb1
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -306,21 +361,18 @@ def main():
     out = {
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
-                   "deferred_stragglers": args.defer, "deferred_max_lag_blocks": args.defer_lag,
-                   "pipelining": ("encoder of chunk step i+1 on a second HIP stream overlaps the decode loop of step i"
-                                  if args.overlap else "none"),
+                   "semantics": "strict lock-step: every block completes inside its chunk step (the reference's per-call results)",
+                   "engine": "C++ (sc_push, csrc/streams.hip)" if args.engine == "native" else "python (engine.StreamBatch)",
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
         "chunk_steps_per_s": round(world * args.streams * args.steps / elapsed, 2),
-        "decode_steps_per_hop": round(dec_steps / max(args.steps, 1), 2),
-        "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
+        "decode_steps_per_hop": round(dec_steps_per_hop, 2),
+        "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "deferred": deferred,
     }
-    if sb.timing is not None:
-        out["host_phase_ms_per_step"] = {k: round(v / args.steps * 1e3, 3) for k, v in sb.timing.items()}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -431,6 +431,10 @@ int sc_get_hyps(sc_streams *streams, int stream, int nbest, int max_len, int32_t
 int sc_reset(sc_streams *streams, int stream);
 int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
 int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
+/* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
+ * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
+int sc_streams_set_graphs(sc_streams *streams, int on);
+long sc_streams_take_xattn_rows(sc_streams *streams);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);
 float *sc_streams_pcm(sc_streams *streams, long *capacity);

@@ -149,6 +149,8 @@ _SIGS = {
     "sc_reset": (C.c_int, [vp, C.c_int]),
     "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
+    "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_hip_stream": (vp, [vp]),
     "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),
     "sc_streams_write_pcm": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_long]),

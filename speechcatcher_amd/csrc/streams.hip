@@ -131,7 +131,8 @@ struct sc_streams {
   bool decode_prepared = false;
   std::map<int, hipGraphExec_t> dec_graphs;
   std::map<std::vector<long>, hipGraphExec_t> enc_graphs;
-  long dec_steps = 0, dec_blocks = 0, enc_calls = 0;
+  long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows = 0;
+  bool use_graphs = true;
 
   ~sc_streams() {
     for (auto &g : dec_graphs) (void)hipGraphExecDestroy(g.second);
@@ -411,6 +412,7 @@ int enc_layers_launch(sc_streams *b, int nblk, int R, bool masked, const int32_t
                              b->ws_xn, b->ws_qkv, b->ws_att, b->ws_ffh, c.d_model, c.enc_heads, c.ffn_dim, c.ln_eps,
                              b->stream);
   };
+  if (!b->use_graphs) return launch();
   // ~6 launches per layer: replayed from a hipGraph keyed by everything that shapes the launch sequence
   std::vector<long> key{nblk, R, (long)masked, (long)(intptr_t)jobs, ns};
   auto it = b->enc_graphs.find(key);
@@ -536,6 +538,7 @@ void set_rowmap(sc_streams *b, const std::vector<int> &active) {
 
 int decode_step_launch(sc_streams *b) {
   b->sb.n_rows = b->n_rows_step;
+  if (!b->use_graphs) return sc_decode_step(&b->sb, b->stream);
   auto it = b->dec_graphs.find(b->n_rows_step);
   if (it == b->dec_graphs.end()) {
     RC_TRY(sc_decode_step(&b->sb, b->stream));   // warm-up launch (also validates arguments); executes the step
@@ -663,6 +666,8 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     set_rowmap(b, active);
     RC_TRY(upload_ctrl(b));
     b->dec_steps++;
+    for (int i = 0; i < n; ++i)
+      if (live[i]) b->xattn_rows += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
     RC_TRY(decode_step_launch(b));
     HIP_TRY(hipMemcpyAsync(b->flags_host, b->sb.flags, (size_t)S * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1228,6 +1233,20 @@ extern "C" int sc_stream_info(const sc_streams *b, int stream, sc_stream_info_t 
   out->pcm_buffered = (int32_t)(st.pcm_end - st.pcm_start);
   out->frontend_started = st.fe_started;
   return SC_OK;
+}
+
+// measurement aids (bench.py roofline leg): hipGraph replay off so that every launch can be bracketed by HIP
+// events (sc_prof_enable); encoder K|V rows read by the cross-attention since the last call (returns and clears)
+extern "C" int sc_streams_set_graphs(sc_streams *b, int on) {
+  SC_CHECK_ARG(b, "null");
+  b->use_graphs = on != 0;
+  return SC_OK;
+}
+extern "C" long sc_streams_take_xattn_rows(sc_streams *b) {
+  if (!b) return 0;
+  const long v = b->xattn_rows;
+  b->xattn_rows = 0;
+  return v;
 }
 
 extern "C" int sc_streams_stats(const sc_streams *b, long *enc_calls, long *dec_steps, long *dec_blocks) {

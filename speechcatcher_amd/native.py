@@ -227,6 +227,12 @@ class NativeStreamBatch:
         self.lib.sc_streams_read_enc(self.handle, int(s), a.ctypes.data, T)
         return a
 
+    def set_graphs(self, on: bool):
+        self.lib.sc_streams_set_graphs(self.handle, int(bool(on)))
+
+    def take_xattn_rows(self) -> int:
+        return int(self.lib.sc_streams_take_xattn_rows(self.handle))
+
     @property
     def hip_stream(self) -> int:
         return int(self.lib.sc_streams_hip_stream(self.handle) or 0)

@@ -353,7 +353,7 @@ def load_model(tag, device="cuda", beam_size=5, quiet=False, cache_dir="~/.cache
     if fp16:
         logger.warning("FP16 is not supported with the native decoder yet. Disabling FP16.")  # :205-210
     p = Path(str(tag)).expanduser()
-    if p.is_dir():
+    if p.is_dir() or (p.is_file() and p.suffix == BLOB_SUFFIX):
         model_dir = p
     else:
         try:

@@ -138,7 +138,8 @@ def test_oracle_is_only_used_as_the_checker():
 
     for path in sorted((ROOT / "speechcatcher_amd").rglob("*.py")):
         assert oracle_imports(path) == [], f"{path.relative_to(ROOT)} imports the oracle"
-    assert set(oracle_imports(ROOT / "bench.py")) == {"cpu_baseline"}
+    # (the worker function of the cpu_baseline leg: it runs in spawned processes, so it is a top-level function)
+    assert set(oracle_imports(ROOT / "bench.py")) == {"cpu_baseline_worker"}
     assert set(oracle_imports(ROOT / "__graft_entry__.py")) == {"smoke"}
     # the product's only compute backend is the HIP library: no torch arithmetic fallback in the engine
     engine_src = (ROOT / "speechcatcher_amd" / "engine.py").read_text()

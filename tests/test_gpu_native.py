@@ -214,3 +214,70 @@ def test_c_host_program_reproduces_the_reference_fixture(tmp_path):
         if call["n_blocks"]:
             got = sorted(tuple(int(t) for t in h.split()) for h in hyps)
             assert got == sorted(tuple(y) for y in js["blocks"][nblk - 1]["yseq"])
+
+
+def test_cli_round_trips_a_wav(tmp_path):
+    """``python -m speechcatcher_amd -m <model dir> -b 3 recording.wav``: the reference CLI's file mode (flags of
+    speechcatcher.py:756-808) as a child process; the .txt / .json next to the input carry what the library gives
+    for the same recording (one slot = the reference's serial segment loop on one model)."""
+    import sys
+    import wave
+    from speechcatcher_amd.config import TINY, SearchConfig
+    from speechcatcher_amd.native import NativeStreamBatch
+    from speechcatcher_amd.segmenter import recognize_recording
+    from speechcatcher_amd.speech2text_streaming import load_model
+    mdir = synth.write_model_dir(tmp_path / "tiny", TINY, seed=1234, stats_kind="meanstd")
+    rate = 16000
+    x = synth.synth_audio(40, 70 * rate) * 20000
+    for t0 in (18, 41):
+        x[t0 * rate:(t0 + 2) * rate] *= 0.01
+    x = x.astype(np.int16)
+    wav = tmp_path / "rec.wav"
+    with wave.open(str(wav), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(rate)
+        f.writeframes(x.tobytes())
+    res = subprocess.run([sys.executable, "-m", "speechcatcher_amd", "-m", str(mdir), "-b", "3", "--quiet", "--no-progress",
+                          str(wav)], cwd=str(ROOT), capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "Wrote transcription to" in res.stdout
+    out = json.loads((tmp_path / "rec.wav.json").read_text())
+    assert (tmp_path / "rec.wav.txt").read_text() == out["complete_text"]
+    s2t = load_model(str(mdir), device="cuda", beam_size=3, use_bbd=True)
+    sb = NativeStreamBatch(s2t.weights, 1, SearchConfig(beam_size=3, use_bbd=True), max_frames=2000, max_tokens=1200,
+                           pcm_capacity=1 << 21, engine=s2t.batch.engine)
+    text, info = recognize_recording(sb, x, rate, chunk_length=8192, token_list=s2t.token_list, reference_finalize=True)
+    assert out["complete_text"] == text and len(out["paragraphs"]) == len(info)
+    assert out["paragraphs"][0]["tokens"] == info[0]["tokens"]
+    # wrong input format is refused with the conversion hint
+    bad = tmp_path / "bad.wav"
+    with wave.open(str(bad), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(8000)
+        f.writeframes(x[:1000].tobytes())
+    res = subprocess.run([sys.executable, "-m", "speechcatcher_amd", "-m", str(mdir), str(bad)], cwd=str(ROOT),
+                         capture_output=True, text=True)
+    assert res.returncode != 0 and "16 kHz mono" in (res.stderr + res.stdout)
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """The N > 1 path of bench.py, launch-ready: two fresh child processes (one per rank, world size 2, gloo
+    rendezvous on 127.0.0.1, both on the one GPU of this box: SC_BENCH_SINGLE_DEVICE=1) shard the streams, run the
+    barrier / max-over-ranks timing contract and the final gather; rank 0 prints the whole-job JSON line."""
+    import os
+    import socket
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SC_DIST_BACKEND="gloo", SC_BENCH_SINGLE_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "3",
+                                       "--warmup", "2", "--roofline-steps", "0", "--no-cpu-baseline"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert not any(ln.startswith("{") for ln in outs[1][0].splitlines())     # only rank 0 prints the JSON line
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 2 * 8 * 3 * 0.64 / (line["ms_per_step"] * 3e-3)) < 1e-2 * line["value"]   # whole-job aggregate
