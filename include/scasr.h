@@ -120,6 +120,10 @@ typedef struct sc_search {
    * projections [S*W][H][d] and the feed-forward partial sums [max_ffn_part][S*W][d]; NULL: not used */
   float *ph1, *ph2, *ffn_part;
   int32_t max_ffn_part;
+  /* column-major copy of the CTC table [S][V][tct] (tct = TCAP rounded up to a multiple of 4), maintained by
+   * sc_ctc_extend_state and streamed by sc_ctc_prefix_scan; NULL: the scan gathers from ctcx */
+  int32_t tct;
+  float *ctcxT;
 } sc_search;
 
 const char *sc_last_error(void);

@@ -227,7 +227,11 @@ class SpecBackend:
         V = sb.cfg.vocab_size
         for s in range(sb.S):
             act, cur, fin, T, L, nh, has, told = [int(v) for v in ctrl[s]]
-            if not act or not has or told >= T:
+            if not act or told >= T:
+                continue
+            if getattr(sb, "ctcxT", None) is not None:   # column-major copy of the new table rows (sc_ctc_extend_state)
+                sb.ctcxT.view(sb.S, V, -1)[s, :, told:T] = sb.ctcx.view(sb.S, sb.TCAP, V)[s, told:T].t()
+            if not has:
                 continue
             xb = sb.ctcx.view(sb.S, sb.TCAP, V)[s, :, sb.cfg.blank_id]
             r = sb.ctc_r[cur, s]

@@ -46,7 +46,7 @@ class Search(C.Structure):
                              "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
-           ("max_ffn_part", C.c_int32)]
+           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp)]
     )
 
 

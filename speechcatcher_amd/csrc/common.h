@@ -53,9 +53,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.  One of the two
-// exponentials is exp(0) == 1 exactly, so only the other one is evaluated.
+// log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.  One of the two exponentials is exp(0) == 1
+// exactly, so only the other one is evaluated - with the bare hardware transcendentals (v_exp_f32 / v_log_f32:
+// the argument of the log lies in [1, 2], the exponent is <= 0, so none of the range / denormal fix-ups that
+// __expf / __logf carry under -fno-fast-math are needed; they made up most of the prefix scan's 170
+// instructions per frame).
+#define SC_LOG2E 1.4426950408889634f
+#define SC_LN2 0.6931471805599453f
+__device__ __forceinline__ float sc_exp_neg(float x) {   // exp(x) for x <= 0 (flushes below 2^-126)
+  return __builtin_amdgcn_exp2f(x * SC_LOG2E);
+}
+__device__ __forceinline__ float sc_max_raw(float a, float b) {   // one v_max_f32 (fmaxf adds two canonicalising
+  float m;                                                         // v_max x,x under IEEE mode; no NaNs occur here)
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
 __device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  return m + __logf(1.f + __expf(-fabsf(a - b)));
+  const float m = sc_max_raw(a, b);
+  return m + SC_LN2 * __builtin_amdgcn_logf(1.f + sc_exp_neg(-fabsf(a - b)));
 }

@@ -960,6 +960,8 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(ctcx, (size_t)S * b->TCAP * V);
   A(ckv, (size_t)S * c.dec_layers * b->TCAP * 2 * d);
   sb.ctcx = ctcx; sb.ckv = ckv;
+  sb.tct = (b->TCAP + 3) / 4 * 4;
+  A(sb.ctcxT, (size_t)S * V * sb.tct);
   A(sb.skv, (size_t)S * c.dec_layers * b->LCAP * W * 2 * d);
   A(sb.yseq, (size_t)2 * n * b->LCAP);
   A(sb.xpos, (size_t)2 * n * b->LCAP);

@@ -159,6 +159,7 @@ class StreamBatch:
         self.jobs_ctx = z(S, 4, dtype=torch.int32)
         # ---- search state
         self.ctcx = z(S * self.TCAP, V)
+        self.ctcxT = z(S * V, (self.TCAP + 3) // 4 * 4)     # column-major copy streamed by the prefix scan
         self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d)
         self.skv = z(S * cfg.dec_layers * self.LCAP * W, 2 * d)
         self.yseq = z(2, S, W, self.LCAP, dtype=i32)

@@ -211,6 +211,8 @@ class HipBackend:
         s.layers = C.cast(layers, C.c_void_p).value
         s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
         s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
+        if getattr(sb, "ctcxT", None) is not None:  # column-major CTC table copy
+            s.ctcxT, s.tct = sb.ctcxT.data_ptr(), sb.ctcxT.shape[-1]
         if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)
             s.ph1, s.ph2, s.ffn_part = sb.ph1.data_ptr(), sb.ph2.data_ptr(), sb.ffn_part.data_ptr()
             s.max_ffn_part = sb.ffn_part.shape[0]

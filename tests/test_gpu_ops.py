@@ -445,3 +445,93 @@ def test_attention_full_batch_variants_lockstep(hip, monkeypatch, nopre):
         assert ls.calls.get("dec_layer_self", 0) > 0 and ls.calls.get("dec_layer_cross", 0) > 0
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
+
+
+def _scan_setup(hip, S, T, L, has, seed=0):
+    """Two identical batches (CPU spec / GPU) with a random CTC table of T frames, random pre-beam candidates
+    (incl. the last token, eos and blank) and, if `has`, random forward variables of the previous prefix."""
+    from oracle.kernel_spec import SpecBackend
+    from test_engine_spec import make_batch
+    kw = dict(n_streams=S, max_frames=T + 12, max_tokens=L + 8, pcm_capacity=1 << 12)
+    sc = make_batch("TINY", 1234, "meanstd", 10, False, backend=SpecBackend(), **kw)
+    sg = make_batch("TINY", 1234, "meanstd", 10, False, backend=hip, device="cuda:0", **kw)
+    g = torch.Generator().manual_seed(seed)
+    V, W, K = sc.cfg.vocab_size, sc.W, sc.K
+    x = torch.log_softmax(torch.randn(S, sc.TCAP, V, generator=g) * 2.0, -1)
+    x[:, 24:] = torch.randn(S, sc.TCAP - 24, V, generator=g) * 2.0 - 4.0      # later rows are raw logits (A1)
+    sc.ctcx.view(S, sc.TCAP, V).copy_(x)
+    sc.ctcxT.view(S, V, -1)[:, :, :sc.TCAP] = x.transpose(1, 2)
+    for s in range(S):
+        for h in range(W):
+            ids = torch.randperm(V - 2, generator=g)[:K] + 1
+            last = int(ids[3])
+            ids[5], ids[7] = V - 1, 0                                        # eos and blank among the candidates
+            sc.pre_ids[s * W + h] = ids.to(torch.int32)
+            sc.yseq[0, s, h, :L] = torch.randint(1, V - 1, (L,), generator=g).to(torch.int32)
+            sc.yseq[0, s, h, L - 1] = last
+    if has:
+        r = torch.randn(S, sc.TCAP, 2, W, generator=g) * 3.0 - 30.0
+        sc.ctc_r[0].copy_(r)
+    sc.ctrl.copy_(torch.tensor([[1, 0, 0, T, L, W, int(has), 0]] * S, dtype=torch.int32))
+    for k, v in vars(sc).items():
+        if isinstance(v, torch.Tensor) and k in ("ctcx", "ctcxT", "pre_ids", "yseq", "ctc_r", "ctrl"):
+            getattr(sg, k).copy_(v)
+    return sc, sg
+
+
+@pytest.mark.parametrize("T,L,has", [(4500, 300, True), (4500, 1, False), (37, 9, True), (16, 2, False), (450, 120, True)])
+def test_ctc_prefix_scan_long_table(hip, T, L, has):
+    """CTCPrefixScoreTH.__call__ (ctc_prefix_score_full.py:146-291) at the table length of a 180 s CLI segment
+    (T = 4500 encoder frames) and at chunk-boundary lengths: the column-streaming HIP scan against its spec -
+    log psi of all W x K candidates, the eos score and every forward variable r[t]."""
+    from oracle.kernel_spec import SpecBackend
+    sc, sg = _scan_setup(hip, 2, T, L, has)
+    SpecBackend().ctc_prefix_scan(sc)
+    hip.ctc_prefix_scan(sg)
+    torch.cuda.synchronize()
+    W, K = sc.W, sc.K
+    psi_c, psi_g = sc.psi.view(-1), sg.psi.cpu().view(-1)
+    fin = psi_c > -1e9
+    assert torch.equal(fin, psi_g > -1e9)
+    tol = 2e-4 + 2e-6 * T      # T dependent log-add-exps in fp32 on values of magnitude 1e1..1e4
+    assert float((psi_c[fin] - psi_g[fin]).abs().max()) <= tol * max(1.0, float(psi_c[fin].abs().max()) * 1e-2)
+    np.testing.assert_allclose(sg.psi_eos.cpu().numpy(), sc.psi_eos.numpy(), rtol=1e-5, atol=1e-3)
+    rc = sc.ctc_rnew.view(2, sc.TCAP, 2, W * K)[:, :T]
+    rg = sg.ctc_rnew.cpu().view(2, sc.TCAP, 2, W * K)[:, :T]
+    live = rc > -1e9
+    assert torch.equal(live, rg > -1e9)
+    assert float(((rc - rg).abs() / rc.abs().clamp(min=1.0))[live].max()) <= 1e-4
+
+
+def test_ctc_prefix_scan_time_at_long_tables(hip):
+    """Time per launch of the scan at T = 4500 (8 active streams, hypotheses of 300 tokens): the column-streaming
+    kernel against the row-gather kernel it replaces; numbers -> gpurun_out/r02_ctc_scan_timing.json."""
+    import json
+    import os
+    out = {}
+    for T, L in ((450, 250), (4500, 300)):
+        sc, sg = _scan_setup(hip, 8, T, L, True)
+        st = hip.search_struct(sg)
+        for name in ("column_streaming", "row_gather"):
+            keep = st.ctcxT
+            if name == "row_gather":
+                st.ctcxT = None
+            for _ in range(3):
+                hip.ctc_prefix_scan(sg)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                hip.ctc_prefix_scan(sg)
+            b.record()
+            torch.cuda.synchronize()
+            out[f"T{T}_{name}_us"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+            st.ctcxT = keep
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r02_ctc_scan_timing.json", "w") as f:
+        json.dump(out, f)
+    print(out)
+    # 4200 sequential frames x ~45 dependent-ish instructions of ONE wave per SIMD: ~0.16 us per frame measured
+    # (r01: 0.29); the next step is splitting the r^n / r^b / psi chains over waves of different SIMDs (DESIGN 9)
+    assert out["T4500_column_streaming_us"] < 800.0
+    assert out["T4500_column_streaming_us"] <= 1.05 * out["T4500_row_gather_us"]
