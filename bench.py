@@ -55,12 +55,15 @@ def make_weights(device):
     return PackedWeights(sd, XL, device, mean, std)
 
 
+KV_DTYPE = "float32"   # --kv-dtype float16: K|V caches in fp16 (BASELINE configs[4]'s storage mode), never the default
+
+
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None):
     from speechcatcher_amd.native import NativeStreamBatch
     frames, tokens = capacities(n_steps_total)
     return NativeStreamBatch(w, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
                              max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
-                             engine=engine)
+                             engine=engine, kv_dtype=KV_DTYPE)
 
 
 def build_python_engine(w, n_streams, beam, bbd, n_steps_total, device):
@@ -68,7 +71,8 @@ def build_python_engine(w, n_streams, beam, bbd, n_steps_total, device):
     from speechcatcher_amd.hip_backend import HipBackend
     frames, tokens = capacities(n_steps_total)
     return StreamBatch(w, HipBackend(device), n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
-                       max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK)
+                       max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
+                       kv_dtype=KV_DTYPE)
 
 
 def preload_audio(sb, n_steps_total, stream_offset=0):
@@ -180,9 +184,13 @@ def main():
                     help="threshold of the EXTRA deferred-stragglers run (Python engine): end a chunk step's decode loop "
                          "when at most this many streams are still inside their block; -1: 3/8 of the streams")
     ap.add_argument("--defer-lag", type=int, default=1)
+    ap.add_argument("--kv-dtype", choices=["float32", "float16"], default="float32",
+                    help="float16: self-/cross-attention K|V caches stored in fp16, arithmetic fp32 (opt-in; results "
+                         "differ from the fp32 reference within the tolerance stated in tests/test_gpu_native.py)")
     args = ap.parse_args()
-    global CHUNK
+    global CHUNK, KV_DTYPE
     CHUNK = args.chunk
+    KV_DTYPE = args.kv_dtype
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -362,7 +370,7 @@ def main():
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if KV_DTYPE == "float32" else "f32 arithmetic, fp16 K|V caches", "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,

@@ -124,6 +124,10 @@ typedef struct sc_search {
    * sc_ctc_extend_state and streamed by sc_ctc_prefix_scan; NULL: the scan gathers from ctcx */
   int32_t tct;
   float *ctcxT;
+  /* 1: the K|V caches ckv / skv hold IEEE fp16 elements (same element offsets, half the bytes); attention
+   * arithmetic, softmax and everything else stay fp32.  Written through sc_kv_rows_to_half (cross) and by the
+   * self-attention kernels (self); read by the single-pass attention kernels. */
+  int32_t kv_half;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -306,6 +310,11 @@ int sc_encoder_layers(const sc_enc_layer *layers /*HOST*/, int n_layers, float *
 int sc_ctc_extend_state(const sc_search *sb /*HOST*/, void *stream);
 /* embed*sqrt(d)+PE of the newest token (transformer_decoder.py:231) */
 int sc_dec_embed(const sc_search *sb, void *stream);
+/* kv_half: cross-attention K|V rows of all layers from an fp32 staging buffer [n_layers][m][d2] (the output of
+ * the K|V projection GEMMs for m new encoder frames) into the fp16 cache: row j of layer li -> row
+ * rows[j] + li*TCAP. */
+int sc_kv_rows_to_half(const float *stage, const int32_t *rows, int m, int n_layers, int TCAP, int d2,
+                       void *ckv_half, void *stream);
 /* decoder self-attention with K/V cache + ancestor table (decoder_layer.py:85-101) */
 int sc_dec_self_attn(const sc_search *sb, int layer, void *stream);
 /* decoder cross-attention over the shared per-stream K/V (decoder_layer.py:106-115) */
@@ -398,6 +407,7 @@ typedef struct sc_stream_options {
   int32_t pcm_capacity;      /* samples buffered per stream (0: 1 << 20) */
   int32_t max_chunk_samples; /* longest single call (0: 32768) */
   int32_t strict_reference;  /* reset() leaves the stale CTC table / PE counter like the reference (scorers.py:342-350) */
+  int32_t kv_half;           /* K|V caches in fp16 (fp32 arithmetic): BASELINE configs[4]'s storage mode; 0 = fp32 */
 } sc_stream_options;
 
 typedef struct sc_stream_info_t {

@@ -45,3 +45,20 @@ __device__ __forceinline__ void attn_merge_dpp(AttnState &st) {
   st.a.w = st.a.w * ca + pw * cb;
 }
 
+
+// K|V caches in half precision (sc_search.kv_half: fp16 storage, fp32 arithmetic): element offsets are the same
+// as for the fp32 caches, the elements are 2 bytes.  4 consecutive elements <-> one float4.
+typedef _Float16 sc_half4 __attribute__((ext_vector_type(4)));
+template <bool KVH>
+__device__ __forceinline__ float4 kv_load4(const float *base, long elem) {
+  if (KVH) {
+    const sc_half4 h = *reinterpret_cast<const sc_half4 *>(reinterpret_cast<const _Float16 *>(base) + elem);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  return *reinterpret_cast<const float4 *>(base + elem);
+}
+template <bool KVH>
+__device__ __forceinline__ void kv_store1(float *base, long elem, float v) {
+  if (KVH) reinterpret_cast<_Float16 *>(base)[elem] = (_Float16)v;
+  else base[elem] = v;
+}

@@ -79,7 +79,7 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
   return dl_region_floats(D, DK, W, self, pre) + WM * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
 }
 
-template <int D, int DK, int WM, bool SELF, int UNR, bool PRE, bool FIRST>
+template <int D, int DK, int WM, bool SELF, int UNR, bool PRE, bool FIRST, bool KVH>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   constexpr int LPR = DK / 4;    // lanes per K/V row
   constexpr int NG = 256 / LPR;  // row groups per workgroup
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       for (int j = 0; j < 4; ++j) Ps[(wave * 16 + 4 * kk + j) * LDP + t * 16 + r] = acc[t][j];
   }
   __syncthreads();
-  float *skv = sb.skv + ((long)s * sb.n_layers + p.li) * LCAP * W * 2 * D + head * DK;
+  const long skv0 = ((long)s * sb.n_layers + p.li) * LCAP * W * 2 * D + head * DK;   // element offset (fp32 or fp16 cache)
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       } else if (SELF) {
         kvn[w * 2 * DK + (which - 1) * DK + c] = v;
         // append this token's K|V row at (position L-1, slot w); later steps read it from the cache
-        if (w < nh) skv[((long)(L - 1) * W + w) * 2 * D + (which - 1) * D + c] = v;
+        if (w < nh) kv_store1<KVH>(sb.skv, skv0 + ((long)(L - 1) * W + w) * 2 * D + (which - 1) * D + c, v);
       }
     }
   }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   int *rows = PRE ? (int *)region : (int *)(red_a + NPART * W * DK);  // PRE: aliases the partial states
   int *wtot = (int *)region + (PRE ? max(red_floats, NPRE * PCH * W) : red_floats + (SELF ? PCH * W : 0));
   int *ucnt = wtot + 4;
-  const float *ckv = sb.ckv + ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
+  const long ckv0 = ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
 
   AttnState st[WM];
   if (!(SELF && PRE)) {
@@ -371,9 +371,9 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
         for (int i = 0; i < UNR; ++i) {
           e[i] = rw[min(j0 + i * NG, U - 1)];
           const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
-          const float *kp = skv + ((long)pp * W + u) * 2 * D;
-          k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
-          v[i] = *reinterpret_cast<const float4 *>(kp + D + 4 * cq);
+          const long kp = skv0 + ((long)pp * W + u) * 2 * D;
+          k[i] = kv_load4<KVH>(sb.skv, kp + 4 * cq);
+          v[i] = kv_load4<KVH>(sb.skv, kp + D + 4 * cq);
         }
 #pragma unroll
         for (int i = 0; i < UNR; ++i)
@@ -413,9 +413,9 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       float4 k[UNR], v[UNR];
 #pragma unroll
       for (int i = 0; i < UNR; ++i) {
-        const float *kp = ckv + (long)min(j0 + i * NG, T - 1) * 2 * D;
-        k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
-        v[i] = *reinterpret_cast<const float4 *>(kp + D + 4 * cq);
+        const long kp = ckv0 + (long)min(j0 + i * NG, T - 1) * 2 * D;
+        k[i] = kv_load4<KVH>(sb.ckv, kp + 4 * cq);
+        v[i] = kv_load4<KVH>(sb.ckv, kp + D + 4 * cq);
       }
 #pragma unroll
       for (int i = 0; i < UNR; ++i)
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, int DK, bool SELF, bool FIRST>
-static int launch_dec_layer(const DecLayerArgs &p, hipStream_t st) {
+template <int D, int DK, bool SELF, bool FIRST, bool KVH>
+static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   const sc_search &sb = p.sb;
   const dim3 grid(sb.rowmap ? sb.n_rows / sb.W : sb.S, sb.H);   // streams of the compaction bucket only
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
@@ -525,17 +525,22 @@ static int launch_dec_layer(const DecLayerArgs &p, hipStream_t st) {
   const bool pre_ok = !getenv("SC_SELF_ATTN_NOPRE");                    // tests: row lists interleaved with the walk
   auto lds = [&](int wm, bool pre) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF, pre) * sizeof(float); };
   if (sb.W <= 5) {
-    dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST><<<grid, 256, lds(5, false), st>>>(p);
+    dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST, KVH><<<grid, 256, lds(5, false), st>>>(p);
   } else if (sb.W <= 10) {
-    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, false, FIRST><<<grid, 256, lds(10, false), st>>>(p);
+    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
     else if (SELF && sb.LCAP <= 4 * 128 && pre_ok)
-      dec_layer_attn_kernel<D, DK, 10, SELF, 2, SELF, FIRST><<<grid, 256, lds(10, true), st>>>(p);
-    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, false, FIRST><<<grid, 256, lds(10, false), st>>>(p);
+      dec_layer_attn_kernel<D, DK, 10, SELF, 2, SELF, FIRST, KVH><<<grid, 256, lds(10, true), st>>>(p);
+    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
   } else {
-    dec_layer_attn_kernel<D, DK, 16, SELF, 2, false, FIRST><<<grid, 256, lds(16, false), st>>>(p);
+    dec_layer_attn_kernel<D, DK, 16, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(16, false), st>>>(p);
   }
   SC_CHECK_LAUNCH();
   return SC_OK;
+}
+
+template <int D, int DK, bool SELF, bool FIRST>
+static int launch_dec_layer(const DecLayerArgs &p, hipStream_t st) {
+  return p.sb.kv_half ? launch_dec_layer_kvh<D, DK, SELF, FIRST, true>(p, st) : launch_dec_layer_kvh<D, DK, SELF, FIRST, false>(p, st);
 }
 
 template <bool SELF, bool FIRST>

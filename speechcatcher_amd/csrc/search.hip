@@ -74,6 +74,27 @@ extern "C" int sc_ctc_extend_state(const sc_search *sbp, void *stream) {
 }
 
 // ---------------------------------------------------------------------------
+// Cross-attention K|V rows of all layers, fp32 staging [n_layers][m][2d] -> fp16 cache rows (kv_half): row j of
+// layer li goes to cache row rows[j] + li*TCAP (the row table of the projection GEMMs).
+__global__ void kv_rows_to_half_kernel(const float *stage, const int32_t *rows, int m, int TCAP, int d2, _Float16 *ckv) {
+  const int li = blockIdx.y;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)m * d2; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e / d2), c = (int)(e % d2);
+    ckv[((long)rows[j] + (long)li * TCAP) * d2 + c] = (_Float16)stage[((long)li * m + j) * d2 + c];
+  }
+}
+
+extern "C" int sc_kv_rows_to_half(const float *stage, const int32_t *rows, int m, int n_layers, int TCAP, int d2,
+                                  void *ckv_half, void *stream) {
+  SC_CHECK_ARG(stage && rows && ckv_half && m >= 0 && n_layers > 0 && d2 > 0, "bad arguments");
+  if (m == 0) return SC_OK;
+  const int gx = (int)(((long)m * d2 + 255) / 256 > 1024 ? 1024 : ((long)m * d2 + 255) / 256);
+  kv_rows_to_half_kernel<<<dim3(gx, n_layers), 256, 0, (hipStream_t)stream>>>(stage, rows, m, TCAP, d2, (_Float16 *)ckv_half);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
 __global__ void dec_embed_kernel(sc_search sb, float sq) {
   const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
   if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li
 // the first row is walked - into the LDS region that later holds the partial states - so that the
 // 60 registers of running softmax state are not live across the list build (the interleaved form
 // spills 15 VGPRs per thread = 15 MB of scratch writes per launch at 128 streams).
-template <int DK, int WM, bool SELF, int UNR, bool PRE = false>
+template <int DK, int WM, bool SELF, int UNR, bool PRE = false, bool KVH = false>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_flash_kernel(sc_search sb, int li) {
   constexpr int LPR = DK / 4;    // lanes per K/V row
   constexpr int NG = 256 / LPR;  // row groups per workgroup
@@ -236,16 +257,17 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
   // SELF: q|k|v of the new token in dqkv (hypothesis h at + h*3d); CROSS: q in dq
   const float *qbase = SELF ? sb.dqkv + (long)s * W * 3 * d + head * DK : sb.dq + (long)s * W * d + head * DK;
   const int qld = SELF ? 3 * d : d;
-  float *skv = sb.skv + ((long)s * sb.n_layers + li) * LCAP * W * 2 * d + head * DK;
-  const float *ckv = sb.ckv + ((long)s * sb.n_layers + li) * sb.TCAP * 2 * d + head * DK;
+  // element offsets of this (stream, layer, head) in the K|V caches (fp32, or fp16 when KVH: same offsets)
+  const long skv0 = ((long)s * sb.n_layers + li) * LCAP * W * 2 * d + head * DK;
+  const long ckv0 = ((long)s * sb.n_layers + li) * sb.TCAP * 2 * d + head * DK;
   if (SELF) {
     // append this token's K|V rows at (position L-1, slot h); this launch reads
     // them from dqkv, later steps from the cache
     for (int e = tid; e < nh * DK; e += 256) {
       const int h = e / DK, c = e % DK;
-      float *dst = skv + ((long)(L - 1) * W + h) * 2 * d;
-      dst[c] = qbase[(long)h * 3 * d + d + c];
-      dst[d + c] = qbase[(long)h * 3 * d + 2 * d + c];
+      const long dst = skv0 + ((long)(L - 1) * W + h) * 2 * d;
+      kv_store1<KVH>(sb.skv, dst + c, qbase[(long)h * 3 * d + d + c]);
+      kv_store1<KVH>(sb.skv, dst + d + c, qbase[(long)h * 3 * d + 2 * d + c]);
     }
   }
   // queries of all hypotheses, pre-divided by sqrt(dk) (rows >= nh: a valid row, never used)
@@ -341,9 +363,15 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
         for (int i = 0; i < UNR; ++i) {
           e[i] = rw[min(j0 + i * NG, U - 1)];
           const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
-          const float *kp = (pp == L - 1) ? qbase + (long)u * 3 * d + d : skv + ((long)pp * W + u) * 2 * d;
-          k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
-          v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
+          if (pp == L - 1) {   // this step's own row: still in dqkv (fp32)
+            const float *kp = qbase + (long)u * 3 * d + d;
+            k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
+            v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
+          } else {
+            const long kp = skv0 + ((long)pp * W + u) * 2 * d;
+            k[i] = kv_load4<KVH>(sb.skv, kp + 4 * cq);
+            v[i] = kv_load4<KVH>(sb.skv, kp + d + 4 * cq);
+          }
         }
 #pragma unroll
         for (int i = 0; i < UNR; ++i)
@@ -378,9 +406,9 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
       float4 k[UNR], v[UNR];
 #pragma unroll
       for (int i = 0; i < UNR; ++i) {
-        const float *kp = ckv + (long)min(j0 + i * NG, T - 1) * 2 * d;
-        k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
-        v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
+        const long kp = ckv0 + (long)min(j0 + i * NG, T - 1) * 2 * d;
+        k[i] = kv_load4<KVH>(sb.ckv, kp + 4 * cq);
+        v[i] = kv_load4<KVH>(sb.ckv, kp + d + 4 * cq);
       }
 #pragma unroll
       for (int i = 0; i < UNR; ++i)
@@ -444,23 +472,29 @@ static size_t attn_flash_lds(const sc_search &sb, int dk, bool self) {
   return (npart * sb.W * (dk + 2) + (self ? (size_t)128 * sb.W : 0) + 8 + (size_t)16 * dk) * sizeof(float);
 }
 
-template <int DK, bool SELF>
-static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
+template <int DK, bool SELF, bool KVH>
+static void launch_attn_flash_kvh(const sc_search &sb, int layer, hipStream_t st) {
   const dim3 grid(sb.H, sb.rowmap ? sb.n_rows / sb.W : sb.S);   // streams of the compaction bucket only
   const size_t lds = attn_flash_lds(sb, DK, SELF);
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = getenv("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4><<<grid, 256, lds, st>>>(sb, layer);
+  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
   else if (sb.W <= 10) {
-    if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8><<<grid, 256, lds, st>>>(sb, layer);
+    if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
     else if (SELF && sb.LCAP <= 4 * 128 && !getenv("SC_SELF_ATTN_NOPRE")) {
       // all row lists first, aliased with the partial states (see the kernel's PRE note)
       const size_t red = (size_t)16 * sb.W * (DK + 2), lists = (size_t)4 * 128 * sb.W;
       const size_t lds_pre = ((red > lists ? red : lists) + 8 + (size_t)16 * DK) * sizeof(float);
-      dec_attn_flash_kernel<DK, 10, SELF, 2, true><<<grid, 256, lds_pre, st>>>(sb, layer);
-    } else dec_attn_flash_kernel<DK, 10, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
-  } else dec_attn_flash_kernel<DK, 16, SELF, 2><<<grid, 256, lds, st>>>(sb, layer);
+      dec_attn_flash_kernel<DK, 10, SELF, 2, true, KVH><<<grid, 256, lds_pre, st>>>(sb, layer);
+    } else dec_attn_flash_kernel<DK, 10, SELF, 2, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
+  } else dec_attn_flash_kernel<DK, 16, SELF, 2, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
+}
+
+template <int DK, bool SELF>
+static void launch_attn_flash(const sc_search &sb, int layer, hipStream_t st) {
+  if (sb.kv_half) launch_attn_flash_kvh<DK, SELF, true>(sb, layer, st);
+  else launch_attn_flash_kvh<DK, SELF, false>(sb, layer, st);
 }
 
 extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
@@ -479,6 +513,7 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
     SC_CHECK_LAUNCH();
     return SC_OK;
   }
+  SC_CHECK_ARG(!sb.kv_half, "half-precision K|V caches need the single-pass attention kernels");
   if (dk == 32) dec_self_attn_kernel<32><<<grid, 256, 0, st>>>(sb, layer);
   else if (dk == 16) dec_self_attn_kernel<16><<<grid, 256, 0, st>>>(sb, layer);
   else { sc_set_error("sc_dec_self_attn: unsupported head dim %d", dk); return SC_ERR_ARG; }
@@ -640,6 +675,7 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
     SC_CHECK_LAUNCH();
     return SC_OK;
   }
+  SC_CHECK_ARG(!sb.kv_half, "half-precision K|V caches need the single-pass attention kernels");
   dim3 grid(seq ? 1 : cdiv(sb.TCAP, 256), sb.H, sb.S);
   size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 4 * sb.W + sb.W * dk) * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "beam too wide for the cross-attention LDS tile");

@@ -121,6 +121,8 @@ struct sc_streams {
         *c1 = nullptr, *c2 = nullptr, *xblk = nullptr, *ws_xn = nullptr, *ws_qkv = nullptr, *ws_att = nullptr,
         *ws_ffh = nullptr;
   int32_t *jobs_ctx = nullptr, *ctrlmap = nullptr, *arena_dev = nullptr;
+  float *kv_stage = nullptr;   // kv_half: fp32 staging [dec_layers][kv_stage_rows][2d] of the K|V projections
+  int kv_stage_rows = 0;
   sc_search sb{};
   // pinned host
   int32_t *ctrlmap_host = nullptr, *ctrl0_host = nullptr, *flags_host = nullptr, *arena_host = nullptr;
@@ -616,9 +618,21 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     if (!same_rows || !ar) RC_TRY(b->itensor(krows, &ar));
     const int32_t *kvt;
     RC_TRY(b->itensor(kv0, &kvt));   // one row table for all layers: layer li's rows start li*TCAP rows further
-    for (int li = 0; li < Ld; ++li)
-      RC_TRY(sc_gemm(b->enc, ar, d, e->wkv[li], e->bkv[li], const_cast<float *>(b->sb.ckv) + (size_t)li * b->TCAP * 2 * d,
-                     kvt, 2 * d, (int)kv0.size(), 2 * d, d, 0, 0, b->stream));
+    const int m = (int)kv0.size();
+    if (!b->sb.kv_half) {
+      for (int li = 0; li < Ld; ++li)
+        RC_TRY(sc_gemm(b->enc, ar, d, e->wkv[li], e->bkv[li], const_cast<float *>(b->sb.ckv) + (size_t)li * b->TCAP * 2 * d,
+                       kvt, 2 * d, m, 2 * d, d, 0, 0, b->stream));
+    } else {
+      // fp16 cache: project into the fp32 staging buffer (dense rows), then convert + scatter all layers at once
+      for (int r0 = 0; r0 < m; r0 += b->kv_stage_rows) {
+        const int mm = std::min(b->kv_stage_rows, m - r0);
+        for (int li = 0; li < Ld; ++li)
+          RC_TRY(sc_gemm(b->enc, ar + r0, d, e->wkv[li], e->bkv[li], b->kv_stage + (size_t)li * mm * 2 * d, nullptr, 2 * d,
+                         mm, 2 * d, d, 0, 0, b->stream));
+        RC_TRY(sc_kv_rows_to_half(b->kv_stage, kvt + r0, mm, Ld, b->TCAP, 2 * d, const_cast<float *>(b->sb.ckv), b->stream));
+      }
+    }
   }
   if (!b->decode_prepared) {
     b->decode_prepared = true;
@@ -958,11 +972,17 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   sb.w_dec = 1.0f - o->ctc_weight; sb.w_ctc = o->ctc_weight; sb.ln_eps = c.ln_eps;
   float *ctcx = nullptr, *ckv = nullptr;
   A(ctcx, (size_t)S * b->TCAP * V);
-  A(ckv, (size_t)S * c.dec_layers * b->TCAP * 2 * d);
+  sb.kv_half = o->kv_half != 0;
+  const size_t kvdiv = sb.kv_half ? 2 : 1;   // fp16 elements: half the bytes
+  A(ckv, (size_t)S * c.dec_layers * b->TCAP * 2 * d / kvdiv + 4);
   sb.ctcx = ctcx; sb.ckv = ckv;
+  if (sb.kv_half) {
+    b->kv_stage_rows = std::max(256, S * 24);
+    A(b->kv_stage, (size_t)c.dec_layers * b->kv_stage_rows * 2 * d);
+  }
   sb.tct = (b->TCAP + 3) / 4 * 4;
   A(sb.ctcxT, (size_t)S * V * sb.tct);
-  A(sb.skv, (size_t)S * c.dec_layers * b->LCAP * W * 2 * d);
+  A(sb.skv, (size_t)S * c.dec_layers * b->LCAP * W * 2 * d / kvdiv + 4);
   A(sb.yseq, (size_t)2 * n * b->LCAP);
   A(sb.xpos, (size_t)2 * n * b->LCAP);
   A(sb.anc, (size_t)2 * S * b->LCAP * W);

@@ -110,7 +110,7 @@ class StreamBatch:
     def __init__(self, weights: PackedWeights, backend, n_streams: int,
                  search: SearchConfig = SearchConfig(), max_frames: int = 1600,
                  max_tokens: int = 640, pcm_capacity: int = 1 << 20,
-                 max_chunk_samples: int = 32768, strict_reference: bool = True):
+                 max_chunk_samples: int = 32768, strict_reference: bool = True, kv_dtype: str = "float32"):
         self.w = weights
         self.cfg = cfg = weights.cfg
         self.be = backend
@@ -160,8 +160,15 @@ class StreamBatch:
         # ---- search state
         self.ctcx = z(S * self.TCAP, V)
         self.ctcxT = z(S * V, (self.TCAP + 3) // 4 * 4)     # column-major copy streamed by the prefix scan
-        self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d)
-        self.skv = z(S * cfg.dec_layers * self.LCAP * W, 2 * d)
+        # K|V caches: fp32 (the reference's arithmetic) or fp16 storage (kv_dtype="float16": half the attention
+        # kernels' HBM stream; arithmetic stays fp32; HIP backend only)
+        kvt = {"float32": f32, "float16": torch.float16}[kv_dtype]
+        if kvt != f32 and not hasattr(backend, "kv_rows_to_half"):
+            raise EngineError("half-precision K|V caches need the HIP backend")
+        self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d, dtype=kvt)
+        self.skv = z(S * cfg.dec_layers * self.LCAP * W, 2 * d, dtype=kvt)
+        self.kv_stage_rows = max(256, S * 24)
+        self.kv_stage = z(cfg.dec_layers * self.kv_stage_rows, 2 * d) if kvt != f32 else None
         self.yseq = z(2, S, W, self.LCAP, dtype=i32)
         self.xpos = z(2, S, W, self.LCAP, dtype=i32)
         self.anc = z(2, S, self.LCAP, W, dtype=i32)
@@ -945,6 +952,23 @@ class StreamBatch:
     # ------------------------------------------------------------------
     # _decode_one_block for a lock-step group of streams
     # ------------------------------------------------------------------
+    def _project_cross_kv(self, ar, kvt, m):
+        """Cross-attention K|V rows of m new encoder frames, all decoder layers (projected ONCE per frame and
+        shared by every hypothesis and step: decoder_layer.py:106-115 recomputes them per call)."""
+        cfg, be, w = self.cfg, self.be, self.w
+        d, Ld = cfg.d_model, cfg.dec_layers
+        if self.kv_stage is None:
+            for li in range(Ld):
+                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
+                        kvt, 2 * d, m, 2 * d, d)
+            return
+        for r0 in range(0, m, self.kv_stage_rows):      # fp16 cache: fp32 staging, then convert + scatter all layers
+            mm = min(self.kv_stage_rows, m - r0)
+            for li in range(Ld):
+                be.gemm(self.enc, ar[r0:], d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.kv_stage[li * mm:], None, 2 * d,
+                        mm, 2 * d, d)
+            be.kv_rows_to_half(self.kv_stage, kvt[r0:], mm, Ld, self.TCAP, 2 * d, self.ckv)
+
     def _decode_blocks(self, todo: List[Tuple[int, int, bool]]):
         """_decode_one_block (beam_search.py:655-838) for a lock-step group of
         streams.  Per-stream scalars are handled as numpy vectors so the host
@@ -993,9 +1017,7 @@ class StreamBatch:
                 ar = self._itensor(rows)
             m = int(kv0.shape[0])
             kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
-            for li in range(Ld):
-                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
-                        kvt, 2 * d, m, 2 * d, d)
+            self._project_cross_kv(ar, kvt, m)
         if not self._decode_prepared:
             # one-time: capture the per-bucket decode graphs while every stream is idle on the device
             self._decode_prepared = True
@@ -1174,9 +1196,7 @@ class StreamBatch:
                 ar = self._itensor(np.concatenate(krows))
             m = int(kv0.shape[0])
             kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
-            for li in range(Ld):
-                be.gemm(self.enc, ar, d, w.dec[li]["wkv"], w.dec[li]["bkv"], self.ckv[li * self.TCAP:],
-                        kvt, 2 * d, m, 2 * d, d)
+            self._project_cross_kv(ar, kvt, m)
 
     def _decode_deferred(self, threshold: int):
         """Resumable form of _decode_blocks over S-sized state vectors (self._d / self._db)."""

@@ -108,6 +108,10 @@ class HipBackend:
                                            _p(R), _p(C_out), C_out.shape[-1], _p(g2), _p(b2), _p(LN2),
                                            self._stream()), "sc_rowtile_proj")
 
+    def kv_rows_to_half(self, stage, rows, m, n_layers, tcap, d2, ckv):
+        self._chk(self.lib.sc_kv_rows_to_half(_p(stage), _p(rows), m, n_layers, tcap, d2, _p(ckv), self._stream()),
+                  "sc_kv_rows_to_half")
+
     def copy_rows(self, src, src_rows, dst, dst_rows, n, width):
         self._chk(self.lib.sc_copy_rows(_p(src), _p(src_rows), _p(dst), _p(dst_rows), n, width,
                                         self._stream()), "sc_copy_rows")
@@ -211,6 +215,7 @@ class HipBackend:
         s.layers = C.cast(layers, C.c_void_p).value
         s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
         s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
+        s.kv_half = 1 if sb.ckv.dtype == torch.float16 else 0
         if getattr(sb, "ctcxT", None) is not None:  # column-major CTC table copy
             s.ctcxT, s.tct = sb.ctcxT.data_ptr(), sb.ctcxT.shape[-1]
         if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)
