@@ -106,6 +106,22 @@ int dalloc(T **p, size_t n) {
 
 }  // namespace
 
+struct EncPlan {
+  std::vector<int32_t> conv_jobs, a_rows, lin_dst, feat_src, feat_dst, blk_jobs, sjobs, emit_src, emit_dst, sub_src,
+      sub_dst;
+  struct Short { int s, ubase, U, pe_pos, dst_T; };
+  std::vector<Short> shorts;
+  int n_conv = 0, max_t1 = 0;
+};
+
+// frontend + encoder launches of one push, planned (host state already advanced) but not yet issued
+struct PendingEnc {
+  bool valid = false;
+  std::vector<int32_t> fe_jobs;
+  int n_fe = 0, max_keep = 0;
+  EncPlan P;
+};
+
 struct sc_streams {
   sc_engine *eng = nullptr;
   sc_config cfg{};
@@ -114,7 +130,16 @@ struct sc_streams {
   long PCAP = 0;
   bool use_bbd = false, strict = true;
   hipStream_t stream = nullptr;
-  void *ws = nullptr;
+  // Encoder side of a chunk step on its OWN HIP stream: frontend + encoder of a push do not feed the decode blocks
+  // whose frames were already there before the push (the block schedule runs one hop behind the encoder, SURVEY
+  // A7), so both proceed concurrently - the encoder's MFMA-bound grids fill the CUs that the latency-bound decode
+  // iterations leave idle.  `es` is the stream the current phase launches into.
+  hipStream_t stream_enc = nullptr, es = nullptr;
+  hipEvent_t ev_enc_done = nullptr;
+  bool enc_pending = false;      // the encoder stage of this push has been launched and may still be running
+  PendingEnc *pend = nullptr;   // ... has been planned but not launched yet (launched when the decode loop thins out)
+  int enc_start_thr = 0;         // launch it when at most this many streams are still in the step loop
+  void *ws = nullptr, *ws_enc = nullptr;
   std::vector<void *> owned;
   // device buffers
   float *pcm = nullptr, *featbuf = nullptr, *subbuf = nullptr, *prev_addin = nullptr, *past_ctx = nullptr, *enc = nullptr,
@@ -140,6 +165,12 @@ struct sc_streams {
     for (auto &g : dec_graphs) (void)hipGraphExecDestroy(g.second);
     for (auto &g : enc_graphs) (void)hipGraphExecDestroy(g.second);
     if (stream) (void)sc_set_stream_workspace(stream, nullptr, 0);
+    if (stream_enc) {
+      (void)sc_set_stream_workspace(stream_enc, nullptr, 0);
+      (void)hipStreamDestroy(stream_enc);
+    }
+    if (ev_enc_done) (void)hipEventDestroy(ev_enc_done);
+    delete pend;
     for (void *p : owned) (void)hipFree(p);
     if (ctrlmap_host) (void)hipHostFree(ctrlmap_host);
     if (ctrl0_host) (void)hipHostFree(ctrl0_host);
@@ -169,7 +200,7 @@ struct sc_streams {
     arena_off = off + ((n + 63) & ~size_t(63));
     if (n) {
       memcpy(arena_host + off, a.data(), n * sizeof(int32_t));
-      HIP_TRY(hipMemcpyAsync(arena_dev + off, arena_host + off, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(arena_dev + off, arena_host + off, n * sizeof(int32_t), hipMemcpyHostToDevice, es));
     }
     *out = arena_dev + off;
     return SC_OK;
@@ -264,13 +295,6 @@ int compact_pcm(sc_streams *b, int s) {
 
 struct Chunk { int s; const float *pcm; long n; bool fin; };
 
-struct EncPlan {
-  std::vector<int32_t> conv_jobs, a_rows, lin_dst, feat_src, feat_dst, blk_jobs, sjobs, emit_src, emit_dst, sub_src,
-      sub_dst;
-  struct Short { int s, ubase, U; };
-  std::vector<Short> shorts;
-  int n_conv = 0, max_t1 = 0;
-};
 
 // forward_infer planning for the listed streams; pure host state changes.
 // Throws StreamFault for per-stream failures.
@@ -344,7 +368,10 @@ void encode_plan(sc_streams *b, const std::vector<int> &streams, const std::map<
       nb = (int)std::ceil((double)(U - offset - c.look_ahead) / (double)c.hop_size);
       if (st.n_blocks == 0 && U <= c.block_size) {
         if (st.T_enc + U > b->TCAP) throw StreamFault{s, SC_ERR_CAPACITY, "encoder-frame capacity exceeded (max_frames)"};
-        P.shorts.push_back({s, ubase, U});
+        // short-segment path (:345-351): the host state advances at planning time (the launch may come later)
+        P.shorts.push_back({s, ubase, U, st.short_pos, st.T_enc});
+        st.short_pos += U;   // StreamPositionalEncoding's internal counter (A13)
+        st.T_enc += U;
         continue;
       }
     } else {
@@ -412,7 +439,7 @@ int enc_layers_launch(sc_streams *b, int nblk, int R, bool masked, const int32_t
   auto launch = [&]() {
     return sc_encoder_layers(e->enc.data(), (int)e->enc.size(), b->xblk, nblk, R, masked ? 1 : 0, jobs, ns, b->past_ctx,
                              b->ws_xn, b->ws_qkv, b->ws_att, b->ws_ffh, c.d_model, c.enc_heads, c.ffn_dim, c.ln_eps,
-                             b->stream);
+                             b->es);
   };
   if (!b->use_graphs) return launch();
   // ~6 launches per layer: replayed from a hipGraph keyed by everything that shapes the launch sequence
@@ -420,35 +447,33 @@ int enc_layers_launch(sc_streams *b, int nblk, int R, bool masked, const int32_t
   auto it = b->enc_graphs.find(key);
   if (it == b->enc_graphs.end()) {
     if (b->enc_graphs.size() >= 16) return launch();   // ragged callers: do not hoard graphs
-    RC_TRY(sc_graph_capture_begin(b->stream));
+    RC_TRY(sc_graph_capture_begin(b->es));
     const int rc = launch();
     void *g = nullptr;
-    const int rc2 = sc_graph_capture_end(b->stream, &g);
+    const int rc2 = sc_graph_capture_end(b->es, &g);
     if (rc != SC_OK) return rc;
     if (rc2 != SC_OK) return rc2;
     it = b->enc_graphs.emplace(key, (hipGraphExec_t)g).first;
   }
-  return sc_graph_launch(it->second, b->stream);
+  return sc_graph_launch(it->second, b->es);
 }
 
-int encode_short(sc_streams *b, int s, int ubase, int U) {
+int encode_short(sc_streams *b, const EncPlan::Short &sh) {
   // short-segment path (:345-351): one un-blocked pass, no mask, no context slots, A13 counter
   const sc_config &c = b->cfg;
   sc_engine *e = b->eng;
-  St &st = b->st[s];
+  const int U = sh.U;
   const int32_t *jd, *src, *dst;
-  RC_TRY(b->itensor({ubase, U, st.short_pos, 0, 1, 0}, &jd));
-  st.short_pos += U;
-  RC_TRY(sc_block_pack(b->subbuf, jd, 1, U, e->f("pe"), c.d_model, b->xblk, b->stream));
+  RC_TRY(b->itensor({sh.ubase, U, sh.pe_pos, 0, 1, 0}, &jd));
+  RC_TRY(sc_block_pack(b->subbuf, jd, 1, U, e->f("pe"), c.d_model, b->xblk, b->es));
   RC_TRY(sc_encoder_layers(e->enc.data(), (int)e->enc.size(), b->xblk, 1, U, 0, nullptr, 0, b->past_ctx, b->ws_xn,
-                           b->ws_qkv, b->ws_att, b->ws_ffh, c.d_model, c.enc_heads, c.ffn_dim, c.ln_eps, b->stream));
+                           b->ws_qkv, b->ws_att, b->ws_ffh, c.d_model, c.enc_heads, c.ffn_dim, c.ln_eps, b->es));
   std::vector<int32_t> a(U), d(U);
-  for (int i = 0; i < U; ++i) { a[i] = i; d[i] = s * b->TCAP + st.T_enc + i; }
+  for (int i = 0; i < U; ++i) { a[i] = i; d[i] = sh.s * b->TCAP + sh.dst_T + i; }
   RC_TRY(b->itensor(a, &src));
   RC_TRY(b->itensor(d, &dst));
   RC_TRY(sc_layernorm(b->xblk, src, c.d_model, b->enc, dst, c.d_model, U, c.d_model, e->f("enc_norm_g"), e->f("enc_norm_b"),
-                      c.ln_eps, b->stream));
-  st.T_enc += U;
+                      c.ln_eps, b->es));
   return SC_OK;
 }
 
@@ -459,18 +484,18 @@ int encode_launch(sc_streams *b, EncPlan &P) {
   b->enc_calls++;
   const int32_t *cj, *ar, *ld;
   RC_TRY(b->itensor(P.conv_jobs, &cj));
-  RC_TRY(sc_conv1(b->featbuf, c.n_mels, cj, P.n_conv, P.max_t1, e->f("conv1_w"), e->f("conv1_b"), d, b->c1, b->stream));
+  RC_TRY(sc_conv1(b->featbuf, c.n_mels, cj, P.n_conv, P.max_t1, e->f("conv1_w"), e->f("conv1_b"), d, b->c1, b->es));
   RC_TRY(b->itensor(P.a_rows, &ar));
   RC_TRY(sc_gemm(b->c1, ar, d, e->f("conv2_w"), e->f("conv2_b"), b->c2, nullptr, d, (int)P.a_rows.size(), d, 9 * d,
-                 SC_GEMM_RELU, F1, b->stream));
+                 SC_GEMM_RELU, F1, b->es));
   RC_TRY(b->itensor(P.lin_dst, &ld));
   RC_TRY(sc_gemm(b->c2, nullptr, F2 * d, e->f("sub_out_w"), e->f("sub_out_b"), b->subbuf, ld, d, (int)P.lin_dst.size(), d,
-                 F2 * d, 0, 0, b->stream));
+                 F2 * d, 0, 0, b->es));
   if (!P.feat_src.empty()) {
     const int32_t *a, *z;
     RC_TRY(b->itensor(P.feat_src, &a));
     RC_TRY(b->itensor(P.feat_dst, &z));
-    RC_TRY(sc_copy_rows(b->featbuf, a, b->featbuf, z, (int)P.feat_src.size(), c.n_mels, b->stream));
+    RC_TRY(sc_copy_rows(b->featbuf, a, b->featbuf, z, (int)P.feat_src.size(), c.n_mels, b->es));
   }
   const int nbk = (int)P.blk_jobs.size() / 6, ns = (int)P.sjobs.size() / 5;
   if (nbk > 0) {
@@ -480,7 +505,7 @@ int encode_launch(sc_streams *b, EncPlan &P) {
     }
     const int32_t *bj, *ja;
     RC_TRY(b->itensor(P.blk_jobs, &bj));
-    RC_TRY(sc_block_pack(b->subbuf, bj, nbk, R, e->f("pe"), d, b->xblk, b->stream));
+    RC_TRY(sc_block_pack(b->subbuf, bj, nbk, R, e->f("pe"), d, b->xblk, b->es));
     std::vector<int32_t> j_add(ns * 4), j_ctx(ns * 4);
     for (int i = 0; i < ns; ++i) {
       const int32_t *sj = &P.sjobs[i * 5];
@@ -488,11 +513,11 @@ int encode_launch(sc_streams *b, EncPlan &P) {
       j_ctx[i * 4 + 0] = sj[0]; j_ctx[i * 4 + 1] = sj[1]; j_ctx[i * 4 + 2] = sj[2] * c.enc_layers; j_ctx[i * 4 + 3] = sj[4];
     }
     RC_TRY(b->itensor(j_add, &ja));
-    RC_TRY(sc_ctx_handoff(b->xblk, R, ja, ns, b->prev_addin, 0, d, b->stream));
+    RC_TRY(sc_ctx_handoff(b->xblk, R, ja, ns, b->prev_addin, 0, d, b->es));
     // the layer loop reads its job table from a persistent buffer (stable address: it is replayed from a graph)
     const int32_t *jc;
     RC_TRY(b->itensor(j_ctx, &jc));
-    HIP_TRY(hipMemcpyAsync(b->jobs_ctx, jc, j_ctx.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->jobs_ctx, jc, j_ctx.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, b->es));
     RC_TRY(enc_layers_launch(b, nbk, R, true, b->jobs_ctx, ns));
   }
   if (!P.emit_src.empty()) {
@@ -500,14 +525,14 @@ int encode_launch(sc_streams *b, EncPlan &P) {
     RC_TRY(b->itensor(P.emit_src, &a));
     RC_TRY(b->itensor(P.emit_dst, &z));
     RC_TRY(sc_layernorm(b->xblk, a, d, b->enc, z, d, (int)P.emit_src.size(), d, e->f("enc_norm_g"), e->f("enc_norm_b"),
-                        c.ln_eps, b->stream));
+                        c.ln_eps, b->es));
   }
-  for (auto &sh : P.shorts) RC_TRY(encode_short(b, sh.s, sh.ubase, sh.U));
+  for (auto &sh : P.shorts) RC_TRY(encode_short(b, sh));
   if (!P.sub_src.empty()) {
     const int32_t *a, *z;
     RC_TRY(b->itensor(P.sub_src, &a));
     RC_TRY(b->itensor(P.sub_dst, &z));
-    RC_TRY(sc_copy_rows(b->subbuf, a, b->subbuf, z, (int)P.sub_src.size(), d, b->stream));
+    RC_TRY(sc_copy_rows(b->subbuf, a, b->subbuf, z, (int)P.sub_src.size(), d, b->es));
   }
   return SC_OK;
 }
@@ -570,6 +595,7 @@ int prepare_decode(sc_streams *b) {
 }
 
 struct Todo { int s, T; bool fin; };
+int launch_encoder(sc_streams *b);
 
 // _decode_one_block (beam_search.py:655-838) for a lock-step group of streams
 int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<StreamFault> &faults) {
@@ -676,6 +702,8 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
       int32_t *r = ctrl + todo[i].s * 8;
       r[0] = live[i]; r[1] = cur[i]; r[2] = fin[i]; r[3] = T[i]; r[4] = L[i]; r[5] = nhyp[i]; r[6] = has[i]; r[7] = Ttab[i];
     }
+    // the encoder stage of this push fills the CUs that the thinned-out step loop leaves idle
+    if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
     std::sort(active.begin(), active.end());
     set_rowmap(b, active);
     RC_TRY(upload_ctrl(b));
@@ -734,8 +762,10 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
   return SC_OK;
 }
 
+// t_old (optional): encoder frames every stream had BEFORE this push's encoder stage, which may still be running on
+// the encoder stream: a block that only sees those frames does not wait for it
 int stage_decode(sc_streams *b, const std::map<int, int> &feat_new, const std::map<int, bool> &finals,
-                 std::vector<StreamFault> &faults) {
+                 std::vector<StreamFault> &faults, const std::vector<int> *t_old = nullptr) {
   // decode schedule (beam_search.py:590-634), rounds of lock-step blocks
   const sc_config &c = b->cfg;
   std::map<int, bool> done_final;
@@ -756,6 +786,15 @@ int stage_decode(sc_streams *b, const std::map<int, int> &feat_new, const std::m
       }
     }
     if (todo.empty()) break;
+    if (b->enc_pending || b->pend->valid) {
+      bool needs_new = t_old == nullptr;
+      for (auto &t : todo) needs_new = needs_new || t.T > (*t_old)[t.s];
+      if (needs_new) {   // a block of this round sees frames of this push: order the decode stream behind the encoder
+        RC_TRY(launch_encoder(b));
+        if (b->enc_pending) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_enc_done, 0));
+        b->enc_pending = false;
+      }
+    }
     RC_TRY(decode_blocks(b, todo, faults));
     for (auto &t : todo)
       if (!t.fin) b->st[t.s].processed_block += 1;
@@ -766,7 +805,6 @@ int stage_decode(sc_streams *b, const std::map<int, int> &feat_new, const std::m
 int stage_encode(sc_streams *b, const std::vector<Chunk> &chunks, std::map<int, int> &feat_new, std::map<int, bool> &finals,
                  std::vector<int> &has_out) {
   const sc_config &c = b->cfg;
-  sc_engine *e = b->eng;
   std::vector<int32_t> fe_jobs;
   int n_fe = 0, max_keep = 0;
   for (size_t k = 0; k < chunks.size(); ++k) {
@@ -776,7 +814,7 @@ int stage_encode(sc_streams *b, const std::vector<Chunk> &chunks, std::map<int, 
     if (st.pcm_end + ch.n > b->PCAP) throw StreamFault{ch.s, SC_ERR_CAPACITY, "pcm buffer capacity exceeded"};
     if (ch.n > 0 && ch.pcm)
       if (hipMemcpyAsync(b->pcm + (long)ch.s * b->PCAP + st.pcm_end, ch.pcm, ch.n * sizeof(float), hipMemcpyHostToDevice,
-                         b->stream) != hipSuccess)
+                         b->es) != hipSuccess)
         throw StreamFault{ch.s, SC_ERR_LAUNCH, "copy of the PCM chunk failed"};
     st.pcm_end += ch.n;
     FePlan p = plan_frontend(c, st, ch.fin);
@@ -800,15 +838,39 @@ int stage_encode(sc_streams *b, const std::vector<Chunk> &chunks, std::map<int, 
     if (kv.second >= 3) enc_streams.push_back(kv.first);   // n < 3: encoder skipped, frames discarded (:551-559)
   }
   if (!enc_streams.empty()) encode_plan(b, enc_streams, feat_new, finals, P);
-  if (n_fe) {
-    const int32_t *jobs;
-    if (b->itensor(fe_jobs, &jobs) != SC_OK) return SC_ERR_ARG;
-    RC_TRY(sc_logmel(b->pcm, (int)b->PCAP, jobs, n_fe, max_keep, e->f("window"), e->f("mel_fb"), e->f("twiddle"),
-                     (const double *)e->f("mean64"), (const double *)e->f("std64"), c.mvn_mode, c.n_fft, c.hop_length,
-                     c.win_length, c.n_mels, b->featbuf, b->stream));
-  }
-  if (P.n_conv) RC_TRY(encode_launch(b, P));
+  PendingEnc &pe = *b->pend;
+  pe.valid = n_fe > 0 || P.n_conv > 0;
+  pe.fe_jobs = std::move(fe_jobs);
+  pe.n_fe = n_fe;
+  pe.max_keep = max_keep;
+  pe.P = std::move(P);
   return SC_OK;
+}
+
+// issue the planned frontend + encoder launches (on the encoder stream when there is one)
+int launch_encoder(sc_streams *b) {
+  PendingEnc &pe = *b->pend;
+  if (!pe.valid) return SC_OK;
+  pe.valid = false;
+  const sc_config &c = b->cfg;
+  sc_engine *e = b->eng;
+  b->es = b->stream_enc ? b->stream_enc : b->stream;
+  int rc = SC_OK;
+  if (pe.n_fe) {
+    const int32_t *jobs;
+    rc = b->itensor(pe.fe_jobs, &jobs);
+    if (rc == SC_OK)
+      rc = sc_logmel(b->pcm, (int)b->PCAP, jobs, pe.n_fe, pe.max_keep, e->f("window"), e->f("mel_fb"), e->f("twiddle"),
+                     (const double *)e->f("mean64"), (const double *)e->f("std64"), c.mvn_mode, c.n_fft, c.hop_length,
+                     c.win_length, c.n_mels, b->featbuf, b->es);
+  }
+  if (rc == SC_OK && pe.P.n_conv) rc = encode_launch(b, pe.P);
+  if (b->stream_enc) {
+    (void)hipEventRecord(b->ev_enc_done, b->stream_enc);
+    b->enc_pending = true;
+  }
+  b->es = b->stream;
+  return rc;
 }
 
 }  // namespace
@@ -1019,6 +1081,42 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   sb.out_w = e->f("out_w"); sb.out_b = e->f("out_b"); sb.out_w_q = e->f("out_w_q", false);
   sb.layers = e->dec.data();
   (void)sc_set_stream_workspace(b->stream, b->ws, (size_t)128 << 20);
+  b->es = b->stream;
+  b->pend = new PendingEnc;
+  {
+    // The encoder stage starts when at most 7 % of the streams are still in the step loop (small batches: at once).
+    // Measured at 128 streams (profiles/r02_encoder_overlap_sweep.txt): serial 33.4 ms per chunk step; started with
+    // the first decode iteration 32.2 (its large grids delay the full-batch decode kernels); at 50 % / 25 % / 10 % /
+    // 7 % / 3 % of the streams 31.3 / 31.1 / 30.5 / 30.5 / 30.8.  SC_ENC_START overrides the percentage.
+    const char *th = getenv("SC_ENC_START");
+    b->enc_start_thr = S < 16 ? S : std::max(1, (int)((long)S * (th ? atoi(th) : 7) / 100));
+  }
+  {
+    // second stream for the encoder side (see sc_streams::stream_enc).  SC_ENC_OVERLAP=0 keeps everything on one
+    // stream; SC_ENC_CUS=n restricts the encoder stream to the first n compute units (hipExtStreamCreateWithCUMask)
+    const char *ov = getenv("SC_ENC_OVERLAP");
+    if (!(ov && atoi(ov) == 0)) {
+      const char *cu = getenv("SC_ENC_CUS");
+      const int ncu = cu ? atoi(cu) : 0;
+      hipError_t er;
+      if (ncu > 0 && ncu < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+        er = hipExtStreamCreateWithCUMask(&b->stream_enc, 8, mask);
+      } else {
+        er = hipStreamCreateWithPriority(&b->stream_enc, hipStreamNonBlocking, 0);
+      }
+      if (er == hipSuccess && hipMalloc(&b->ws_enc, (size_t)128 << 20) == hipSuccess &&
+          hipEventCreateWithFlags(&b->ev_enc_done, hipEventDisableTiming) == hipSuccess) {
+        b->owned.push_back(b->ws_enc);
+        (void)sc_set_stream_workspace(b->stream_enc, b->ws_enc, (size_t)128 << 20);
+      } else {
+        (void)hipGetLastError();
+        if (b->stream_enc) (void)hipStreamDestroy(b->stream_enc);
+        b->stream_enc = nullptr;
+      }
+    }
+  }
   const size_t cm = ((size_t)S * 8 + n) * sizeof(int32_t);
   if (hipHostMalloc((void **)&b->ctrlmap_host, cm) != hipSuccess || hipHostMalloc((void **)&b->ctrl0_host, (size_t)S * 32) != hipSuccess ||
       hipHostMalloc((void **)&b->flags_host, (size_t)S * 4) != hipSuccess ||
@@ -1084,7 +1182,7 @@ extern "C" int sc_push(sc_streams *b, const int *stream_ids, const float *const 
   std::vector<StreamFault> faults;
   std::map<int, int> feat_new;
   std::map<int, bool> finals;
-  std::vector<int> has_out;
+  std::vector<int> has_out, t_old;
   while (true) {
     for (auto &ch : chunks) {   // compaction moves device data: settle it before the snapshot
       St &st = b->st[ch.s];
@@ -1095,9 +1193,16 @@ extern "C" int sc_push(sc_streams *b, const int *stream_ids, const float *const 
     finals.clear();
     has_out.assign(chunks.size(), 0);
     try {
-      RC_TRY(stage_encode(b, chunks, feat_new, finals, has_out));
+      b->es = b->stream_enc ? b->stream_enc : b->stream;   // (the PCM chunks are copied on the encoder's stream)
+      const int rc_enc = stage_encode(b, chunks, feat_new, finals, has_out);
+      b->es = b->stream;
+      if (rc_enc != SC_OK) return rc_enc;
+      if (!b->stream_enc) RC_TRY(launch_encoder(b));        // one stream: encoder first, as the reference does
+      t_old.assign(b->S, 0);
+      for (int s = 0; s < b->S; ++s) t_old[s] = snap[s].T_enc;
       break;
     } catch (const StreamFault &f) {
+      b->es = b->stream;
       b->st = snap;   // planning is pure host work that precedes every launch: undo = restore the mirrors
       b->arena_off = 0;
       faults.push_back(f);
@@ -1110,8 +1215,11 @@ extern "C" int sc_push(sc_streams *b, const int *stream_ids, const float *const 
       if (chunks.empty()) break;
     }
   }
-  if (!chunks.empty()) RC_TRY(stage_decode(b, feat_new, finals, faults));
+  if (!chunks.empty()) RC_TRY(stage_decode(b, feat_new, finals, faults, &t_old));
+  RC_TRY(launch_encoder(b));   // (if no decode iteration got to it)
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->stream_enc) HIP_TRY(hipStreamSynchronize(b->stream_enc));
+  b->enc_pending = false;
   if (status)
     for (size_t k = 0; k < chunks.size(); ++k) status[pos[k]] = has_out[k];
   for (auto &f : faults) {
