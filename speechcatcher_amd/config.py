@@ -64,6 +64,11 @@ class ModelConfig:
 # SURVEY.md section 0).
 XL = ModelConfig()
 
+# The reference's no-config defaults (speech2text_streaming.py:223-227,238-240: output_size 256, 4 heads, 12 + 6
+# blocks) - what a model directory without encoder_conf / decoder_conf builds, and the best available stand-in for
+# the `_m` checkpoints (BASELINE configs[0]; their config.yaml is not available offline).  Head dim 64.
+M_DEFAULTS = ModelConfig(d_model=256, enc_heads=4, enc_layers=12, dec_heads=4, dec_layers=6)
+
 # Small model used for full-tensor golden fixtures.
 TINY = ModelConfig(d_model=64, enc_heads=4, enc_layers=2, dec_heads=4,
                    dec_layers=2, ffn_dim=2048)

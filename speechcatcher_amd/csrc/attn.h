@@ -15,12 +15,13 @@ __device__ __forceinline__ float dpp_mov(float v) {
 #define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
 #define SC_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16 lanes
 
-// sum over the LPR (4 or 8) adjacent lanes of a row group; every lane gets the total
+// sum over the LPR (4, 8 or 16) adjacent lanes of a row group; every lane gets the total
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
   v += dpp_mov<SC_DPP_XOR1>(v);
   v += dpp_mov<SC_DPP_XOR2>(v);
-  if (LPR == 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+  if (LPR >= 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+  if (LPR == 16) v += dpp_mov<SC_DPP_ROW_MIRROR>(v);
   return v;
 }
 

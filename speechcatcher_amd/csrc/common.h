@@ -11,6 +11,12 @@
 
 void sc_set_error(const char *fmt, ...);
 
+// Test / measurement hooks.  The SC_* environment switches (kernel variants forced for parity tests, A/B runs and
+// tuning sweeps) are consulted ONLY when the process was started with SC_TEST_HOOKS=1 (tests/conftest.py and the
+// tools/ scripts set it); a production process never reads them, so nothing a server's environment contains can
+// change which kernels a captured graph holds.  gemm.hip.
+const char *sc_hook(const char *name);
+
 #define SC_CHECK_ARG(cond, msg)      \
   do {                               \
     if (!(cond)) {                   \

@@ -521,8 +521,8 @@ static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   const dim3 grid(sb.rowmap ? sb.n_rows / sb.W : sb.S, sb.H);   // streams of the compaction bucket only
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
-  if (const char *fd = getenv("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  const bool pre_ok = !getenv("SC_SELF_ATTN_NOPRE");                    // tests: row lists interleaved with the walk
+  if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
+  const bool pre_ok = !sc_hook("SC_SELF_ATTN_NOPRE");                    // tests: row lists interleaved with the walk
   auto lds = [&](int wm, bool pre) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF, pre) * sizeof(float); };
   if (sb.W <= 5) {
     dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST, KVH><<<grid, 256, lds(5, false), st>>>(p);

@@ -244,7 +244,7 @@ extern "C" int sc_proj_ln_proj(const float *A, int lda, const float *W1q, const 
   // rows per panel: the smallest that keeps the launch within one round of workgroups and
   // the weight re-streaming (every workgroup reads all of W) modest (tools/panel4_probe.py)
   int rpp = M <= 1024 ? 4 : (M <= 2048 ? 8 : 16);   // <= 256 workgroups (measured sweep: one round is what matters)
-  if (const char *e = getenv("SC_PANEL_ROWS")) {
+  if (const char *e = sc_hook("SC_PANEL_ROWS")) {
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) rpp = v;
   }
@@ -419,7 +419,7 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
   const int nblocks = N / D;
   // rows per panel: keep panels * column blocks within one round of workgroups
   int rpp = (long)cdiv(M, 4) * nblocks <= 256 ? 4 : ((long)cdiv(M, 8) * nblocks <= 256 ? 8 : 16);
-  if (const char *e = getenv("SC_PANEL_ROWS")) {
+  if (const char *e = sc_hook("SC_PANEL_ROWS")) {
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) rpp = v;
   }

@@ -522,7 +522,7 @@ extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, i
   const int dk = d / H;
   const int grid = cdiv(nblk * H, 4);
   hipStream_t st = (hipStream_t)stream;
-  const char *sp = getenv("SC_ENC_ATTN");   // =wave: one wave per (block, head) (A/B switch)
+  const char *sp = sc_hook("SC_ENC_ATTN");   // =wave: one wave per (block, head) (A/B switch)
   const bool split = !(sp && !strcmp(sp, "wave"));
   if (dk == 32 && split) {   // LDS: the merge buffer [4][64][dk+2] (>= the K + V + Q staging it aliases)
     enc_attention_split_kernel<32><<<nblk * H, 256, 4 * 64 * (32 + 2) * sizeof(float), st>>>(qkv, att, nblk, R, H, d,
@@ -554,12 +554,12 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   SC_CHECK_ARG(L && x && xn && qkv && att && ffh, "null pointer");
   const int M = nblk * R;
   if (M <= 0) return SC_OK;
-  const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
+  const char *fe = sc_hook("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
   const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
                          sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
   // row-tile projections with the norms folded in (faster at every batch size: tools/rowtile_bench.py);
   // SC_ENC_ROWTILE=0: LayerNorm + GEMM launches instead (A/B switch)
-  const char *re = getenv("SC_ENC_ROWTILE");
+  const char *re = sc_hook("SC_ENC_ROWTILE");
   const bool rowtile_ok = sc_rowtile_proj_supported(d, d) && !(re && atoi(re) == 0);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)

@@ -552,6 +552,14 @@ static std::mutex g_ws_mutex;
 static thread_local float *g_ws = nullptr;       // resolved per sc_gemm call
 static thread_local size_t g_ws_bytes = 0;
 
+const char *sc_hook(const char *name) {
+  static const bool enabled = [] {
+    const char *e = getenv("SC_TEST_HOOKS");
+    return e && atoi(e) != 0;
+  }();
+  return enabled ? getenv(name) : nullptr;
+}
+
 extern "C" int sc_set_workspace(void *ptr, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_ws_mutex);
   g_ws_default = Workspace{(float *)ptr, bytes};
@@ -584,10 +592,10 @@ extern "C" size_t sc_workspace_bytes(void *stream) {
 static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *variant_out, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K;
   if (g_force_naive < 0) {
-    const char *e = getenv("SC_GEMM_NAIVE");
+    const char *e = sc_hook("SC_GEMM_NAIVE");
     g_force_naive = (e && e[0] == '1') ? 1 : 0;
-    if (const char *m = getenv("SC_SKINNY_MAX_M")) g_skinny_max_m = atoi(m);
-    if (const char *m = getenv("SC_GEMM_BK")) g_bk64 = atoi(m) == 64;
+    if (const char *m = sc_hook("SC_SKINNY_MAX_M")) g_skinny_max_m = atoi(m);
+    if (const char *m = sc_hook("SC_GEMM_BK")) g_bk64 = atoi(m) == 64;
   }
   bool aligned = (K % 32 == 0) && (g.lda % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
                  (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
@@ -1217,7 +1225,7 @@ extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const floa
       if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; }
     }
   }
-  if (const char *f = getenv("SC_ROWTILE_FORCE")) {   // tools/rowtile_bench.py sweep: "rtt,cpw"
+  if (const char *f = sc_hook("SC_ROWTILE_FORCE")) {   // tools/rowtile_bench.py sweep: "rtt,cpw"
     int r = 0, c = 0;
     if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 4 && c >= 1 && nch % c == 0) {
       best_rtt = r;
@@ -1284,7 +1292,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     }
     SC_CHECK_ARG(best < 1e29, "workspace too small for sc_ffn_ln");
     SC_CHECK_ARG(!Wq || slab == M, "workspace too small for the fused projection (rows do not fit one slab)");
-    if (const char *f = getenv("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
+    if (const char *f = sc_hook("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
       int r = 0, c = 0;
       if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && nch % c == 0 &&
           (long)(M - m_done) * (nch / c) <= ws_rows_per_part) {

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
 #pragma unroll
   for (int h = 0; h < WM; ++h) {
     if (LPR == 4) attn_merge_dpp<SC_DPP_ROR4>(st[h]);
-    attn_merge_dpp<SC_DPP_ROR8>(st[h]);
+    if (LPR <= 8) attn_merge_dpp<SC_DPP_ROR8>(st[h]);   // LPR 16 (d_k = 64): one row group per DPP row, nothing to merge
   }
   if ((g % GPR) == 0) {
     const int pp = g / GPR;
@@ -478,11 +478,11 @@ static void launch_attn_flash_kvh(const sc_search &sb, int layer, hipStream_t st
   const size_t lds = attn_flash_lds(sb, DK, SELF);
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
-  if (const char *fd = getenv("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
+  if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
   if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
   else if (sb.W <= 10) {
     if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
-    else if (SELF && sb.LCAP <= 4 * 128 && !getenv("SC_SELF_ATTN_NOPRE")) {
+    else if (SELF && sb.LCAP <= 4 * 128 && !sc_hook("SC_SELF_ATTN_NOPRE")) {
       // all row lists first, aliased with the partial states (see the kernel's PRE note)
       const size_t red = (size_t)16 * sb.W * (DK + 2), lists = (size_t)4 * 128 * sb.W;
       const size_t lds_pre = ((red > lists ? red : lists) + 8 + (size_t)16 * DK) * sizeof(float);
@@ -503,11 +503,12 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
   const int dk = sb.d / sb.H;
   const int grid = cdiv(sb.S * sb.W * sb.H, 4);
   hipStream_t st = (hipStream_t)stream;
-  const char *mode = getenv("SC_SELF_ATTN");   // test / A-B hook: "legacy"
+  const char *mode = sc_hook("SC_SELF_ATTN");   // test / A-B hook: "legacy"
   const bool legacy = mode && mode[0] == 'l';
-  if (!legacy && sb.W <= 16 && (dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024) {
+  if (!legacy && sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024) {
     ProfScope prof = sc_prof_begin(st);
-    if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
+    if (dk == 64) launch_attn_flash<64, true>(sb, layer, st);
+    else if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
     else launch_attn_flash<16, true>(sb, layer, st);
     sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);   // traffic depends on device-side state (L, ancestors)
     SC_CHECK_LAUNCH();
@@ -659,17 +660,18 @@ extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) 
   // also the faster form for few streams (measured: 1 / 8 / 16 streams 58.3 / 266.9 / 452.5
   // vs 58.3 / 260.8 / 433.6 audio-s/s for the split + merge pair); the legacy kernel
   // pair only splits T when S*H workgroups would not fill the chip.
-  const bool flash_ok = sb.W <= 16 && (dk == 32 || dk == 16);
+  const bool flash_ok = sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, false) <= 64 * 1024;
   bool seq = flash_ok || sb.S * sb.H >= 192;
-  if (const char *e = getenv("SC_XATTN_MODE")) {   // test hook: "seq" / "split"
+  if (const char *e = sc_hook("SC_XATTN_MODE")) {   // test hook: "seq" / "split"
     if (e[0] == 's' && e[1] == 'e') seq = true;
     else if (e[0] == 's' && e[1] == 'p') seq = false;
   }
-  const char *xm = getenv("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
+  const char *xm = sc_hook("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
   if (seq && !(xm && xm[0] == 'l') && flash_ok) {
     // one workgroup per (stream, head), single pass, coalesced K/V rows
     ProfScope prof = sc_prof_begin(st);
-    if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
+    if (dk == 64) launch_attn_flash<64, false>(sb, layer, st);
+    else if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
     else launch_attn_flash<16, false>(sb, layer, st);
     sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
     SC_CHECK_LAUNCH();
@@ -713,17 +715,17 @@ static int decoder_layers_impl(const sc_search *sbp, void *stream, bool fuse_log
   SC_CHECK_ARG(n > 0 && n <= sb.S * sb.W, "n_rows out of range");
   const int lnf = rows ? SC_GEMM_LN_AT_CROWS : 0;
   // SC_DEC_PANEL=0 keeps the three-launch form (GEMM, reduce+LN, GEMM) for A/B runs
-  const char *pe = getenv("SC_DEC_PANEL");
+  const char *pe = sc_hook("SC_DEC_PANEL");
   const bool panel_env = !(pe && atoi(pe) == 0);
   const bool panel = panel_env && sc_proj_ln_proj_supported(d);
-  const char *fe = getenv("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
+  const char *fe = sc_hook("SC_FFN_FUSED");      // =0: two GEMMs with the hidden activations in HBM
   const bool ffn_fused = !(fe && atoi(fe) == 0) && sc_ffn_ln_supported(d, F) &&
                          sc_workspace_bytes(stream) >= (size_t)(F / 128) * 80 * d * sizeof(float);
   // the FFN's reduce kernel also projects what consumes its LayerNorm (next layer's Q|K|V, output
   // layer): needs the row panels, the fused FFN, lane-packed weights and a workspace for all rows.
   // x then ping-pongs between dx and dxn (the reduce kernel must not update x in place), and the
   // LayerNorm before the FFN goes to dq (free after the cross-attention).
-  const char *qe = getenv("SC_FFN_PROJ");
+  const char *qe = sc_hook("SC_FFN_PROJ");
   const bool chain = !(qe && atoi(qe) == 0) && panel && ffn_fused && sb.layers[0].wqkv_q &&
                      sc_workspace_bytes(stream) >= (size_t)(F / 128) * n * d * sizeof(float);
   int rc;
@@ -1437,7 +1439,7 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 // 28.9 / 28.1 / 29.0 ms per chunk step with the limit at 0 / 640 / 1280 rows).
 #define SC_FUSED_MAX_ROWS 640
 static bool dec_fused_ok(const sc_search &sb) {
-  if (const char *e = getenv("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
+  if (const char *e = sc_hook("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
     return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;
   if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > SC_FUSED_MAX_ROWS) return false;
   return sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.ph2 && sb.ffn_part &&

@@ -983,7 +983,8 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   const int K = std::min(pre_beam, c.vocab_size);
   SC_CHECK_ARG(o->beam_size <= K && o->beam_size <= 16, "beam size must not exceed 16 (and the pre-beam size 40)");
   const int dk = c.d_model / c.dec_heads;
-  SC_CHECK_ARG(c.d_model % c.dec_heads == 0 && (dk == 16 || dk == 32), "decoder head dim must be 16 or 32");
+  SC_CHECK_ARG(c.d_model % c.dec_heads == 0 && (dk == 16 || dk == 32 || (dk == 64 && o->beam_size <= 10)),
+               "decoder head dim must be 16, 32 or 64 (64: beam <= 10)");
   HIP_TRY(hipSetDevice(e->device));
   sc_streams *b = new sc_streams;
   b->eng = e;
@@ -1088,15 +1089,15 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     // Measured at 128 streams (profiles/r02_encoder_overlap_sweep.txt): serial 33.4 ms per chunk step; started with
     // the first decode iteration 32.2 (its large grids delay the full-batch decode kernels); at 50 % / 25 % / 10 % /
     // 7 % / 3 % of the streams 31.3 / 31.1 / 30.5 / 30.5 / 30.8.  SC_ENC_START overrides the percentage.
-    const char *th = getenv("SC_ENC_START");
+    const char *th = sc_hook("SC_ENC_START");
     b->enc_start_thr = S < 16 ? S : std::max(1, (int)((long)S * (th ? atoi(th) : 7) / 100));
   }
   {
     // second stream for the encoder side (see sc_streams::stream_enc).  SC_ENC_OVERLAP=0 keeps everything on one
     // stream; SC_ENC_CUS=n restricts the encoder stream to the first n compute units (hipExtStreamCreateWithCUMask)
-    const char *ov = getenv("SC_ENC_OVERLAP");
+    const char *ov = sc_hook("SC_ENC_OVERLAP");
     if (!(ov && atoi(ov) == 0)) {
-      const char *cu = getenv("SC_ENC_CUS");
+      const char *cu = sc_hook("SC_ENC_CUS");
       const int ncu = cu ? atoi(cu) : 0;
       hipError_t er;
       if (ncu > 0 && ncu < 256) {

@@ -40,10 +40,11 @@ class HipBackend:
         """Reject, at construction time, model dimensions the decode kernels have no instantiation for
         (the first decode step would otherwise fail in the middle of a stream)."""
         dk = cfg.d_model // cfg.dec_heads
-        if cfg.d_model % cfg.dec_heads or dk not in (16, 32):
+        if cfg.d_model % cfg.dec_heads or dk not in (16, 32, 64) or (dk == 64 and beam_size > 10):
             raise _abi.ScasrError(
-                f"decoder head dim {dk} (d_model {cfg.d_model} / {cfg.dec_heads} heads) is not supported: the HIP "
-                "decoder attention kernels are instantiated for head dims 16 and 32 (csrc/search.hip)")
+                f"decoder head dim {dk} (d_model {cfg.d_model} / {cfg.dec_heads} heads) with beam {beam_size} is not "
+                "supported: the HIP decoder attention kernels are instantiated for head dims 16, 32 and 64 (64: beam <= 10; "
+                "csrc/search.hip)")
         ek = cfg.d_model // cfg.enc_heads
         if cfg.d_model % cfg.enc_heads or ek not in (16, 32, 64):
             raise _abi.ScasrError(f"encoder head dim {ek} is not supported (16, 32 or 64)")

@@ -6,6 +6,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+os.environ.setdefault("SC_TEST_HOOKS", "1")   # the library reads its SC_* variant switches only with this set (csrc/common.h)
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

@@ -296,3 +296,37 @@ def test_fp16_kv_caches_keep_the_token_ids_of_the_fp32_reference(name, engine):
     else:
         from speechcatcher_amd.hip_backend import HipBackend
         run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", score_tol=2e-2, kv_dtype="float16")
+
+
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_m_like_dimensions_head_dim_64(engine):
+    """The reference's no-config defaults (d = 256, 4 heads of 64: config.M_DEFAULTS, the stand-in for the `_m`
+    checkpoints of BASELINE configs[0]) with fewer layers: decoder attention at head dim 64, row panels and fused
+    FFN at d = 256; beam 10 and greedy, against the oracle run on the same box."""
+    import helpers
+    import test_engine_spec
+    from oracle.ref_port import RefPortStreaming
+    from speechcatcher_amd.config import ModelConfig
+    from test_engine_spec import check_against_blocks, make_batch
+    helpers.CFGS["M4"] = test_engine_spec.CFGS["M4"] = ModelConfig(d_model=256, enc_heads=4, enc_layers=3, dec_heads=4,
+                                                                   dec_layers=2)
+    for beam in (10, 1):
+        ora = RefPortStreaming(helpers.oracle_model("M4", 1234, "meanstd"), beam_size=beam, use_bbd=False)
+        backend = "native"
+        if engine == "python":
+            from speechcatcher_amd.hip_backend import HipBackend
+            backend = HipBackend("cuda:0")
+        sb = make_batch("M4", 1234, "meanstd", beam, False, backend=backend, device="cuda:0", max_frames=200,
+                        max_tokens=400, pcm_capacity=1 << 18)
+        audio = synth.synth_audio(77, 16000 * 6)
+        for pos in range(0, len(audio), 8192):
+            end = min(pos + 8192, len(audio))
+            fin = end >= len(audio)
+            ora(audio[pos:end], is_final=fin, finalize_all=fin)
+            sb.push([(0, audio[pos:end], fin)])
+        ref = ora.running_hyps
+        blk = {"yseq": [list(h.yseq) for h in ref], "xpos": [list(h.xpos) for h in ref],
+               "score": [h.score for h in ref], "score_dec": [h.scores.get("decoder", 0.0) for h in ref],
+               "score_ctc": [h.scores.get("ctc", 0.0) for h in ref], "process_idx": ora.process_idx}
+        check_against_blocks(sb, 0, blk, 5e-3)
+        assert len(sb.hypotheses(0)[0]["yseq"]) > 5

@@ -4,6 +4,7 @@ row counts the compaction buckets produce; prints time per call for each forced
 configuration (env SC_FFN_FORCE="rtt,cpw") next to the cost model's choice.
 Usage (GPU box): python tools/ffn_sweep.py"""
 import os
+os.environ.setdefault("SC_TEST_HOOKS", "1")   # the library reads its SC_* switches only with this set
 import subprocess
 import sys
 

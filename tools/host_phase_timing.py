@@ -3,6 +3,7 @@
 time goes as seen from the host thread (frontend / encoder enqueue, decode-graph launches, waiting for the
 stop flags).  Usage (GPU box): python tools/host_phase_timing.py [streams] [steps]"""
 import os
+os.environ.setdefault("SC_TEST_HOOKS", "1")   # the library reads its SC_* switches only with this set
 import sys
 os.environ["SC_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

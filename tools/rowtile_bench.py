@@ -5,6 +5,7 @@ Also: the encoder block attention with the keys of a (block, head) split over 4 
 Usage (GPU box): python tools/rowtile_bench.py [rows ...]"""
 import sys
 import os
+os.environ.setdefault("SC_TEST_HOOKS", "1")   # the library reads its SC_* switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechcatcher_amd.hip_backend import HipBackend

@@ -3,6 +3,7 @@
 SC_ROWTILE_FORCE, next to the launcher's own choice.  Usage (GPU box): python tools/rowtile_sweep.py [rows ...]"""
 import sys
 import os
+os.environ.setdefault("SC_TEST_HOOKS", "1")   # the library reads its SC_* switches only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechcatcher_amd.hip_backend import HipBackend
