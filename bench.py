@@ -227,7 +227,7 @@ def main():
 
     # Roofline leg: the SAME workload continues for a few more steps with hipGraph replay switched off, so that
     # every launch of the hot kernels can be bracketed by HIP events on its launch stream.
-    NK = 9   # scasr.h: SC_PROF_KINDS
+    NK = 10   # scasr.h: SC_PROF_KINDS
     ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
     ev_over_ms, xattn_bytes = 0.0, 0.0
@@ -276,7 +276,8 @@ def main():
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
              "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "decoder self-attention (dec_attn_flash / dec_layer_attn<self>)",
-             "decoder cross-attention (dec_attn_flash / dec_layer_attn<cross>)", "rowtile_proj_kernel<256,*>"]
+             "decoder cross-attention (dec_attn_flash / dec_layer_attn<cross>)", "rowtile_proj_kernel<256,*>",
+             "ffn_fused_kernel<256,*,PRO> (decoder layer FFN with reduce + norm3 prologue, small buckets)"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
     per_kernel = []

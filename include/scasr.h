@@ -244,7 +244,8 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_ATTN_SELF 6
 #define SC_PROF_ATTN_CROSS 7
 #define SC_PROF_ROWTILE_PROJ 8
-#define SC_PROF_KINDS 9
+#define SC_PROF_FFN_PRO 9 /* ffn_fused_kernel<.., PRO>: sc_dec_layer_ffn (head-partial reduce + norm3 prologue) */
+#define SC_PROF_KINDS 10
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);

@@ -1390,7 +1390,7 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);
   else launch_ffn_rtt<128, true>(p, best_rtt, ngrp, st);
   // algorithmic: 4*D*F flop per row; x + H head partials read, W1 + W2 read once, x and the partials written
-  sc_prof_end(prof, SC_PROF_FFN_FUSED, 4.0 * (double)M * D * F,
+  sc_prof_end(prof, SC_PROF_FFN_PRO, 4.0 * (double)M * D * F,
               4.0 * ((double)M * D * (2 + sb.H) + 2.0 * (double)D * F + (double)ngrp * M * D));
   SC_CHECK_LAUNCH();
   *n_part = ngrp;
