@@ -449,6 +449,9 @@ int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps
 /* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
  * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
 int sc_streams_set_graphs(sc_streams *streams, int on);
+/* host seconds the decode step loop spent issuing a step (ctrl upload + graph launch) and waiting for its stop
+ * flags, since the last call (returned and cleared) */
+int sc_streams_host_times(sc_streams *streams, double *launch_s, double *wait_s);
 long sc_streams_take_xattn_rows(sc_streams *streams);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);

@@ -151,6 +151,7 @@ _SIGS = {
     "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
+    "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_hip_stream": (vp, [vp]),
     "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),
