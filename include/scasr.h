@@ -128,6 +128,11 @@ typedef struct sc_search {
    * arithmetic, softmax and everything else stay fp32.  Written through sc_kv_rows_to_half (cross) and by the
    * self-attention kernels (self); read by the single-pass attention kernels. */
   int32_t kv_half;
+  /* persistent stream-cluster decoder (sc_dec_cluster_layers): DEVICE copy of `layers`, one barrier counter per
+   * stream [S], one error word; NULL: not used */
+  const sc_dec_layer *layers_dev;
+  uint32_t *cbar;
+  int32_t *cl_err;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -354,6 +359,18 @@ int sc_dec_layer_cross(const sc_search *sb, int layer, const float *x_in, float 
  * feed_forward.py:48-50) as partial sums ffn_part[z][row], z < *n_part (HOST out; <= max_part). */
 int sc_dec_layer_ffn(const sc_search *sb, int layer, const float *x_in, float *x_out, float *ffn_part,
                      int max_part, int *n_part /*HOST*/, void *stream);
+/* ALL decoder layers of one step in ONE launch for small compaction buckets (at most sc_dec_cluster_max_streams()
+ * streams): the H workgroups of a stream stay resident and walk the layers together, ordered by a system-scope
+ * cluster barrier per stream; per-head partial products travel with 16-byte system-scope accesses
+ * (csrc/decoder_cluster.hip).  Leaves x (before the last feed-forward's residual) in x_out and the last layer's
+ * feed-forward partial sums in sb->ffn_part[h], h < H: follow with sc_dec_output_logits(sb, x_out, other, ffn_part, H).
+ * dev_layers: DEVICE copy of sb->layers; cbar [S] (zeroed by this call), err [1] (set to 1 if a barrier timed out). */
+int sc_dec_cluster_supported(int d, int H, int W, int F);
+int sc_dec_cluster_max_streams(void);
+/* profiling aid (SC_TEST_HOOKS=1 SC_CLUSTER_DBG=1): shader-clock stamps of one workgroup at the phase boundaries of the last launch */
+int sc_dec_cluster_debug(long long *host_out, int n);
+int sc_dec_cluster_layers(const sc_search *sb, const sc_dec_layer *dev_layers, float *x_out, unsigned *cbar, int *err,
+                          void *stream);
 /* tail: x = x_in + b2[last] + sum_z ffn_part -> x_out; logits = after_norm(x) . out_w^T + out_b
  * (transformer_decoder.py:243-249); needs sb->out_w_q. */
 int sc_dec_output_logits(const sc_search *sb, const float *x_in, float *x_out, const float *ffn_part,
@@ -452,6 +469,8 @@ int sc_streams_set_graphs(sc_streams *streams, int on);
 /* host seconds the decode step loop spent issuing a step (ctrl upload + graph launch) and waiting for its stop
  * flags, since the last call (returned and cleared) */
 int sc_streams_host_times(sc_streams *streams, double *launch_s, double *wait_s);
+/* ... and by compaction bucket: seconds[17], iterations[17] (index = bucket size in units of n_streams/16) */
+int sc_streams_bucket_times(sc_streams *streams, double *seconds, long *iterations);
 long sc_streams_take_xattn_rows(sc_streams *streams);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);

@@ -46,7 +46,8 @@ class Search(C.Structure):
                              "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
-           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32)]
+           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32),
+           ("layers_dev", vp), ("cbar", vp), ("cl_err", vp)]
     )
 
 
@@ -136,6 +137,10 @@ _SIGS = {
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "sc_dec_cluster_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sc_dec_cluster_max_streams": (C.c_int, []),
+    "sc_dec_cluster_debug": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
+    "sc_dec_cluster_layers": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     # stream-level API
     "sc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(NamedTensor), C.c_int, C.c_int, C.POINTER(vp)]),
     "sc_engine_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
@@ -152,6 +157,7 @@ _SIGS = {
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
+    "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_hip_stream": (vp, [vp]),
     "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),

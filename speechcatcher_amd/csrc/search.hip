@@ -1447,12 +1447,30 @@ static bool dec_fused_ok(const sc_search &sb) {
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
 }
 
+// the persistent stream-cluster kernel (decoder_cluster.hip) runs this bucket: few streams, supported dims, buffers
+// EXPERIMENTAL, off unless the test hook SC_DEC_CLUSTER=1 is set: correct (lock-step parity at XL dims) but slower
+// than the launches it replaces - 83-93 us per layer against 45 us for the three head-parallel launches at 1-8
+// streams (phase timing: tools/cluster_phase_times.py): eight CUs per stream are too few
+// for the feed-forward's 4 MB of weights per layer, which the launched form spreads over 80 workgroups.
+static bool dec_cluster_ok(const sc_search &sb) {
+  const char *e = sc_hook("SC_DEC_CLUSTER");
+  if (!e || atoi(e) == 0) return false;
+  const int nstreams = (sb.rowmap ? sb.n_rows : sb.S * sb.W) / sb.W;
+  return nstreams <= sc_dec_cluster_max_streams() && sc_dec_cluster_supported(sb.d, sb.H, sb.W, sb.F) && sb.layers_dev &&
+         sb.cbar && sb.cl_err && sb.ph1 && sb.ph2 && sb.ffn_part && sb.max_ffn_part >= sb.H && sb.out_w_q &&
+         sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp && sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
+}
+
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
-  if (dec_fused_ok(sb)) {
+  if (dec_cluster_ok(sb)) {
+    // all layers in one persistent launch; then the tail (feed-forward residual, after_norm, output layer)
+    SC_TRY(sc_dec_cluster_layers(sbp, sb.layers_dev, sb.dxn, sb.cbar, sb.cl_err, stream));
+    SC_TRY(sc_dec_output_logits(sbp, sb.dxn, sb.dx, sb.ffn_part, sb.H, stream));
+  } else if (dec_fused_ok(sb)) {
     // 3 launches per layer; x ping-pongs dx <-> dxn
     float *xa = sb.dx, *xb = sb.dxn;
     int npart = 0;

@@ -161,6 +161,8 @@ struct sc_streams {
   std::map<std::vector<long>, hipGraphExec_t> enc_graphs;
   long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows = 0;
   double t_launch = 0, t_wait = 0, t_host = 0;   // seconds in the step loop: issuing, waiting for the flags, bookkeeping
+  double t_bucket[17] = {0};                     // ... waiting, by compaction bucket (n_rows_step / (row_bucket*W))
+  long n_bucket[17] = {0};
   bool use_graphs = true;
 
   ~sc_streams() {
@@ -722,6 +724,11 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     const auto tp2 = std::chrono::steady_clock::now();
     b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
     b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
+    {
+      const int bk = std::min(16, b->n_rows_step / std::max(1, b->row_bucket * W));
+      b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
+      b->n_bucket[bk] += 1;
+    }
     for (int i = 0; i < n; ++i) {
       if (!live[i]) continue;
       const int f = b->flags_host[todo[i].s];
@@ -1075,6 +1082,15 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     A(sb.ph2, n * c.dec_heads * d);
     A(sb.ffn_part, (size_t)(F / 128) * n * d);
     sb.max_ffn_part = F / 128;
+    if (sc_dec_cluster_supported(d, c.dec_heads, W, F) && rc == SC_OK) {   // persistent stream-cluster decoder
+      sc_dec_layer *ld = nullptr;
+      A(ld, e->dec.size());
+      if (rc == SC_OK && hipMemcpy(ld, e->dec.data(), e->dec.size() * sizeof(sc_dec_layer), hipMemcpyHostToDevice) != hipSuccess)
+        rc = SC_ERR_LAUNCH;
+      sb.layers_dev = ld;
+      A(sb.cbar, (size_t)S);
+      A(sb.cl_err, 1);
+    }
   }
   if (rc == SC_OK && hipMalloc(&b->ws, (size_t)128 << 20) != hipSuccess) rc = SC_ERR_LAUNCH;
   if (rc == SC_OK) b->owned.push_back(b->ws);
@@ -1397,6 +1413,19 @@ extern "C" long sc_streams_take_xattn_rows(sc_streams *b) {
   const long v = b->xattn_rows;
   b->xattn_rows = 0;
   return v;
+}
+
+// seconds and iterations of the decode step loop by compaction bucket (index = active streams / (S/16), 17 entries),
+// since the last call (returned and cleared)
+extern "C" int sc_streams_bucket_times(sc_streams *b, double *seconds, long *iterations) {
+  SC_CHECK_ARG(b && seconds && iterations, "null");
+  for (int i = 0; i < 17; ++i) {
+    seconds[i] = b->t_bucket[i];
+    iterations[i] = b->n_bucket[i];
+    b->t_bucket[i] = 0;
+    b->n_bucket[i] = 0;
+  }
+  return SC_OK;
 }
 
 extern "C" int sc_streams_host_times(sc_streams *b, double *launch_s, double *wait_s) {

@@ -250,8 +250,10 @@ class StreamBatch:
             self.ph1 = z(n, cfg.dec_heads, d)
             self.ph2 = z(n, cfg.dec_heads, d)
             self.ffn_part = z(F // 128, n, d)
+            self.cbar = z(S, dtype=i32)          # persistent stream-cluster decoder: barrier counters, error word
+            self.cl_err = z(1, dtype=i32)
         else:
-            self.ph1 = self.ph2 = self.ffn_part = None
+            self.ph1 = self.ph2 = self.ffn_part = self.cbar = self.cl_err = None
         self.xchunk = 256
         nch = (self.TCAP + self.xchunk - 1) // self.xchunk
         self.xpart = z(n * cfg.dec_heads * nch, (d // cfg.dec_heads) + 2)
