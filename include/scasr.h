@@ -389,9 +389,14 @@ int sc_glu_dwconv_bn_swish(const float *y, int B, int T, int C, int ksize, const
 
 /* RelPositionMultiHeadedAttention.forward core (model/attention/multi_head_attention.py:
  * 343-378, rel_shift :300-314): qkv [B*T][3d] projected q|k|v, p [T][d] = linear_pos(pos_emb),
- * bias_u / bias_v [H][dk] -> out [B*T][d] (before linear_out).  T <= 128. */
+ * bias_u / bias_v [H][dk] -> out [B*T][d] (before linear_out).  Any T. */
 int sc_relpos_attention(const float *qkv, const float *p, const float *bias_u, const float *bias_v,
                         float *out, int B, int T, int H, int d, void *stream);
+/* ... with the reference's attention masks (:366-372): mask_mode 1 = mask [B][T] over keys (batch, 1, time_k),
+ * 2 = mask [B][T][T] (batch, time_q, time_k), bytes, 0 = masked out; a fully masked query row gives zeros. */
+int sc_relpos_attention_masked(const float *qkv, const float *p, const float *bias_u, const float *bias_v,
+                               float *out, int B, int T, int H, int d, const uint8_t *mask, int mask_mode,
+                               void *stream);
 
 /* ==== stream-level API: the decoder as a C library ==========================================
  * What a reference maintainer binds instead of Speech2TextStreaming's torch modules:

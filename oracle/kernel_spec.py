@@ -186,8 +186,9 @@ class SpecBackend:
         z = z * torch.sigmoid(z)
         out.view(B, T, Cc).copy_(z.transpose(1, 2))
 
-    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H):
-        """multi_head_attention.py:343-375 (mask None) incl. rel_shift :300-314."""
+    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H, mask=None):
+        """multi_head_attention.py:343-375 incl. rel_shift :300-314 and the masks of :366-372
+        (mask: uint8 [B][T] over keys or [B][T][T]; 0 = masked out)."""
         d = out.shape[-1]
         dk = d // H
         q, k, v = qkv.view(B, T, 3, H, dk).unbind(2)
@@ -197,7 +198,12 @@ class SpecBackend:
         bd = torch.matmul(q + bias_v.view(1, H, 1, dk), pp.transpose(-2, -1))
         zp = torch.zeros((B, H, T, 1))
         bd = torch.cat([zp, bd], dim=-1).view(B, H, T + 1, T)[:, :, 1:].reshape(B, H, T, T)
-        att = torch.softmax((ac + bd) / math.sqrt(dk), dim=-1)
+        scores = (ac + bd) / math.sqrt(dk)
+        if mask is not None:
+            mm = (mask.view(B, 1, 1, T) if mask.dim() == 2 else mask.view(B, 1, T, T)) == 0
+            att = torch.softmax(scores.masked_fill(mm, torch.finfo(scores.dtype).min), dim=-1).masked_fill(mm, 0.0)
+        else:
+            att = torch.softmax(scores, dim=-1)
         out.view(B, T, d).copy_(torch.matmul(att, v).transpose(1, 2).reshape(B, T, d))
 
     def encoder_layers(self, w, x, nblk, R, masked, jobs, ns, past_ctx, xn, qkv, att, ffh):

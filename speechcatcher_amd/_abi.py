@@ -120,6 +120,7 @@ _SIGS = {
     "sc_glu_dwconv_bn_swish": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                          C.c_float, vp, vp]),
     "sc_relpos_attention": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "sc_relpos_attention_masked": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "sc_ctc_extend_state": (C.c_int, [vp, vp]),
     "sc_dec_embed": (C.c_int, [vp, vp]),
     "sc_kv_rows_to_half": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -52,9 +52,13 @@ def pack_relpos_mha(sd, device):
     }
 
 
-def relpos_mha(be, w, x, pos_emb):
-    """RelPositionMultiHeadedAttention.forward(x, x, x, pos_emb, mask=None)
-    (model/attention/multi_head_attention.py:316-378).  x (B, T, d), pos_emb (T, d)."""
+def relpos_mha(be, w, x, pos_emb, mask=None):
+    """RelPositionMultiHeadedAttention.forward(x, x, x, pos_emb, mask)
+    (model/attention/multi_head_attention.py:316-378).  x (B, T, d), pos_emb (T, d); mask None, (B, 1, T) or
+    (B, T, T) like the reference's (0 = masked out); any T."""
+    if mask is not None:
+        mask = (mask != 0).to(torch.uint8)
+        mask = (mask.reshape(mask.shape[0], -1) if mask.shape[1] == 1 else mask).contiguous().to(x.device)
     B, T, d = x.shape
     M = B * T
     x2 = x.reshape(M, d).contiguous()
@@ -63,7 +67,7 @@ def relpos_mha(be, w, x, pos_emb):
     p = torch.empty(T, d, device=x.device)
     be.gemm(pos_emb.contiguous(), None, d, w["wpos"], None, p, None, d, T, d, d)
     ctx = torch.empty(M, d, device=x.device)
-    be.relpos_attention(qkv, p, w["bias_u"], w["bias_v"], ctx, B, T, w["H"])
+    be.relpos_attention(qkv, p, w["bias_u"], w["bias_v"], ctx, B, T, w["H"], mask=mask)
     out = torch.empty(M, d, device=x.device)
     be.gemm(ctx, None, d, w["wo"], w["bo"], out, None, d, M, d, d)
     return out.view(B, T, d)

@@ -142,9 +142,12 @@ class HipBackend:
                                                   _p(bn_mean), _p(bn_var), eps, _p(out), self._stream()),
                   "sc_glu_dwconv_bn_swish")
 
-    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H):
-        self._chk(self.lib.sc_relpos_attention(_p(qkv), _p(p), _p(bias_u), _p(bias_v), _p(out), B, T, H,
-                                               out.shape[-1], self._stream()), "sc_relpos_attention")
+    def relpos_attention(self, qkv, p, bias_u, bias_v, out, B, T, H, mask=None):
+        """mask: None, uint8 [B][T] (keys) or [B][T][T]; 0 = masked out"""
+        mode = 0 if mask is None else (1 if mask.dim() == 2 else 2)
+        self._chk(self.lib.sc_relpos_attention_masked(_p(qkv), _p(p), _p(bias_u), _p(bias_v), _p(out), B, T, H,
+                                                      out.shape[-1], _p(mask), mode, self._stream()),
+                  "sc_relpos_attention_masked")
 
     def _enc_layer_table(self, w):
         # cached ON the weights object (never keyed by id(): ids are recycled)
