@@ -227,10 +227,10 @@ def main():
 
     # Roofline leg: the SAME workload continues for a few more steps with hipGraph replay switched off, so that
     # every launch of the hot kernels can be bracketed by HIP events on its launch stream.
-    NK = 10   # scasr.h: SC_PROF_KINDS
+    NK = 12   # scasr.h: SC_PROF_KINDS
     ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
-    ev_over_ms, xattn_bytes = 0.0, 0.0
+    ev_over_ms, xattn_bytes = 0.0, {}
     if args.roofline_steps > 0:
         if args.engine == "native":
             sb.set_graphs(False)
@@ -245,14 +245,15 @@ def main():
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
         if args.engine == "native":
             sb.set_graphs(True)
-            rows = sb.take_xattn_rows()
+            rows = sb.take_xattn_rows_by_kernel()
             ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.hip_stream))
         else:
             sb.be.use_graphs = True
-            rows = sb.stats.get("xattn_rows", 0)
+            tot = sb.stats.get("xattn_rows", 0)
+            rows = (tot, 0) if nn[7] else (0, tot)   # the Python engine counts one total (one kernel family per run)
             ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
         # cross-attention: K|V rows of every active stream are read once per layer and step
-        xattn_bytes = float(rows) * 2 * XL.d_model * 4
+        xattn_bytes = {7: float(rows[0]) * 2 * XL.d_model * 4, 11: float(rows[1]) * 2 * XL.d_model * 4}
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
@@ -275,9 +276,11 @@ def main():
     value = audio_s / elapsed
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
-             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "decoder self-attention (dec_attn_flash / dec_layer_attn<self>)",
-             "decoder cross-attention (dec_attn_flash / dec_layer_attn<cross>)", "rowtile_proj_kernel<256,*>",
-             "ffn_fused_kernel<256,*,PRO> (decoder layer FFN with reduce + norm3 prologue, small buckets)"]
+             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<self> (decoder self-attention, large buckets)",
+             "dec_attn_flash_kernel<cross> (decoder cross-attention, large buckets)", "rowtile_proj_kernel<256,*>",
+             "ffn_fused_kernel<256,*,PRO> (decoder layer FFN with reduce + norm3 prologue, small buckets)",
+             "dec_layer_attn_kernel<self> (head-parallel layer: reduce + norm1 + Q|K|V + self-attention + out-projection, small buckets)",
+             "dec_layer_attn_kernel<cross> (head-parallel layer: reduce + norm2 + q + cross-attention + out-projection, small buckets)"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
     per_kernel = []
@@ -289,8 +292,8 @@ def main():
         if fl[i] > 0:
             ent["tflops"] = round(fl[i] / (max(net[i], 1e-9) * 1e-3) / 1e12, 3)
             ent["frac_of_f32_mfma_peak"] = round(ent["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
-        if i == 7 and xattn_bytes > 0:
-            ent["hbm_gbs_algorithmic"] = round(xattn_bytes / (max(net[i], 1e-9) * 1e-3) / 1e9, 1)
+        if xattn_bytes.get(i, 0) > 0:
+            ent["hbm_gbs_algorithmic"] = round(xattn_bytes[i] / (max(net[i], 1e-9) * 1e-3) / 1e9, 1)
             ent["frac_of_hbm_peak"] = round(ent["hbm_gbs_algorithmic"] / PEAK_HBM_GBS, 4)
         per_kernel.append(ent)
     roof = None
@@ -316,7 +319,7 @@ def main():
                     "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 4)",
                     "algorithmic_bytes_per_launch_avg": int(by[v] / nn[v])}
         else:
-            bytes_v = xattn_bytes if v == 7 else 0.0
+            bytes_v = xattn_bytes.get(v, 0.0)
             ach = bytes_v / (t_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4),

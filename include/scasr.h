@@ -250,7 +250,11 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_ATTN_CROSS 7
 #define SC_PROF_ROWTILE_PROJ 8
 #define SC_PROF_FFN_PRO 9 /* ffn_fused_kernel<.., PRO>: sc_dec_layer_ffn (head-partial reduce + norm3 prologue) */
-#define SC_PROF_KINDS 10
+#define SC_PROF_LAYER_SELF 10  /* dec_layer_attn_kernel<.., SELF>: sc_dec_layer_self (head-parallel layer, small buckets) */
+#define SC_PROF_LAYER_CROSS 11 /* dec_layer_attn_kernel<.., cross>: sc_dec_layer_cross */
+#define SC_PROF_KINDS 12
+/* decoder layers run as head-parallel launches (sc_dec_layer_*) for compaction buckets up to this many rows */
+#define SC_FUSED_MAX_ROWS 640
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
@@ -477,6 +481,8 @@ int sc_streams_host_times(sc_streams *streams, double *launch_s, double *wait_s)
 /* ... and by compaction bucket: seconds[17], iterations[17] (index = bucket size in units of n_streams/16) */
 int sc_streams_bucket_times(sc_streams *streams, double *seconds, long *iterations);
 long sc_streams_take_xattn_rows(sc_streams *streams);
+/* ... split by the kernel that read them: rows[0] dec_attn_flash (large buckets), rows[1] sc_dec_layer_cross */
+int sc_streams_take_xattn_rows_by_kernel(sc_streams *streams, long *rows);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);
 float *sc_streams_pcm(sc_streams *streams, long *capacity);

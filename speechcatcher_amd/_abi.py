@@ -160,6 +160,7 @@ _SIGS = {
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
+    "sc_streams_take_xattn_rows_by_kernel": (C.c_int, [vp, vp]),
     "sc_streams_hip_stream": (vp, [vp]),
     "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),
     "sc_streams_write_pcm": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_long]),

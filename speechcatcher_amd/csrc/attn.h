@@ -1,30 +1,4 @@
 // Device helpers shared by the decoder attention kernels (search.hip, decoder_layer.hip):
-// DPP lane permutations, row-group reductions and the online-softmax state of one hypothesis.
-#pragma once
-#include "common.h"
-
-// DPP lane permutations (no LDS round trip, unlike ds_bpermute-based __shfl)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-#define SC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
-#define SC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
-#define SC_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
-#define SC_DPP_ROR4 0x124        // rotate by 4 inside each 16 lanes
-#define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
-#define SC_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16 lanes
-
-// sum over the LPR (4, 8 or 16) adjacent lanes of a row group; every lane gets the total
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-  v += dpp_mov<SC_DPP_XOR1>(v);
-  v += dpp_mov<SC_DPP_XOR2>(v);
-  if (LPR >= 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
-  if (LPR == 16) v += dpp_mov<SC_DPP_ROW_MIRROR>(v);
-  return v;
-}
-
 struct AttnState {
   float m, l;
   float4 a;
@@ -63,3 +37,161 @@ __device__ __forceinline__ void kv_store1(float *base, long elem, float v) {
   if (KVH) reinterpret_cast<_Float16 *>(base)[elem] = (_Float16)v;
   else base[elem] = v;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core form of the decoder attention of one (stream, head) workgroup.  All (up to 16) hypotheses of the
+// stream are the N dimension of v_mfma_f32_16x16x4_f32, 16 K/V rows ("keys") the M dimension:
+//     S^T[key][hyp]  = K[key][:] . Q[hyp][:]          A = K rows (lane: key m, dims DPL*kg .. +DPL), B = Q
+//     O^T[dim][hyp] += V[key][dim] * P[key][hyp]       A = V^T (lane: dims m*NDT .. +NDT of key 4*kg+j), B = P
+// The accumulator layout of S^T (lane: hyp n = lane & 15, keys 4*kg + j) IS the B-operand layout of P, so the
+// probabilities never leave their registers, and every per-hypothesis factor (running maximum, rescale) is
+// lane-local.  The VALU form this replaces spent ~30 instructions per (key, hypothesis) on a 16-lane-wide SIMD
+// (4 cycles per wave instruction): 4-7 us of a 14-19 us decoder layer launch, and the flash kernels of a full
+// 128-stream bucket were VALU-bound at 2-3x their HBM time (tools/layer_phase_times.py).
+// A wave walks the tiles wave, wave+4, ... NT tiles at a time (two passes per batch: scores and their maximum,
+// then exponentials and P.V), so the online-softmax rescale happens once per batch.  Masked keys (not an
+// ancestor of the hypothesis / beyond the end) get probability 0.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int DK>
+struct MAttn {
+  f32x4v o[DK / 16];   // O^T: o[dt][jj] = dim (4*kg + jj) * NDT + dt of hypothesis n
+  float m, l;          // running maximum (same in the 4 lanes of a hypothesis), this lane's share of the sum
+};
+template <int DK>
+__device__ __forceinline__ void mattn_init(MAttn<DK> &a) {
+#pragma unroll
+  for (int t = 0; t < DK / 16; ++t) a.o[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  a.m = -INFINITY;
+  a.l = 0.f;
+}
+
+typedef _Float16 sc_half2 __attribute__((ext_vector_type(2)));
+template <int N, bool KVH>
+__device__ __forceinline__ void kv_loadn(const float *base, long elem, float *out) {
+  static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 elements");
+  if (KVH) {
+    const _Float16 *h = reinterpret_cast<const _Float16 *>(base) + elem;
+    if (N == 4) {
+      const sc_half4 v = *reinterpret_cast<const sc_half4 *>(h);
+      out[0] = (float)v.x; out[1] = (float)v.y; out[2] = (float)v.z; out[3] = (float)v.w;
+    } else if (N == 2) {
+      const sc_half2 v = *reinterpret_cast<const sc_half2 *>(h);
+      out[0] = (float)v.x; out[1] = (float)v.y;
+    } else {
+      out[0] = (float)*h;
+    }
+  } else {
+    if (N == 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(base + elem);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else if (N == 2) {
+      const float2 v = *reinterpret_cast<const float2 *>(base + elem);
+      out[0] = v.x; out[1] = v.y;
+    } else {
+      out[0] = base[elem];
+    }
+  }
+}
+
+// rowfn(idx, k_elem, hyp_mask): element offset of K row `idx` of the walk (V follows vofs elements later) and the
+// bit set of hypotheses that attend to it; it must be safe for any idx (clamp) - tiles >= ntiles are masked here.
+// qs: LDS [16][DK] queries / sqrt(dk), rows of unused hypotheses zero.
+template <int DK, int NT, bool KVH, class RowFn>
+__device__ __forceinline__ void mattn_walk(MAttn<DK> &st, const float *qs, const float *kv, int vofs, int ntiles,
+                                           int wave, int lane, RowFn rowfn) {
+  constexpr int DPL = DK / 4, NDT = DK / 16;
+  const int n = lane & 15, kg = lane >> 4;
+  float qb[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) qb[i] = qs[n * DK + DPL * kg + i];
+  for (int t0 = wave; t0 < ntiles; t0 += 4 * NT) {
+    float kr[NT][DPL], vr[NT][4][NDT];
+    unsigned hm[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int t = t0 + 4 * i;
+      long ke;
+      unsigned unused;
+      rowfn(16 * t + n, ke, unused);
+#pragma unroll
+      for (int q = 0; q < DPL / 4; ++q) kv_loadn<4, KVH>(kv, ke + DPL * kg + 4 * q, &kr[i][4 * q]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        long ve;
+        rowfn(16 * t + 4 * kg + j, ve, hm[i][j]);
+        kv_loadn<NDT, KVH>(kv, ve + vofs + n * NDT, vr[i][j]);
+        if (t >= ntiles) hm[i][j] = 0u;
+      }
+    }
+    f32x4v s[NT];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      s[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < DPL; ++q) s[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i][q], qb[q], s[i], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[i][j] = ((hm[i][j] >> n) & 1u) ? s[i][j] : -INFINITY;
+        mloc = fmaxf(mloc, s[i][j]);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(st.m, mloc);
+    const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+    const float corr = (st.m == -INFINITY) ? 0.f : __expf(st.m - muse);
+    st.m = mnew;
+    st.l *= corr;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) st.o[dt] *= corr;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p = (s[i][j] == -INFINITY) ? 0.f : __expf(s[i][j] - muse);
+        st.l += p;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) st.o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[i][j][dt], p, st.o[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// partial state of a wave -> LDS slot `slot`: pm / pl [slots][16], pO [slots*16][DK+1]
+template <int DK>
+__device__ __forceinline__ void mattn_store_partial(const MAttn<DK> &st, float *pm, float *pl, float *pO, int slot, int lane) {
+  constexpr int NDT = DK / 16, LDP = DK + 1;
+  const int n = lane & 15, kg = lane >> 4;
+  float l = st.l;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (kg == 0) {
+    pm[slot * 16 + n] = st.m;
+    pl[slot * 16 + n] = l;
+  }
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) pO[(slot * 16 + n) * LDP + (4 * kg + jj) * NDT + dt] = st.o[dt][jj];
+}
+
+// context element (h, c) out of NP partial states (a hypothesis without any key: 0)
+template <int DK, int NP>
+__device__ __forceinline__ float mattn_final(const float *pm, const float *pl, const float *pO, int h, int c) {
+  constexpr int LDP = DK + 1;
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < NP; ++w) M = fmaxf(M, pm[w * 16 + h]);
+  float num = 0.f, den = 0.f;
+#pragma unroll
+  for (int w = 0; w < NP; ++w) {
+    const float mw = pm[w * 16 + h];
+    const float g = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+    den = fmaf(g, pl[w * 16 + h], den);
+    num = fmaf(g, pO[(w * 16 + h) * LDP + c], num);
+  }
+  return den > 0.f ? num / den : 0.f;
+}
+// LDS floats of the partial states
+__host__ __device__ static inline int mattn_partial_floats(int DK, int np) { return np * 16 * (DK + 3); }

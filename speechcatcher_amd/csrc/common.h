@@ -48,15 +48,48 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
                              int by_row = 0);
 
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// DPP lane permutations (no LDS round trip, unlike the ds_bpermute behind __shfl)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#define SC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define SC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define SC_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8 lanes
+#define SC_DPP_ROR4 0x124        // rotate by 4 inside each 16 lanes
+#define SC_DPP_ROR8 0x128        // rotate by 8 inside each 16 lanes
+#define SC_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16 lanes
+
+// sum over the LPR (4, 8 or 16) adjacent lanes of a row group; every lane gets the total
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<SC_DPP_XOR1>(v);
+  v += dpp_mov<SC_DPP_XOR2>(v);
+  if (LPR >= 8) v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+  if (LPR == 16) v += dpp_mov<SC_DPP_ROW_MIRROR>(v);
   return v;
 }
+
+// Wave-wide reductions (all 64 lanes must be active - every call site is wave-uniform): four DPP steps reduce each
+// 16-lane row in registers, the four row results are combined through scalar registers.  The six dependent
+// ds_bpermute steps of a __shfl_xor butterfly cost ~0.3 us per reduction - 2 us for the LayerNorm of a
+// decoder layer's ten rows (tools/layer_phase_times.py).
+__device__ __forceinline__ float sc_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<SC_DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<SC_DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<SC_DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<SC_DPP_ROW_MIRROR>(v));
+  return fmaxf(fmaxf(sc_lane(v, 0), sc_lane(v, 16)), fmaxf(sc_lane(v, 32), sc_lane(v, 48)));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<SC_DPP_XOR1>(v);
+  v += dpp_mov<SC_DPP_XOR2>(v);
+  v += dpp_mov<SC_DPP_HALF_MIRROR>(v);
+  v += dpp_mov<SC_DPP_ROW_MIRROR>(v);
+  return (sc_lane(v, 0) + sc_lane(v, 16)) + (sc_lane(v, 32) + sc_lane(v, 48));
 }
 
 // log(exp(a)+exp(b)) the way torch.logsumexp does it: max first.  One of the two exponentials is exp(0) == 1
@@ -78,3 +111,21 @@ __device__ __forceinline__ float lse2(float a, float b) {
   const float m = sc_max_raw(a, b);
   return m + SC_LN2 * __builtin_amdgcn_logf(1.f + sc_exp_neg(-fabsf(a - b)));
 }
+
+// Phase stamps for tools/layer_phase_times.py: compiled in only with -DSC_PHASE_DBG (make EXTRA=-DSC_PHASE_DBG, never
+// in the shipped library).  Workgroup (0,0), thread 0 stores the 100 MHz shader real-time counter at phase
+// boundaries into a per-source-file table that sc_phase_debug_<file>() copies out.
+#ifdef SC_PHASE_DBG
+static __device__ long long sc_phase_stamps[4][32];
+#define SC_STAMP(k, i)                                                                        \
+  do {                                                                                        \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc_phase_stamps[k][i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define SC_PHASE_GETTER(name)                                                                 \
+  extern "C" int name(long long *out) {                                                       \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_phase_stamps), sizeof(long long) * 4 * 32) == hipSuccess ? 0 : -1; \
+  }
+#else
+#define SC_STAMP(k, i) do {} while (0)
+#define SC_PHASE_GETTER(name)
+#endif

@@ -67,29 +67,23 @@ __host__ __device__ static inline int dl_region_floats(int D, int DK, int W, boo
   const int nt = (self ? 3 : 1) * (DK / 16);
   const int xn = 16 * (D + 4);
   const int ps = 4 * 16 * (nt * 16 + 4);
-  const int red = 16 * W * (DK + 2);
-  const int lists = self ? (pre ? 4 * 128 * W : 128 * W) : 0;
-  const int attn = (pre ? (red > lists ? red : lists) : red + lists) + 8;
+  const int attn = mattn_partial_floats(DK, self ? 5 : 4) + (self ? 128 * W : 0) + 8;   // partial states, row list, wtot
   const int outp = 16 * 36 + 16 * (D + 4);
   int r = xn > ps ? xn : ps;
   r = r > outp ? r : outp;
   return r > attn ? r : attn;
 }
 __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, bool pre) {
-  return dl_region_floats(D, DK, W, self, pre) + WM * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
+  return dl_region_floats(D, DK, W, self, pre) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/ +
+         2 * D /*LayerNorm gamma | beta*/;
 }
 
 template <int D, int DK, int WM, bool SELF, int UNR, bool PRE, bool FIRST, bool KVH>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
-  constexpr int LPR = DK / 4;    // lanes per K/V row
-  constexpr int NG = 256 / LPR;  // row groups per workgroup
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
-  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
-  constexpr int NPART = NG / GPR;
-  constexpr int NPRE = 4;
-  constexpr int EL = D / 64, LDX = D + 4, KI = D / 32, KPW = KI / 4;
+  constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
   constexpr int NTQ = DK / 16, NT = (SELF ? 3 : 1) * NTQ, LDP = NT * 16 + 4;
-  static_assert(KI % 4 == 0 && NPART == 16, "d_model must be a multiple of 128, head dim 16 or 32");
+  static_assert(KI % 4 == 0 && (DK == 16 || DK == 32), "d_model must be a multiple of 128, head dim 16 or 32");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sc_search &sb = p.sb;
   // grid.x runs over the compaction bucket: the k-th stream of rowmap's active-first order (scasr.h: rowmap)
@@ -102,14 +96,19 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   const int W = sb.W, LCAP = sb.LCAP, H = sb.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *region = smem;
-  float *qs = smem + dl_region_floats(D, DK, W, SELF, PRE);  // [WM][DK] queries / sqrt(dk)
-  float *kvn = qs + WM * DK;                                 // SELF: [WM][2*DK] k|v of the new token
+  float *qs = smem + dl_region_floats(D, DK, W, SELF, PRE);  // [16][DK] queries / sqrt(dk), rows >= W zero
+  float *kvn = qs + 16 * DK;                                 // SELF: [WM][2*DK] k|v of the new token
   float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
+  float *gb = ctx + WM * DK;                                 // [2][D] LayerNorm gamma | beta
 
   // ------------------------------------------------------------------ L2 warm-up of this head's weight slices
   // One dword per 128-B line of the projection fragments and of the output-projection fragments, issued before
   // anything else: when few streams are active the weights come from the Infinity Cache / HBM (0.4-0.9 us per
   // dependent miss); the loads that feed the MFMAs later then hit L2.  The values only keep the loads alive.
+  SC_STAMP(SELF ? 0 : 1, 0);
+  // LayerNorm parameters: issued first, parked in LDS once the partial sums (issued later, returned later) are in
+  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < D / 2) gbv = *reinterpret_cast<const float4 *>((tid < D / 4 ? p.ln_g : p.ln_b) + 4 * (tid % (D / 4)));
   float touch = 0.f;
   {
     constexpr int NW = (SELF ? 3 : 1);
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     float *Xn = region;  // [16][LDX], rows >= W zero
     constexpr int C4 = D / 4, QT = 16 * C4 / 256;           // float4 pieces per row; pieces per thread (16 rows)
     constexpr int QN = (WM * C4 + 255) / 256;               // ... of the rows that can be live (W <= WM)
-    constexpr int ZB = (UNR >= 8) ? 8 : 4;          // partial sums per batch (register budget of the variant)
+    constexpr int ZB = (UNR >= 8) ? 16 : 4;         // partial sums per batch (register budget of the variant)
     float4 xv[QN];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
@@ -193,30 +192,42 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       *reinterpret_cast<float4 *>(Xn + i * LDX + 4 * c4) = v;
       if (head == 0 && i < W) *reinterpret_cast<float4 *>(p.xout + ((long)s * W + i) * D + 4 * c4) = v;
     }
+    if (tid < D / 2) *reinterpret_cast<float4 *>(gb + 4 * tid) = gbv;
     if (touch == 123456.789f) Xn[0] = touch;   // never true: keeps the warm-up loads (they have returned by now:
     __syncthreads();                           // loads return in order and the partial sums were waited for)
-    for (int i = wave; i < W; i += 4) {   // LayerNorm in place, one wave per row
-      float x[EL];
+    SC_STAMP(SELF ? 0 : 1, 1);
+    {   // LayerNorm in place: 16 lanes per row, all 16 rows of the tile at once (DPP reductions)
+      constexpr int Q4 = D / 64;
+      const int i = tid >> 4, sub = tid & 15;
+      float4 x[Q4];
       float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < EL; ++e) {
-        x[e] = Xn[i * LDX + lane + 64 * e];
-        sum += x[e];
+      for (int q = 0; q < Q4; ++q) {
+        x[q] = *reinterpret_cast<const float4 *>(Xn + i * LDX + 4 * (sub + 16 * q));
+        sum += (x[q].x + x[q].y) + (x[q].z + x[q].w);
       }
-      const float mean = wave_sum(sum) / (float)D;
+      const float mean = group_sum<16>(sum) / (float)D;
       float q2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < EL; ++e) {
-        const float c = x[e] - mean;
-        q2 += c * c;
+      for (int q = 0; q < Q4; ++q) {
+        const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, e = x[q].w - mean;
+        q2 += (a * a + b * b) + (c * c + e * e);
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + sb.ln_eps);
+      const float rstd = 1.0f / sqrtf(group_sum<16>(q2) / (float)D + sb.ln_eps);
+      if (i < W) {   // rows >= W stay zero
 #pragma unroll
-      for (int e = 0; e < EL; ++e)
-        Xn[i * LDX + lane + 64 * e] = (x[e] - mean) * rstd * p.ln_g[lane + 64 * e] + p.ln_b[lane + 64 * e];
+        for (int q = 0; q < Q4; ++q) {
+          const float4 gm = *reinterpret_cast<const float4 *>(gb + 4 * (sub + 16 * q));
+          const float4 bt = *reinterpret_cast<const float4 *>(gb + D + 4 * (sub + 16 * q));
+          *reinterpret_cast<float4 *>(Xn + i * LDX + 4 * (sub + 16 * q)) =
+              make_float4((x[q].x - mean) * rstd * gm.x + bt.x, (x[q].y - mean) * rstd * gm.y + bt.y,
+                          (x[q].z - mean) * rstd * gm.z + bt.z, (x[q].w - mean) * rstd * gm.w + bt.w);
+        }
+      }
     }
   }
   __syncthreads();
+  SC_STAMP(SELF ? 0 : 1, 2);
 
   // ------------------------------------------------------------------ projection of the head's columns
   // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
@@ -251,10 +262,12 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       for (int j = 0; j < 4; ++j) Ps[(wave * 16 + 4 * kk + j) * LDP + t * 16 + r] = acc[t][j];
   }
   __syncthreads();
+  SC_STAMP(SELF ? 0 : 1, 3);
   const long skv0 = ((long)s * sb.n_layers + p.li) * LCAP * W * 2 * D + head * DK;   // element offset (fp32 or fp16 cache)
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
+    for (int e = WM * DK + tid; e < 16 * DK; e += 256) qs[e] = 0.f;   // hypothesis rows the MFMA tiles pad with
     for (int e = tid; e < WM * NT * 16; e += 256) {
       const int w = e / (NT * 16), n = e % (NT * 16);
       const int which = n / DK, c = n % DK;
@@ -276,56 +289,25 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     }
   }
   __syncthreads();
+  SC_STAMP(SELF ? 0 : 1, 4);
 
   // ------------------------------------------------------------------ attention of this head (all hypotheses)
-  const int g = tid / LPR, cq = tid % LPR;
-  float *red_m = region;
-  float *red_l = red_m + NPART * W;
-  float *red_a = red_l + NPART * W;
-  const int red_floats = NPART * W * (DK + 2);
-  int *rows = PRE ? (int *)region : (int *)(red_a + NPART * W * DK);  // PRE: aliases the partial states
-  int *wtot = (int *)region + (PRE ? max(red_floats, NPRE * PCH * W) : red_floats + (SELF ? PCH * W : 0));
-  int *ucnt = wtot + 4;
+  // matrix-core form (attn.h: mattn_*): the hypotheses are the N dimension, 16 K/V rows a tile; the four waves
+  // take tiles round-robin and leave one partial state each (+ one for the new token's own row, SELF)
+  constexpr int NTW = (UNR >= 8) ? 4 : 2;   // tiles per wave and batch
+  constexpr int NP = SELF ? 5 : 4;
+  float *pm = region;
+  float *pl = pm + NP * 16;
+  float *pO = pl + NP * 16;
+  int *rows = (int *)(region + mattn_partial_floats(DK, NP));
+  int *wtot = rows + (SELF ? PCH * W : 0);
   const long ckv0 = ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
-
-  AttnState st[WM];
-  if (!(SELF && PRE)) {
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      st[h].m = -INFINITY;
-      st[h].l = 0.f;
-      st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  auto process = [&](const float4 &k, const float4 &v, unsigned hm) {
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      const float4 qh = *reinterpret_cast<const float4 *>(qs + h * DK + 4 * cq);
-      float sdot = qh.x * k.x;
-      sdot = fmaf(qh.y, k.y, sdot);
-      sdot = fmaf(qh.z, k.z, sdot);
-      sdot = fmaf(qh.w, k.w, sdot);
-      sdot = group_sum<LPR>(sdot);
-      if ((hm >> h) & 1u) {
-        if (sdot > st[h].m) {  // rescale only when the running max moves
-          const float corr = __expf(st[h].m - sdot);  // exp(-inf) = 0 on the first row
-          st[h].l *= corr;
-          st[h].a.x *= corr; st[h].a.y *= corr; st[h].a.z *= corr; st[h].a.w *= corr;
-          st[h].m = sdot;
-        }
-        const float pe = __expf(sdot - st[h].m);
-        st[h].l += pe;
-        st[h].a.x = fmaf(pe, v.x, st[h].a.x);
-        st[h].a.y = fmaf(pe, v.y, st[h].a.y);
-        st[h].a.z = fmaf(pe, v.z, st[h].a.z);
-        st[h].a.w = fmaf(pe, v.w, st[h].a.w);
-      }
-    }
-  };
+  MAttn<DK> st;
+  mattn_init(st);
 
   if (SELF) {
     const int *anc = ANC(cur, s);
-    const int Lc = L - 1;  // cached positions; the new token's rows come from LDS afterwards
+    const int Lc = L - 1;  // cached positions; the new token's row is the fifth partial state
     const int nchunk = cdiv(Lc, PCH);
     // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
     // entry = local position | slot << 8 | hypothesis bit set << 12
@@ -363,117 +345,46 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       __syncthreads();  // list complete; wtot may be rewritten
       return U;
     };
-    auto walk = [&](const int *rw, int U, int c0) {
-      for (int j0 = g; j0 < U; j0 += NG * UNR) {
-        int e[UNR];
-        float4 k[UNR], v[UNR];
-#pragma unroll
-        for (int i = 0; i < UNR; ++i) {
-          e[i] = rw[min(j0 + i * NG, U - 1)];
-          const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
-          const long kp = skv0 + ((long)pp * W + u) * 2 * D;
-          k[i] = kv_load4<KVH>(sb.skv, kp + 4 * cq);
-          v[i] = kv_load4<KVH>(sb.skv, kp + D + 4 * cq);
-        }
-#pragma unroll
-        for (int i = 0; i < UNR; ++i)
-          if (j0 + i * NG < U) process(k[i], v[i], (unsigned)e[i] >> 12);  // uniform inside a row group
-      }
-    };
-    if (PRE) {
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const int U = build(rows + ch * PCH * W, ch * PCH);
-        if (tid == 0) ucnt[ch] = U;
-      }
-      __syncthreads();  // ucnt
-#pragma unroll
-      for (int h = 0; h < WM; ++h) {
-        st[h].m = -INFINITY;
-        st[h].l = 0.f;
-        st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      for (int ch = 0; ch < nchunk; ++ch) walk(rows + ch * PCH * W, ucnt[ch], ch * PCH);
-    } else {
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const int U = build(rows, ch * PCH);
-        walk(rows, U, ch * PCH);
-        if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
-      }
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int c0 = ch * PCH;
+      const int U = build(rows, c0);
+      mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+        const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
+        hm = (unsigned)e >> 12;
+        ke = skv0 + ((long)(c0 + (e & 255)) * W + ((e >> 8) & 15)) * 2 * D;
+      });
+      if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
     }
-    // the new token: hypothesis h attends to its own row (slot h at position L-1) only
-    if (g < nh) {
-      const float4 k = *reinterpret_cast<const float4 *>(kvn + g * 2 * DK + 4 * cq);
-      const float4 v = *reinterpret_cast<const float4 *>(kvn + g * 2 * DK + DK + 4 * cq);
-      process(k, v, 1u << g);
+    // the new token: hypothesis h attends to its own row (slot h at position L-1, still in LDS) only
+    if (tid < 16) {
+      const int h = tid;
+      float sdot = -INFINITY;
+      if (h < nh) {
+        sdot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DK; ++c) sdot = fmaf(qs[h * DK + c], kvn[h * 2 * DK + c], sdot);
+#pragma unroll
+        for (int c = 0; c < DK; ++c) pO[(4 * 16 + h) * (DK + 1) + c] = kvn[h * 2 * DK + DK + c];
+      }
+      pm[4 * 16 + h] = sdot;
+      pl[4 * 16 + h] = h < nh ? 1.f : 0.f;
     }
-    __syncthreads();  // the lists are dead: their LDS becomes the partial states
   } else {
     const unsigned all = (1u << nh) - 1u;
-    for (int j0 = g; j0 < T; j0 += NG * UNR) {
-      float4 k[UNR], v[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        const long kp = ckv0 + (long)min(j0 + i * NG, T - 1) * 2 * D;
-        k[i] = kv_load4<KVH>(sb.ckv, kp + 4 * cq);
-        v[i] = kv_load4<KVH>(sb.ckv, kp + D + 4 * cq);
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i)
-        if (j0 + i * NG < T) process(k[i], v[i], all);
-    }
-    __syncthreads();  // Ps (read by the q reduce above) is dead before the partial states are written
+    mattn_walk<DK, NTW, KVH>(st, qs, sb.ckv, D, cdiv(T, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+      hm = idx < T ? all : 0u;
+      ke = ckv0 + (long)min(idx, T - 1) * 2 * D;
+    });
   }
-
-  // ---- merge the row groups: inside a 16-lane DPP row in registers, then LDS ----
-#pragma unroll
-  for (int h = 0; h < WM; ++h) {
-    if (LPR == 4) attn_merge_dpp<SC_DPP_ROR4>(st[h]);
-    attn_merge_dpp<SC_DPP_ROR8>(st[h]);
-  }
-  if ((g % GPR) == 0) {
-    const int pp = g / GPR;
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      if (h < nh) {
-        if (cq == 0) {
-          red_m[pp * W + h] = st[h].m;
-          red_l[pp * W + h] = st[h].l;
-        }
-        *reinterpret_cast<float4 *>(red_a + ((long)(pp * W + h)) * DK + 4 * cq) = st[h].a;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < nh * NPART) {
-    const int h = tid / NPART, pp = tid % NPART;
-    const float mp = red_m[pp * W + h];
-    float M = mp;
-    M = fmaxf(M, dpp_mov<SC_DPP_XOR1>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_XOR2>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_HALF_MIRROR>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_ROW_MIRROR>(M));
-    const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
-    float den = w * red_l[pp * W + h];
-    den += dpp_mov<SC_DPP_XOR1>(den);
-    den += dpp_mov<SC_DPP_XOR2>(den);
-    den += dpp_mov<SC_DPP_HALF_MIRROR>(den);
-    den += dpp_mov<SC_DPP_ROW_MIRROR>(den);
-    red_m[pp * W + h] = w;  // each element is read and written by this thread only
-    if (pp == 0) red_l[h] = den;
-  }
+  SC_STAMP(SELF ? 0 : 1, 5);
+  mattn_store_partial<DK>(st, pm, pl, pO, wave, lane);
   __syncthreads();
   for (int e = tid; e < WM * DK; e += 256) {
     const int h = e / DK, c = e % DK;
-    float o = 0.f;  // rows >= nh: zero context (their partial products stay finite)
-    if (h < nh) {
-      float num = 0.f;
-#pragma unroll
-      for (int pp = 0; pp < NPART; ++pp) num = fmaf(red_m[pp * W + h], red_a[((long)(pp * W + h)) * DK + c], num);
-      o = num / red_l[h];
-    }
-    ctx[e] = o;
+    ctx[e] = h < nh ? mattn_final<DK, NP>(pm, pl, pO, h, c) : 0.f;  // rows >= nh: zero context (their partial products stay finite)
   }
   __syncthreads();
+  SC_STAMP(SELF ? 0 : 1, 6);
 
   // ------------------------------------------------------------------ this head's share of the output projection
   // ph[row][head][n] = sum_c ctx[w][c] * Wo[n][head*DK + c]: f32 MFMA over the k-block of 32 input columns that
@@ -506,13 +417,16 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = acc[j];
     }
     __syncthreads();
+    SC_STAMP(SELF ? 0 : 1, 7);
     for (int e = tid; e < W * (D / 4); e += 256) {
       const int w = e / (D / 4), c4 = e % (D / 4);
       *reinterpret_cast<float4 *>(p.ph + (((long)s * W + w) * H + head) * D + 4 * c4) =
           *reinterpret_cast<const float4 *>(Os + w * LDO + 4 * c4);
     }
   }
+  SC_STAMP(SELF ? 0 : 1, 8);
 }
+SC_PHASE_GETTER(sc_phase_debug_layer)
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, int DK, bool SELF, bool FIRST, bool KVH>
@@ -522,14 +436,11 @@ static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  const bool pre_ok = !sc_hook("SC_SELF_ATTN_NOPRE");                    // tests: row lists interleaved with the walk
   auto lds = [&](int wm, bool pre) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF, pre) * sizeof(float); };
   if (sb.W <= 5) {
     dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST, KVH><<<grid, 256, lds(5, false), st>>>(p);
   } else if (sb.W <= 10) {
     if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
-    else if (SELF && sb.LCAP <= 4 * 128 && pre_ok)
-      dec_layer_attn_kernel<D, DK, 10, SELF, 2, SELF, FIRST, KVH><<<grid, 256, lds(10, true), st>>>(p);
     else dec_layer_attn_kernel<D, DK, 10, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
   } else {
     dec_layer_attn_kernel<D, DK, 16, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(16, false), st>>>(p);
@@ -574,7 +485,10 @@ extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *x
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = layer == 0 ? launch_dec_layer_dims<true, true>(p, st) : launch_dec_layer_dims<true, false>(p, st);
-  sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);  // traffic depends on device-side state (L, ancestors)
+  {   // MFMA part: Q|K|V projection + out-projection of the bucket's rows (the attention itself depends on device state)
+    const double M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
+    sc_prof_end(prof, SC_PROF_LAYER_SELF, 8.0 * M * sb.d * sb.d, 4.0 * sb.d * sb.d * 4.0);
+  }
   return rc;
 }
 
@@ -590,6 +504,9 @@ extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = launch_dec_layer_dims<false, false>(p, st);
-  sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
+  {   // MFMA part: q projection + out-projection; K|V bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
+    const double M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
+    sc_prof_end(prof, SC_PROF_LAYER_CROSS, 4.0 * M * sb.d * sb.d, 2.0 * sb.d * sb.d * 4.0);
+  }
   return rc;
 }

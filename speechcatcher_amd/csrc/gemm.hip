@@ -816,53 +816,74 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int NV = RT * D / 4;
   constexpr int NQ = NV / 512;
   static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
+  SC_STAMP(PRO ? 2 : 3, 0);
   if (PRO) {
-    // one wave per row: sum of the producer's per-head partial products (fixed head order), residual,
-    // LayerNorm - recomputed by every chunk group of the row tile (cheap, L2-resident) so that the
-    // attention output projection needs no launch of its own
-    constexpr int EL = D / 64;
-    float gam[EL], bet[EL], pb[EL];
+    // sum of the producer's per-head partial products (fixed head order) + residual, then LayerNorm - recomputed
+    // by every chunk group of the row tile (cheap, L2-resident) so that the attention output projection needs no
+    // launch of its own.  Element-parallel: every thread owns float4 pieces of the RT x D tile and has the loads of
+    // all head partials of a piece in flight together (one memory round trip behind the row ids); the LayerNorm
+    // then runs on the LDS tile with 16 lanes per row (DPP reductions).
+    constexpr int C4 = D / 4, Q4 = D / 64;
+    const int sub = threadIdx.x & 15;
+    float4 gam[Q4], bet[Q4];   // issued first: they have arrived when the partial sums have
 #pragma unroll
-    for (int e = 0; e < EL; ++e) {
-      gam[e] = p.g[lane + 64 * e];
-      bet[e] = p.b[lane + 64 * e];
-      pb[e] = p.pbias ? p.pbias[lane + 64 * e] : 0.f;
+    for (int q = 0; q < Q4; ++q) {
+      gam[q] = *reinterpret_cast<const float4 *>(p.g + 4 * (sub + 16 * q));
+      bet[q] = *reinterpret_cast<const float4 *>(p.b + 4 * (sub + 16 * q));
     }
-    for (int i = wave; i < RT; i += 8) {
-      const int m = min(m0 + i, p.M - 1);
-      const long row = p.rows ? p.rows[m] : m;
-      if (lane == 0) rowid[i] = (int)row;
-      float x[EL], y[EL];
+    long rowv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = min(m0 + (threadIdx.x + q * 512) / C4, p.M - 1);
+      rowv[q] = p.rows ? p.rows[m] : m;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * 512, i = e / C4, c4 = e % C4;
+      const long row = rowv[q];
+      if (c4 == 0) rowid[i] = (int)row;
+      const float4 xi = *reinterpret_cast<const float4 *>(p.Xin + row * D + 4 * c4);
+      float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.pbias) pb = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int z0 = 0; z0 < p.nph; z0 += 8) {
-        float pv[EL][8];
+        float4 pv[8];
 #pragma unroll
-        for (int e = 0; e < EL; ++e)
+        for (int z = 0; z < 8; ++z)
+          pv[z] = *reinterpret_cast<const float4 *>(p.PH + (row * p.nph + min(z0 + z, p.nph - 1)) * D + 4 * c4);
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            pv[e][q] = p.PH[(row * p.nph + min(z0 + q, p.nph - 1)) * D + lane + 64 * e];
-#pragma unroll
-        for (int e = 0; e < EL; ++e)
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (z0 + q < p.nph) y[e] = (z0 + q == 0) ? pv[e][0] : y[e] + pv[e][q];
+        for (int z = 0; z < 8; ++z)
+          if (z0 + z < p.nph) {
+            if (z0 + z == 0) y = pv[0];
+            else { y.x += pv[z].x; y.y += pv[z].y; y.z += pv[z].z; y.w += pv[z].w; }
+          }
       }
+      const float4 x = make_float4(xi.x + (y.x + pb.x), xi.y + (y.y + pb.y), xi.z + (y.z + pb.z), xi.w + (y.w + pb.w));
+      if (grp == 0 && m0 + i < p.M) *reinterpret_cast<float4 *>(p.Xout + row * D + 4 * c4) = x;
+      *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * c4) = x;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x >> 4; i < RT; i += 32) {   // uniform per 16-lane row group
+      float4 x[Q4];
       float sum = 0.f;
 #pragma unroll
-      for (int e = 0; e < EL; ++e) {
-        x[e] = p.Xin[row * D + lane + 64 * e] + (y[e] + pb[e]);
-        if (grp == 0 && m0 + i < p.M) p.Xout[row * D + lane + 64 * e] = x[e];
-        sum += x[e];
+      for (int q = 0; q < Q4; ++q) {
+        x[q] = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * (sub + 16 * q));
+        sum += (x[q].x + x[q].y) + (x[q].z + x[q].w);
       }
-      const float mean = wave_sum(sum) / (float)D;
+      const float mean = group_sum<16>(sum) / (float)D;
       float q2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < EL; ++e) {
-        const float c = x[e] - mean;
-        q2 += c * c;
+      for (int q = 0; q < Q4; ++q) {
+        const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, e = x[q].w - mean;
+        q2 += (a * a + b * b) + (c * c + e * e);
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + p.eps);
+      const float rstd = 1.0f / sqrtf(group_sum<16>(q2) / (float)D + p.eps);
 #pragma unroll
-      for (int e = 0; e < EL; ++e) Xs[i * LDX + lane + 64 * e] = (x[e] - mean) * rstd * gam[e] + bet[e];
+      for (int q = 0; q < Q4; ++q)
+        *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * (sub + 16 * q)) =
+            make_float4((x[q].x - mean) * rstd * gam[q].x + bet[q].x, (x[q].y - mean) * rstd * gam[q].y + bet[q].y,
+                        (x[q].z - mean) * rstd * gam[q].z + bet[q].z, (x[q].w - mean) * rstd * gam[q].w + bet[q].w);
     }
   } else {
     long rowv[NQ];
@@ -898,6 +919,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   };
   load_b1(grp * p.cpw);
   __syncthreads();
+  SC_STAMP(PRO ? 2 : 3, 1);
 
   for (int cc = 0; cc < p.cpw; ++cc) {
     const int chunk = grp * p.cpw + cc;
@@ -975,6 +997,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       for (int j = 0; j < 4; ++j)
         Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] = acc2[rt][t][j];
   __syncthreads();
+  SC_STAMP(PRO ? 2 : 3, 2);
   float *dst = p.part + ((long)grp * p.M + m0) * D;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -985,7 +1008,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       *reinterpret_cast<float4 *>(o + 4 * c4) = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
     }
   }
+  SC_STAMP(PRO ? 2 : 3, 3);
 }
+SC_PHASE_GETTER(sc_phase_debug_ffn)
 
 template <int D, int RTT, bool PRO = false>
 static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {

@@ -207,32 +207,21 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li
 //                   chunk into an LDS list with the bit set of hypotheses
 //                   using each row;
 //           CROSS - the T encoder frames, used by every hypothesis.
-//   * DK/4 lanes per row load 16 B each of K and of V (full-line coalesced; a
-//     per-lane row walk costs one cache-line lookup per lane and was the
-//     limiter of the per-hypothesis kernels), UNR rows in flight per group;
-//   * the group's lanes reduce the 4-dim partial dot products with DPP adds,
-//     every lane then runs the online softmax of the hypothesis in registers
-//     (running max / sum per hypothesis, its own 4 dims of the context);
-//   * partial states of the row groups are merged with DPP (inside a 16-lane
-//     row) and through LDS.
+//   * arithmetic on the matrix cores (attn.h: mattn_walk): tiles of 16 K/V rows x all hypotheses,
+//     S^T = K.Q^T and O^T += V^T.P with v_mfma_f32_16x16x4_f32; the four waves take tiles round-robin,
+//     K rows are loaded 32 B per lane (full lines per 4 lanes), V rows 8 B per lane (full lines per 16 lanes);
+//   * online softmax per batch of NTW tiles (running maximum per hypothesis = per lane), the waves' partial
+//     states and - SELF - the new token's own row are merged through LDS.
 // Scores use q/sqrt(dk) . k and exp2-based __expf: differences to the reference's
 // softmax(q.k/sqrt(dk)) are rounding-level (parity tests: 2e-4).
 // ---------------------------------------------------------------------------
-// UNR = K/V rows in flight per row group.  2 keeps the kernel at 128 VGPRs so that all S*H
-// workgroups of a full batch are resident at once (bandwidth-bound regime); 8 is used when
-// at most half of the streams are active (ragged-batch compaction bucket): then occupancy is
-// no issue and the kernel is bound by the number of serial HBM round trips per workgroup.
-// PRE (self-attention, LCAP <= 4*128 positions): the row lists of ALL position chunks are built before
-// the first row is walked - into the LDS region that later holds the partial states - so that the
-// 60 registers of running softmax state are not live across the list build (the interleaved form
-// spills 15 VGPRs per thread = 15 MB of scratch writes per launch at 128 streams).
-template <int DK, int WM, bool SELF, int UNR, bool PRE = false, bool KVH = false>
-__global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_flash_kernel(sc_search sb, int li) {
-  constexpr int LPR = DK / 4;    // lanes per K/V row
-  constexpr int NG = 256 / LPR;  // row groups per workgroup
+// UNR selects the batch depth: 8 -> 4 tiles per wave in flight (at most half of the streams active: occupancy is
+// no issue, serial HBM round trips are), otherwise 2 (all S*H workgroups of a full batch resident at once).
+template <int DK, int WM, bool SELF, int UNR, bool KVH = false>
+__global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) void dec_attn_flash_kernel(sc_search sb, int li) {
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
-  constexpr int GPR = 16 / LPR;  // row groups per 16-lane DPP row
-  constexpr int NPART = NG / GPR;
+  constexpr int NTW = (UNR >= 8) ? 4 : 2;   // key tiles per wave and batch (attn.h: mattn_walk)
+  constexpr int NP = SELF ? 5 : 4;          // partial states: one per wave (+ the new token's own row)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // grid.y runs over the compaction bucket: the k-th stream of rowmap's active-first order (scasr.h: rowmap)
   const int head = blockIdx.x, s = sb.rowmap ? sb.rowmap[blockIdx.y * sb.W] / sb.W : blockIdx.y;
@@ -242,17 +231,13 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
   const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
   const int W = sb.W, d = sb.d, LCAP = sb.LCAP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = tid / LPR, cq = tid % LPR;
-  // LDS: partial states red_m/red_l [NPART][W], red_a [NPART][W][DK]; rows[PCH*W]; wtot[4]
-  float *red_m = smem;
-  float *red_l = red_m + NPART * W;
-  float *red_a = red_l + NPART * W;
-  constexpr int NPRE = 4;   // chunks of a PRE launch (host: LCAP <= NPRE * PCH)
-  const int red_floats = NPART * W * (DK + 2);
-  int *rows = PRE ? (int *)smem : (int *)(red_a + NPART * W * DK);   // PRE: aliases the partial states
-  int *wtot = (int *)smem + (PRE ? max(red_floats, NPRE * PCH * W) : red_floats + (SELF ? PCH * W : 0));
-  int *ucnt = wtot + 4;              // PRE: distinct rows per chunk
-  float *qs = (float *)(wtot + 8);   // [W][DK] queries / sqrt(dk)
+  // LDS: partial states pm / pl [NP][16], pO [NP*16][DK+1]; rows[PCH*W]; wtot[8]; qs [16][DK]
+  float *pm = smem;
+  float *pl = pm + NP * 16;
+  float *pO = pl + NP * 16;
+  int *rows = (int *)(smem + mattn_partial_floats(DK, NP));
+  int *wtot = rows + (SELF ? PCH * W : 0);
+  float *qs = (float *)(wtot + 8);   // queries / sqrt(dk), rows >= nh zero
 
   // SELF: q|k|v of the new token in dqkv (hypothesis h at + h*3d); CROSS: q in dq
   const float *qbase = SELF ? sb.dqkv + (long)s * W * 3 * d + head * DK : sb.dq + (long)s * W * d + head * DK;
@@ -270,68 +255,32 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
       kv_store1<KVH>(sb.skv, dst + d + c, qbase[(long)h * 3 * d + 2 * d + c]);
     }
   }
-  // queries of all hypotheses, pre-divided by sqrt(dk) (rows >= nh: a valid row, never used)
+  // queries of the hypotheses, pre-divided by sqrt(dk); the rows that pad the MFMA tile are zero
   const float scale = sqrtf((float)DK);
-  // (kept in LDS, not registers: the kernel must stay under 128 VGPRs so that all
-  // S*H workgroups of a 128-stream batch are resident at once)
-  for (int e = tid; e < WM * DK; e += 256) {
+  for (int e = tid; e < 16 * DK; e += 256) {
     const int h = e / DK, c = e % DK;
-    qs[e] = qbase[(long)min(h, nh - 1) * qld + c] / scale;
+    qs[e] = h < nh ? qbase[(long)h * qld + c] / scale : 0.f;
   }
-  AttnState st[WM];
-  if (!(SELF && PRE)) {
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      st[h].m = -INFINITY;
-      st[h].l = 0.f;
-      st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-
-  auto process = [&](const float4 &k, const float4 &v, unsigned hm) {
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      const float4 qh = *reinterpret_cast<const float4 *>(qs + h * DK + 4 * cq);
-      float sdot = qh.x * k.x;
-      sdot = fmaf(qh.y, k.y, sdot);
-      sdot = fmaf(qh.z, k.z, sdot);
-      sdot = fmaf(qh.w, k.w, sdot);
-      sdot = group_sum<LPR>(sdot);
-      if ((hm >> h) & 1u) {
-        if (sdot > st[h].m) {   // rescale only when the running max moves
-          const float corr = __expf(st[h].m - sdot);   // exp(-inf) = 0 on the first row
-          st[h].l *= corr;
-          st[h].a.x *= corr; st[h].a.y *= corr; st[h].a.z *= corr; st[h].a.w *= corr;
-          st[h].m = sdot;
-        }
-        const float pe = __expf(sdot - st[h].m);
-        st[h].l += pe;
-        st[h].a.x = fmaf(pe, v.x, st[h].a.x);
-        st[h].a.y = fmaf(pe, v.y, st[h].a.y);
-        st[h].a.z = fmaf(pe, v.z, st[h].a.z);
-        st[h].a.w = fmaf(pe, v.w, st[h].a.w);
-      }
-    }
-  };
+  MAttn<DK> st;
+  mattn_init(st);
 
   if (SELF) {
     const int *anc = ANC(cur, s);
-    const int nchunk = cdiv(L, PCH);
+    const int Lc = L - 1;   // cached positions; the new token's row (still in dqkv) is the fifth partial state
+    const int nchunk = cdiv(Lc, PCH);
     // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
     // entry = local position | slot << 8 | hypothesis bit set << 12
     auto build = [&](int *rw, int c0) -> int {
       for (int e = tid; e < PCH * W; e += 256) rw[e] = 0;
       const int p = c0 + tid;
-      const bool live = tid < PCH && p < L;
+      const bool live = tid < PCH && p < Lc;
       int sl[WM];
 #pragma unroll
       for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? p : 0) * W + min(h, nh - 1)];
       unsigned mask = 0;
 #pragma unroll
-      for (int h = 0; h < WM; ++h) {
-        if (p == L - 1) sl[h] = h;
+      for (int h = 0; h < WM; ++h)
         if (h < nh) mask |= 1u << sl[h];
-      }
       const int cnt = live ? __popc(mask) : 0;
       int incl = cnt;
 #pragma unroll
@@ -340,7 +289,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
         if (lane >= o) incl += t;
       }
       if (lane == 63) wtot[wave] = incl;
-      __syncthreads();   // also orders the zero fill before the ORs
+      __syncthreads();   // also orders the zero fill (and qs) before the ORs
       const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
       const int U = wtot[0] + wtot[1];
       if (live) {
@@ -355,121 +304,50 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_attn_
       __syncthreads();   // list complete; wtot may be rewritten
       return U;
     };
-    auto walk = [&](const int *rw, int U, int c0) {
-      for (int j0 = g; j0 < U; j0 += NG * UNR) {
-        int e[UNR];
-        float4 k[UNR], v[UNR];
+    if (nchunk == 0) __syncthreads();   // qs
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int c0 = ch * PCH;
+      const int U = build(rows, c0);
+      mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, d, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+        const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
+        hm = (unsigned)e >> 12;
+        ke = skv0 + ((long)(c0 + (e & 255)) * W + ((e >> 8) & 15)) * 2 * d;
+      });
+      if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+    }
+    // the new token: hypothesis h attends to its own row (slot h at position L-1) only
+    if (tid < 16) {
+      const int h = tid;
+      float sdot = -INFINITY;
+      if (h < nh) {
+        const float *kp = qbase + (long)h * 3 * d + d;
+        sdot = 0.f;
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) {
-          e[i] = rw[min(j0 + i * NG, U - 1)];
-          const int pp = c0 + (e[i] & 255), u = (e[i] >> 8) & 15;
-          if (pp == L - 1) {   // this step's own row: still in dqkv (fp32)
-            const float *kp = qbase + (long)u * 3 * d + d;
-            k[i] = *reinterpret_cast<const float4 *>(kp + 4 * cq);
-            v[i] = *reinterpret_cast<const float4 *>(kp + d + 4 * cq);
-          } else {
-            const long kp = skv0 + ((long)pp * W + u) * 2 * d;
-            k[i] = kv_load4<KVH>(sb.skv, kp + 4 * cq);
-            v[i] = kv_load4<KVH>(sb.skv, kp + d + 4 * cq);
-          }
-        }
+        for (int c = 0; c < DK; ++c) sdot = fmaf(qs[h * DK + c], kp[c], sdot);
 #pragma unroll
-        for (int i = 0; i < UNR; ++i)
-          if (j0 + i * NG < U) process(k[i], v[i], (unsigned)e[i] >> 12);   // uniform inside a row group
+        for (int c = 0; c < DK; ++c) pO[(4 * 16 + h) * (DK + 1) + c] = kp[d + c];
       }
-    };
-    if (PRE) {
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const int U = build(rows + ch * PCH * W, ch * PCH);
-        if (tid == 0) ucnt[ch] = U;
-      }
-      __syncthreads();   // ucnt
-#pragma unroll
-      for (int h = 0; h < WM; ++h) {
-        st[h].m = -INFINITY;
-        st[h].l = 0.f;
-        st[h].a = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      for (int ch = 0; ch < nchunk; ++ch) walk(rows + ch * PCH * W, ucnt[ch], ch * PCH);
-      __syncthreads();   // the lists are dead: their LDS becomes the partial states
-    } else {
-      for (int ch = 0; ch < nchunk; ++ch) {
-        const int U = build(rows, ch * PCH);
-        walk(rows, U, ch * PCH);
-        if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
-      }
+      pm[4 * 16 + h] = sdot;
+      pl[4 * 16 + h] = h < nh ? 1.f : 0.f;
     }
   } else {
     __syncthreads();   // qs
     const unsigned all = (1u << nh) - 1u;
-    for (int j0 = g; j0 < T; j0 += NG * UNR) {
-      float4 k[UNR], v[UNR];
-#pragma unroll
-      for (int i = 0; i < UNR; ++i) {
-        const long kp = ckv0 + (long)min(j0 + i * NG, T - 1) * 2 * d;
-        k[i] = kv_load4<KVH>(sb.ckv, kp + 4 * cq);
-        v[i] = kv_load4<KVH>(sb.ckv, kp + d + 4 * cq);
-      }
-#pragma unroll
-      for (int i = 0; i < UNR; ++i)
-        if (j0 + i * NG < T) process(k[i], v[i], all);
-    }
+    mattn_walk<DK, NTW, KVH>(st, qs, sb.ckv, d, cdiv(T, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+      hm = idx < T ? all : 0u;
+      ke = ckv0 + (long)min(idx, T - 1) * 2 * d;
+    });
   }
-
-  // ---- merge the row groups: inside a 16-lane DPP row in registers, then LDS ----
-#pragma unroll
-  for (int h = 0; h < WM; ++h) {
-    if (LPR == 4) attn_merge_dpp<SC_DPP_ROR4>(st[h]);
-    if (LPR <= 8) attn_merge_dpp<SC_DPP_ROR8>(st[h]);   // LPR 16 (d_k = 64): one row group per DPP row, nothing to merge
-  }
-  if ((g % GPR) == 0) {
-    const int pp = g / GPR;
-#pragma unroll
-    for (int h = 0; h < WM; ++h) {
-      if (h < nh) {
-        if (cq == 0) {
-          red_m[pp * W + h] = st[h].m;
-          red_l[pp * W + h] = st[h].l;
-        }
-        *reinterpret_cast<float4 *>(red_a + ((long)(pp * W + h)) * DK + 4 * cq) = st[h].a;
-      }
-    }
-  }
+  mattn_store_partial<DK>(st, pm, pl, pO, wave, lane);
   __syncthreads();
-  // ---- final merge.  Step 1: one thread per (hypothesis, partial): weight of the partial
-  // exp(m - max m) and the normaliser, reduced inside the 16 lanes of a hypothesis with DPP ----
-  static_assert(NPART == 16, "the final merge maps a hypothesis to one 16-lane DPP row");
-  if (tid < nh * NPART) {
-    const int h = tid / NPART, pp = tid % NPART;
-    const float mp = red_m[pp * W + h];
-    float M = mp;
-    M = fmaxf(M, dpp_mov<SC_DPP_XOR1>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_XOR2>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_HALF_MIRROR>(M));
-    M = fmaxf(M, dpp_mov<SC_DPP_ROW_MIRROR>(M));
-    const float w = (mp == -INFINITY) ? 0.f : __expf(mp - M);
-    float den = w * red_l[pp * W + h];
-    den += dpp_mov<SC_DPP_XOR1>(den);
-    den += dpp_mov<SC_DPP_XOR2>(den);
-    den += dpp_mov<SC_DPP_HALF_MIRROR>(den);
-    den += dpp_mov<SC_DPP_ROW_MIRROR>(den);
-    red_m[pp * W + h] = w;            // each element is read and written by this thread only
-    if (pp == 0) red_l[h] = den;
-  }
-  __syncthreads();
-  // ---- step 2: context = sum of the weighted partial contexts / normaliser ----
   for (int e = tid; e < nh * DK; e += 256) {
     const int h = e / DK, c = e % DK;
-    float num = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < NPART; ++pp) num = fmaf(red_m[pp * W + h], red_a[((long)(pp * W + h)) * DK + c], num);
-    sb.datt[((long)s * W + h) * d + head * DK + c] = num / red_l[h];
+    sb.datt[((long)s * W + h) * d + head * DK + c] = mattn_final<DK, NP>(pm, pl, pO, h, c);
   }
 }
 
 static size_t attn_flash_lds(const sc_search &sb, int dk, bool self) {
-  const size_t npart = 16;   // NG / GPR for dk 16 and 32
-  return (npart * sb.W * (dk + 2) + (self ? (size_t)128 * sb.W : 0) + 8 + (size_t)16 * dk) * sizeof(float);
+  return ((size_t)mattn_partial_floats(dk, self ? 5 : 4) + (self ? (size_t)128 * sb.W : 0) + 8 + (size_t)16 * dk) * sizeof(float);
 }
 
 template <int DK, bool SELF, bool KVH>
@@ -479,16 +357,11 @@ static void launch_attn_flash_kvh(const sc_search &sb, int layer, hipStream_t st
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
+  if (sb.W <= 5) dec_attn_flash_kernel<DK, 5, SELF, 4, KVH><<<grid, 256, lds, st>>>(sb, layer);
   else if (sb.W <= 10) {
-    if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
-    else if (SELF && sb.LCAP <= 4 * 128 && !sc_hook("SC_SELF_ATTN_NOPRE")) {
-      // all row lists first, aliased with the partial states (see the kernel's PRE note)
-      const size_t red = (size_t)16 * sb.W * (DK + 2), lists = (size_t)4 * 128 * sb.W;
-      const size_t lds_pre = ((red > lists ? red : lists) + 8 + (size_t)16 * DK) * sizeof(float);
-      dec_attn_flash_kernel<DK, 10, SELF, 2, true, KVH><<<grid, 256, lds_pre, st>>>(sb, layer);
-    } else dec_attn_flash_kernel<DK, 10, SELF, 2, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
-  } else dec_attn_flash_kernel<DK, 16, SELF, 2, false, KVH><<<grid, 256, lds, st>>>(sb, layer);
+    if (deep) dec_attn_flash_kernel<DK, 10, SELF, 8, KVH><<<grid, 256, lds, st>>>(sb, layer);
+    else dec_attn_flash_kernel<DK, 10, SELF, 2, KVH><<<grid, 256, lds, st>>>(sb, layer);
+  } else dec_attn_flash_kernel<DK, 16, SELF, 2, KVH><<<grid, 256, lds, st>>>(sb, layer);
 }
 
 template <int DK, bool SELF>
@@ -1437,7 +1310,6 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 // all partial sums of its stream costs more fabric traffic than the launches it saves, and the six-launch form
 // (row panels + stand-alone attention) is faster (profiles/r02_fused_threshold_sweep.txt: strict lock-step
 // 28.9 / 28.1 / 29.0 ms per chunk step with the limit at 0 / 640 / 1280 rows).
-#define SC_FUSED_MAX_ROWS 640
 static bool dec_fused_ok(const sc_search &sb) {
   if (const char *e = sc_hook("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
     return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;

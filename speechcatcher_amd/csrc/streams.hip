@@ -159,7 +159,7 @@ struct sc_streams {
   bool decode_prepared = false;
   std::map<int, hipGraphExec_t> dec_graphs;
   std::map<std::vector<long>, hipGraphExec_t> enc_graphs;
-  long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows = 0;
+  long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows[2] = {0, 0};   // [0] flash kernels, [1] layer kernels
   double t_launch = 0, t_wait = 0, t_host = 0;   // seconds in the step loop: issuing, waiting for the flags, bookkeeping
   double t_bucket[17] = {0};                     // ... waiting, by compaction bucket (n_rows_step / (row_bucket*W))
   long n_bucket[17] = {0};
@@ -714,7 +714,7 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     RC_TRY(upload_ctrl(b));
     b->dec_steps++;
     for (int i = 0; i < n; ++i)
-      if (live[i]) b->xattn_rows += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
+      if (live[i]) b->xattn_rows[b->n_rows_step > SC_FUSED_MAX_ROWS ? 0 : 1] += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
     RC_TRY(decode_step_launch(b));
     // the stop flags live in host-mapped pinned memory: the prune kernel stores them there directly (no copy
     // command).  (Spinning on hipStreamQuery instead of hipStreamSynchronize measured no difference: 826 vs 833 us
@@ -1410,9 +1410,16 @@ extern "C" int sc_streams_set_graphs(sc_streams *b, int on) {
 }
 extern "C" long sc_streams_take_xattn_rows(sc_streams *b) {
   if (!b) return 0;
-  const long v = b->xattn_rows;
-  b->xattn_rows = 0;
+  const long v = b->xattn_rows[0] + b->xattn_rows[1];
+  b->xattn_rows[0] = b->xattn_rows[1] = 0;
   return v;
+}
+extern "C" int sc_streams_take_xattn_rows_by_kernel(sc_streams *b, long *rows) {
+  SC_CHECK_ARG(b && rows, "null");
+  rows[0] = b->xattn_rows[0];
+  rows[1] = b->xattn_rows[1];
+  b->xattn_rows[0] = b->xattn_rows[1] = 0;
+  return SC_OK;
 }
 
 // seconds and iterations of the decode step loop by compaction bucket (index = active streams / (S/16), 17 entries),

@@ -238,6 +238,12 @@ class NativeStreamBatch:
     def take_xattn_rows(self) -> int:
         return int(self.lib.sc_streams_take_xattn_rows(self.handle))
 
+    def take_xattn_rows_by_kernel(self):
+        """(rows read by the dec_attn_flash launches, rows read by the sc_dec_layer_cross launches)"""
+        r = (C.c_long * 2)()
+        _abi.check(self.lib.sc_streams_take_xattn_rows_by_kernel(self.handle, r), "sc_streams_take_xattn_rows_by_kernel")
+        return int(r[0]), int(r[1])
+
     @property
     def hip_stream(self) -> int:
         return int(self.lib.sc_streams_hip_stream(self.handle) or 0)

@@ -431,24 +431,21 @@ def test_encoder_layers_rowtile(hip, monkeypatch):
         assert float((gctx - ref_ctx).abs().max()) <= 1e-3 * max(scale, 1.0), mode
 
 
-@pytest.mark.parametrize("nopre", [False, True])
-def test_attention_full_batch_variants_lockstep(hip, monkeypatch, nopre):
-    """The attention kernels of FULL batches (2 K/V rows in flight at <= 128 VGPRs; self-attention with all
-    row lists built up front, or interleaved with the walk) are picked by batch size; force them on the
-    single-stream fixtures so that every launch is compared with its spec on identical inputs."""
+@pytest.mark.parametrize("dims", ["xl", "tiny"])
+def test_attention_full_batch_variants_lockstep(hip, monkeypatch, dims):
+    """The attention kernels of FULL batches (2 key tiles per wave in flight, <= 128 VGPRs) are picked by batch
+    size; force them on the single-stream fixtures so that every launch is compared with its spec on identical
+    inputs: XL dims (d_k = 32, head-parallel layer kernels), tiny dims (d_k = 16, stand-alone attention kernels,
+    whole utterance)."""
     from lockstep import LockstepBackend
     monkeypatch.setenv("SC_ATTN_DEEP", "0")
     monkeypatch.setenv("SC_DEC_CLUSTER", "0")
     monkeypatch.setattr(LockstepBackend, "cluster_layers", False)
-    if nopre:
-        monkeypatch.setenv("SC_SELF_ATTN_NOPRE", "1")
-    if nopre:   # tiny dims (d_k = 16), whole utterance
+    if dims == "tiny":
         ls = _lockstep_run(hip, "tiny_c10240_b10_bbd0")
-    else:       # XL dims (d_k = 32), first decode blocks
-        ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
-    if nopre:
         assert ls.calls.get("dec_self_attn", 0) > 0 and ls.calls.get("dec_cross_attn", 0) > 0
-    else:   # XL dims run the head-parallel layer kernels (attention fused with the projections around it)
+    else:   # first decode blocks
+        ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
         assert ls.calls.get("dec_layer_self", 0) > 0 and ls.calls.get("dec_layer_cross", 0) > 0
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
