@@ -109,14 +109,41 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // LayerNorm parameters: issued first, parked in LDS once the partial sums (issued later, returned later) are in
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < D / 2) gbv = *reinterpret_cast<const float4 *>((tid < D / 4 ? p.ln_g : p.ln_b) + 4 * (tid % (D / 4)));
-  float touch = 0.f;
-  {
-    constexpr int NW = (SELF ? 3 : 1);
-    const int ofs = tid * 32;   // floats: 128 B per thread, 32 KB per workgroup and instruction
+  // PF (few streams active: registers are plentiful): the projection's B fragments are fetched into registers
+  // right here instead, so that the MFMAs behind the LayerNorm wait for nothing.
+  constexpr bool PF = UNR >= 8;
+  float4 pfb[PF ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
+  // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
+  int slp[(PF && SELF) ? WM : 1];
+  if (PF && SELF) {
+    const int *anc0 = ANC(cur, s);
+    const bool live0 = tid < PCH && tid < L - 1;
 #pragma unroll
-    for (int wh = 0; wh < NW; ++wh) {
-      const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
-      if (ofs < NTQ * KI * 512) touch += base[ofs];
+    for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? tid : 0) * W + min(h, nh - 1)];
+  }
+  float touch = 0.f;
+  // (loads return in issue order: the fragments are requested right BEHIND the first batch of partial sums, which
+  // the LayerNorm needs first)
+  auto prefetch_w = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
+      const float4 *wq = reinterpret_cast<const float4 *>(p.wp) + ((long)tile * KI + wave * KPW) * 128 + lane;
+      pfb[t * 2] = wq[0];
+      pfb[t * 2 + 1] = wq[64];
+    }
+  };
+  {
+    if (PF) {
+      if (FIRST) prefetch_w();
+    } else {
+      constexpr int NW = (SELF ? 3 : 1);
+      const int ofs = tid * 32;   // floats: 128 B per thread, 32 KB per workgroup and instruction
+#pragma unroll
+      for (int wh = 0; wh < NW; ++wh) {
+        const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
+        if (ofs < NTQ * KI * 512) touch += base[ofs];
+      }
     }
     // output projection: D/16 tiles, k-block (head*DK)/32, 2 KB each
     constexpr int TPW = D / 16 * 16;   // lines: 16 per tile
@@ -131,7 +158,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     float *Xn = region;  // [16][LDX], rows >= W zero
     constexpr int C4 = D / 4, QT = 16 * C4 / 256;           // float4 pieces per row; pieces per thread (16 rows)
     constexpr int QN = (WM * C4 + 255) / 256;               // ... of the rows that can be live (W <= WM)
-    constexpr int ZB = (UNR >= 8) ? 16 : 4;         // partial sums per batch (register budget of the variant)
+    constexpr int ZB = (UNR >= 8) ? 8 : 4;          // partial sums per batch (register budget of the variant)
     float4 xv[QN];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
@@ -160,6 +187,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
           for (int z = 0; z < ZB; ++z)
             pv[q][z] = *reinterpret_cast<const float4 *>(p.part + (long)min(z0 + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4);
         }
+        if (PF && z0 == 0) prefetch_w();
 #pragma unroll
         for (int q = 0; q < QN; ++q)
 #pragma unroll
@@ -238,12 +266,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kq = 0; kq < KPW; ++kq) {
-      const int ki = wave * KPW + kq;
-      const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
-      const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
-      float4 b0[NT], b1[NT];
+    auto load_b = [&](int ki, float4 (&b0)[NT], float4 (&b1)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
@@ -251,8 +274,33 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
         b0[t] = wq[0];
         b1[t] = wq[64];
       }
+    };
+    float4 b0[NT], b1[NT];
+    if (PF) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        b0[t] = pfb[t * 2];
+        b1[t] = pfb[t * 2 + 1];
+      }
+    } else {
+      load_b(wave * KPW, b0, b1);
+    }
+#pragma unroll
+    for (int kq = 0; kq < KPW; ++kq) {
+      const int ki = wave * KPW + kq;
+      const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
+      const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+      float4 n0[NT], n1[NT];
+      if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = dl_mfma8(acc[t], a0, a1, b0[t], b1[t]);
+      if (kq + 1 < KPW) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          b0[t] = n0[t];
+          b1[t] = n1[t];
+        }
+      }
     }
     __syncthreads();  // every wave is done reading Xn: the region becomes the partial products
     float *Ps = region;  // [4][16][LDP]
@@ -294,6 +342,17 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // ------------------------------------------------------------------ attention of this head (all hypotheses)
   // matrix-core form (attn.h: mattn_*): the hypotheses are the N dimension, 16 K/V rows a tile; the four waves
   // take tiles round-robin and leave one partial state each (+ one for the new token's own row, SELF)
+  // PF: the output projection's B fragments travel while the attention runs
+  constexpr int TWO = D / 16 / 4;
+  float4 ob[PF ? TWO * 2 : 1];
+  if (PF) {
+#pragma unroll
+    for (int t = 0; t < TWO; ++t) {
+      const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32) * 128 + lane;
+      ob[2 * t] = wq[0];
+      ob[2 * t + 1] = wq[64];
+    }
+  }
   constexpr int NTW = (UNR >= 8) ? 4 : 2;   // tiles per wave and batch
   constexpr int NP = SELF ? 5 : 4;
   float *pm = region;
@@ -317,7 +376,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       const bool live = tid < PCH && pp < Lc;
       int sl[WM];
 #pragma unroll
-      for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
+      for (int h = 0; h < WM; ++h) sl[h] = (PF && c0 == 0) ? slp[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
       unsigned mask = 0;
 #pragma unroll
       for (int h = 0; h < WM; ++h)
@@ -400,12 +459,18 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       As[w * LDA + c] = (w < WM && c >= koff && c < koff + DK) ? ctx[w * DK + c - koff] : 0.f;
     }
     const int r = lane & 15, kk = lane >> 4;
+    static_assert(TW == TWO, "tiles per wave");
     float4 b0[TW], b1[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
-      const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
-      b0[t] = wq[0];
-      b1[t] = wq[64];
+      if (PF) {
+        b0[t] = ob[2 * t];
+        b1[t] = ob[2 * t + 1];
+      } else {
+        const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
+        b0[t] = wq[0];
+        b1[t] = wq[64];
+      }
     }
     __syncthreads();
     const float *ab = As + r * LDA + 8 * kk;

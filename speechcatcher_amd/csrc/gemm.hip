@@ -817,6 +817,31 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int NQ = NV / 512;
   static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
   SC_STAMP(PRO ? 2 : 3, 0);
+  float4 bf[KI1][2];  // GEMM 1 weights of this wave's 16 hidden columns (all of K)
+  auto load_b1 = [&](int chunk) {
+    const float4 *wp = reinterpret_cast<const float4 *>(p.W1p) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
+#pragma unroll
+    for (int ki = 0; ki < KI1; ++ki) {
+      bf[ki][0] = wp[ki * 128];
+      bf[ki][1] = wp[ki * 128 + 64];
+    }
+  };
+  // (requesting the first chunk's W1 / W2 fragments ahead of the prologue's partial sums was measured and lost:
+  // loads return in issue order, the prologue then waits for 256 KB of weights - 197 -> 233 stamp units per launch;
+  // the GEMM phase itself is bound by the 256 MFMAs per SIMD of a 16-row tile, not by its loads)
+  float4 b2f[KI2][NT2][2];
+  auto load_b2 = [&](int chunk) {
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      const float4 *wp = reinterpret_cast<const float4 *>(p.W2p) +
+                         ((long)(wave * NT2 + t) * KF + chunk * KI2) * 128 + lane;
+#pragma unroll
+      for (int k = 0; k < KI2; ++k) {
+        b2f[k][t][0] = wp[k * 128];
+        b2f[k][t][1] = wp[k * 128 + 64];
+      }
+    }
+  };
   if (PRO) {
     // sum of the producer's per-head partial products (fixed head order) + residual, then LayerNorm - recomputed
     // by every chunk group of the row tile (cheap, L2-resident) so that the attention output projection needs no
@@ -908,15 +933,6 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int t = 0; t < NT2; ++t) acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 bf[KI1][2];  // GEMM 1 weights of this wave's 16 hidden columns (all of K)
-  auto load_b1 = [&](int chunk) {
-    const float4 *wp = reinterpret_cast<const float4 *>(p.W1p) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
-#pragma unroll
-    for (int ki = 0; ki < KI1; ++ki) {
-      bf[ki][0] = wp[ki * 128];
-      bf[ki][1] = wp[ki * 128 + 64];
-    }
-  };
   load_b1(grp * p.cpw);
   __syncthreads();
   SC_STAMP(PRO ? 2 : 3, 1);
@@ -947,17 +963,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
     }
     // GEMM 2 weights of this chunk: in flight during the epilogue
-    float4 b2f[KI2][NT2][2];
-#pragma unroll
-    for (int t = 0; t < NT2; ++t) {
-      const float4 *wp = reinterpret_cast<const float4 *>(p.W2p) +
-                         ((long)(wave * NT2 + t) * KF + chunk * KI2) * 128 + lane;
-#pragma unroll
-      for (int k = 0; k < KI2; ++k) {
-        b2f[k][t][0] = wp[k * 128];
-        b2f[k][t][1] = wp[k * 128 + 64];
-      }
-    }
+    load_b2(chunk);
     if (cc > 0) __syncthreads();  // previous chunk's GEMM 2 is done reading Hs
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt)
