@@ -254,7 +254,7 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_LAYER_CROSS 11 /* dec_layer_attn_kernel<.., cross>: sc_dec_layer_cross */
 #define SC_PROF_KINDS 12
 /* decoder layers run as head-parallel launches (sc_dec_layer_*) for compaction buckets up to this many rows */
-#define SC_FUSED_MAX_ROWS 640
+#define SC_FUSED_MAX_ROWS 960
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);

@@ -1306,14 +1306,16 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 // ---------------------------------------------------------------------------
 // The head-parallel layer kernels (decoder_layer.hip: 3 launches per layer) are used for compaction buckets of at
 // most SC_FUSED_MAX_ROWS hypothesis rows.  They win where the step is a chain of latency-bound launches (few
-// active streams: 45 vs 51 us per layer at 8 streams); at large buckets every (stream, head) workgroup re-reading
-// all partial sums of its stream costs more fabric traffic than the launches it saves, and the six-launch form
-// (row panels + stand-alone attention) is faster (profiles/r02_fused_threshold_sweep.txt: strict lock-step
-// 28.9 / 28.1 / 29.0 ms per chunk step with the limit at 0 / 640 / 1280 rows).
+// active streams); at large buckets every (stream, head) workgroup re-reading all partial sums of its stream costs
+// as much fabric traffic as the launches save, and the six-launch form (row panels + stand-alone attention) is
+// level or faster (profiles/r02_fused_threshold_sweep.txt, tools/fused_threshold_sweep.sh: strict lock-step
+// 27.21 / 26.95 / 26.65 / 27.01 ms per chunk step with the limit at 320 / 640 / 960 / 1280 rows).
 static bool dec_fused_ok(const sc_search &sb) {
   if (const char *e = sc_hook("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
     return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;
-  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > SC_FUSED_MAX_ROWS) return false;
+  int max_rows = SC_FUSED_MAX_ROWS;
+  if (const char *e = sc_hook("SC_FUSED_MAX")) max_rows = atoi(e);   // tools: threshold sweep
+  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > max_rows) return false;
   return sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.ph2 && sb.ffn_part &&
          sb.max_ffn_part >= 1 && sb.out_w_q && sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp &&
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
