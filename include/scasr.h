@@ -342,6 +342,11 @@ int sc_beam_prune(const sc_search *sb, void *stream);
 int sc_ctc_gather_state(const sc_search *sb, void *stream);
 /* one full beam-search step = all of the above in order (beam_search.py:701-758) */
 int sc_decode_step(const sc_search *sb, void *stream);
+/* device-side step control behind sc_decode_step: the accept / stop rules of the step loop (beam_search.py:759-821)
+ * applied to every active stream's ctrl row IN PLACE (accepted: CUR flipped, L+1, NHYP = min(W, NHYP*W), HAS = 1;
+ * stopped: ACTIVE = 0), and the step's stop flags copied to ring[(L & 1) * S + s] (ring: device-visible int32[2][S],
+ * L = the token count of the step that produced them).  Lets a host enqueue step i+1 before reading step i. */
+int sc_step_advance(const sc_search *sb, int use_bbd, int32_t *ring, void *stream);
 
 /* ---- head-parallel decoder layers: 3 launches per layer (decoder_layer.py:80-132) --------------------
  * The residual stream x ping-pongs between two [S*W][d] buffers (x_in != x_out in every call): sibling
@@ -472,6 +477,10 @@ int sc_get_hyps(sc_streams *streams, int stream, int nbest, int max_len, int32_t
 int sc_reset(sc_streams *streams, int stream);
 int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
 int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
+/* device-side step control (sc_step_advance): decode iterations enqueued before the host had read their predecessor's
+ * stop flags, and how many of those ran with every stream already stopped; on/off (default on; results identical) */
+int sc_streams_speculation(const sc_streams *streams, long *launched, long *wasted);
+int sc_streams_set_speculation(sc_streams *streams, int on);
 /* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
  * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
 int sc_streams_set_graphs(sc_streams *streams, int on);

@@ -132,6 +132,7 @@ _SIGS = {
     "sc_fuse_topw": (C.c_int, [vp, vp]),
     "sc_beam_prune": (C.c_int, [vp, vp]),
     "sc_ctc_gather_state": (C.c_int, [vp, vp]),
+    "sc_step_advance": (C.c_int, [vp, C.c_int, vp, vp]),
     "sc_decode_step": (C.c_int, [vp, vp]),
     "sc_dec_layer_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sc_dec_layer_self": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp]),
@@ -159,6 +160,8 @@ _SIGS = {
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
+    "sc_streams_speculation": (C.c_int, [vp, vp, vp]),
+    "sc_streams_set_speculation": (C.c_int, [vp, C.c_int]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_take_xattn_rows_by_kernel": (C.c_int, [vp, vp]),
     "sc_streams_hip_stream": (vp, [vp]),

@@ -1335,6 +1335,43 @@ static bool dec_cluster_ok(const sc_search &sb) {
          sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp && sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
 }
 
+// ---------------------------------------------------------------------------
+// Device-side step control (csrc/streams.hip: the host enqueues iteration i+1 before it has read the stop flags of
+// iteration i).  Runs behind sc_decode_step: derives the NEXT ctrl row of every active stream from its stop flags -
+// the accept / stop rules of the step loop (beam_search.py:759-821) - in place: an accepted step flips the buffer
+// side, appends a token (L+1), widens the beam to min(W, nhyp*W) and marks the CTC state as present; a stream that
+// stops becomes inactive (its row is rewritten by the host when its next block starts).  The flags of the step are
+// also published to `ring` (host-mapped, [2][S]: slot = L & 1 of the step that produced them, so the host can read
+// step i while step i+1 is running).
+// ---------------------------------------------------------------------------
+__global__ void step_advance_kernel(sc_search sb, int use_bbd, int32_t *ring) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= sb.S) return;
+  int32_t *c = const_cast<int32_t *>(sb.ctrl) + (long)s * 8;
+  if (!c[SC_C_ACTIVE]) return;
+  const int f = sb.flags[s], L = c[SC_C_L], fin = c[SC_C_FINAL], nh = c[SC_C_NHYP];
+  ring[(L & 1) * sb.S + s] = f;
+  const bool f_any = f & SC_F_ANY_EOS, f_best = f & SC_F_BEST_EOS, f_all = f & SC_F_ALL_EOS, f_rep = f & SC_F_REPEAT;
+  const bool stop_eos = f_any && (!fin || f_best);
+  const bool stop_bbd = use_bbd && !stop_eos && f_rep && !fin;
+  const bool stop_all = !stop_eos && !stop_bbd && f_all && fin;
+  if (stop_eos || stop_bbd || stop_all) {
+    c[SC_C_ACTIVE] = 0;
+  } else {
+    c[SC_C_CUR] = 1 - c[SC_C_CUR];
+    c[SC_C_L] = L + 1;
+    c[SC_C_NHYP] = min(sb.W, nh * sb.W);
+    c[SC_C_HAS] = 1;
+  }
+}
+
+extern "C" int sc_step_advance(const sc_search *sbp, int use_bbd, int32_t *ring, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->ctrl && sbp->flags && ring, "null");
+  step_advance_kernel<<<cdiv(sbp->S, 256), 256, 0, (hipStream_t)stream>>>(*sbp, use_bbd, ring);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;

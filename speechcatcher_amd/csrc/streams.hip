@@ -137,6 +137,15 @@ struct sc_streams {
   // iterations leave idle.  `es` is the stream the current phase launches into.
   hipStream_t stream_enc = nullptr, es = nullptr;
   hipEvent_t ev_enc_done = nullptr;
+  hipEvent_t ev_iter[2] = {nullptr, nullptr};   // end of decode iteration k (k & 1)
+  int32_t *flags_dev = nullptr, *ring_dev = nullptr;   // stop flags of a step (device); device view of flags_host [2][S]
+  int32_t *rm_host[2] = {nullptr, nullptr};     // pinned rowmap images (double-buffered: one may still be in a copy queue)
+  int rm_idx = 0;
+  bool rm_dirty = false;                        // rm_host[rm_idx] differs from the device rowmap
+  bool speculate = false;                       // device-side step control: enqueue iteration i+1 before reading the
+                                                // flags of i (opt-in, graphs on only; measured: no gain - DESIGN 4 (q))
+  int graph_key() const { return n_rows_step * 2 + (speculate ? 1 : 0); }
+  long spec_launched = 0, spec_wasted = 0;
   bool enc_pending = false;      // the encoder stage of this push has been launched and may still be running
   PendingEnc *pend = nullptr;   // ... has been planned but not launched yet (launched when the decode loop thins out)
   int enc_start_thr = 0;         // launch it when at most this many streams are still in the step loop
@@ -174,6 +183,10 @@ struct sc_streams {
       (void)hipStreamDestroy(stream_enc);
     }
     if (ev_enc_done) (void)hipEventDestroy(ev_enc_done);
+    for (int i = 0; i < 2; ++i) {
+      if (ev_iter[i]) (void)hipEventDestroy(ev_iter[i]);
+      if (rm_host[i]) (void)hipHostFree(rm_host[i]);
+    }
     delete pend;
     for (void *p : owned) (void)hipFree(p);
     if (ctrlmap_host) (void)hipHostFree(ctrlmap_host);
@@ -190,7 +203,7 @@ struct sc_streams {
     return SC_OK;
   }
   int32_t *ctrl_host() { return ctrlmap_host; }              // [S][8]
-  int32_t *rowmap_host() { return ctrlmap_host + S * 8; }     // [S*W]
+  int32_t *rowmap_host() { return rm_host[rm_idx]; }          // [S*W]
 
   // host int table -> device (pinned arena, async copy on the batch's stream; launches that read it are
   // ordered behind the copy; the arena is recycled at the start of every push)
@@ -541,9 +554,15 @@ int encode_launch(sc_streams *b, EncPlan &P) {
   return SC_OK;
 }
 
+// the host's ctrl rows -> device (block start, and whenever the host, not the advance kernel, decides the next step)
 int upload_ctrl(sc_streams *b) {
-  HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)(b->S * 8 + b->S * b->W) * sizeof(int32_t),
+  HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)b->S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  return SC_OK;
+}
+int upload_rowmap(sc_streams *b) {
+  HIP_TRY(hipMemcpyAsync(b->ctrlmap + b->S * 8, b->rm_host[b->rm_idx], (size_t)b->S * b->W * sizeof(int32_t),
                          hipMemcpyHostToDevice, b->stream));
+  b->rm_dirty = false;
   return SC_OK;
 }
 
@@ -555,6 +574,8 @@ void set_rowmap(sc_streams *b, const std::vector<int> &active) {
   const int nb = std::min(S, (na + b->row_bucket - 1) / b->row_bucket * b->row_bucket);
   if (active != b->rowmap_key) {
     b->rowmap_key = active;
+    b->rm_idx ^= 1;       // the other image may still be queued for a copy (at most one step back)
+    b->rm_dirty = true;
     int32_t *rm = b->rowmap_host();
     std::vector<char> isact(S, 0);
     for (int s : active) isact[s] = 1;
@@ -567,19 +588,28 @@ void set_rowmap(sc_streams *b, const std::vector<int> &active) {
   b->n_rows_step = nb * W;
 }
 
+// one decode step; with the device-side step control also the advance kernel (ctrl rows of the next step, flags ->
+// ring).  Without it the prune kernel stores the stop flags straight into the host-mapped array (sb.flags = ring).
+static int step_and_advance(sc_streams *b) {
+  b->sb.flags = b->speculate ? b->flags_dev : b->ring_dev;
+  RC_TRY(sc_decode_step(&b->sb, b->stream));
+  if (!b->speculate) return SC_OK;
+  return sc_step_advance(&b->sb, b->use_bbd ? 1 : 0, b->ring_dev, b->stream);
+}
+
 int decode_step_launch(sc_streams *b) {
   b->sb.n_rows = b->n_rows_step;
-  if (!b->use_graphs) return sc_decode_step(&b->sb, b->stream);
-  auto it = b->dec_graphs.find(b->n_rows_step);
+  if (!b->use_graphs) return step_and_advance(b);
+  auto it = b->dec_graphs.find(b->graph_key());
   if (it == b->dec_graphs.end()) {
-    RC_TRY(sc_decode_step(&b->sb, b->stream));   // warm-up launch (also validates arguments); executes the step
+    RC_TRY(step_and_advance(b));   // warm-up launch (also validates arguments); executes the step
     RC_TRY(sc_graph_capture_begin(b->stream));
-    const int rc = sc_decode_step(&b->sb, b->stream);
+    const int rc = step_and_advance(b);
     void *g = nullptr;
     const int rc2 = sc_graph_capture_end(b->stream, &g);
     if (rc != SC_OK) return rc;
     if (rc2 != SC_OK) return rc2;
-    b->dec_graphs[b->n_rows_step] = (hipGraphExec_t)g;
+    b->dec_graphs[b->graph_key()] = (hipGraphExec_t)g;
     return SC_OK;   // the warm-up launch already executed this step
   }
   return sc_graph_launch(it->second, b->stream);
@@ -592,7 +622,7 @@ int prepare_decode(sc_streams *b) {
   const int keep = b->n_rows_step;
   for (int nb = b->row_bucket; nb < b->S + b->row_bucket; nb += b->row_bucket) {
     b->n_rows_step = std::min(nb, b->S) * b->W;
-    if (!b->dec_graphs.count(b->n_rows_step)) RC_TRY(decode_step_launch(b));
+    if (!b->dec_graphs.count(b->graph_key())) RC_TRY(decode_step_launch(b));
   }
   b->n_rows_step = keep;
   return SC_OK;
@@ -687,7 +717,16 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
   int32_t *ctrl = b->ctrl_host();
   memset(ctrl, 0, (size_t)S * 8 * sizeof(int32_t));
   // ---- step loop (:701-821)
+  // Device-side step control (opt-in, sc_streams_set_speculation): sc_step_advance behind every step derives the
+  // next ctrl rows on the device, so iteration k+1 can be enqueued BEFORE the host has read the stop flags of
+  // iteration k ("speculated": same compaction bucket, the streams that stop in k are inactive in k+1 by their device
+  // ctrl row); the host reads the flags of k (ring slot L & 1) while k+1 runs.  Not speculated: a step after which a
+  // stream would hit max_length / max_tokens (the host decides those), fewer than two live streams (the likely last
+  // iteration of a round would run for nothing), buckets that can still shrink, graphs off.  Measured at 128 streams:
+  // 3050-3071 with, 3052-3065 audio-s/s without - the host turnaround is not on the critical path - hence off.
   std::vector<int> active;
+  bool inflight = false;   // iteration `iter` has already been enqueued
+  long iter = 0;
   while (true) {
     active.clear();
     bool any = false;
@@ -701,27 +740,51 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
       }
       if (act) { any = true; active.push_back(todo[i].s); }
     }
-    if (!any) break;
-    for (int i = 0; i < n; ++i) {
-      int32_t *r = ctrl + todo[i].s * 8;
-      r[0] = live[i]; r[1] = cur[i]; r[2] = fin[i]; r[3] = T[i]; r[4] = L[i]; r[5] = nhyp[i]; r[6] = has[i]; r[7] = Ttab[i];
+    if (!any) {
+      if (inflight) b->spec_wasted++;   // runs with every stream inactive
+      break;
     }
-    // the encoder stage of this push fills the CUs that the thinned-out step loop leaves idle
-    if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
     const auto tp0 = std::chrono::steady_clock::now();
     std::sort(active.begin(), active.end());
     set_rowmap(b, active);
-    RC_TRY(upload_ctrl(b));
-    b->dec_steps++;
+    if (!inflight) {
+      for (int i = 0; i < n; ++i) {
+        int32_t *r = ctrl + todo[i].s * 8;
+        r[0] = live[i]; r[1] = cur[i]; r[2] = fin[i]; r[3] = T[i]; r[4] = L[i]; r[5] = nhyp[i]; r[6] = has[i]; r[7] = Ttab[i];
+      }
+      // the encoder stage of this push fills the CUs that the thinned-out step loop leaves idle
+      if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
+      if (b->rm_dirty) {   // one copy command for both (nothing is in flight here: the pinned image is free)
+        memcpy(b->ctrlmap_host + S * 8, b->rm_host[b->rm_idx], (size_t)S * W * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)(S * 8 + S * W) * sizeof(int32_t), hipMemcpyHostToDevice,
+                               b->stream));
+        b->rm_dirty = false;
+      } else {
+        RC_TRY(upload_ctrl(b));
+      }
+      RC_TRY(decode_step_launch(b));
+      HIP_TRY(hipEventRecord(b->ev_iter[iter & 1], b->stream));
+    }
     for (int i = 0; i < n; ++i)
       if (live[i]) b->xattn_rows[b->n_rows_step > SC_FUSED_MAX_ROWS ? 0 : 1] += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
-    RC_TRY(decode_step_launch(b));
-    // the stop flags live in host-mapped pinned memory: the prune kernel stores them there directly (no copy
-    // command).  (Spinning on hipStreamQuery instead of hipStreamSynchronize measured no difference: 826 vs 833 us
-    // of wait per iteration at one stream - the wait is the GPU's 48-92 dependent kernels, not the wake-up.)
+    // (speculating at every size measured 2 % SLOWER than not at all: the compaction bucket then follows the active
+    // set one iteration late, which costs what the hidden host turnaround saves - so only where the bucket cannot
+    // shrink any more: the tail of the step loop in the smallest bucket)
+    bool spec = b->speculate && b->use_graphs && active.size() >= 2 && (int)active.size() <= b->row_bucket;
+    for (int i = 0; i < n && spec; ++i)
+      if (live[i] && (pidx[i] + 1 >= b->max_length || L[i] + 2 > b->LCAP)) spec = false;
+    if (spec) {   // iteration iter + 1, assuming nothing about iter's outcome
+      if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
+      if (b->rm_dirty) RC_TRY(upload_rowmap(b));
+      RC_TRY(decode_step_launch(b));
+      HIP_TRY(hipEventRecord(b->ev_iter[(iter + 1) & 1], b->stream));
+      b->spec_launched++;
+    }
+    // the stop flags live in host-mapped pinned memory (the advance kernel stores them there: no copy command)
     const auto tp1 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipEventSynchronize(b->ev_iter[iter & 1]));
     const auto tp2 = std::chrono::steady_clock::now();
+    b->dec_steps++;
     b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
     b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
     {
@@ -729,9 +792,12 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
       b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
       b->n_bucket[bk] += 1;
     }
+    inflight = spec;
+    iter++;
     for (int i = 0; i < n; ++i) {
       if (!live[i]) continue;
-      const int f = b->flags_host[todo[i].s];
+      // with the device-side step control: the ring slot of the step that ran at this length
+      const int f = b->flags_host[(b->speculate ? (L[i] & 1) * S : 0) + todo[i].s];
       const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
       out_idx[i] += 1;
       nsteps[i] += 1;
@@ -1069,7 +1135,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(sb.ctc_r, (size_t)2 * S * b->TCAP * 2 * W);
   A(sb.ctc_s, 2 * n);
   A(sb.ctc_rnew, (size_t)S * b->TCAP * 2 * W * K);
-  // (sb.flags is set below: the device view of the pinned host array flags_host)
+  A(b->flags_dev, (size_t)S);   // (sb.flags: set per step - flags_dev, or the host-mapped array itself)
   A(sb.dx, n * d); A(sb.dxn, n * d); A(sb.dqkv, n * 3 * d); A(sb.datt, n * d); A(sb.dq, n * d); A(sb.dffh, n * F);
   A(sb.logits, n * V); A(sb.logp, n * V);
   A(sb.pre_ids, n * K); A(sb.psi, n * K); A(sb.psi_eos, n);
@@ -1145,13 +1211,17 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   }
   const size_t cm = ((size_t)S * 8 + n) * sizeof(int32_t);
   if (hipHostMalloc((void **)&b->ctrlmap_host, cm) != hipSuccess || hipHostMalloc((void **)&b->ctrl0_host, (size_t)S * 32) != hipSuccess ||
-      hipHostMalloc((void **)&b->flags_host, (size_t)S * 4) != hipSuccess ||
+      hipHostMalloc((void **)&b->flags_host, (size_t)S * 8) != hipSuccess ||
+      hipHostMalloc((void **)&b->rm_host[0], n * sizeof(int32_t)) != hipSuccess ||
+      hipHostMalloc((void **)&b->rm_host[1], n * sizeof(int32_t)) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ev_iter[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ev_iter[1], hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void **)&b->arena_host, b->arena_cap * 4) != hipSuccess) {
     sc_set_error("sc_streams_create: pinned host allocation failed");
     delete b;
     return SC_ERR_LAUNCH;
   }
-  memset(b->flags_host, 0, (size_t)S * 4);
+  memset(b->flags_host, 0, (size_t)S * 8);
   {
     void *dv = nullptr;
     if (hipHostGetDevicePointer(&dv, b->flags_host, 0) != hipSuccess || !dv) {
@@ -1159,11 +1229,14 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
       delete b;
       return SC_ERR_LAUNCH;
     }
-    sb.flags = (int32_t *)dv;
+    b->ring_dev = (int32_t *)dv;
+    sb.flags = b->ring_dev;
   }
+  if (const char *sp = sc_hook("SC_SPECULATE")) b->speculate = atoi(sp) != 0;   // tests / A-B runs
   memset(b->ctrlmap_host, 0, cm);
-  for (size_t i = 0; i < n; ++i) b->rowmap_host()[i] = (int32_t)i;
-  (void)hipMemcpy(b->ctrlmap, b->ctrlmap_host, cm, hipMemcpyHostToDevice);
+  for (size_t i = 0; i < n; ++i) b->rm_host[0][i] = b->rm_host[1][i] = (int32_t)i;
+  (void)hipMemcpy(b->ctrlmap, b->ctrlmap_host, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->ctrlmap + S * 8, b->rm_host[0], n * sizeof(int32_t), hipMemcpyHostToDevice);
   b->rowmap_key.resize(S);
   for (int s = 0; s < S; ++s) b->rowmap_key[s] = s;
   b->row_bucket = std::max(1, S / 16);
@@ -1440,6 +1513,19 @@ extern "C" int sc_streams_host_times(sc_streams *b, double *launch_s, double *wa
   *launch_s = b->t_launch;
   *wait_s = b->t_wait;
   b->t_launch = b->t_wait = 0;
+  return SC_OK;
+}
+
+// decode iterations enqueued ahead of their predecessor's stop flags, and how many of those found every stream stopped
+extern "C" int sc_streams_speculation(const sc_streams *b, long *launched, long *wasted) {
+  SC_CHECK_ARG(b, "null");
+  if (launched) *launched = b->spec_launched;
+  if (wasted) *wasted = b->spec_wasted;
+  return SC_OK;
+}
+extern "C" int sc_streams_set_speculation(sc_streams *b, int on) {
+  SC_CHECK_ARG(b, "null");
+  b->speculate = on != 0;   // the decode graphs of the other mode stay cached (graph_key)
   return SC_OK;
 }
 

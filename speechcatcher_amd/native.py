@@ -133,7 +133,14 @@ class NativeStreamBatch:
     def stats(self):
         a, b, c = C.c_long(), C.c_long(), C.c_long()
         self.lib.sc_streams_stats(self.handle, C.byref(a), C.byref(b), C.byref(c))
-        return {"enc_calls": a.value, "dec_steps": b.value, "dec_blocks": c.value}
+        d, e = C.c_long(), C.c_long()
+        self.lib.sc_streams_speculation(self.handle, C.byref(d), C.byref(e))
+        return {"enc_calls": a.value, "dec_steps": b.value, "dec_blocks": c.value,
+                "spec_launched": d.value, "spec_wasted": e.value}
+
+    def set_speculation(self, on: bool):
+        """decode iterations enqueued ahead of their predecessor's stop flags (default on; results identical)"""
+        _abi.check(self.lib.sc_streams_set_speculation(self.handle, 1 if on else 0), "sc_streams_set_speculation")
 
     def _call(self, fn, ids, ptrs, counts, finals, keep, isolate_faults):
         n = len(ids)

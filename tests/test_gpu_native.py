@@ -81,15 +81,17 @@ def test_native_capacity_faults_are_isolated():
 
 def test_native_batch_of_distinct_streams_equals_one_by_one():
     """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
-    head-parallel and six-launch layer forms by bucket size) = every stream alone."""
+    head-parallel and six-launch layer forms by bucket size, decode iterations enqueued ahead of their predecessor's
+    stop flags) = every stream alone (never speculated: one live stream) = the batch with the speculation off."""
     from test_engine_spec import make_batch
     S, chunk, beam = 32, 10240, 5
     lens = [chunk * (2 + (i * 7) % 5) + (i * 1234) % 4000 for i in range(S)]
     audio = [synth.synth_audio(100 + i, n) for i, n in enumerate(lens)]
 
-    def run(streams):
+    def run(streams, speculate=True):
         sb = make_batch("TINY", 1234, "meanstd", beam, False, n_streams=len(streams), backend="native",
                         max_frames=400, max_tokens=500, pcm_capacity=1 << 17)
+        sb.set_speculation(speculate)
         pos = 0
         while True:
             items = []
@@ -101,15 +103,68 @@ def test_native_batch_of_distinct_streams_equals_one_by_one():
                 break
             sb.push(items)
             pos += chunk
-        return [sb.hypotheses(slot) for slot in range(len(streams))]
+        return [sb.hypotheses(slot) for slot in range(len(streams))], sb.stats
 
-    batch = run(list(range(S)))
+    batch, st = run(list(range(S)))
+    assert st["spec_launched"] > 0 and st["spec_wasted"] <= st["dec_blocks"], st
+    plain, st0 = run(list(range(S)), speculate=False)
+    assert st0["spec_launched"] == 0 and st0["dec_steps"] == st["dec_steps"]
+    for a, b in zip(batch, plain):
+        assert [(h["yseq"], h["xpos"]) for h in a] == [(h["yseq"], h["xpos"]) for h in b]
+        for x, y in zip(a, b):
+            assert abs(x["score"] - y["score"]) < 1e-3
     for i in range(0, S, 3):
-        solo = run([i])
+        solo, sts = run([i])
+        assert sts["spec_launched"] == 0
         assert len(solo[0]) == len(batch[i]) > 0
         for x, y in zip(solo[0], batch[i]):
             assert x["yseq"] == y["yseq"] and x["xpos"] == y["xpos"], i
             assert abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(x["score"])), i
+
+
+def test_step_advance_kernel_applies_the_stop_rules():
+    """sc_step_advance against the accept / stop rules of the step loop (beam_search.py:759-821) for every
+    combination of stop flags, final flag and block-boundary detection."""
+    import ctypes as C
+    import torch
+    from speechcatcher_amd import _abi
+    lib = _abi.load()
+    S, W = 64, 10
+    g = torch.Generator().manual_seed(3)
+    for use_bbd in (0, 1):
+        ctrl = torch.zeros(S, 8, dtype=torch.int32)
+        ctrl[:, 0] = (torch.arange(S) % 5 != 4).int()           # active
+        ctrl[:, 1] = torch.randint(0, 2, (S,), generator=g).int()   # cur
+        ctrl[:, 2] = (torch.arange(S) // 16 % 2).int()           # final
+        ctrl[:, 3] = 100
+        ctrl[:, 4] = torch.randint(1, 50, (S,), generator=g).int()  # L
+        ctrl[:, 5] = torch.where(torch.arange(S) % 3 == 0, 1, W).int()   # nhyp
+        ctrl[:, 6] = torch.randint(0, 2, (S,), generator=g).int()
+        ctrl[:, 7] = 100
+        flags = (torch.arange(S) % 16).int()                     # every combination of the 4 flag bits
+        sb = _abi.Search()
+        sb.S, sb.W = S, W
+        dc, df = ctrl.cuda(), flags.cuda()
+        ring = torch.full((2, S), -1, dtype=torch.int32, device="cuda:0")
+        sb.ctrl, sb.flags = dc.data_ptr(), df.data_ptr()
+        _abi.check(lib.sc_step_advance(C.byref(sb), use_bbd, ring.data_ptr(), 0), "sc_step_advance")
+        torch.cuda.synchronize()
+        out, rg = dc.cpu(), ring.cpu()
+        for s in range(S):
+            act, cur, fin, T, L, nh, has, tt = (int(v) for v in ctrl[s])
+            f = int(flags[s])
+            if not act:
+                assert out[s].tolist() == ctrl[s].tolist() and int(rg[L & 1, s]) == -1
+                continue
+            assert int(rg[L & 1, s]) == f and int(rg[1 - (L & 1), s]) == -1
+            f_any, f_best, f_all, f_rep = bool(f & 1), bool(f & 2), bool(f & 4), bool(f & 8)
+            stop_eos = f_any and (not fin or f_best)
+            stop_bbd = bool(use_bbd) and not stop_eos and f_rep and not fin
+            stop_all = not stop_eos and not stop_bbd and f_all and bool(fin)
+            if stop_eos or stop_bbd or stop_all:
+                assert out[s].tolist() == [0, cur, fin, T, L, nh, has, tt], (s, f)
+            else:
+                assert out[s].tolist() == [1, 1 - cur, fin, T, L + 1, min(W, nh * W), 1, tt], (s, f)
 
 
 def test_native_xl_batch_equals_python_engine():
