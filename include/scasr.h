@@ -334,6 +334,10 @@ int sc_decoder_layers(const sc_search *sb, void *stream);
 int sc_logsoftmax_topk(const sc_search *sb, void *stream);
 /* CTCPrefixScoreTH.__call__ on the K candidates (ctc_prefix_score_full.py:88-291) */
 int sc_ctc_prefix_scan(const sc_search *sb, void *stream);
+/* the same scores; streams with at least split_min (> 0) frames behind their first scanned frame are walked by 16
+ * threads per (hypothesis, candidate) - segment-wise affine maps of the recurrence, combined, then re-walked - instead
+ * of one: for long tables (T = 4500: a 180 s segment) while few streams are active */
+int sc_ctc_prefix_scan_split(const sc_search *sb, int split_min, void *stream);
 /* score fusion + per-hypothesis top-W (beam_search.py:113-185,723) */
 int sc_fuse_topw(const sc_search *sb, void *stream);
 /* expand / prune / bookkeeping / stop flags (beam_search.py:721-809, hypothesis.py:132-142) */
@@ -342,6 +346,9 @@ int sc_beam_prune(const sc_search *sb, void *stream);
 int sc_ctc_gather_state(const sc_search *sb, void *stream);
 /* one full beam-search step = all of the above in order (beam_search.py:701-758) */
 int sc_decode_step(const sc_search *sb, void *stream);
+/* ... with the CTC prefix scan of streams that have >= scan_split_min frames to walk split over T
+ * (sc_ctc_prefix_scan_split; 0: never) */
+int sc_decode_step_ex(const sc_search *sb, int scan_split_min, void *stream);
 /* device-side step control behind sc_decode_step: the accept / stop rules of the step loop (beam_search.py:759-821)
  * applied to every active stream's ctrl row IN PLACE (accepted: CUR flipped, L+1, NHYP = min(W, NHYP*W), HAS = 1;
  * stopped: ACTIVE = 0), and the step's stop flags copied to ring[(L & 1) * S + s] (ring: device-visible int32[2][S],

@@ -134,6 +134,8 @@ _SIGS = {
     "sc_ctc_gather_state": (C.c_int, [vp, vp]),
     "sc_step_advance": (C.c_int, [vp, C.c_int, vp, vp]),
     "sc_decode_step": (C.c_int, [vp, vp]),
+    "sc_decode_step_ex": (C.c_int, [vp, C.c_int, vp]),
+    "sc_ctc_prefix_scan_split": (C.c_int, [vp, C.c_int, vp]),
     "sc_dec_layer_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sc_dec_layer_self": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp]),
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),

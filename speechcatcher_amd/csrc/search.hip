@@ -972,8 +972,15 @@ struct CtcChunkT {
   float4 xc[4], xb[4];
   float pn[16], pb[16];
 };
+// a stream's scan is split over T (ctc_prefix_scan_tpar_kernel) when it has at least split_min frames to walk
+__device__ __forceinline__ bool ctc_scan_is_split(int T, int L, int split_min) {
+  const int out_len = L - 1;
+  int start = out_len > 1 ? out_len : 1;
+  if (start > T) start = T;
+  return split_min > 0 && T - start >= split_min;
+}
 
-__global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search sb) {
+__global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search sb, int split_min) {
   const int s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP), K = sb.K, W = sb.W, V = sb.V;
@@ -981,6 +988,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
   if (e >= nh * K) return;
   const int h = e / K, k = e % K;
   const int T = SC_CTC_T(s), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  if (ctc_scan_is_split(T, L, split_min)) return;   // ctc_prefix_scan_tpar_kernel's stream
   const bool has = CTRL(s, SC_C_HAS);
   const long row = (long)s * W + h;
   const int c = sb.pre_ids[row * K + k];
@@ -1081,16 +1089,219 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
   if (k == 0) sb.psi_eos[row] = rsum_last;
 }
 
-extern "C" int sc_ctc_prefix_scan(const sc_search *sbp, void *stream) {
+// ---------------------------------------------------------------------------
+// The scan split over T for long tables and few active streams (a 180 s segment has T = 4500: 0.66 ms per decode
+// iteration for the sequential walk, whatever the number of streams).  The recurrence is affine in the probability
+// domain -  n' = (n + phi) * pc,  b' = (n + b) * pb  - so a segment of frames acts on its start state as
+//     n_end = A * n0 + Un,      b_end = C * n0 + D * b0 + Ub
+// with five coefficients that a thread accumulates over its segment WITHOUT knowing the start state (log domain:
+// A += xc, D += xb, Un = lse(Un, phi) + xc, C = lse(A, C) + xb, Ub = lse(Un, Ub) + xb).  A workgroup holds 16
+// (hypothesis, candidate) pairs x 32 segments: pass 1 = coefficients (+ the segment's share of psi, which does not
+// depend on the state at all), a 16-step combine in LDS gives every segment its start state, pass 2 re-walks the
+// segment with the plain recurrence and stores r[t].  Twice the arithmetic, 1/16 of the dependent chain.
+// Rounding differs from the sequential walk at the level of the fp32 log-add-exps (same magnitudes).
+// ---------------------------------------------------------------------------
+#define CTC_NSEG 32   // segments per (hypothesis, candidate) pair
+#define CTC_EB (256 / CTC_NSEG)   // pairs per workgroup
+__global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb, int split_min) {
+  __shared__ float co[8][CTC_NSEG][CTC_EB];    // A, C, D, Un, Ub, psi max, psi sum, blank sum of every (segment, pair)
+  __shared__ float st0[2][CTC_NSEG][CTC_EB];   // start state (n, b) of every segment
+  __shared__ float cum0[CTC_NSEG][CTC_EB];     // !has: running blank sum at the segment start
+  const int s = blockIdx.y;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int nh = CTRL(s, SC_C_NHYP), K = sb.K, W = sb.W, V = sb.V;
+  const int T = SC_CTC_T(s), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
+  if (!ctc_scan_is_split(T, L, split_min)) return;   // the sequential kernel's stream
+  if ((int)blockIdx.x * CTC_EB >= nh * K) return;
+  const int el = threadIdx.x % CTC_EB, p = threadIdx.x / CTC_EB;
+  const int e_raw = blockIdx.x * CTC_EB + el;
+  const bool valid = e_raw < nh * K;
+  const int e = valid ? e_raw : nh * K - 1;   // surplus lanes shadow the last pair (no stores)
+  const int h = e / K, k = e % K;
+  const bool has = CTRL(s, SC_C_HAS);
+  const long row = (long)s * W + h;
+  const int c = sb.pre_ids[row * K + k];
+  const int last = YSEQ(cur, s, h)[L - 1];
+  const bool same = (c == last);
+  const int tct = sb.tct;
+  const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
+  const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
+  const float *__restrict__ rp = CTCR(cur, s);
+  float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
+  const int WK = W * K;
+  const int out_len = L - 1;
+  int start = out_len > 1 ? out_len : 1;
+  if (start > T) start = T;
+  if (valid)
+    for (int t = p; t < start - 1; t += CTC_NSEG) {   // rows before start-1 are never read again; keep them at logzero
+      rn[((long)t * 2) * WK + e] = SC_LOGZERO;
+      rn[((long)t * 2 + 1) * WK + e] = SC_LOGZERO;
+    }
+  const float r_n0 = (out_len == 0) ? xcol[0] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
+  const float r_b0 = SC_LOGZERO;
+  if (valid && p == 0) {
+    rn[((long)(start - 1) * 2) * WK + e] = r_n0;
+    rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b0;
+  }
+  // segments: boundaries at multiples of 16 frames (the loads are 16-frame chunks)
+  const int base = start & ~15;
+  const int seg = 16 * cdiv(T - base, 16 * CTC_NSEG);
+  const int t_lo = max(start, base + p * seg), t_hi = min(T, base + (p + 1) * seg);
+
+  auto fetch = [&](CtcChunkT &q, int tb) {   // frames [tb, tb+16), tb a multiple of 16
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t4 = min(tb + 4 * j, tct - 4);
+      q.xc[j] = *reinterpret_cast<const float4 *>(xcol + t4);
+      q.xb[j] = *reinterpret_cast<const float4 *>(xblk + t4);
+    }
+    if (has) {  // uniform per workgroup
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int t = tb + i;
+        t = t < T ? (t < 1 ? 1 : t) : T - 1;
+        q.pn[i] = rp[((long)(t - 1) * 2) * W + h];
+        q.pb[i] = rp[((long)(t - 1) * 2 + 1) * W + h];
+      }
+    }
+  };
+  // walk the frames [lo, hi) in 16-frame chunks, one chunk fetched ahead: body(q, i, t) per frame
+  auto walk = [&](int lo, int hi, auto body) {
+    if (lo >= hi) return;
+    CtcChunkT qa, qb;
+    int tb = lo & ~15;
+    fetch(qa, tb);
+    while (true) {
+      if (tb + 16 < hi) fetch(qb, tb + 16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (tb + i >= lo && tb + i < hi) body(qa, i, tb + i);
+      tb += 16;
+      if (tb >= hi) break;
+      if (tb + 16 < hi) fetch(qa, tb + 16);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (tb + i >= lo && tb + i < hi) body(qb, i, tb + i);
+      tb += 16;
+      if (tb >= hi) break;
+    }
+  };
+  auto comp = [](const float4 &v, int i) { return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
+
+  // ---- pass 0 (no previous prefix): the blank log-prob sum in front of every segment ----
+  float cum = 0.f;
+  if (!has) {
+    float bs = 0.f;
+    if (p == 0)
+      for (int t = 0; t < start; ++t) bs += xblk[t];
+    walk(t_lo, t_hi, [&](const CtcChunkT &q, int i, int) { bs += comp(q.xb[i >> 2], i); });
+    co[7][p][el] = bs;
+    __syncthreads();
+    for (int q = 0; q < p; ++q) cum += co[7][q][el];
+    if (p == 0) {
+      cum = 0.f;
+      for (int t = 0; t < start; ++t) cum += xblk[t];
+    } else {
+      // segment 0's sum already contains the frames before start
+    }
+    cum0[p][el] = cum;
+  }
+  // ---- pass 1: the segment's affine map and its share of psi ----
+  float A = 0.f, C = SC_LOGZERO, D = 0.f, Un = SC_LOGZERO, Ub = SC_LOGZERO;
+  float pm = SC_LOGZERO, ps = 0.f;
+  {
+    float cu = cum;
+    walk(t_lo, t_hi, [&](const CtcChunkT &q, int i, int) {
+      const float xc = comp(q.xc[i >> 2], i), xb = comp(q.xb[i >> 2], i);
+      const float pn = has ? q.pn[i] : SC_LOGZERO;
+      const float pb = has ? q.pb[i] : cu;     // r_prev[t-1]
+      const float phi = same ? pb : lse2(pn, pb);
+      const float nUb = lse2(Un, Ub) + xb;
+      const float nC = lse2(A, C) + xb;
+      Un = lse2(Un, phi) + xc;
+      Ub = nUb;
+      C = nC;
+      A += xc;
+      D += xb;
+      const float v = phi + xc;       // branch-free running log-sum-exp
+      const float m = sc_max_raw(pm, v);
+      ps = ps * sc_exp_neg(pm - m) + sc_exp_neg(v - m);
+      pm = m;
+      if (!has) cu += xb;
+    });
+  }
+  co[0][p][el] = A; co[1][p][el] = C; co[2][p][el] = D; co[3][p][el] = Un; co[4][p][el] = Ub;
+  co[5][p][el] = pm; co[6][p][el] = ps;
+  __syncthreads();
+  // ---- combine: start state of every segment, psi ----
+  if (p == 0) {
+    float n = r_n0, b = r_b0;
+    float gm = r_n0, gs = 1.f;   // psi = logsumexp over {phi[t-1] + x[t,c]} and r[start-1][n]
+    for (int q = 0; q < CTC_NSEG; ++q) {
+      st0[0][q][el] = n;
+      st0[1][q][el] = b;
+      const float nn = lse2(co[0][q][el] + n, co[3][q][el]);
+      const float nb = lse2(lse2(co[1][q][el] + n, co[2][q][el] + b), co[4][q][el]);
+      n = nn;
+      b = nb;
+      const float m = sc_max_raw(gm, co[5][q][el]);
+      gs = gs * sc_exp_neg(gm - m) + co[6][q][el] * sc_exp_neg(co[5][q][el] - m);
+      gm = m;
+    }
+    if (valid) {
+      float psi = gm + logf(gs);
+      float total = 0.f;   // !has: blank sum over all T frames
+      if (!has)
+        for (int q = 0; q < CTC_NSEG; ++q) total += co[7][q][el];
+      const float pn_last = has ? rp[((long)(T - 1) * 2) * W + h] : SC_LOGZERO;
+      const float pb_last = has ? rp[((long)(T - 1) * 2 + 1) * W + h] : total;
+      const float rsum_last = lse2(pn_last, pb_last);
+      if (c == sb.eos) psi = rsum_last;
+      if (c == sb.blank) psi = SC_LOGZERO;
+      sb.psi[row * K + k] = psi;
+      if (k == 0) sb.psi_eos[row] = rsum_last;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: the plain recurrence from the segment's start state, r[t] stored ----
+  {
+    float r_n = st0[0][p][el], r_b = st0[1][p][el];
+    float cu = has ? 0.f : cum0[p][el];
+    walk(t_lo, t_hi, [&](const CtcChunkT &q, int i, int t) {
+      const float xc = comp(q.xc[i >> 2], i), xb = comp(q.xb[i >> 2], i);
+      const float pn = has ? q.pn[i] : SC_LOGZERO;
+      const float pb = has ? q.pb[i] : cu;
+      const float phi = same ? pb : lse2(pn, pb);
+      const float nr_n = lse2(r_n, phi) + xc;
+      const float nr_b = lse2(r_n, r_b) + xb;
+      r_n = nr_n;
+      r_b = nr_b;
+      if (valid) {
+        rn[((long)t * 2) * WK + e] = r_n;
+        rn[((long)t * 2 + 1) * WK + e] = r_b;
+      }
+      if (!has) cu += xb;
+    });
+  }
+}
+
+// split_min > 0: streams with at least split_min frames to walk take the T-parallel kernel
+extern "C" int sc_ctc_prefix_scan_split(const sc_search *sbp, int split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   dim3 grid(cdiv(sbp->W * sbp->K, 256), sbp->S);
-  if (sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0)
-    ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp);
+  const bool colmajor = sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0;
+  if (!colmajor) split_min = 0;
+  if (colmajor)
+    ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   else
     ctc_prefix_scan_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp);
+  if (split_min > 0)
+    ctc_prefix_scan_tpar_kernel<<<dim3(cdiv(sbp->W * sbp->K, CTC_EB), sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
+
+extern "C" int sc_ctc_prefix_scan(const sc_search *sbp, void *stream) { return sc_ctc_prefix_scan_split(sbp, 0, stream); }
 
 // ---------------------------------------------------------------------------
 // score fusion + per-hypothesis top-W
@@ -1372,7 +1583,9 @@ extern "C" int sc_step_advance(const sc_search *sbp, int use_bbd, int32_t *ring,
   return SC_OK;
 }
 
-extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
+extern "C" int sc_decode_step(const sc_search *sbp, void *stream) { return sc_decode_step_ex(sbp, 0, stream); }
+
+extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
@@ -1400,7 +1613,7 @@ extern "C" int sc_decode_step(const sc_search *sbp, void *stream) {
     SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
   }
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
-  SC_TRY(sc_ctc_prefix_scan(sbp, stream));
+  SC_TRY(sc_ctc_prefix_scan_split(sbp, scan_split_min, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));
   SC_TRY(sc_beam_prune(sbp, stream));
   SC_TRY(sc_ctc_gather_state(sbp, stream));

@@ -142,6 +142,7 @@ struct sc_streams {
   int32_t *rm_host[2] = {nullptr, nullptr};     // pinned rowmap images (double-buffered: one may still be in a copy queue)
   int rm_idx = 0;
   bool rm_dirty = false;                        // rm_host[rm_idx] differs from the device rowmap
+  int scan_split_min = 256, scan_split_streams = 48;   // T-parallel CTC scan: frames to walk >=, bucket streams <=
   bool speculate = false;                       // device-side step control: enqueue iteration i+1 before reading the
                                                 // flags of i (opt-in, graphs on only; measured: no gain - DESIGN 4 (q))
   int graph_key() const { return n_rows_step * 2 + (speculate ? 1 : 0); }
@@ -592,7 +593,10 @@ void set_rowmap(sc_streams *b, const std::vector<int> &active) {
 // ring).  Without it the prune kernel stores the stop flags straight into the host-mapped array (sb.flags = ring).
 static int step_and_advance(sc_streams *b) {
   b->sb.flags = b->speculate ? b->flags_dev : b->ring_dev;
-  RC_TRY(sc_decode_step(&b->sb, b->stream));
+  // CTC prefix scan split over T while few streams are active (a function of the compaction bucket, so every
+  // captured graph has one form): the sequential walk costs 0.15 us per frame whatever the number of streams
+  const int split_min = b->n_rows_step <= b->scan_split_streams * b->W ? b->scan_split_min : 0;
+  RC_TRY(sc_decode_step_ex(&b->sb, split_min, b->stream));
   if (!b->speculate) return SC_OK;
   return sc_step_advance(&b->sb, b->use_bbd ? 1 : 0, b->ring_dev, b->stream);
 }
@@ -1233,6 +1237,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     sb.flags = b->ring_dev;
   }
   if (const char *sp = sc_hook("SC_SPECULATE")) b->speculate = atoi(sp) != 0;   // tests / A-B runs
+  if (const char *sp = sc_hook("SC_SCAN_SPLIT_MIN")) b->scan_split_min = atoi(sp);   // tests: 0 = never, small = always
   memset(b->ctrlmap_host, 0, cm);
   for (size_t i = 0; i < n; ++i) b->rm_host[0][i] = b->rm_host[1][i] = (int32_t)i;
   (void)hipMemcpy(b->ctrlmap, b->ctrlmap_host, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice);

@@ -280,8 +280,9 @@ class HipBackend:
     def logsoftmax_topk(self, sb):
         self._sb_call("sc_logsoftmax_topk", sb)
 
-    def ctc_prefix_scan(self, sb):
-        self._sb_call("sc_ctc_prefix_scan", sb)
+    def ctc_prefix_scan(self, sb, split_min=0):
+        """split_min > 0: streams with that many frames to walk take the T-parallel kernel (same scores)"""
+        self._sb_call("sc_ctc_prefix_scan_split", sb, int(split_min))
 
     def fuse_topw(self, sb):
         self._sb_call("sc_fuse_topw", sb)

@@ -33,6 +33,15 @@ def test_native_engine_matches_reference_xl(name):
     run_case(name, backend="native", score_tol=5e-3)
 
 
+@pytest.mark.parametrize("name", ["tiny_c10240_b10_bbd0", "tiny_c8192_b10_bbd1", "xl_c10240_b10_bbd0"])
+def test_native_engine_with_the_t_parallel_ctc_scan(name, monkeypatch):
+    """the same fixtures with the CTC prefix scan split over T from 32 frames on (default: 256): every block after
+    the first one takes the 16-segment kernel"""
+    from test_engine_spec import run_case
+    monkeypatch.setenv("SC_SCAN_SPLIT_MIN", "32")
+    run_case(name, backend="native", score_tol=5e-3)
+
+
 def test_native_short_utterances_and_the_reference_exception():
     from test_engine_spec import make_batch, check_against_blocks
     js = json.loads((GOLDEN / "tiny_short.json").read_text())

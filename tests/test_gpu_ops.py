@@ -483,15 +483,18 @@ def _scan_setup(hip, S, T, L, has, seed=0):
     return sc, sg
 
 
-@pytest.mark.parametrize("T,L,has", [(4500, 300, True), (4500, 1, False), (37, 9, True), (16, 2, False), (450, 120, True)])
-def test_ctc_prefix_scan_long_table(hip, T, L, has):
+@pytest.mark.parametrize("split", [0, 48])
+@pytest.mark.parametrize("T,L,has", [(4500, 300, True), (4500, 1, False), (37, 9, True), (16, 2, False), (450, 120, True),
+                                     (300, 1, False), (1000, 960, True)])
+def test_ctc_prefix_scan_long_table(hip, T, L, has, split):
     """CTCPrefixScoreTH.__call__ (ctc_prefix_score_full.py:146-291) at the table length of a 180 s CLI segment
     (T = 4500 encoder frames) and at chunk-boundary lengths: the column-streaming HIP scan against its spec -
-    log psi of all W x K candidates, the eos score and every forward variable r[t]."""
+    log psi of all W x K candidates, the eos score and every forward variable r[t]; split = 48: tables with at least
+    48 frames to walk take the T-parallel kernel (16 segments per pair), the short ones stay sequential."""
     from oracle.kernel_spec import SpecBackend
     sc, sg = _scan_setup(hip, 2, T, L, has)
     SpecBackend().ctc_prefix_scan(sc)
-    hip.ctc_prefix_scan(sg)
+    hip.ctc_prefix_scan(sg, split_min=split)
     torch.cuda.synchronize()
     W, K = sc.W, sc.K
     psi_c, psi_g = sc.psi.view(-1), sg.psi.cpu().view(-1)
@@ -513,23 +516,24 @@ def test_ctc_prefix_scan_time_at_long_tables(hip):
     import json
     import os
     out = {}
-    for T, L in ((450, 250), (4500, 300)):
+    for T, L in ((450, 250), (450, 60), (4500, 300)):
         sc, sg = _scan_setup(hip, 8, T, L, True)
         st = hip.search_struct(sg)
-        for name in ("column_streaming", "row_gather"):
+        for name in ("column_streaming", "row_gather", "t_parallel"):
             keep = st.ctcxT
             if name == "row_gather":
                 st.ctcxT = None
+            split = 256 if name == "t_parallel" else 0
             for _ in range(3):
-                hip.ctc_prefix_scan(sg)
+                hip.ctc_prefix_scan(sg, split_min=split)
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(20):
-                hip.ctc_prefix_scan(sg)
+                hip.ctc_prefix_scan(sg, split_min=split)
             b.record()
             torch.cuda.synchronize()
-            out[f"T{T}_{name}_us"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+            out[f"T{T}{'_L60' if L == 60 else ''}_{name}_us"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
             st.ctcxT = keep
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/r02_ctc_scan_timing.json", "w") as f:
@@ -539,3 +543,5 @@ def test_ctc_prefix_scan_time_at_long_tables(hip):
     # (r01: 0.29); the next step is splitting the r^n / r^b / psi chains over waves of different SIMDs
     assert out["T4500_column_streaming_us"] < 800.0
     assert out["T4500_column_streaming_us"] <= 1.05 * out["T4500_row_gather_us"]
+    assert out["T4500_t_parallel_us"] < 150.0
+    # (T = 450 with 250-token hypotheses has 201 frames to walk: below the 256-frame threshold, not split)
