@@ -48,14 +48,15 @@ def capacities(n_steps_total):
     return int(16 * hops) + 64, min(2048, int(14 * hops) + 32)
 
 
+FFN_DTYPE = "float32"  # --ffn-dtype float16: fp16 feed-forward weights + fp16 MFMA inputs (configs[4]), never the default
+KV_DTYPE = "float32"   # --kv-dtype float16: K|V caches in fp16 (BASELINE configs[4]'s storage mode), never the default
+
+
 def make_weights(device):
     from speechcatcher_amd.weights import PackedWeights
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    return PackedWeights(sd, XL, device, mean, std)
-
-
-KV_DTYPE = "float32"   # --kv-dtype float16: K|V caches in fp16 (BASELINE configs[4]'s storage mode), never the default
+    return PackedWeights(sd, XL, device, mean, std, ffn_dtype=FFN_DTYPE)
 
 
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None):
@@ -187,10 +188,14 @@ def main():
     ap.add_argument("--kv-dtype", choices=["float32", "float16"], default="float32",
                     help="float16: self-/cross-attention K|V caches stored in fp16, arithmetic fp32 (opt-in; results "
                          "differ from the fp32 reference within the tolerance stated in tests/test_gpu_native.py)")
+    ap.add_argument("--ffn-dtype", choices=["float32", "float16"], default="float32",
+                    help="float16: feed-forward weights in fp16 and fp16 MFMA inputs (fp32 accumulation) in the fused FFN "
+                         "kernels of encoder and decoder (opt-in, BASELINE configs[4]; never the headline)")
     args = ap.parse_args()
-    global CHUNK, KV_DTYPE
+    global CHUNK, KV_DTYPE, FFN_DTYPE
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
+    FFN_DTYPE = args.ffn_dtype
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -374,7 +379,12 @@ def main():
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if KV_DTYPE == "float32" else "f32 arithmetic, fp16 K|V caches", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f32" if KV_DTYPE == "float32" and FFN_DTYPE == "float32" else
+                  "f32 except: " + ", ".join(x for x in (("fp16 K|V caches" if KV_DTYPE != "float32" else ""),
+                                                         ("fp16 feed-forward weights and MFMA inputs (fp32 accumulation)"
+                                                          if FFN_DTYPE != "float32" else "")) if x)),
+        "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,

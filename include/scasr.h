@@ -69,6 +69,8 @@ typedef struct sc_enc_layer {
   const float *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
   const float *w1_p, *w2_p; /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
   const float *wqkv_p, *wo_p; /* sc_pack_panel_weight of wqkv, wo (used when sc_rowtile_proj_supported(d, d)) */
+  const void *w1_h, *w2_h;    /* fp16 copies of w1_p / w2_p (same fragment order) or NULL: the fused FFN then runs
+                                 fp16 MFMA inputs with fp32 accumulation (sc_ffn_ln_h) */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -79,6 +81,7 @@ typedef struct sc_dec_layer {
   const float *w1_p, *w2_p;         /* sc_pack_panel_weight of w1, w2 (used when sc_ffn_ln_supported(d, F)) */
   const float *wqkv_q;              /* sc_pack_lane_weight of wqkv (sc_ffn_ln_proj of the layer before) */
   const float *wqkv_pp, *wq_pp, *wo_pp, *wo2_pp; /* sc_pack_panel_weight of wqkv, wq, wo, wo2 (sc_dec_layer_self / _cross), or NULL */
+  const void *w1_h, *w2_h;          /* fp16 copies of w1_p / w2_p or NULL (see sc_enc_layer) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -221,6 +224,15 @@ int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D, int F, co
                    const float *b1, const float *W2p, const float *b2, const float *Xin, float *Xout,
                    const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, const float *Wq,
                    const float *bq, float *Q, int N, void *stream);
+/* ... with fp16 weights: W1h / W2h = the fragment-packed copies with 2-byte elements; fp16 MFMA inputs (activations
+ * rounded to fp16 when staged), fp32 accumulation, bias, ReLU input, partial sums, residual and LayerNorm in fp32 */
+int sc_ffn_ln_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h, const float *b1,
+                const void *W2h, const float *b2, float *X, const float *ln_g, const float *ln_b, float ln_eps,
+                float *ln_out, void *stream);
+int sc_ffn_ln_proj_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h, const float *b1,
+                     const void *W2h, const float *b2, const float *Xin, float *Xout, const float *ln_g,
+                     const float *ln_b, float ln_eps, float *ln_out, const float *Wq, const float *bq, float *Q, int N,
+                     void *stream);
 /* bytes of the split-K workspace registered for `stream` (0: none).  sc_decoder_layers /
  * sc_encoder_layers use the fused FFN only when a workspace is available and fall back to
  * two GEMMs otherwise. */
@@ -434,7 +446,7 @@ typedef struct sc_named_tensor {
   const char *name; /* PackedWeights names: "window", "conv2_w", "enc.3.wqkv_p", "dec.0.wkv", ... */
   const void *data; /* DEVICE pointer, borrowed for the lifetime of the engine */
   int64_t numel;
-  int32_t dtype; /* 0 = f32, 1 = f64 (mean64 / std64) */
+  int32_t dtype; /* 0 = f32, 1 = f64 (mean64 / std64), 2 = f16 (w1_h / w2_h) */
 } sc_named_tensor;
 
 typedef struct sc_stream_options {

@@ -25,14 +25,14 @@ vp = C.c_void_p
 class EncLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "w1_p", "w2_p",
-                                  "wqkv_p", "wo_p")]
+                                  "wqkv_p", "wo_p", "w1_h", "w2_h")]
 
 
 class DecLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
-                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp")]
+                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp", "w1_h", "w2_h")]
 
 
 class Search(C.Structure):
@@ -87,6 +87,9 @@ _SIGS = {
     "sc_pack_panel_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "sc_pack_lane_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "sc_ffn_ln": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
+    "sc_ffn_ln_h": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
+    "sc_ffn_ln_proj_h": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp,
+                                   vp, vp, vp, C.c_int, vp]),
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_rowtile_proj": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
                                   C.c_int, vp, vp, vp, vp]),

@@ -582,7 +582,10 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
       SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
     }
     if (ffn_fused) {
-      SC_TRY(sc_ffn_ln(xn, nullptr, M, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
+      if (w.w1_h && w.w2_h)   // fp16 weights: fp16 MFMA inputs, fp32 accumulation
+        SC_TRY(sc_ffn_ln_h(xn, nullptr, M, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
+      else
+        SC_TRY(sc_ffn_ln(xn, nullptr, M, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
     } else {
       SC_TRY(sc_gemm(xn, nullptr, d, w.w1, w.b1, ffh, nullptr, F, M, F, d, SC_GEMM_RELU, 0, stream));
       SC_TRY(sc_gemm(ffh, nullptr, F, w.w2, w.b2, x, nullptr, d, M, d, F, SC_GEMM_RESIDUAL, 0, stream));

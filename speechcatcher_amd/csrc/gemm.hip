@@ -795,17 +795,39 @@ struct FfnArgs {
   const float *g, *b;
   float eps;
   int part_rows;
+  int w_half;   // W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation
 };
 
-template <int D, int RTT, bool PRO = false>
+// WH: fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
+// 8 k values a lane holds per 32-wide k block feed 2 instructions instead of 8), fp32 accumulation, fp32 partial sums
+// and LayerNorms.  The row tile and the hidden activations then live in LDS as fp16 (converted once, when staged).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 ffn_mma_h(f32x4 acc, const h16x8 &a, const h16x4 &b0, const h16x4 &b1) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h16x4{a[0], a[1], a[2], a[3]}, b0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h16x4{a[4], a[5], a[6], a[7]}, b1, acc, 0, 0, 0);
+  return acc;
+}
+// LDS bytes of one workgroup (host and device)
+__host__ __device__ static inline size_t ffn_lds_bytes(int D, int RT, bool pro, bool wh) {
+  if (!wh) return (size_t)(RT * (D + 4) + RT * (128 + 4) + (pro ? RT : 0)) * sizeof(float);
+  return (size_t)RT * (D + 4) * 4 + (size_t)RT * (D + 8) * 2 + (size_t)RT * (128 + 8) * 2 + (pro ? RT * 4 : 0);
+}
+
+template <int D, int RTT, bool PRO = false, bool WH = false>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int RT = 16 * RTT, FC = 128;
   constexpr int KI1 = D / 32, KI2 = FC / 32, NT2 = D / 128;
   constexpr int LDX = D + 4, LDH = FC + 4;
+  constexpr int LDXH = D + 8, LDHH = FC + 8;   // WH: row strides of the fp16 tiles (elements)
   extern __shared__ __attribute__((aligned(16))) float ffn_smem[];
-  float *Xs = ffn_smem;            // [RT][LDX]  xn tile; re-used to stage the partial result
-  float *Hs = ffn_smem + RT * LDX; // [RT][LDH]  relu(h) of the current chunk
-  int *rowid = reinterpret_cast<int *>(ffn_smem + RT * LDX + RT * LDH);   // PRO: [RT] row ids of the tile
+  float *Xs = ffn_smem;            // [RT][LDX]  xn tile (WH: fp32 staging of the prologue only); re-used to stage the partial result
+  float *Hs = ffn_smem + RT * LDX; // [RT][LDH]  relu(h) of the current chunk (not WH)
+  _Float16 *XsH = reinterpret_cast<_Float16 *>(ffn_smem + RT * LDX);   // WH: [RT][LDXH] xn tile
+  _Float16 *HsH = XsH + RT * LDXH;                                       // WH: [RT][LDHH] relu(h)
+  int *rowid = WH ? reinterpret_cast<int *>(HsH + RT * LDHH)
+                  : reinterpret_cast<int *>(ffn_smem + RT * LDX + RT * LDH);   // PRO: [RT] row ids of the tile
+  typedef typename std::conditional<WH, h16x4, float4>::type BF;   // 4 weight elements
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int grp = blockIdx.x, m0 = blockIdx.y * RT;
@@ -817,9 +839,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   constexpr int NQ = NV / 512;
   static_assert(NV % 512 == 0, "tile must be a multiple of the workgroup");
   SC_STAMP(PRO ? 2 : 3, 0);
-  float4 bf[KI1][2];  // GEMM 1 weights of this wave's 16 hidden columns (all of K)
+  BF bf[KI1][2];  // GEMM 1 weights of this wave's 16 hidden columns (all of K)
   auto load_b1 = [&](int chunk) {
-    const float4 *wp = reinterpret_cast<const float4 *>(p.W1p) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
+    const BF *wp = reinterpret_cast<const BF *>(p.W1p) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
 #pragma unroll
     for (int ki = 0; ki < KI1; ++ki) {
       bf[ki][0] = wp[ki * 128];
@@ -829,11 +851,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   // (requesting the first chunk's W1 / W2 fragments ahead of the prologue's partial sums was measured and lost:
   // loads return in issue order, the prologue then waits for 256 KB of weights - 197 -> 233 stamp units per launch;
   // the GEMM phase itself is bound by the 256 MFMAs per SIMD of a 16-row tile, not by its loads)
-  float4 b2f[KI2][NT2][2];
+  BF b2f[KI2][NT2][2];
   auto load_b2 = [&](int chunk) {
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
-      const float4 *wp = reinterpret_cast<const float4 *>(p.W2p) +
+      const BF *wp = reinterpret_cast<const BF *>(p.W2p) +
                          ((long)(wave * NT2 + t) * KF + chunk * KI2) * 128 + lane;
 #pragma unroll
       for (int k = 0; k < KI2; ++k) {
@@ -905,10 +927,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
       const float rstd = 1.0f / sqrtf(group_sum<16>(q2) / (float)D + p.eps);
 #pragma unroll
-      for (int q = 0; q < Q4; ++q)
-        *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * (sub + 16 * q)) =
-            make_float4((x[q].x - mean) * rstd * gam[q].x + bet[q].x, (x[q].y - mean) * rstd * gam[q].y + bet[q].y,
-                        (x[q].z - mean) * rstd * gam[q].z + bet[q].z, (x[q].w - mean) * rstd * gam[q].w + bet[q].w);
+      for (int q = 0; q < Q4; ++q) {
+        const float4 o = make_float4((x[q].x - mean) * rstd * gam[q].x + bet[q].x, (x[q].y - mean) * rstd * gam[q].y + bet[q].y,
+                                     (x[q].z - mean) * rstd * gam[q].z + bet[q].z, (x[q].w - mean) * rstd * gam[q].w + bet[q].w);
+        if (WH)
+          *reinterpret_cast<h16x4 *>(XsH + i * LDXH + 4 * (sub + 16 * q)) =
+              h16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+        else
+          *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * (sub + 16 * q)) = o;
+      }
     }
   } else {
     long rowv[NQ];
@@ -924,7 +951,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int e = threadIdx.x + q * 512;
-      *reinterpret_cast<float4 *>(Xs + (e / (D / 4)) * LDX + 4 * (e % (D / 4))) = stage[q];
+      if (WH)
+        *reinterpret_cast<h16x4 *>(XsH + (e / (D / 4)) * LDXH + 4 * (e % (D / 4))) =
+            h16x4{(_Float16)stage[q].x, (_Float16)stage[q].y, (_Float16)stage[q].z, (_Float16)stage[q].w};
+      else
+        *reinterpret_cast<float4 *>(Xs + (e / (D / 4)) * LDX + 4 * (e % (D / 4))) = stage[q];
     }
   }
   f32x4 acc2[RTT][NT2];
@@ -944,7 +975,19 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     f32x4 acc1[RTT];
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {  // A operands are fetched one step ahead of the MFMAs that use them
+    if constexpr (WH) {
+      constexpr int NS = RTT * KI1;
+      const _Float16 *ab = XsH + r * LDXH + 8 * kk;
+      h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        h16x8 n = a;
+        if (st + 1 < NS) n = *reinterpret_cast<const h16x8 *>(ab + ((st + 1) % RTT) * 16 * LDXH + ((st + 1) / RTT) * 32);
+        acc1[rt] = ffn_mma_h(acc1[rt], a, bf[ki][0], bf[ki][1]);
+        a = n;
+      }
+    } else {  // A operands are fetched one step ahead of the MFMAs that use them
       constexpr int NS = RTT * KI1;
       const float *ab = Xs + r * LDX + 8 * kk;
       float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
@@ -968,12 +1011,28 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        Hs[(rt * 16 + 4 * kk + j) * LDH + wave * 16 + r] = fmaxf(acc1[rt][j] + bias, 0.f);
+      for (int j = 0; j < 4; ++j) {
+        const float hv = fmaxf(acc1[rt][j] + bias, 0.f);
+        if (WH) HsH[(rt * 16 + 4 * kk + j) * LDHH + wave * 16 + r] = (_Float16)hv;
+        else Hs[(rt * 16 + 4 * kk + j) * LDH + wave * 16 + r] = hv;
+      }
     if (cc + 1 < p.cpw) load_b1(chunk + 1);  // next chunk's GEMM 1 weights, overlapped with GEMM 2
     __syncthreads();
     // ---- GEMM 2: partial y[RT x D/8] of this wave ----
-    {
+    if constexpr (WH) {
+      constexpr int NS = RTT * KI2;
+      const _Float16 *ab = HsH + r * LDHH + 8 * kk;
+      h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int k = st / RTT, rt = st % RTT;
+        h16x8 n = a;
+        if (st + 1 < NS) n = *reinterpret_cast<const h16x8 *>(ab + ((st + 1) % RTT) * 16 * LDHH + ((st + 1) / RTT) * 32);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[rt][t] = ffn_mma_h(acc2[rt][t], a, b2f[k][t][0], b2f[k][t][1]);
+        a = n;
+      }
+    } else {
       constexpr int NS = RTT * KI2;
       const float *ab = Hs + r * LDH + 8 * kk;
       float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
@@ -1018,17 +1077,22 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 }
 SC_PHASE_GETTER(sc_phase_debug_ffn)
 
-template <int D, int RTT, bool PRO = false>
-static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
+template <int D, int RTT, bool PRO, bool WH>
+static void launch_ffn_wh(const FfnArgs &p, int ngrp, hipStream_t st) {
   constexpr int RT = 16 * RTT;
-  const size_t lds = (size_t)(RT * (D + 4) + RT * (128 + 4) + (PRO ? RT : 0)) * sizeof(float);
+  const size_t lds = ffn_lds_bytes(D, RT, PRO, WH);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<D, RTT, PRO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_kernel<D, RTT, PRO, WH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  ffn_fused_kernel<D, RTT, PRO><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+  ffn_fused_kernel<D, RTT, PRO, WH><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+}
+template <int D, int RTT, bool PRO = false>
+static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
+  if (p.w_half) launch_ffn_wh<D, RTT, PRO, true>(p, ngrp, st);
+  else launch_ffn_wh<D, RTT, PRO, false>(p, ngrp, st);
 }
 
 template <int D, bool PRO = false>
@@ -1286,7 +1350,7 @@ extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128)
 static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
                    const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
                    const float *ln_b, float ln_eps, float *ln_out, float *Xout, const float *Wq,
-                   const float *bq, float *Q, int N, void *stream) {
+                   const float *bq, float *Q, int N, void *stream, bool w_half = false) {
   SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
   SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
   SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
@@ -1334,6 +1398,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     }
     const int ngrp = nch / best_cpw;
     FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
+    p.w_half = w_half ? 1 : 0;
     // without a row table the slab is addressed by offsetting the base pointers
     const float *xn_base = rows ? XN : XN + (long)m_done * D;
     p.XN = xn_base;
@@ -1368,6 +1433,23 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
                          const float *ln_b, float ln_eps, float *ln_out, void *stream) {
   return ffn_run(XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr, nullptr, nullptr,
                  nullptr, 0, stream);
+}
+
+// fp16 weights (fragment-packed like W1p / W2p, 2-byte elements): fp16 MFMA inputs, fp32 accumulation and output
+extern "C" int sc_ffn_ln_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h,
+                           const float *b1, const void *W2h, const float *b2, float *X, const float *ln_g,
+                           const float *ln_b, float ln_eps, float *ln_out, void *stream) {
+  return ffn_run(XN, rows, M, D, F, (const float *)W1h, b1, (const float *)W2h, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr,
+                 nullptr, nullptr, nullptr, 0, stream, true);
+}
+extern "C" int sc_ffn_ln_proj_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h,
+                                const float *b1, const void *W2h, const float *b2, const float *Xin, float *Xout,
+                                const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, const float *Wq,
+                                const float *bq, float *Q, int N, void *stream) {
+  SC_CHECK_ARG(Xin && Xout && Xin != Xout && Wq && Q && ln_g && ln_b, "null / aliased operand");
+  SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N > 0 && N % D == 0, "projection width must be a multiple of D");
+  return ffn_run(XN, rows, M, D, F, (const float *)W1h, b1, (const float *)W2h, b2, const_cast<float *>(Xin), ln_g, ln_b,
+                 ln_eps, ln_out, Xout, Wq, bq, Q, N, stream, true);
 }
 
 extern "C" int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
@@ -1414,8 +1496,9 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   }
   SC_CHECK_ARG(best < 1e29, "max_part too small");
   const int ngrp = nch / best_cpw;
-  FfnArgs p{nullptr, rows, w.w1_p, w.b1, w.w2_p, ffn_part, M, F, best_cpw,
-            sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W};
+  const bool wh = w.w1_h && w.w2_h;   // fp16 copies present: fp16 MFMA inputs
+  FfnArgs p{nullptr, rows, wh ? (const float *)w.w1_h : w.w1_p, w.b1, wh ? (const float *)w.w2_h : w.w2_p, ffn_part, M, F,
+            best_cpw, sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wh ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);

@@ -635,19 +635,24 @@ static int decoder_layers_impl(const sc_search *sbp, void *stream, bool fuse_log
     }
     // feed-forward + residual, then the NEXT layer's LN1 + Q|K|V (or after_norm + output layer)
     if (chain && (!last || (fuse_logits && sb.out_w_q && sb.V % d == 0))) {
-      if (!last) {
-        SC_TRY(sc_ffn_ln_proj(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr,
-                              sb.layers[li + 1].wqkv_q, sb.layers[li + 1].bqkv, sb.dqkv, 3 * d, stream));
-      } else {
-        SC_TRY(sc_ffn_ln_proj(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr,
-                              sb.out_w_q, sb.out_b, sb.logits, sb.V, stream));
-        if (logits_done) *logits_done = true;
-      }
+      const bool wh = w.w1_h && w.w2_h;   // fp16 weights: fp16 MFMA inputs, fp32 accumulation
+      const float *pw = last ? sb.out_w_q : sb.layers[li + 1].wqkv_q, *pb = last ? sb.out_b : sb.layers[li + 1].bqkv;
+      float *pq = last ? sb.logits : sb.dqkv;
+      const int pn = last ? sb.V : 3 * d;
+      if (wh)
+        SC_TRY(sc_ffn_ln_proj_h(ffn_in, rows, n, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr, pw, pb,
+                                pq, pn, stream));
+      else
+        SC_TRY(sc_ffn_ln_proj(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr, pw, pb,
+                              pq, pn, stream));
+      if (last && logits_done) *logits_done = true;
       float *t = x; x = xalt; xalt = t;
       continue;
     }
     float *ln_next = chain ? (x == sb.dx ? sb.dxn : sb.dx) : sb.dxn;   // a buffer that is not x
-    if (ffn_fused) {
+    if (ffn_fused && w.w1_h && w.w2_h) {
+      SC_TRY(sc_ffn_ln_h(ffn_in, rows, n, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));
+    } else if (ffn_fused) {
       SC_TRY(sc_ffn_ln(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));
     } else {
       SC_TRY(sc_gemm(ffn_in, rows, d, w.w1, w.b1, sb.dffh, rows, F, n, F, d, SC_GEMM_RELU, 0, stream));

@@ -43,7 +43,7 @@ namespace {
 struct Tensor {
   void *ptr = nullptr;
   int64_t numel = 0;
-  int dtype = 0;  // 0 f32, 1 f64
+  int dtype = 0;  // 0 f32, 1 f64, 2 f16
   bool owned = false;
 };
 
@@ -987,6 +987,8 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
     ENC(ln1_g) ENC(ln1_b) ENC(wqkv) ENC(bqkv) ENC(wo) ENC(bo) ENC(ln2_g) ENC(ln2_b) ENC(w1) ENC(b1) ENC(w2) ENC(b2)
     ENC(w1_p) ENC(w2_p) ENC(wqkv_p) ENC(wo_p)
 #undef ENC
+    l.w1_h = e->f(p + "w1_h", false);   // optional fp16 copies: fp16 MFMA inputs in the fused FFN
+    l.w2_h = e->f(p + "w2_h", false);
   }
   e->dec.resize(cfg->dec_layers);
   e->wkv.resize(cfg->dec_layers);
@@ -998,7 +1000,7 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
 #define DEC_OPT(fld) l.fld = e->f(p + #fld, false);
     DEC(ln1_g) DEC(ln1_b) DEC(wqkv) DEC(bqkv) DEC(wo) DEC(bo) DEC(ln2_g) DEC(ln2_b) DEC(wq) DEC(bq) DEC(wo2) DEC(bo2)
     DEC(ln3_g) DEC(ln3_b) DEC(w1) DEC(b1) DEC(w2) DEC(b2) DEC(wo_p) DEC(wq_p) DEC(wo2_p) DEC(w1_p) DEC(w2_p) DEC(wqkv_q)
-    DEC_OPT(wqkv_pp) DEC_OPT(wq_pp) DEC_OPT(wo_pp) DEC_OPT(wo2_pp)
+    DEC_OPT(wqkv_pp) DEC_OPT(wq_pp) DEC_OPT(wo_pp) DEC_OPT(wo2_pp) DEC_OPT(w1_h) DEC_OPT(w2_h)
 #undef DEC
 #undef DEC_OPT
     e->wkv[i] = e->f(p + "wkv");
@@ -1034,7 +1036,7 @@ extern "C" int sc_engine_load(const char *path, int device, sc_engine **out) {
     names[i].resize(nl);
     if (fread(&names[i][0], 1, nl, fp) != (size_t)nl || fread(&dt, 4, 1, fp) != 1 || fread(&numel, 8, 1, fp) != 1)
       return bad("truncated tensor header");
-    const size_t bytes = (size_t)numel * (dt == 1 ? 8 : 4);
+    const size_t bytes = (size_t)numel * (dt == 1 ? 8 : dt == 2 ? 2 : 4);
     buf.resize(bytes);
     if (bytes && fread(buf.data(), 1, bytes, fp) != bytes) return bad("truncated tensor data");
     void *p = nullptr;

@@ -97,6 +97,12 @@ class HipBackend:
         self._chk(self.lib.sc_ffn_ln(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(X),
                                      _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln")
 
+    def ffn_ln_h(self, XN, rows, M, D, F, W1h, b1, W2h, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
+        """sc_ffn_ln with fp16 weights (the packed fragments as torch.float16): fp16 MFMA inputs, fp32 accumulation"""
+        assert W1h.dtype == torch.float16 and W2h.dtype == torch.float16
+        self._chk(self.lib.sc_ffn_ln_h(_p(XN), _p(rows), M, D, F, _p(W1h), _p(b1), _p(W2h), _p(b2), _p(X),
+                                       _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln_h")
+
     def ffn_ln_proj(self, XN, rows, M, D, F, W1p, b1, W2p, b2, Xin, Xout, ln_g, ln_b, Wq, bq, Q, N, eps=1e-12):
         self._chk(self.lib.sc_ffn_ln_proj(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(Xin),
                                           _p(Xout), _p(ln_g), _p(ln_b), eps, None, _p(Wq), _p(bq), _p(Q), N,
@@ -156,7 +162,7 @@ class HipBackend:
             arr = (_abi.EncLayer * len(w.enc))()
             for i, lw in enumerate(w.enc):
                 for name, _ in _abi.EncLayer._fields_:
-                    setattr(arr[i], name, lw[name].data_ptr())
+                    setattr(arr[i], name, lw[name].data_ptr() if name in lw else None)   # w1_h / w2_h: optional
             w._sc_enc_layer_table = arr
         return arr
 

@@ -42,7 +42,7 @@ class NativeEngine:
             arr = (_abi.NamedTensor * len(ts))()
             for i, (n, t) in enumerate(ts):
                 arr[i].name, arr[i].data, arr[i].numel = self._names[i], t.data_ptr(), t.numel()
-                arr[i].dtype = 1 if t.dtype == torch.float64 else 0
+                arr[i].dtype = {torch.float64: 1, torch.float16: 2}.get(t.dtype, 0)
             _abi.check(self.lib.sc_engine_create(C.byref(c), arr, len(ts), self.device.index or 0, C.byref(h)),
                        "sc_engine_create")
         self.handle = h

@@ -76,7 +76,12 @@ def rowtile_proj_supported(d: int, N: int) -> bool:
 
 class PackedWeights:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
-                 mean=None, std=None):
+                 mean=None, std=None, ffn_dtype: str = "float32"):
+        """``ffn_dtype="float16"``: additional fp16 copies of the fragment-packed feed-forward weights (w1_h / w2_h);
+        the fused FFN kernels then run fp16 MFMA inputs with fp32 accumulation (BASELINE configs[4]; never the
+        default - the reference computes in fp32)."""
+        assert ffn_dtype in ("float32", "float16")
+        self.ffn_dtype = ffn_dtype
         self.cfg = cfg
         self.device = torch.device(device)
         d, F2 = cfg.d_model, cfg.conv_freq2
@@ -163,6 +168,8 @@ class PackedWeights:
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]
+                if ffn_dtype == "float16" and ffn_fused_supported(d, cfg.ffn_dim):
+                    lw[n + "_h"] = lw[n + "_p"].to(torch.float16).contiguous()   # same fragment order, 2-byte elements
         self.dec_norm_g = dev(g("decoder.after_norm.weight"))
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))
@@ -213,8 +220,9 @@ class PackedWeights:
                 a = t.detach().cpu().contiguous().numpy()
                 f.write(struct.pack("<i", len(nb)))
                 f.write(nb)
-                f.write(struct.pack("<iq", 1 if a.dtype == np.float64 else 0, a.size))
-                f.write(a.astype(np.float64 if a.dtype == np.float64 else np.float32).tobytes())
+                code = {np.dtype(np.float64): 1, np.dtype(np.float16): 2}.get(a.dtype, 0)
+                f.write(struct.pack("<iq", code, a.size))
+                f.write(a.astype((np.float32, np.float64, np.float16)[code]).tobytes())
         return path
 
     def n_bytes(self, part="all") -> int:

@@ -17,7 +17,7 @@ from speechcatcher_amd.weights import PackedWeights
 CFGS = {"TINY": TINY, "XL": XL}
 
 
-def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", **kw):
+def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", ffn_dtype="float32", **kw):
     """backend: None = the torch spec backend (CPU), a HipBackend = the Python engine over the HIP kernels,
     "native" = the C++ engine behind the stream-level C ABI (speechcatcher_amd.native)."""
     from oracle.kernel_spec import SpecBackend
@@ -27,8 +27,8 @@ def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, devi
     sc = SearchConfig(beam_size=beam, use_bbd=bbd)
     if isinstance(backend, str) and backend == "native":
         from speechcatcher_amd.native import NativeStreamBatch
-        return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std), n_streams, sc, **kw)
-    w = PackedWeights(sd, cfg, device, mean, std)
+        return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std, ffn_dtype=ffn_dtype), n_streams, sc, **kw)
+    w = PackedWeights(sd, cfg, device, mean, std, ffn_dtype=ffn_dtype)
     return StreamBatch(w, backend or SpecBackend(), n_streams, sc, **kw)
 
 

@@ -363,6 +363,24 @@ def test_fp16_kv_caches_keep_the_token_ids_of_the_fp32_reference(name, engine):
 
 
 @pytest.mark.parametrize("engine", ["native", "python"])
+@pytest.mark.parametrize("name", XL_CASES)
+def test_fp16_ffn_weights_on_the_xl_fixtures(name, engine):
+    """BASELINE configs[4], second stage: feed-forward weights in fp16 and fp16 MFMA inputs (fp32 accumulation) in the
+    fused FFN kernels of all 30 encoder and 14 decoder layers, next to the fp16 K|V caches.  Parity definition for
+    this mode (no fp16 run of the reference's native decoder exists): the token ids / positions of the BEST hypothesis
+    of every block of the six XL fixtures equal the fp32 reference's and its score is within 0.5 (sums of magnitude
+    1e2..1e3; the operands of two of the three big GEMMs of every layer carry 2^-11 rounding) - the engine checks
+    this through check_against_blocks' tolerance window for reordering among near-equal hypotheses."""
+    from test_engine_spec import run_case
+    kw = dict(score_tol=0.5, kv_dtype="float16", ffn_dtype="float16")
+    if engine == "native":
+        run_case(name, backend="native", **kw)
+    else:
+        from speechcatcher_amd.hip_backend import HipBackend
+        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("engine", ["native", "python"])
 def test_m_like_dimensions_head_dim_64(engine):
     """The reference's no-config defaults (d = 256, 4 heads of 64: config.M_DEFAULTS, the stand-in for the `_m`
     checkpoints of BASELINE configs[0]) with fewer layers: decoder attention at head dim 64, row panels and fused

@@ -163,6 +163,43 @@ def test_ffn_fused(hip, M, D, F, with_ln):
         np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
+@pytest.mark.parametrize("M,D,F", [(80, 256, 2048), (1280, 256, 2048), (5376, 256, 2048), (37, 128, 512), (640, 256, 2048)])
+def test_ffn_fused_fp16_weights(hip, M, D, F):
+    """The fused feed-forward with fp16 weights (sc_ffn_ln_h: v_mfma_f32_16x16x16_f16, activations rounded to fp16
+    when staged, fp32 accumulation / bias / residual / LayerNorm) against the same arithmetic in torch: operands
+    rounded to fp16, products and sums in fp32."""
+    from speechcatcher_amd.weights import pack_panel_weight
+    XN, X0, L0 = _rand(M + 5, D, seed=61), _rand(M + 5, D, seed=62), _rand(M + 5, D, seed=63)
+    W1, b1 = _rand(F, D, seed=64, scale=D ** -0.5), _rand(F, seed=65)
+    W2, b2 = _rand(D, F, seed=66, scale=F ** -0.5), _rand(D, seed=67)
+    g, be_ = 1 + 0.1 * _rand(D, seed=68), _rand(D, seed=69)
+    W1h, W2h = pack_panel_weight(W1).half(), pack_panel_weight(W2).half()
+    r16 = lambda t: t.half().float()   # noqa: E731
+    for rows in (None, torch.randperm(M + 5, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32)):
+        idx = torch.arange(M) if rows is None else rows.long()
+        h = torch.relu(r16(XN[idx]).double() @ r16(W1).double().t() + b1.double()).float()
+        y = (r16(h).double() @ r16(W2).double().t()).float() + b2
+        refX = X0.clone()
+        refX[idx] = X0[idx] + y
+        refL = L0.clone()
+        refL[idx] = torch.nn.functional.layer_norm(refX[idx], (D,), g, be_, 1e-12)
+        Xg, Lg = X0.cuda(), L0.cuda()
+        hip.ffn_ln_h(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, W1h.cuda(), b1.cuda(), W2h.cuda(),
+                     b2.cuda(), Xg, g.cuda(), be_.cuda(), Lg)
+        torch.cuda.synchronize()
+        # the hidden activations are rounded to fp16 after an fp32 sum whose order differs from torch's: a value on a
+        # rounding boundary may land on the neighbouring fp16 (2^-11 relative of ONE of 2048 terms)
+        np.testing.assert_allclose(Xg.cpu().numpy(), refX.numpy(), atol=2e-3, rtol=1e-3)
+        np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=2e-3, rtol=1e-3)
+        # ... and against the fp32 kernel: the fp16 rounding of the operands shows (not the same numbers), bounded
+        Xf = X0.cuda()
+        hip.ffn_ln(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, pack_panel_weight(W1).cuda(), b1.cuda(),
+                   pack_panel_weight(W2).cuda(), b2.cuda(), Xf, g.cuda(), be_.cuda(), None)
+        torch.cuda.synchronize()
+        diff = float((Xf - Xg).abs().max())
+        assert 0.0 < diff < 3e-2, diff
+
+
 @pytest.mark.parametrize("H,dk,R,nblk,masked", [(8, 32, 42, 5, True), (8, 32, 42, 130, True), (8, 32, 7, 3, False),
                                                 (8, 32, 1, 2, False), (8, 32, 2, 2, True), (8, 32, 64, 2, False),
                                                 (4, 16, 42, 3, True), (4, 64, 42, 3, True)])
