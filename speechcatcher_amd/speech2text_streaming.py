@@ -234,7 +234,11 @@ class Speech2TextStreaming:
         """``max_chunk_samples``: longest single call (the reference accepts any length per call and its frame
         arithmetic depends on the call boundaries, so a long call cannot be split internally; the scratch for one
         call is sized from this: 30 s by default, ~80 MB).  ``strict_reference``: reset() behaves like the
-        reference's (stale CTC table, A13 counter: StreamBatch.reset); False gives a clean stream."""
+        reference's (stale CTC table, A13 counter: StreamBatch.reset); False gives a clean stream.
+        ``dtype="float16"`` (the reference keeps fp32 weights under autocast for this constructor argument,
+        speech2text_streaming.py:57,64-70): fp16 feed-forward weights with fp16 MFMA inputs and fp16 K|V caches, every
+        sum / softmax / LayerNorm / score in fp32 (BASELINE configs[4]; `load_model(fp16=True)` stays fp32 with the
+        reference's warning)."""
         self.model_dir = Path(model_dir)
         self.beam_size = beam_size
         self.ctc_weight = ctc_weight
@@ -242,10 +246,11 @@ class Speech2TextStreaming:
         if not str(self.device).startswith("cuda"):
             raise _abi.ScasrError(
                 "speechcatcher_amd has no CPU path; pass device='cuda' (use the reference package for CPU)")
-        if dtype != "float32":
-            # the reference force-disables fp16 for the native decoder (speechcatcher.py:205-210, A9)
-            logger.warning("dtype %s requested; the native decoder path is fp32 only", dtype)
-        self.dtype = torch.float32
+        if dtype not in ("float32", "float16"):
+            logger.warning("dtype %s requested; using float32", dtype)
+            dtype = "float32"
+        self.dtype = torch.float32     # activations, scores and results
+        half = dtype == "float16"
         self.use_bbd = use_bbd
         self.result_format = result_format
         if self.model_dir.is_file() and self.model_dir.suffix == BLOB_SUFFIX:
@@ -255,7 +260,8 @@ class Speech2TextStreaming:
             self.cfg = config_from_dir(self.model_dir, sd)
             self.mean, self.std = load_stats(self.model_dir)
             self.token_list = load_token_list(self.model_dir)
-        self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std)
+        self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std,
+                                     ffn_dtype="float16" if half else "float32")
         self.model = self.weights
         # the decoder itself: the C++ engine behind the stream-level C ABI (csrc/streams.hip); raises without
         # the built library or without a GPU - there is no fallback
@@ -265,7 +271,8 @@ class Speech2TextStreaming:
                                            SearchConfig(beam_size=beam_size, ctc_weight=ctc_weight, use_bbd=use_bbd),
                                            max_frames=max_frames, max_tokens=max_tokens,
                                            pcm_capacity=max(1 << 20, 2 * max_chunk_samples),
-                                           max_chunk_samples=max_chunk_samples, strict_reference=strict_reference)
+                                           max_chunk_samples=max_chunk_samples, strict_reference=strict_reference,
+                                           kv_dtype="float16" if half else "float32")
         except EngineError as e:
             raise _abi.ScasrError(str(e)) from e
         self.stream = 0
