@@ -63,7 +63,7 @@ struct DecLayerArgs {
 };
 
 // LDS floats of one workgroup (host and device use the same formula)
-__host__ __device__ static inline int dl_region_floats(int D, int DK, int W, bool self, bool pre) {
+__host__ __device__ static inline int dl_region_floats(int D, int DK, int W, bool self) {
   const int nt = (self ? 3 : 1) * (DK / 16);
   const int xn = 16 * (D + 4);
   const int ps = 4 * 16 * (nt * 16 + 4);
@@ -73,12 +73,12 @@ __host__ __device__ static inline int dl_region_floats(int D, int DK, int W, boo
   r = r > outp ? r : outp;
   return r > attn ? r : attn;
 }
-__host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, bool pre) {
-  return dl_region_floats(D, DK, W, self, pre) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/ +
+__host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self) {
+  return dl_region_floats(D, DK, W, self) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/ +
          2 * D /*LayerNorm gamma | beta*/;
 }
 
-template <int D, int DK, int WM, bool SELF, int UNR, bool PRE, bool FIRST, bool KVH>
+template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
   constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   const int W = sb.W, LCAP = sb.LCAP, H = sb.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *region = smem;
-  float *qs = smem + dl_region_floats(D, DK, W, SELF, PRE);  // [16][DK] queries / sqrt(dk), rows >= W zero
+  float *qs = smem + dl_region_floats(D, DK, W, SELF);  // [16][DK] queries / sqrt(dk), rows >= W zero
   float *kvn = qs + 16 * DK;                                 // SELF: [WM][2*DK] k|v of the new token
   float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
   float *gb = ctx + WM * DK;                                 // [2][D] LayerNorm gamma | beta
@@ -501,14 +501,14 @@ static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  auto lds = [&](int wm, bool pre) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF, pre) * sizeof(float); };
+  auto lds = [&](int wm) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF) * sizeof(float); };
   if (sb.W <= 5) {
-    dec_layer_attn_kernel<D, DK, 5, SELF, 4, false, FIRST, KVH><<<grid, 256, lds(5, false), st>>>(p);
+    dec_layer_attn_kernel<D, DK, 5, SELF, 4, FIRST, KVH><<<grid, 256, lds(5), st>>>(p);
   } else if (sb.W <= 10) {
-    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
-    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(10, false), st>>>(p);
+    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, FIRST, KVH><<<grid, 256, lds(10), st>>>(p);
+    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, FIRST, KVH><<<grid, 256, lds(10), st>>>(p);
   } else {
-    dec_layer_attn_kernel<D, DK, 16, SELF, 2, false, FIRST, KVH><<<grid, 256, lds(16, false), st>>>(p);
+    dec_layer_attn_kernel<D, DK, 16, SELF, 2, FIRST, KVH><<<grid, 256, lds(16), st>>>(p);
   }
   SC_CHECK_LAUNCH();
   return SC_OK;
