@@ -773,8 +773,9 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
       if (live[i]) b->xattn_rows[b->n_rows_step > SC_FUSED_MAX_ROWS ? 0 : 1] += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
     // (speculating at every size measured 2 % SLOWER than not at all: the compaction bucket then follows the active
     // set one iteration late, which costs what the hidden host turnaround saves - so only where the bucket cannot
-    // shrink any more: the tail of the step loop in the smallest bucket)
-    bool spec = b->speculate && b->use_graphs && active.size() >= 2 && (int)active.size() <= b->row_bucket;
+    // shrink much any more: the tail of the step loop (at most 8 streams))
+    bool spec = b->speculate && b->use_graphs && active.size() >= 2 &&
+                (int)active.size() <= std::max(b->row_bucket, std::min(8, S / 4));
     for (int i = 0; i < n && spec; ++i)
       if (live[i] && (pidx[i] + 1 >= b->max_length || L[i] + 2 > b->LCAP)) spec = false;
     if (spec) {   // iteration iter + 1, assuming nothing about iter's outcome
@@ -792,7 +793,7 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
     b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
     {
-      const int bk = std::min(16, b->n_rows_step / std::max(1, b->row_bucket * W));
+      const int bk = std::min(16, (int)((long)b->n_rows_step * 16 / std::max(1, S * W)));
       b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
       b->n_bucket[bk] += 1;
     }
@@ -1246,7 +1247,8 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   (void)hipMemcpy(b->ctrlmap + S * 8, b->rm_host[0], n * sizeof(int32_t), hipMemcpyHostToDevice);
   b->rowmap_key.resize(S);
   for (int s = 0; s < S; ++s) b->rowmap_key[s] = s;
-  b->row_bucket = std::max(1, S / 16);
+  b->row_bucket = std::max(1, S / 32);   // 32 compaction buckets (graphs): 16 -> 32 measured +1 % at 128 streams, 64 nothing more
+  if (const char *rb = sc_hook("SC_ROW_BUCKETS")) b->row_bucket = std::max(1, S / std::max(1, atoi(rb)));   // tools: sweep
   b->n_rows_step = S * W;
   b->st.assign(S, St());
   for (int s = 0; s < S; ++s) init_hyp(b, s);
