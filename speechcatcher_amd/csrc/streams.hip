@@ -145,7 +145,9 @@ struct sc_streams {
   int scan_split_min = 256, scan_split_streams = 48;   // T-parallel CTC scan: frames to walk >=, bucket streams <=
   bool speculate = false;                       // device-side step control: enqueue iteration i+1 before reading the
                                                 // flags of i (opt-in, graphs on only; measured: no gain - DESIGN 4 (q))
-  int graph_key() const { return n_rows_step * 2 + (speculate ? 1 : 0); }
+  bool scan_long = false;                       // this step: a live stream has >= scan_split_min frames to walk
+  int step_split_min() const { return (scan_long && n_rows_step <= scan_split_streams * W) ? scan_split_min : 0; }
+  int graph_key() const { return n_rows_step * 4 + (speculate ? 2 : 0) + (step_split_min() > 0 ? 1 : 0); }
   long spec_launched = 0, spec_wasted = 0;
   bool enc_pending = false;      // the encoder stage of this push has been launched and may still be running
   PendingEnc *pend = nullptr;   // ... has been planned but not launched yet (launched when the decode loop thins out)
@@ -595,8 +597,7 @@ static int step_and_advance(sc_streams *b) {
   b->sb.flags = b->speculate ? b->flags_dev : b->ring_dev;
   // CTC prefix scan split over T while few streams are active (a function of the compaction bucket, so every
   // captured graph has one form): the sequential walk costs 0.15 us per frame whatever the number of streams
-  const int split_min = b->n_rows_step <= b->scan_split_streams * b->W ? b->scan_split_min : 0;
-  RC_TRY(sc_decode_step_ex(&b->sb, split_min, b->stream));
+  RC_TRY(sc_decode_step_ex(&b->sb, b->step_split_min(), b->stream));
   if (!b->speculate) return SC_OK;
   return sc_step_advance(&b->sb, b->use_bbd ? 1 : 0, b->ring_dev, b->stream);
 }
@@ -751,6 +752,9 @@ int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<Stre
     const auto tp0 = std::chrono::steady_clock::now();
     std::sort(active.begin(), active.end());
     set_rowmap(b, active);
+    b->scan_long = false;   // the graph with the T-parallel scan only when a stream's table is long enough for it
+    for (int i = 0; i < n && b->scan_split_min > 0; ++i)
+      if (live[i] && Ttab[i] - std::max(L[i] - 1, 1) >= b->scan_split_min) b->scan_long = true;
     if (!inflight) {
       for (int i = 0; i < n; ++i) {
         int32_t *r = ctrl + todo[i].s * 8;

@@ -20,9 +20,10 @@ def main():
                             f"order by d.start"))
     # a decode step starts with dec_embed (six-launch layers) or with the FIRST variant of the head-parallel
     # self-attention layer kernel (last template argument true)
-    starts = [i for i, r in enumerate(rows)
-              if "dec_embed" in r[0] or ("dec_layer_attn_kernel" in r[0] and "ELb1EEv12DecLayerArgs" in r[0])
-              or ("dec_layer_attn_kernel" in r[0] and r[0].rstrip(">").endswith("true"))]
+    import re
+    # mangled: dec_layer_attn_kernel<D, DK, WM, SELF = true, UNR, FIRST = true, KVH>
+    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01]EEv")
+    starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0] or first.search(r[0])]
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
     seg = rows[a:b]
     busy = sum(r[2] - r[1] for r in seg)
