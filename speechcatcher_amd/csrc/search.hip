@@ -1460,19 +1460,37 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
   const int *asrc = ANC(cur, s);
   int *adst = ANC(o, s);
   bool rep = false;
-  for (int e = tid; e < nout * (L + 1); e += 256) {
-    const int i = e / (L + 1), p = e % (L + 1);
-    const int h = win_h[i], tok = win_tok[i];
-    int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
-    if (p < L) {
-      const int y = YSEQ(cur, s, h)[p];
-      ydst[p] = y;
-      xdst[p] = XPOS(cur, s, h)[p];
-      if (p >= 1 && y == tok && tok != sb.sos && tok != sb.eos) rep = true;
-      adst[(long)p * W + i] = (p < L - 1) ? asrc[(long)p * W + h] : h;
-    } else {
-      ydst[L] = tok;
-      xdst[L] = T - 1;
+  // (source and destination are the two sides of the ping-pong buffers: the loads of a batch of UB elements are all
+  // issued before the first store - one memory round trip per batch instead of one per element)
+  constexpr int UB = 4;
+  const int ntot = nout * (L + 1);
+  for (int e0 = tid; e0 < ntot; e0 += 256 * UB) {
+    int yv[UB], xv[UB], av[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = min(e0 + 256 * u, ntot - 1);
+      const int i = e / (L + 1), p = min(e % (L + 1), L - 1);
+      const int h = win_h[i];
+      yv[u] = YSEQ(cur, s, h)[p];
+      xv[u] = XPOS(cur, s, h)[p];
+      av[u] = asrc[(long)p * W + h];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + 256 * u;
+      if (e >= ntot) break;
+      const int i = e / (L + 1), p = e % (L + 1);
+      const int h = win_h[i], tok = win_tok[i];
+      int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
+      if (p < L) {
+        ydst[p] = yv[u];
+        xdst[p] = xv[u];
+        if (p >= 1 && yv[u] == tok && tok != sb.sos && tok != sb.eos) rep = true;
+        adst[(long)p * W + i] = (p < L - 1) ? av[u] : h;
+      } else {
+        ydst[L] = tok;
+        xdst[L] = T - 1;
+      }
     }
   }
   if (rep) atomicOr(&fl_rep, 1);
