@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
 #pragma unroll
     for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? tid : 0) * W + min(h, nh - 1)];
   }
-  float touch = 0.f;
+  float touch = 0.f, kvtouch = 0.f;
   // (loads return in issue order: the fragments are requested right BEHIND the first batch of partial sums, which
   // the LayerNorm needs first)
   auto prefetch_w = [&]() {
@@ -210,6 +210,19 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
           xv[q] = make_float4(xi.x + (yv[q].x + pb.x), xi.y + (yv[q].y + pb.y), xi.z + (yv[q].z + pb.z),
                               xi.w + (yv[q].w + pb.w));
         }
+      }
+    }
+    if (PF && !SELF) {
+      // warm-up of this head's encoder K|V lines (one element per 128-B K line and V line of every frame): requested
+      // now, behind everything the prologue waits for, they travel from HBM / the Infinity Cache while the LayerNorm
+      // and the q projection run; the attention's operand loads then hit L2.  Consumed at the very end.
+      const long ck0 = ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
+      for (int t = tid; t < T; t += 256) {
+        float e2[1];
+        kv_loadn<1, KVH>(sb.ckv, ck0 + (long)t * 2 * D, e2);
+        kvtouch += e2[0];
+        kv_loadn<1, KVH>(sb.ckv, ck0 + (long)t * 2 * D + D, e2);
+        kvtouch += e2[0];
       }
     }
 #pragma unroll
@@ -489,6 +502,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
           *reinterpret_cast<const float4 *>(Os + w * LDO + 4 * c4);
     }
   }
+  if (kvtouch == 123456.789f) p.ph[0] = kvtouch;   // never true: keeps the K|V warm-up loads
   SC_STAMP(SELF ? 0 : 1, 8);
 }
 SC_PHASE_GETTER(sc_phase_debug_layer)
