@@ -126,10 +126,15 @@ __device__ __forceinline__ void mattn_walk(MAttn<DK> &st, const float *qs, const
     f32x4v s[NT];
     float mloc = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      s[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i) s[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // k-steps outermost: consecutive MFMAs go to different tiles' accumulators (a dependent accumulate waits 40
+    // cycles, the pipe issues every 32)
 #pragma unroll
-      for (int q = 0; q < DPL; ++q) s[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i][q], qb[q], s[i], 0, 0, 0);
+    for (int q = 0; q < DPL; ++q)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) s[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i][q], qb[q], s[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         s[i][j] = ((hm[i][j] >> n) & 1u) ? s[i][j] : -INFINITY;

@@ -46,6 +46,23 @@ __device__ __forceinline__ f32x4 dl_mfma8(f32x4 acc, const float4 &a0, const flo
   return acc;
 }
 
+// the same 8 k-steps for NA independent accumulators, interleaved: consecutive MFMAs never share an accumulator
+// (v_mfma_f32_16x16x4_f32 issues every 32 cycles per SIMD but a dependent accumulate waits 40: with one wave per
+// SIMD - small buckets - eight back-to-back steps on one accumulator run at 80 % of the matrix rate)
+template <int NA>
+__device__ __forceinline__ void dl_mfma8_il(f32x4 (&acc)[NA], const float4 &a0, const float4 &a1, const float4 (&b0)[NA],
+                                            const float4 (&b1)[NA]) {
+  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const float4 &bb = j < 4 ? b0[t] : b1[t];
+      const float bj = (j & 3) == 0 ? bb.x : (j & 3) == 1 ? bb.y : (j & 3) == 2 ? bb.z : bb.w;
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bj, acc[t], 0, 0, 0);
+    }
+}
+
 struct DecLayerArgs {
   sc_search sb;
   int li;
@@ -305,8 +322,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
       float4 n0[NT], n1[NT];
       if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = dl_mfma8(acc[t], a0, a1, b0[t], b1[t]);
+      dl_mfma8_il<NT>(acc, a0, a1, b0, b1);
       if (kq + 1 < KPW) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -488,12 +504,14 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     __syncthreads();
     const float *ab = As + r * LDA + 8 * kk;
     const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+    f32x4 oacc[TW];
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-      f32x4 acc = dl_mfma8(f32x4{0.f, 0.f, 0.f, 0.f}, a0, a1, b0[t], b1[t]);
+    for (int t = 0; t < TW; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dl_mfma8_il<TW>(oacc, a0, a1, b0, b1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = acc[j];
-    }
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = oacc[t][j];
     __syncthreads();
     SC_STAMP(SELF ? 0 : 1, 7);
     for (int e = tid; e < W * (D / 4); e += 256) {
