@@ -176,6 +176,58 @@ def test_step_advance_kernel_applies_the_stop_rules():
                 assert out[s].tolist() == [1, 1 - cur, fin, T, L + 1, min(W, nh * W), 1, tt], (s, f)
 
 
+@pytest.mark.parametrize("seed,bbd,speculate", [(0, False, False), (1, True, False), (2, False, True), (3, True, True)])
+def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate):
+    """Randomised sessions on 16 stream slots (tiny dims): every push feeds a random subset of the streams with chunks
+    of random length (a few hundred samples to 1.5 s), utterances end at random and their slots are reset and reused -
+    block schedules, ragged buckets, final calls, resets and the early `return []` calls interleave in ways no fixture
+    covers.  The C++ engine (optionally with the device-side step control) and the Python engine over the same kernels
+    must end every push with the same hypotheses for every stream."""
+    from speechcatcher_amd.hip_backend import HipBackend
+    from test_engine_spec import make_batch
+    S, beam = 16, 5
+    kw = dict(n_streams=S, max_frames=400, max_tokens=400, pcm_capacity=1 << 17, strict_reference=False)
+    nat = make_batch("TINY", 1234, "meanstd", beam, bbd, backend="native", **kw)
+    nat.set_speculation(speculate)
+    pye = make_batch("TINY", 1234, "meanstd", beam, bbd, backend=HipBackend("cuda:0"), device="cuda:0", **kw)
+    rng = np.random.default_rng(seed)
+    fed = [0] * S            # samples fed to the current utterance of a slot
+    utt = list(range(S))     # audio stream id of the current utterance
+    next_utt = S
+    longest, resets = 0, 0
+    for step in range(40):
+        items = []
+        for s in range(S):
+            if rng.random() < 0.35:
+                continue
+            n = int(rng.choice([300, 700, 1600, 4000, 8192, 10240, 16000, 24000]))
+            audio = synth.synth_audio(utt[s], fed[s] + n)[fed[s]:]
+            fin = bool(rng.random() < 0.12 and fed[s] + n > 12000)
+            items.append((s, audio, fin))
+            fed[s] += n
+        if not items:
+            continue
+        a = nat.push(items, isolate_faults=True)
+        b = pye.push(items, isolate_faults=True)
+        for s, _, fin in items:
+            fa, fb = isinstance(a[s], Exception), isinstance(b[s], Exception)
+            assert fa == fb, (step, s, a[s], b[s])
+            if not fa:
+                assert bool(a[s]) == bool(b[s]), (step, s)
+                ha, hb = nat.hypotheses(s), pye.hypotheses(s)
+                assert [(h["yseq"], h["xpos"]) for h in ha] == [(h["yseq"], h["xpos"]) for h in hb], (step, s)
+                for x, y in zip(ha, hb):
+                    assert abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(y["score"])), (step, s)
+                longest = max([longest] + [len(h["yseq"]) for h in ha])
+            if fin or fa or fed[s] > 90000:
+                nat.reset(s)
+                pye.reset(s)
+                fed[s], utt[s] = 0, next_utt
+                next_utt += 1
+                resets += 1
+    assert longest > 30 and resets >= 5, (longest, resets)   # the sessions did decode and did end
+
+
 def test_native_xl_batch_equals_python_engine():
     """XL dims, 12 streams: the C++ engine and the Python engine (same kernels) end with identical hypotheses."""
     from speechcatcher_amd.hip_backend import HipBackend
