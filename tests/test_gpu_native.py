@@ -176,15 +176,19 @@ def test_step_advance_kernel_applies_the_stop_rules():
                 assert out[s].tolist() == [1, 1 - cur, fin, T, L + 1, min(W, nh * W), 1, tt], (s, f)
 
 
-@pytest.mark.parametrize("seed,bbd,speculate", [(0, False, False), (1, True, False), (2, False, True), (3, True, True)])
-def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate):
+@pytest.mark.parametrize("seed,bbd,speculate,split", [(0, False, False, None), (1, True, False, None), (2, False, True, None),
+                                                      (3, True, True, "32"), (4, False, False, "32")])
+def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate, split, monkeypatch):
     """Randomised sessions on 16 stream slots (tiny dims): every push feeds a random subset of the streams with chunks
     of random length (a few hundred samples to 1.5 s), utterances end at random and their slots are reset and reused -
     block schedules, ragged buckets, final calls, resets and the early `return []` calls interleave in ways no fixture
     covers.  The C++ engine (optionally with the device-side step control) and the Python engine over the same kernels
-    must end every push with the same hypotheses for every stream."""
+    must end every push with the same hypotheses for every stream.  split: the CTC scan of the C++ engine split over T
+    from 32 frames on (the Python engine always walks sequentially)."""
     from speechcatcher_amd.hip_backend import HipBackend
     from test_engine_spec import make_batch
+    if split:
+        monkeypatch.setenv("SC_SCAN_SPLIT_MIN", split)
     S, beam = 16, 5
     kw = dict(n_streams=S, max_frames=400, max_tokens=400, pcm_capacity=1 << 17, strict_reference=False)
     nat = make_batch("TINY", 1234, "meanstd", beam, bbd, backend="native", **kw)
