@@ -6,18 +6,29 @@ Conv2d subsampling, contextual-block encoder, blockwise-synchronous beam search 
 EVERY stream of the batch (S streams per GPU, default 128 = BASELINE.json configs[2]; `--streams 1` gives
 configs[1]), run to completion inside the step: every stream's result is available when its call returns, exactly
 like the reference's per-call semantics (STRICT lock-step).  The step runs on the C++ engine behind the stream-level
-C ABI (sc_push; csrc/streams.hip) - the product path of Speech2TextStreaming and of the scheduler.
-Weights: de_streaming_transformer_xl dimensions, seeded synthetic (no checkpoints offline); audio: seeded Gaussian
-noise, already resident in HBM when the timed region starts.
+C ABI (sc_push + sc_get_hyps_batch; csrc/streams.hip) - the product path of Speech2TextStreaming and of the scheduler.
 
-    python bench.py --gpus 1 --steps 20 --warmup 6
+The timed region contains the BOUNDARY the reference's step has (speech2text_streaming.py:402-539): every step takes
+its 128 chunks from HOST memory (pinned staging, one H2D copy) and hands the best hypothesis of every stream (token
+ids + encoder-frame positions + scores) back to the host (one pack launch + one D2H copy).  The same window with the
+audio resident in HBM and no read-back is reported under `resident_no_readback`.
+
+Window: the streams are first rolled (untimed) to the MIDDLE of SURVEY 8(d)'s 60 s utterance - `--preroll` 21 steps
+in front of the warm-up, so that with the driver's `--warmup 5 --steps 20` the timed steps are hops 27-46 of every
+stream (T = 430..740 encoder frames, 200..350 tokens per hypothesis) instead of its cheap beginning.
+
+Weights: de_streaming_transformer_xl dimensions, seeded synthetic (no checkpoints offline); audio: seeded Gaussian
+noise.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
 Prints ONE JSON line (rank 0).  value = whole-job audio-seconds processed per wall-clock second = number of
-concurrent real-time streams the job sustains.  Extra keys: `deferred` (the opt-in deferred-stragglers mode of the
-Python engine: results of some streams one chunk period late - NOT the headline), `roofline`, `cpu_baseline`,
-`single_stream`, `whole_step`.
+concurrent real-time streams the job sustains.  Extra keys: `served` (continuous batching through sc_submit / sc_poll:
+the same chunks, the same per-call results, every stream gets its next chunk as soon as its previous reply has been
+delivered), `resident_no_readback`, `long_context` (T ~ 1000 and T ~ 4500 encoder frames), `roofline`,
+`cpu_baseline`, `single_stream`, `whole_step`.
 """
 import argparse
 import ctypes as C
@@ -26,6 +37,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,8 +56,10 @@ GFLOP_PER_DECODE_STEP = 0.437  # at beam 10
 
 
 def capacities(n_steps_total):
+    """encoder frames / tokens per hypothesis a window of n steps can reach (the reference stops extending a
+    hypothesis at process_idx 500: beam_search.py:701, so 520 tokens always suffice)"""
     hops = (n_steps_total + 2) * CHUNK / 10240.0       # encoder hops (16 frames each) in the window
-    return int(16 * hops) + 64, min(2048, int(14 * hops) + 32)
+    return int(16 * hops) + 64, min(520, int(14 * hops) + 32)
 
 
 FFN_DTYPE = "float32"  # --ffn-dtype float16: fp16 feed-forward weights + fp16 MFMA inputs (configs[4]), never the default
@@ -67,50 +81,111 @@ def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None):
                              engine=engine, kv_dtype=KV_DTYPE)
 
 
-def build_python_engine(w, n_streams, beam, bbd, n_steps_total, device):
-    from speechcatcher_amd.engine import StreamBatch
-    from speechcatcher_amd.hip_backend import HipBackend
-    frames, tokens = capacities(n_steps_total)
-    return StreamBatch(w, HipBackend(device), n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
-                       max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
-                       kv_dtype=KV_DTYPE)
+def make_audio(n_streams, n_steps, stream_offset=0, shared=False):
+    """[n_streams][n_steps * CHUNK] float32.  Per-stream seeded noise; shared=True: windows of ONE long
+    seeded noise buffer at per-stream offsets (long-context runs: 128 x 180 s of torch.randn would take minutes)."""
+    n = CHUNK * n_steps
+    if not shared:
+        return np.stack([synth.synth_audio(stream_offset + s, n) for s in range(n_streams)])
+    base = synth.synth_audio(stream_offset, n + 7919 * n_streams)
+    return np.stack([base[7919 * s:7919 * s + n] for s in range(n_streams)])
 
 
-def preload_audio(sb, n_steps_total, stream_offset=0):
-    """Synthetic audio for every stream, resident in HBM before timing."""
-    n = CHUNK * n_steps_total
+def preload_audio(sb, audio, upto_step):
+    """the first `upto_step` chunks of every stream -> the device PCM ring (for the untimed pre-roll / resident mode)"""
     for s in range(sb.S):
-        a = synth.synth_audio(stream_offset + s, n)
-        if hasattr(sb, "write_pcm"):
-            sb.write_pcm(s, 0, a)
-        else:
-            sb.pcm[s, :n].copy_(torch.from_numpy(a))
+        sb.write_pcm(s, 0, audio[s, :upto_step * CHUNK])
     torch.cuda.synchronize()
 
 
-def run_steps(sb, n):
+def run_resident(sb, n):
     items = [(s, CHUNK, False) for s in range(sb.S)]
     for _ in range(n):
         sb.push(items, pcm_resident=True)
 
 
-def timed(sb, warmup, steps, dist=None):
-    run_steps(sb, warmup)
-    sb.flush()
+def step_blocks(audio, k0, k1):
+    """contiguous [S][CHUNK] host blocks of steps k0..k1-1 (what a transport hands the engine every 640 ms)"""
+    return [np.ascontiguousarray(audio[:, k * CHUNK:(k + 1) * CHUNK]) for k in range(k0, k1)]
+
+
+def run_host(sb, blocks, ids):
+    """the served chunk step: host PCM in (pinned staging + one H2D inside sc_push), best hypothesis of every stream
+    out (ids + positions + scores; one pack launch + one D2H inside sc_get_hyps_batch)"""
+    out = None
+    for blk in blocks:
+        st = sb.push_block(ids, blk)
+        assert (st >= 0).all()
+        out = sb.hypotheses_arrays(ids, nbest=1)
+    return out
+
+
+def n_dec_steps(sb):
+    return sum(st.n_steps_total for st in sb.st)
+
+
+def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None):
+    """roll `preroll + warmup` steps untimed (resident audio), then time `steps` steps in `mode`"""
+    ids = np.arange(sb.S, dtype=np.int32)
+    k0 = preroll + warmup
+    preload_audio(sb, audio, k0 + (steps if mode == "resident" else 0))
+    run_resident(sb, preroll)
+    if mode == "host":      # warm-up in the timed mode (staging buffers, pack kernel, graphs of the window's buckets)
+        run_host(sb, step_blocks(audio, preroll, k0), ids)
+    else:
+        run_resident(sb, warmup)
+    blocks = step_blocks(audio, k0, k0 + steps) if mode == "host" else None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    steps0 = sum(st.n_steps_total for st in sb.st)
+    steps0 = n_dec_steps(sb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(sb, steps)
-    sb.flush()                      # (deferred mode: pending blocks of the last steps belong to the timed work)
+    if mode == "host":
+        last = run_host(sb, blocks, ids)
+    else:
+        run_resident(sb, steps)
+        last = None
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    dec_steps = (sum(st.n_steps_total for st in sb.st) - steps0) / float(sb.S)
-    return elapsed, dec_steps / max(steps, 1)
+    dec_steps = (n_dec_steps(sb) - steps0) / float(sb.S)
+    return elapsed, dec_steps / max(steps, 1), last
+
+
+def served_window(sb, audio, preroll, warmup, steps, group):
+    """Continuous batching over the same window: after the lock-step pre-roll every stream is served on its own -
+    sc_submit its chunk, sc_poll until replies are ready, read the best hypothesis of the streams that answered
+    (sc_get_hyps_batch), submit THEIR next chunks.  Host PCM in, hypotheses out, as in run_host."""
+    S = sb.S
+    ids = np.arange(S, dtype=np.int32)
+    k0 = preroll + warmup
+    preload_audio(sb, audio, preroll)
+    run_resident(sb, preroll)
+    run_host(sb, step_blocks(audio, preroll, k0), ids)
+    a3 = audio.reshape(S, -1, CHUNK)
+    nxt = np.full(S, k0, np.int64)
+    end = k0 + steps
+    torch.cuda.synchronize()
+    steps0 = n_dec_steps(sb)
+    iters0 = sb.stats["dec_steps"]
+    t0 = time.perf_counter()
+    sb.submit_block(ids, np.ascontiguousarray(a3[:, k0]))
+    nxt += 1
+    n_polls = 0
+    while sb.outstanding:
+        done, st = sb.poll_ids(min(group, sb.outstanding))
+        assert (st >= 0).all()
+        n_polls += 1
+        sb.hypotheses_arrays(done, nbest=1)
+        again = done[nxt[done] < end]
+        if len(again):
+            sb.submit_block(again, a3[again, nxt[again]])
+            nxt[again] += 1
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, (n_dec_steps(sb) - steps0) / float(S) / steps, (sb.stats["dec_steps"] - iters0) / steps, n_polls / steps
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -161,14 +236,43 @@ def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
             "host_cores": ncpu, "torch": torch.__version__, "legs": legs,
             "streams_per_node_on_cpu": {"value": legs[2]["audio_s_per_s"], "processes": legs[2]["processes"],
                                         "note": "N independent single-thread processes (the reference's concurrency "
-                                                "model), aggregate audio-seconds per second"}}
+                                                "model), aggregate audio-seconds per second; each process completes only "
+                                                "12-15 steps in its 10 s budget: +-10 %"}}
+
+
+def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
+    """strict and served throughput with every stream `target_T` encoder frames into its utterance"""
+    hops = max(2, (target_T - 24) // 16 + 2)
+    preroll, warm = hops - 2, 2
+    total = preroll + warm + steps
+    audio = make_audio(streams, total, stream_offset=7000, shared=True)
+    out = {"bbd": int(bbd), "steps": steps, "audio": "windows of one seeded noise buffer at per-stream offsets"}
+    sb = build_native(w, streams, beam, bbd, total)
+    e, dsh, last = timed_window(sb, audio, preroll, warm, steps, "host")
+    T = [st.T_enc for st in sb.st]
+    out.update({"value": round(streams * steps * CHUNK / 16000.0 / e, 2), "unit": "audio_s/s",
+                "ms_per_step": round(e / steps * 1e3, 3), "decode_steps_per_hop": round(dsh, 2),
+                "encoder_frames_T": [min(T), max(T)], "tokens_L": [int(last["lens"].min()), int(last["lens"].max())],
+                "process_idx": [min(st.process_idx for st in sb.st), max(st.process_idx for st in sb.st)]})
+    sb.close()
+    del sb
+    sb = build_native(w, streams, beam, bbd, total)
+    e, dsh, iters, polls = served_window(sb, audio, preroll, warm, steps, group)
+    out["served"] = {"value": round(streams * steps * CHUNK / 16000.0 / e, 2), "ms_per_step_equivalent": round(e / steps * 1e3, 3),
+                     "decode_iterations_per_step": round(iters, 2)}
+    sb.close()
+    del sb, audio
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preroll", type=int, default=21,
+                    help="untimed chunk steps in front of the warm-up: the timed window then sits in the middle of SURVEY "
+                         "8(d)'s 60 s utterance (hops 27-46 with --warmup 5 --steps 20) instead of at its cheap beginning")
     ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
@@ -176,15 +280,13 @@ def main():
                     help="samples per chunk step (10240 = 640 ms = one encoder hop; also 8192 = CLI default, 25600 = block size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
-    ap.add_argument("--no-deferred", action="store_true", help="skip the extra deferred-stragglers measurement")
+    ap.add_argument("--no-served", action="store_true", help="skip the continuous-batching (sc_submit / sc_poll) leg")
+    ap.add_argument("--no-resident", action="store_true", help="skip the resident-audio / no-read-back leg")
+    ap.add_argument("--no-long-context", action="store_true", help="skip the T ~ 1000 / T ~ 4500 legs")
+    ap.add_argument("--served-group", type=int, default=0,
+                    help="sc_poll returns when at least this many replies are ready (0: streams / 8)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the hot kernels")
-    ap.add_argument("--engine", choices=["native", "python"], default="native",
-                    help="native: C++ engine behind sc_push (product path); python: engine.StreamBatch over the same kernels")
-    ap.add_argument("--defer", type=int, default=-1,
-                    help="threshold of the EXTRA deferred-stragglers run (Python engine): end a chunk step's decode loop "
-                         "when at most this many streams are still inside their block; -1: 3/8 of the streams")
-    ap.add_argument("--defer-lag", type=int, default=1)
     ap.add_argument("--kv-dtype", choices=["float32", "float16"], default="float32",
                     help="float16: self-/cross-attention K|V caches stored in fp16, arithmetic fp32 (opt-in; results "
                          "differ from the fp32 reference within the tolerance stated in tests/test_gpu_native.py)")
@@ -196,6 +298,7 @@ def main():
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
     FFN_DTYPE = args.ffn_dtype
+    group = args.served_group or max(1, args.streams // 8)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -218,17 +321,15 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
-    total_steps = args.warmup + args.steps + args.roofline_steps
+    window = args.preroll + args.warmup + args.steps
+    total_steps = window + args.roofline_steps
     w = make_weights(device)
-    if args.engine == "native":
-        sb = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
-        lib = sb.lib
-    else:
-        sb = build_python_engine(w, args.streams, args.beam, bool(args.bbd), total_steps, device)
-        sb.set_defer_threshold(0)
-        lib = sb.be.lib
-    preload_audio(sb, total_steps, stream_offset=rank * args.streams)
-    elapsed, dec_steps_per_hop = timed(sb, args.warmup, args.steps, dist)
+    sb = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
+    lib = sb.lib
+    audio = make_audio(args.streams, total_steps, stream_offset=rank * args.streams)
+    elapsed, dec_steps_per_hop, last = timed_window(sb, audio, args.preroll, args.warmup, args.steps, "host", dist)
+    T_now = [st.T_enc for st in sb.st]
+    L_now = [int(last["lens"].min()), int(last["lens"].max())]
 
     # Roofline leg: the SAME workload continues for a few more steps with hipGraph replay switched off, so that
     # every launch of the hot kernels can be bracketed by HIP events on its launch stream.
@@ -237,40 +338,33 @@ def main():
     nn = (C.c_longlong * NK)()
     ev_over_ms, xattn_bytes = 0.0, {}
     if args.roofline_steps > 0:
-        if args.engine == "native":
-            sb.set_graphs(False)
-            sb.take_xattn_rows()
-        else:
-            sb.be.use_graphs = False
-            sb.stats["xattn_rows"] = 0
+        sb.set_graphs(False)
+        sb.take_xattn_rows()
         lib.sc_prof_enable(1)
-        run_steps(sb, args.roofline_steps)
+        run_host(sb, step_blocks(audio, window, total_steps), np.arange(sb.S, dtype=np.int32))
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
-        if args.engine == "native":
-            sb.set_graphs(True)
-            rows = sb.take_xattn_rows_by_kernel()
-            ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.hip_stream))
-        else:
-            sb.be.use_graphs = True
-            tot = sb.stats.get("xattn_rows", 0)
-            rows = (tot, 0) if nn[7] else (0, tot)   # the Python engine counts one total (one kernel family per run)
-            ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.stream.cuda_stream))
+        sb.set_graphs(True)
+        rows = sb.take_xattn_rows_by_kernel()
+        ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.hip_stream))
         # cross-attention: K|V rows of every active stream are read once per layer and step
-        xattn_bytes = {7: float(rows[0]) * 2 * XL.d_model * 4, 11: float(rows[1]) * 2 * XL.d_model * 4}
+        esz = 2 if KV_DTYPE == "float16" else 4
+        xattn_bytes = {7: float(rows[0]) * 2 * XL.d_model * esz, 11: float(rows[1]) * 2 * XL.d_model * esz}
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the path's single collective: gather of final token ids
+        # the path's single collective: gather of the final text (token ids + positions + length + score)
         from speechcatcher_amd.distributed import gather_final_hypotheses, pack_hypotheses
-        hy = [sb.hypotheses(s) for s in range(args.streams)]
-        ids, sc = pack_hypotheses([h[0]["yseq"] if h else [] for h in hy],
-                                  [h[0]["score"] if h else 0.0 for h in hy], 256, coll_device)
-        gathered = gather_final_hypotheses(ids, sc, args.streams)
-        assert len(gathered) == world
+        a = sb.hypotheses_arrays(list(range(args.streams)), nbest=1)
+        n1 = a["lens"][:, 0]
+        payload = pack_hypotheses([a["ids"][i, 0, :n1[i]] for i in range(args.streams)],
+                                  [a["xpos"][i, 0, :n1[i]] for i in range(args.streams)],
+                                  a["score"][:, 0], 520, coll_device)
+        gathered = gather_final_hypotheses(payload, args.streams)
+        assert len(gathered) == world and len(gathered[0]) == args.streams
 
     if rank != 0:
         if dist is not None:
@@ -338,35 +432,60 @@ def main():
     whole = {"algorithmic_gflop_per_step": round(gflop_step, 1),
              "achieved_tflops_whole_step": round(gflop_step / ms_step, 2),
              "frac_of_f32_mfma_peak": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 4),
-             "note": "128 x (3.83 + 0.437 x decode steps per hop) GFLOP per chunk step (SURVEY 8(d)) / ms_per_step; the step "
-                     "is latency-bound by ~50 dependent launches per decode iteration, not by FLOPs"}
+             "note": f"{args.streams} x (3.83 + 0.437 x decode steps per hop) GFLOP per chunk step (SURVEY 8(d)) / ms_per_step; "
+                     "attention and the CTC scan over the prefix are not in this FLOP count"}
+    sb.close()
+    del sb
 
-    deferred = None
-    if not args.no_deferred and world == 1:
-        # the opt-in deferred-stragglers mode (Python engine): identical per-stream results, but up to `threshold`
-        # streams get theirs one chunk period late.  Reported for information, never as `value`.
-        thr = (3 * args.streams) // 8 if args.defer < 0 else args.defer
-        if thr > 0:
-            del sb
-            sbd = build_python_engine(w, args.streams, args.beam, bool(args.bbd), args.warmup + args.steps, device)
-            preload_audio(sbd, args.warmup + args.steps)
-            sbd.set_defer_threshold(thr, args.defer_lag)
-            e2, _ = timed(sbd, args.warmup, args.steps)
-            deferred = {"value": round(args.streams * args.steps * CHUNK / 16000.0 / e2, 2), "unit": "audio_s/s",
-                        "ms_per_step": round(e2 / args.steps * 1e3, 3), "threshold_streams": thr,
-                        "max_lag_blocks": args.defer_lag, "engine": "python (engine.StreamBatch)",
-                        "note": "NOT the headline: results of up to `threshold_streams` streams arrive one chunk period late"}
-            del sbd
+    resident = None
+    if not args.no_resident and world == 1:
+        sbr = build_native(w, args.streams, args.beam, bool(args.bbd), window)
+        e2, _, _ = timed_window(sbr, audio, args.preroll, args.warmup, args.steps, "resident")
+        v2 = args.streams * args.steps * CHUNK / 16000.0 / e2
+        resident = {"value": round(v2, 2), "unit": "audio_s/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                    "headline_over_this": round(value / v2, 4),
+                    "note": "same window, audio resident in HBM (sc_push with NULL pcm), no hypothesis read-back"}
+        sbr.close()
+        del sbr
+
+    served = None
+    if not args.no_served and world == 1:
+        sbs = build_native(w, args.streams, args.beam, bool(args.bbd), window)
+        e3, dsh3, iters3, polls3 = served_window(sbs, audio, args.preroll, args.warmup, args.steps, group)
+        v3 = args.streams * args.steps * CHUNK / 16000.0 / e3
+        served = {"value": round(v3, 2), "unit": "audio_s/s", "over_strict": round(v3 / value, 4),
+                  "ms_per_step_equivalent": round(e3 / args.steps * 1e3, 3), "poll_min_done": group,
+                  "decode_steps_per_hop": round(dsh3, 2), "decode_iterations_per_step": round(iters3, 2),
+                  "polls_per_step": round(polls3, 2),
+                  "note": "continuous batching (sc_submit / sc_poll), same window and chunks, host PCM in and best hypothesis "
+                          "out per reply: a stream's reply is delivered when ITS blocks are done and its next chunk is "
+                          "admitted at once (the reference server's session loop, speechcatcher_server.py:359-397); per-call "
+                          "results are those of the strict run; includes the drain of the last stragglers"}
+        sbs.close()
+        del sbs
 
     single = None
     if not args.no_single_stream and world == 1:
-        sb1 = build_native(w, 1, args.beam, bool(args.bbd), args.warmup + args.steps)
-        preload_audio(sb1, args.warmup + args.steps)
-        e1, _ = timed(sb1, args.warmup, args.steps)
+        sb1 = build_native(w, 1, args.beam, bool(args.bbd), window)
+        e1, _, _ = timed_window(sb1, audio[:1], args.preroll, args.warmup, args.steps, "host")
         hop_s = CHUNK / 16000.0
         single = {"ms_per_hop": round(e1 / args.steps * 1e3, 3), "rtf": round(e1 / (args.steps * hop_s), 5),
                   "x_realtime": round(args.steps * hop_s / e1, 1)}
+        sb1.close()
         del sb1
+    del audio
+
+    long_ctx = None
+    if not args.no_long_context and world == 1 and CHUNK == 10240:
+        long_ctx = {}
+        try:
+            long_ctx["T1000"] = long_context_leg(w, args.streams, args.beam, 1000, False, 8, group)
+            long_ctx["T4500"] = long_context_leg(w, args.streams, args.beam, 4500, True, 6, group)
+            long_ctx["note"] = ("T1000: search without block-boundary detection like the headline (hypotheses near the "
+                                "reference's 500-step bound); T4500 = a 180 s CLI segment, with block-boundary detection "
+                                "(the reference CLI's default): without it every stream has hit the 500-step bound by then")
+        except Exception as e:  # noqa: BLE001
+            long_ctx["error"] = repr(e)
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -375,6 +494,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
 
+    k0 = args.preroll + args.warmup
     out = {
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -386,14 +506,20 @@ def main():
                                                           if FFN_DTYPE != "float32" else "")) if x)),
         "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
-                               f"(batched encoder + batched beam), beam {args.beam}, chunk 10240 samples, bbd {args.bbd}",
+                               f"(batched encoder + batched beam), beam {args.beam}, chunk {CHUNK} samples, bbd {args.bbd}",
                    "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
                    "semantics": "strict lock-step: every block completes inside its chunk step (the reference's per-call results)",
-                   "engine": "C++ (sc_push, csrc/streams.hip)" if args.engine == "native" else "python (engine.StreamBatch)",
+                   "boundary": "inside the timed region: host PCM chunks in (pinned staging, one H2D per step), best "
+                               "hypothesis of every stream out (token ids + positions + scores, one D2H per step)",
+                   "window": f"chunk steps {k0}..{k0 + args.steps - 1} of every stream ({args.preroll} pre-roll + {args.warmup} warm-up "
+                             f"steps untimed): T = {min(T_now)}..{max(T_now)} encoder frames and {L_now[0]}..{L_now[1]} tokens per "
+                             "hypothesis at the end of the window",
+                   "engine": "C++ (sc_push + sc_get_hyps_batch, csrc/streams.hip)",
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
         "chunk_steps_per_s": round(world * args.streams * args.steps / elapsed, 2),
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
-        "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "deferred": deferred,
+        "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
+        "resident_no_readback": resident, "served": served, "long_context": long_ctx,
     }
     print(json.dumps(out))
     if dist is not None:

@@ -478,28 +478,46 @@ void sc_engine_destroy(sc_engine *engine);
 
 int sc_streams_create(sc_engine *engine, const sc_stream_options *options, sc_streams **out);
 void sc_streams_destroy(sc_streams *streams);
-/* One chunk step for n streams: stream_ids[i] gets n_samples[i] float samples in +-1 from pcm[i] (HOST; NULL =
- * already resident in the device PCM buffer, see sc_streams_pcm) with is_final[i].  Runs frontend -> encoder ->
+/* One chunk step for n streams: stream_ids[i] (each stream at most once per call) gets n_samples[i] float samples
+ * in +-1 from pcm[i] (HOST; NULL = already resident in the device PCM buffer, see sc_streams_pcm) with is_final[i].
+ * The host chunks are staged in pinned memory and reach the device with ONE copy.  Runs frontend -> encoder ->
  * every decode block that became ready (run to completion).  status[i] (HOST out, may be NULL): 1 output, 0 the
- * reference's early `return []`, SC_ERR_CAPACITY / SC_ERR_INPUT: this stream failed and was reset, the others
- * are unaffected. */
+ * reference's early `return []`, SC_ERR_CAPACITY / SC_ERR_INPUT: this stream failed and was reset (message:
+ * sc_stream_last_error), the others are unaffected. */
 int sc_push(sc_streams *streams, const int *stream_ids, const float *const *pcm, const int *n_samples,
             const uint8_t *is_final, int n, int *status);
 /* the same for 2-D (T, n_mels) already-normalised feature matrices (speech2text_streaming.py:438-449) */
 int sc_push_features(sc_streams *streams, const int *stream_ids, const float *const *feats, const int *n_frames,
                      const uint8_t *is_final, int n, int *status);
+/* Continuous batching - the reference server's concurrency unit is an independent stream that is called, answers,
+ * and is called again (recognize_ws / process_audio_chunk, speechcatcher_server.py:205-296,359-397), not a batch in
+ * lock-step.  sc_submit hands the engine ONE chunk for each listed stream (copied; a stream has at most one chunk
+ * outstanding) and returns at once: the chunks are planned and their frontend + encoder stage is issued as one group
+ * on the encoder HIP stream.  sc_poll runs the decode side - one beam-search step per tick for EVERY stream that is
+ * inside a block, whichever call it belongs to - until at least min_done outstanding chunks are complete (or none is
+ * outstanding) and reports up to max_done of them: done_ids[i] = stream, status[i] as in sc_push.  Returns the
+ * number reported, < 0 on error.  A stream's reply is ready when ITS blocks are done; streams that finish early
+ * get their next chunk while the stragglers of the previous one are still decoding.  Per stream the blocks, steps
+ * and results are those of sc_push.  sc_push may be mixed in: it also advances the submitted streams. */
+int sc_submit(sc_streams *streams, const int *stream_ids, const float *const *pcm, const int *n_samples,
+              const uint8_t *is_final, int n);
+int sc_poll(sc_streams *streams, int min_done, int max_done, int *done_ids /*HOST out*/, int *status /*HOST out, may be NULL*/);
+int sc_streams_outstanding(const sc_streams *streams);
+/* message of the stream's last failure (status < 0 from sc_push / sc_poll); "" if it never failed */
+const char *sc_stream_last_error(const sc_streams *streams, int stream);
 /* live hypotheses, best first (BeamState.hypotheses: yseq, xpos, score, scores{decoder, ctc}; hypothesis.py).
  * Returns how many were written (<= nbest) or a negative code. */
 int sc_get_hyps(sc_streams *streams, int stream, int nbest, int max_len, int32_t *ids, int32_t *xpos, int *lens,
                 double *scores, double *score_dec, double *score_ctc);
-/* Speech2TextStreaming.reset (speech2text_streaming.py:252-263) */
+/* ... of n streams at once - what a batch of Speech2TextStreaming.__call__s hands back (speech2text_streaming.py:
+ * 466-539): ONE pack launch and ONE device-to-host copy into pinned memory.  ids / xpos [n][nbest][max_len],
+ * lens / scores / score_dec / score_ctc [n][nbest], n_hyps [n]; any output but n_hyps may be NULL. */
+int sc_get_hyps_batch(sc_streams *streams, const int *stream_ids, int n, int nbest, int max_len, int32_t *ids,
+                      int32_t *xpos, int *lens, int *n_hyps, double *scores, double *score_dec, double *score_ctc);
+/* Speech2TextStreaming.reset (speech2text_streaming.py:252-263); not while the stream has a chunk outstanding */
 int sc_reset(sc_streams *streams, int stream);
 int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
 int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
-/* device-side step control (sc_step_advance): decode iterations enqueued before the host had read their predecessor's
- * stop flags, and how many of those ran with every stream already stopped; on/off (default on; results identical) */
-int sc_streams_speculation(const sc_streams *streams, long *launched, long *wasted);
-int sc_streams_set_speculation(sc_streams *streams, int on);
 /* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
  * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
 int sc_streams_set_graphs(sc_streams *streams, int on);

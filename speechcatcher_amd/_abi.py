@@ -159,14 +159,18 @@ _SIGS = {
     "sc_push_features": (C.c_int, [vp, c_int_p, C.POINTER(vp), c_int_p, C.POINTER(C.c_uint8), C.c_int, c_int_p]),
     "sc_get_hyps": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p,
                               c_double_p]),
+    "sc_get_hyps_batch": (C.c_int, [vp, c_int_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p,
+                                    c_double_p, c_double_p, c_double_p]),
+    "sc_submit": (C.c_int, [vp, c_int_p, C.POINTER(vp), c_int_p, C.POINTER(C.c_uint8), C.c_int]),
+    "sc_poll": (C.c_int, [vp, C.c_int, C.c_int, c_int_p, c_int_p]),
+    "sc_streams_outstanding": (C.c_int, [vp]),
+    "sc_stream_last_error": (C.c_char_p, [vp, C.c_int]),
     "sc_reset": (C.c_int, [vp, C.c_int]),
     "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
-    "sc_streams_speculation": (C.c_int, [vp, vp, vp]),
-    "sc_streams_set_speculation": (C.c_int, [vp, C.c_int]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_take_xattn_rows_by_kernel": (C.c_int, [vp, vp]),
     "sc_streams_hip_stream": (vp, [vp]),

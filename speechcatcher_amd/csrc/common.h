@@ -41,6 +41,9 @@ struct ProfScope { bool on; hipEvent_t a, b; hipStream_t st; };
 ProfScope sc_prof_begin(hipStream_t st);
 void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 
+// search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel, 2 cluster)
+int sc_decode_step_form(const sc_search *sb);
+
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,

@@ -1606,6 +1606,10 @@ extern "C" int sc_step_advance(const sc_search *sbp, int use_bbd, int32_t *ring,
   return SC_OK;
 }
 
+// which form of the decoder layers sc_decode_step runs for this bucket: 0 six launches per layer, 1 head-parallel
+// (3 launches), 2 persistent cluster (streams.hip accounts the cross-attention's K|V traffic by kernel family)
+int sc_decode_step_form(const sc_search *sbp) { return dec_cluster_ok(*sbp) ? 2 : dec_fused_ok(*sbp) ? 1 : 0; }
+
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) { return sc_decode_step_ex(sbp, 0, stream); }
 
 extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void *stream) {

@@ -1,6 +1,6 @@
-// Stream-level C ABI of libscasr (include/scasr.h: sc_engine_* / sc_streams_* / sc_push / sc_get_hyps /
-// sc_reset): the host state machine that turns the kernel-level entry points into a streaming decoder,
-// in C++ - no Python in the loop.  It is the host half of the reference's
+// Stream-level C ABI of libscasr (include/scasr.h: sc_engine_* / sc_streams_* / sc_push / sc_submit / sc_poll /
+// sc_get_hyps(_batch) / sc_reset): the host state machine that turns the kernel-level entry points into a
+// streaming decoder, in C++ - no Python in the loop.  It is the host half of the reference's
 //   Speech2TextStreaming.__call__ / apply_frontend      speechcatcher/speech2text_streaming.py:278-539
 //   ContextualBlockTransformerEncoder.forward_infer     speechcatcher/model/encoder/contextual_block_transformer_encoder.py:241-419
 //   BlockwiseSynchronousBeamSearch.process_block / _decode_one_block / reset
@@ -8,17 +8,31 @@
 // for S streams at once: pure integer bookkeeping (the three nested carry-over buffers of SURVEY.md
 // Appendix D, the block schedule, the step loop with its stop flags, rollback and rewind) that decides
 // WHAT to launch; all arithmetic runs in the HIP kernels.  speechcatcher_amd/engine.py is the same logic in
-// Python (it also runs on the CPU spec backend, which is how the logic is checked against the reference
+// Python (it runs on the CPU spec backend, which is how the logic is checked against the reference
 // fixtures without a GPU); tests/test_gpu_native.py holds both to the same fixtures.
 //
-// Run-to-completion only (every block finishes inside its push: the reference's per-call semantics).
+// One engine, two ways to drive it.  The decode side is a TICK engine over per-stream state: every stream owns a
+// queue of ready decode blocks and the state of the block it is in; one tick starts the blocks that are ready,
+// runs ONE beam-search step for every stream that is inside a block, reads the stop flags and does the
+// accept / rollback / rewind bookkeeping per stream.  The encoder side is a sequence of admission GROUPS
+// (frontend + encoder + CTC / cross-attention K|V projections of the chunks admitted together), each on the
+// encoder HIP stream with an event; a block that sees frames of a group waits for that group only.
+//   sc_push            = admit the listed chunks as one group, tick until every one of them is complete (the
+//                        reference's per-call semantics: strict lock-step of the batch);
+//   sc_submit/sc_poll  = continuous batching: chunks are admitted whenever the host has them, a stream's reply is
+//                        ready when ITS blocks are done, streams that finished early start their next chunk while the
+//                        stragglers of the previous one are still decoding (the reference's concurrency unit is an
+//                        independent stream: speechcatcher_server.py:331-371).
+// Per stream both give the same blocks, the same steps, the same results.
 #include <algorithm>
 #include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -94,7 +108,29 @@ struct St {
   int cur = 0, L = 1, nhyp = 1;
   bool has_ctc = false;
   int T_ctc = 0, T_kv = 0, output_index = 0;
+  // encoder frames whose CTC rows / cross-attention K|V rows have been projected (by the encoder stage that
+  // emitted them); after a strict reset() T_proj restarts at the stale table's extent (scorers.py:342-350)
+  int T_proj = 0, T_projkv = 0;
   long n_steps_total = 0;
+};
+
+// a decode block of the schedule (beam_search.py:590-634): the T frames [0, T) it presents to the scorers, whether
+// it is the final block, and the encoder group whose frames it sees (0: only frames that were there before)
+struct Blk { int T; bool fin; long gen; };
+
+// the block a stream is inside (the loop state of _decode_one_block, beam_search.py:655-838)
+struct Run {
+  bool inblk = false, live = false, took = false, pvalid = false, has = false, hasp = false, fin = false;
+  int cur = 0, L = 1, nhyp = 1, nhp = 1, pidx = 0, T = 0, Tc = 0, out = 0;
+  long nsteps = 0;
+};
+
+// a stream's outstanding chunk (sc_push / sc_submit): open until it has been reported
+struct Job {
+  bool open = false;
+  int has_out = 0;   // 1: the call produced output, 0: the reference's early `return []`
+  int fault = 0;     // SC_ERR_*: the chunk failed, the stream is reset when it is reported
+  long gen = 0;      // encoder group that carries the chunk's frontend / encoder stage (0: nothing was launched)
 };
 
 template <typename T>
@@ -115,13 +151,27 @@ struct EncPlan {
   int n_conv = 0, max_t1 = 0;
 };
 
-// frontend + encoder launches of one push, planned (host state already advanced) but not yet issued
-struct PendingEnc {
-  bool valid = false;
+// One admission group: the frontend + encoder launches of the chunks admitted together, planned (host state already
+// advanced) and issued on the encoder stream either at once (sc_submit) or when the decode loop has thinned out
+// (sc_push).  `ev` completes when the group's encoder output, CTC rows and cross-attention K|V rows are in place.
+struct EncGroup {
+  long gen = 0;
+  bool launched = false, features = false;
+  int slot = 0;                              // job-table arena slot
+  int stage_slot = -1;                       // pinned staging slot holding the group's host input (-1: none)
+  std::vector<long long> copy_jobs;          // [n][3] staging offset, destination offset, count (floats)
+  size_t stage_floats = 0;
   std::vector<int32_t> fe_jobs;
   int n_fe = 0, max_keep = 0;
   EncPlan P;
+  std::vector<int32_t> ctc_rows, kv_src, kv_dst;   // eager projections of the frames the group emits
+  bool same_rows = true;
+  bool empty() const { return !n_fe && !P.n_conv && copy_jobs.empty(); }
 };
+
+constexpr int N_ARENA = 8;   // job-table arena slots = encoder groups that can be in flight
+constexpr int N_STAGE = 4;   // pinned staging slots for host input (a slot is free again when its H2D copy is done)
+constexpr int N_RING = 4;    // block-start tables (ctrl rows, log-softmax row lists): pinned ring
 
 struct sc_streams {
   sc_engine *eng = nullptr;
@@ -131,49 +181,71 @@ struct sc_streams {
   long PCAP = 0;
   bool use_bbd = false, strict = true;
   hipStream_t stream = nullptr;
-  // Encoder side of a chunk step on its OWN HIP stream: frontend + encoder of a push do not feed the decode blocks
-  // whose frames were already there before the push (the block schedule runs one hop behind the encoder, SURVEY
-  // A7), so both proceed concurrently - the encoder's MFMA-bound grids fill the CUs that the latency-bound decode
-  // iterations leave idle.  `es` is the stream the current phase launches into.
+  // Encoder side on its OWN HIP stream: frontend + encoder of a chunk do not feed the decode blocks whose frames
+  // were already there before the chunk (the block schedule runs one hop behind the encoder), so both
+  // proceed concurrently - the encoder's MFMA-bound grids fill the CUs that the latency-bound decode iterations
+  // leave idle.  `es` is the stream the current phase launches into.
   hipStream_t stream_enc = nullptr, es = nullptr;
-  hipEvent_t ev_enc_done = nullptr;
   hipEvent_t ev_iter[2] = {nullptr, nullptr};   // end of decode iteration k (k & 1)
-  int32_t *flags_dev = nullptr, *ring_dev = nullptr;   // stop flags of a step (device); device view of flags_host [2][S]
+  int32_t *ring_dev = nullptr;                  // device view of flags_host [S]: the prune kernel stores the stop flags there
   int32_t *rm_host[2] = {nullptr, nullptr};     // pinned rowmap images (double-buffered: one may still be in a copy queue)
   int rm_idx = 0;
   bool rm_dirty = false;                        // rm_host[rm_idx] differs from the device rowmap
   int scan_split_min = 256, scan_split_streams = 48;   // T-parallel CTC scan: frames to walk >=, bucket streams <=
-  bool speculate = false;                       // device-side step control: enqueue iteration i+1 before reading the
-                                                // flags of i (opt-in, graphs on only; measured: no gain - DESIGN 4 (q))
   bool scan_long = false;                       // this step: a live stream has >= scan_split_min frames to walk
   int step_split_min() const { return (scan_long && n_rows_step <= scan_split_streams * W) ? scan_split_min : 0; }
-  int graph_key() const { return n_rows_step * 4 + (speculate ? 2 : 0) + (step_split_min() > 0 ? 1 : 0); }
-  long spec_launched = 0, spec_wasted = 0;
-  bool enc_pending = false;      // the encoder stage of this push has been launched and may still be running
-  PendingEnc *pend = nullptr;   // ... has been planned but not launched yet (launched when the decode loop thins out)
-  int enc_start_thr = 0;         // launch it when at most this many streams are still in the step loop
+  int graph_key() const { return n_rows_step * 2 + (step_split_min() > 0 ? 1 : 0); }
+  int enc_start_thr = 0;         // sc_push: launch the planned encoder group when at most this many streams are still decoding
   void *ws = nullptr, *ws_enc = nullptr;
-  std::vector<void *> owned;
+  std::vector<void *> owned, owned_host;
   // device buffers
   float *pcm = nullptr, *featbuf = nullptr, *subbuf = nullptr, *prev_addin = nullptr, *past_ctx = nullptr, *enc = nullptr,
         *c1 = nullptr, *c2 = nullptr, *xblk = nullptr, *ws_xn = nullptr, *ws_qkv = nullptr, *ws_att = nullptr,
         *ws_ffh = nullptr;
-  int32_t *jobs_ctx = nullptr, *ctrlmap = nullptr, *arena_dev = nullptr;
+  int32_t *jobs_ctx = nullptr, *ctrlmap = nullptr;
   float *kv_stage = nullptr;   // kv_half: fp32 staging [dec_layers][kv_stage_rows][2d] of the K|V projections
   int kv_stage_rows = 0;
   sc_search sb{};
   // pinned host
-  int32_t *ctrlmap_host = nullptr, *ctrl0_host = nullptr, *flags_host = nullptr, *arena_host = nullptr;
-  size_t arena_cap = 1 << 22, arena_off = 0;
+  int32_t *ctrlmap_host = nullptr, *flags_host = nullptr;
+  // ---- job tables of the encoder groups: N_ARENA slots of one pinned / one device arena --------------------------
+  int32_t *arena_host = nullptr, *arena_dev = nullptr;
+  size_t slot_cap = 0, arena_off = 0;
+  int cur_slot = 0;
+  hipEvent_t ev_group[N_ARENA] = {nullptr};
+  long slot_gen[N_ARENA] = {0};   // group that owns the slot (0: free)
+  // ---- block-start tables (decode side) ------------------------------------------------------------------------------
+  int32_t *bs_host = nullptr, *bs_dev = nullptr;   // [N_RING][S*8 + S*block_size]: ctrl rows, then log-softmax rows
+  size_t bs_cap = 0;
+  int bs_i = 0;
+  // ---- host input staging (sc_push / sc_submit with host pointers): one H2D copy + one scatter launch per group ----
+  float *stage_host = nullptr, *stage_dev = nullptr;
+  size_t stage_cap = 0;           // floats per slot
+  hipEvent_t ev_stage[N_STAGE] = {nullptr};
+  bool stage_busy[N_STAGE] = {false};
+  int stage_next = 0;
+  // ---- batched hypothesis read-back (sc_get_hyps_batch): pack kernel -> one D2H into pinned memory -------------------
+  int32_t *pack_dev = nullptr, *pack_host = nullptr, *pjobs_host = nullptr, *pjobs_dev = nullptr;
+  size_t pack_cap = 0;            // int32 elements
+  // ---- tick engine -----------------------------------------------------------------------------------------------------
   std::vector<St> st;
+  std::vector<Run> run;
+  std::vector<std::deque<Blk>> bq;
+  std::vector<Job> job;
+  std::vector<std::string> fault_msg;
+  std::deque<EncGroup *> groups;   // planned or in flight, oldest first
+  long gen_next = 1, gen_done = 0, gen_ordered = 0;   // groups: issued, known complete, main stream ordered behind
+  int n_open = 0;                  // outstanding chunks
+  long iter = 0;
+  bool poisoned = false;           // a call failed half-way: device and host state may disagree
   std::vector<int> rowmap_key;
   int row_bucket = 1, n_rows_step = 0;
   bool decode_prepared = false;
   std::map<int, hipGraphExec_t> dec_graphs;
   std::map<std::vector<long>, hipGraphExec_t> enc_graphs;
   long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows[2] = {0, 0};   // [0] flash kernels, [1] layer kernels
-  double t_launch = 0, t_wait = 0, t_host = 0;   // seconds in the step loop: issuing, waiting for the flags, bookkeeping
-  double t_bucket[17] = {0};                     // ... waiting, by compaction bucket (n_rows_step / (row_bucket*W))
+  double t_launch = 0, t_wait = 0;               // seconds in the step loop: issuing, waiting for the flags
+  double t_bucket[17] = {0};                     // ... by compaction bucket (n_rows_step / (row_bucket*W))
   long n_bucket[17] = {0};
   bool use_graphs = true;
 
@@ -185,17 +257,15 @@ struct sc_streams {
       (void)sc_set_stream_workspace(stream_enc, nullptr, 0);
       (void)hipStreamDestroy(stream_enc);
     }
-    if (ev_enc_done) (void)hipEventDestroy(ev_enc_done);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
       if (ev_iter[i]) (void)hipEventDestroy(ev_iter[i]);
-      if (rm_host[i]) (void)hipHostFree(rm_host[i]);
-    }
-    delete pend;
+    for (int i = 0; i < N_ARENA; ++i)
+      if (ev_group[i]) (void)hipEventDestroy(ev_group[i]);
+    for (int i = 0; i < N_STAGE; ++i)
+      if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+    for (EncGroup *g : groups) delete g;
     for (void *p : owned) (void)hipFree(p);
-    if (ctrlmap_host) (void)hipHostFree(ctrlmap_host);
-    if (ctrl0_host) (void)hipHostFree(ctrl0_host);
-    if (flags_host) (void)hipHostFree(flags_host);
-    if (arena_host) (void)hipHostFree(arena_host);
+    for (void *p : owned_host) (void)hipHostFree(p);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -205,19 +275,26 @@ struct sc_streams {
     owned.push_back(*p);
     return SC_OK;
   }
+  template <typename T>
+  int halloc(T **p, size_t n) {   // pinned, device-visible
+    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    owned_host.push_back(*p);
+    memset(*p, 0, std::max<size_t>(n, 1) * sizeof(T));
+    return SC_OK;
+  }
   int32_t *ctrl_host() { return ctrlmap_host; }              // [S][8]
   int32_t *rowmap_host() { return rm_host[rm_idx]; }          // [S*W]
 
-  // host int table -> device (pinned arena, async copy on the batch's stream; launches that read it are
-  // ordered behind the copy; the arena is recycled at the start of every push)
+  // host int table -> device (slot `cur_slot` of the pinned arena, async copy on the encoder-side stream; the launches
+  // that read it are ordered behind the copy; a slot is recycled when its group's event has completed)
   int itensor(const std::vector<int32_t> &a, const int32_t **out) {
     const size_t n = a.size();
-    if (arena_off + n > arena_cap) {
-      sc_set_error("sc_push: job-table arena exhausted");
+    if (arena_off + n > slot_cap) {
+      sc_set_error("job-table arena exhausted (%zu + %zu of %zu entries)", arena_off, n, slot_cap);
       return SC_ERR_ARG;
     }
-    const size_t off = arena_off;
-    arena_off = off + ((n + 63) & ~size_t(63));
+    const size_t off = (size_t)cur_slot * slot_cap + arena_off;
+    arena_off += (n + 63) & ~size_t(63);
     if (n) {
       memcpy(arena_host + off, a.data(), n * sizeof(int32_t));
       HIP_TRY(hipMemcpyAsync(arena_dev + off, arena_host + off, n * sizeof(int32_t), hipMemcpyHostToDevice, es));
@@ -227,22 +304,53 @@ struct sc_streams {
   }
 };
 
+
 namespace {
 
 constexpr int F_ANY_EOS = 1, F_BEST_EOS = 2, F_ALL_EOS = 4, F_REPEAT = 8;
 
+// create_initial_hypothesis (hypothesis.py:75-91): yseq=[sos], xpos=[0], scores 0 - side 0, slot 0.  A kernel on
+// the batch's stream: ordered behind whatever still reads the old hypotheses, no host synchronisation.
+__global__ void init_hyp_kernel(sc_search sb, int s) {
+  const size_t o = ((size_t)0 * sb.S + s) * sb.W + 0;
+  sb.yseq[o * sb.LCAP] = sb.sos;
+  sb.xpos[o * sb.LCAP] = 0;
+  sb.score[o] = 0.0;
+  sb.sc_dec[o] = 0.0;
+  sb.sc_ctc[o] = 0.0;
+}
+
+// host input of an admission group, staged contiguously -> its places in the per-stream buffers (PCM ring rows /
+// feature-buffer rows).  jobs[j] = {staging offset, destination offset, count} in floats.
+__global__ __launch_bounds__(256) void scatter_f32_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                          const long long *__restrict__ jobs) {
+  const long long so = jobs[blockIdx.y * 3], dof = jobs[blockIdx.y * 3 + 1], n = jobs[blockIdx.y * 3 + 2];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[dof + i] = src[so + i];
+}
+
+// live hypotheses of the listed streams -> one packed buffer (sc_get_hyps_batch).  jobs[j] = {hypothesis row
+// ((side*S + s)*W + h), L, destination offset (int32 units), 0}: ids at [off, off+L), positions at [off+L, off+2L),
+// then the three float64 totals (score, decoder, ctc) at the next 8-byte boundary.
+__global__ __launch_bounds__(128) void pack_hyps_kernel(sc_search sb, const int32_t *__restrict__ jobs, int32_t *__restrict__ out) {
+  const int32_t *j = jobs + (size_t)blockIdx.x * 4;
+  const size_t row = (size_t)j[0];
+  const int L = j[1];
+  int32_t *o = out + (size_t)j[2];
+  const int32_t *ys = sb.yseq + row * sb.LCAP, *xp = sb.xpos + row * sb.LCAP;
+  for (int i = threadIdx.x; i < L; i += 128) {
+    o[i] = ys[i];
+    o[L + i] = xp[i];
+  }
+  if (threadIdx.x == 0) {
+    double *sc = (double *)(o + ((2 * L + 1) & ~1));
+    sc[0] = sb.score[row];
+    sc[1] = sb.sc_dec[row];
+    sc[2] = sb.sc_ctc[row];
+  }
+}
+
 void init_hyp(sc_streams *b, int s) {
-  // create_initial_hypothesis (hypothesis.py:75-91): yseq=[sos], xpos=[0], scores 0 - side 0, slot 0
-  const sc_search &sb = b->sb;
-  const int32_t sos = b->cfg.sos_id, zero = 0;
-  const double dz = 0.0;
-  const size_t o = ((size_t)0 * b->S + s) * b->W + 0;
-  (void)hipMemcpyAsync(sb.yseq + o * b->LCAP, &sos, 4, hipMemcpyHostToDevice, b->stream);
-  (void)hipMemcpyAsync(sb.xpos + o * b->LCAP, &zero, 4, hipMemcpyHostToDevice, b->stream);
-  (void)hipMemcpyAsync(sb.score + o, &dz, 8, hipMemcpyHostToDevice, b->stream);
-  (void)hipMemcpyAsync(sb.sc_dec + o, &dz, 8, hipMemcpyHostToDevice, b->stream);
-  (void)hipMemcpyAsync(sb.sc_ctc + o, &dz, 8, hipMemcpyHostToDevice, b->stream);
-  (void)hipStreamSynchronize(b->stream);   // the sources are stack variables
+  init_hyp_kernel<<<1, 1, 0, b->stream>>>(b->sb, s);
 }
 
 void reset_stream(sc_streams *b, int s) {
@@ -253,8 +361,11 @@ void reset_stream(sc_streams *b, int s) {
   if (b->strict) {
     ns.short_pos = old.short_pos;
     ns.T_ctc = old.T_ctc;
+    ns.T_proj = old.T_ctc;   // rows behind the stale table's extent belong to the next utterance
   }
   b->st[s] = ns;
+  b->run[s] = Run();
+  b->bq[s].clear();
   init_hyp(b, s);
 }
 
@@ -313,7 +424,6 @@ int compact_pcm(sc_streams *b, int s) {
   return SC_OK;
 }
 
-struct Chunk { int s; const float *pcm; long n; bool fin; };
 
 
 // forward_infer planning for the listed streams; pure host state changes.
@@ -466,7 +576,7 @@ int enc_layers_launch(sc_streams *b, int nblk, int R, bool masked, const int32_t
   std::vector<long> key{nblk, R, (long)masked, (long)(intptr_t)jobs, ns};
   auto it = b->enc_graphs.find(key);
   if (it == b->enc_graphs.end()) {
-    if (b->enc_graphs.size() >= 16) return launch();   // ragged callers: do not hoard graphs
+    if (b->enc_graphs.size() >= 192) return launch();   // (one per group shape; continuous batching varies it)
     RC_TRY(sc_graph_capture_begin(b->es));
     const int rc = launch();
     void *g = nullptr;
@@ -557,18 +667,6 @@ int encode_launch(sc_streams *b, EncPlan &P) {
   return SC_OK;
 }
 
-// the host's ctrl rows -> device (block start, and whenever the host, not the advance kernel, decides the next step)
-int upload_ctrl(sc_streams *b) {
-  HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)b->S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  return SC_OK;
-}
-int upload_rowmap(sc_streams *b) {
-  HIP_TRY(hipMemcpyAsync(b->ctrlmap + b->S * 8, b->rm_host[b->rm_idx], (size_t)b->S * b->W * sizeof(int32_t),
-                         hipMemcpyHostToDevice, b->stream));
-  b->rm_dirty = false;
-  return SC_OK;
-}
-
 // dense decoder kernels process the first n_rows_step entries of rowmap: the hypothesis rows of the streams still
 // in the step loop (active first, both parts in stream order), rounded up to a bucket of row_bucket streams
 void set_rowmap(sc_streams *b, const std::vector<int> &active) {
@@ -591,25 +689,19 @@ void set_rowmap(sc_streams *b, const std::vector<int> &active) {
   b->n_rows_step = nb * W;
 }
 
-// one decode step; with the device-side step control also the advance kernel (ctrl rows of the next step, flags ->
-// ring).  Without it the prune kernel stores the stop flags straight into the host-mapped array (sb.flags = ring).
-static int step_and_advance(sc_streams *b) {
-  b->sb.flags = b->speculate ? b->flags_dev : b->ring_dev;
-  // CTC prefix scan split over T while few streams are active (a function of the compaction bucket, so every
-  // captured graph has one form): the sequential walk costs 0.15 us per frame whatever the number of streams
-  RC_TRY(sc_decode_step_ex(&b->sb, b->step_split_min(), b->stream));
-  if (!b->speculate) return SC_OK;
-  return sc_step_advance(&b->sb, b->use_bbd ? 1 : 0, b->ring_dev, b->stream);
-}
-
+// one beam-search step for every active stream (the prune kernel stores the stop flags straight into the host-mapped
+// flag array).  CTC prefix scan split over T while few streams are active (a function of the compaction bucket, so
+// every captured graph has one form): the sequential walk costs 0.15 us per frame whatever the number of streams.
 int decode_step_launch(sc_streams *b) {
   b->sb.n_rows = b->n_rows_step;
-  if (!b->use_graphs) return step_and_advance(b);
+  b->sb.flags = b->ring_dev;
+  auto step = [&]() { return sc_decode_step_ex(&b->sb, b->step_split_min(), b->stream); };
+  if (!b->use_graphs) return step();
   auto it = b->dec_graphs.find(b->graph_key());
   if (it == b->dec_graphs.end()) {
-    RC_TRY(step_and_advance(b));   // warm-up launch (also validates arguments); executes the step
+    RC_TRY(step());   // warm-up launch (also validates arguments); executes the step
     RC_TRY(sc_graph_capture_begin(b->stream));
-    const int rc = step_and_advance(b);
+    const int rc = step();
     void *g = nullptr;
     const int rc2 = sc_graph_capture_end(b->stream, &g);
     if (rc != SC_OK) return rc;
@@ -623,345 +715,534 @@ int decode_step_launch(sc_streams *b) {
 int prepare_decode(sc_streams *b) {
   // capture the decode graph of every compaction bucket up front, on dry steps (all ctrl rows inactive)
   memset(b->ctrl_host(), 0, (size_t)b->S * 8 * sizeof(int32_t));
-  RC_TRY(upload_ctrl(b));
+  HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)b->S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
   const int keep = b->n_rows_step;
   for (int nb = b->row_bucket; nb < b->S + b->row_bucket; nb += b->row_bucket) {
     b->n_rows_step = std::min(nb, b->S) * b->W;
     if (!b->dec_graphs.count(b->graph_key())) RC_TRY(decode_step_launch(b));
   }
   b->n_rows_step = keep;
+  HIP_TRY(hipStreamSynchronize(b->stream));   // (the pinned ctrl image is rewritten by the first real step)
   return SC_OK;
 }
 
-struct Todo { int s, T; bool fin; };
-int launch_encoder(sc_streams *b);
+// ---- encoder groups -----------------------------------------------------------------------------------------------
+// groups complete in order (one in-order stream): pop every leading group whose event has fired
+int retire_groups(sc_streams *b) {
+  while (!b->groups.empty()) {
+    EncGroup *g = b->groups.front();
+    if (!g->launched) break;
+    const hipError_t q = hipEventQuery(b->ev_group[g->slot]);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+    if (q != hipSuccess) {
+      sc_set_error("encoder group %ld failed: %s", g->gen, hipGetErrorString(q));
+      return SC_ERR_LAUNCH;
+    }
+    b->gen_done = g->gen;
+    b->slot_gen[g->slot] = 0;
+    if (g->stage_slot >= 0) b->stage_busy[g->stage_slot] = false;
+    b->groups.pop_front();
+    delete g;
+  }
+  return SC_OK;
+}
 
-// _decode_one_block (beam_search.py:655-838) for a lock-step group of streams
-int decode_blocks(sc_streams *b, const std::vector<Todo> &todo, std::vector<StreamFault> &faults) {
+// host-blocking wait for the group `gen` (and, the stream being in order, every group before it)
+int wait_group(sc_streams *b, long gen) {
+  if (gen <= b->gen_done) return SC_OK;
+  const int slot = (int)(gen % N_ARENA);
+  HIP_TRY(hipEventSynchronize(b->ev_group[slot]));
+  return retire_groups(b);
+}
+
+// CTC rows and cross-attention K|V rows of the frames a group emits (extend_scorers' encoder-side half,
+// beam_search.py:403-464; scorers.py:342-350 stores RAW logits - the log-softmax of a stream's first block, quirk
+// A1, is applied when that block starts).  They depend on the encoder output only, so they belong to the encoder
+// stage: a decode block then starts with nothing but its CTC state extension.
+int project_rows(sc_streams *b, EncGroup &g) {
   const sc_config &c = b->cfg;
   sc_engine *e = b->eng;
-  const int S = b->S, W = b->W, d = c.d_model, Ld = c.dec_layers, V = c.vocab_size;
-  const int n = (int)todo.size();
-  b->dec_blocks += n;
-  std::vector<int> cur(n), L(n), nhyp(n), pidx(n), told(n), tkv(n), Ttab(n), T(n), nhyp_prev(n), out_idx(n, 0);
-  std::vector<char> has(n), pvalid(n), fin(n), live(n, 1), took_out(n, 0), has_prev(n);
-  std::vector<long> nsteps(n, 0);
-  for (int i = 0; i < n; ++i) {
-    const St &x = b->st[todo[i].s];
-    T[i] = todo[i].T; fin[i] = todo[i].fin;
-    cur[i] = x.cur; L[i] = x.L; nhyp[i] = x.nhyp; has[i] = x.has_ctc; pidx[i] = x.process_idx; pvalid[i] = x.prev_valid;
-    told[i] = x.T_ctc; tkv[i] = x.T_kv;
-    Ttab[i] = std::max(T[i], told[i]);   // the CTC table never shrinks (stale table after reset())
-    if (T[i] > b->TCAP) { sc_set_error("sc_push: max_frames exceeded"); return SC_ERR_ARG; }
-  }
-  // ---- extend_scorers (:403-464): CTC rows, cross-attention K/V rows, r states
-  std::vector<int32_t> rows, lsm, krows, kv0;
-  bool same_rows = true;
-  for (int i = 0; i < n; ++i) {
-    const int s = todo[i].s;
-    same_rows = same_rows && told[i] == tkv[i];
-    for (int t = told[i]; t < T[i]; ++t) rows.push_back(s * b->TCAP + t);
-    if (T[i] > told[i] && told[i] == 0)   // quirk A1: only the first block is log-softmaxed
-      for (int t = 0; t < T[i]; ++t) lsm.push_back(s * b->TCAP + t);
-    for (int t = tkv[i]; t < T[i]; ++t) {
-      krows.push_back(s * b->TCAP + t);
-      kv0.push_back(s * Ld * b->TCAP + t);
-    }
-  }
+  const int d = c.d_model, Ld = c.dec_layers, V = c.vocab_size;
   const int32_t *ar = nullptr;
-  if (!rows.empty()) {
-    RC_TRY(b->itensor(rows, &ar));
-    RC_TRY(sc_gemm(b->enc, ar, d, e->f("ctc_w"), e->f("ctc_b"), const_cast<float *>(b->sb.ctcx), ar, V, (int)rows.size(), V,
-                   d, 0, 0, b->stream));
-    if (!lsm.empty()) {
-      const int32_t *lr;
-      RC_TRY(b->itensor(lsm, &lr));
-      RC_TRY(sc_log_softmax_rows(const_cast<float *>(b->sb.ctcx), lr, (int)lsm.size(), V, b->stream));
-    }
+  if (!g.ctc_rows.empty()) {
+    RC_TRY(b->itensor(g.ctc_rows, &ar));
+    RC_TRY(sc_gemm(b->enc, ar, d, e->f("ctc_w"), e->f("ctc_b"), const_cast<float *>(b->sb.ctcx), ar, V, (int)g.ctc_rows.size(),
+                   V, d, 0, 0, b->es));
   }
-  if (!kv0.empty()) {
-    if (!same_rows || !ar) RC_TRY(b->itensor(krows, &ar));
+  if (!g.kv_dst.empty()) {
+    if (!g.same_rows || !ar) RC_TRY(b->itensor(g.kv_src, &ar));
     const int32_t *kvt;
-    RC_TRY(b->itensor(kv0, &kvt));   // one row table for all layers: layer li's rows start li*TCAP rows further
-    const int m = (int)kv0.size();
+    RC_TRY(b->itensor(g.kv_dst, &kvt));   // one row table for all layers: layer li's rows start li*TCAP rows further
+    const int m = (int)g.kv_dst.size();
     if (!b->sb.kv_half) {
       for (int li = 0; li < Ld; ++li)
         RC_TRY(sc_gemm(b->enc, ar, d, e->wkv[li], e->bkv[li], const_cast<float *>(b->sb.ckv) + (size_t)li * b->TCAP * 2 * d,
-                       kvt, 2 * d, m, 2 * d, d, 0, 0, b->stream));
+                       kvt, 2 * d, m, 2 * d, d, 0, 0, b->es));
     } else {
       // fp16 cache: project into the fp32 staging buffer (dense rows), then convert + scatter all layers at once
       for (int r0 = 0; r0 < m; r0 += b->kv_stage_rows) {
         const int mm = std::min(b->kv_stage_rows, m - r0);
         for (int li = 0; li < Ld; ++li)
           RC_TRY(sc_gemm(b->enc, ar + r0, d, e->wkv[li], e->bkv[li], b->kv_stage + (size_t)li * mm * 2 * d, nullptr, 2 * d,
-                         mm, 2 * d, d, 0, 0, b->stream));
-        RC_TRY(sc_kv_rows_to_half(b->kv_stage, kvt + r0, mm, Ld, b->TCAP, 2 * d, const_cast<float *>(b->sb.ckv), b->stream));
+                         mm, 2 * d, d, 0, 0, b->es));
+        RC_TRY(sc_kv_rows_to_half(b->kv_stage, kvt + r0, mm, Ld, b->TCAP, 2 * d, const_cast<float *>(b->sb.ckv), b->es));
       }
     }
   }
+  return SC_OK;
+}
+
+// issue a planned group: input copy + scatter, frontend, encoder, projections (on the encoder stream when there is one)
+int launch_group(sc_streams *b, EncGroup *g) {
+  if (g->launched) return SC_OK;
+  g->launched = true;
+  const sc_config &c = b->cfg;
+  sc_engine *e = b->eng;
+  b->es = b->stream_enc ? b->stream_enc : b->stream;
+  b->cur_slot = g->slot;
+  b->arena_off = 0;
+  int rc = SC_OK;
+  if (!g->copy_jobs.empty()) {
+    // ONE host-to-device copy of the group's input (pinned staging slot), one scatter launch to its places
+    const size_t so = (size_t)g->stage_slot * b->stage_cap;
+    if (hipMemcpyAsync(b->stage_dev + so, b->stage_host + so, g->stage_floats * sizeof(float), hipMemcpyHostToDevice, b->es) != hipSuccess) {
+      sc_set_error("copy of the input chunks failed");
+      rc = SC_ERR_LAUNCH;
+    }
+    std::vector<int32_t> jt(g->copy_jobs.size() * 2);
+    memcpy(jt.data(), g->copy_jobs.data(), jt.size() * sizeof(int32_t));
+    const int32_t *jd = nullptr;
+    if (rc == SC_OK) rc = b->itensor(jt, &jd);
+    if (rc == SC_OK) {
+      const int nj = (int)g->copy_jobs.size() / 3;
+      long long mx = 1;
+      for (int j = 0; j < nj; ++j) mx = std::max(mx, g->copy_jobs[j * 3 + 2]);
+      dim3 grid((unsigned)std::min<long long>(64, (mx + 1023) / 1024), nj);
+      scatter_f32_kernel<<<grid, 256, 0, b->es>>>(b->stage_dev + so, g->features ? b->featbuf : b->pcm, (const long long *)jd);
+      (void)hipEventRecord(b->ev_stage[g->stage_slot], b->es);   // the pinned slot is free again behind this
+    }
+  }
+  if (rc == SC_OK && g->n_fe) {
+    const int32_t *jobs;
+    rc = b->itensor(g->fe_jobs, &jobs);
+    if (rc == SC_OK)
+      rc = sc_logmel(b->pcm, (int)b->PCAP, jobs, g->n_fe, g->max_keep, e->f("window"), e->f("mel_fb"), e->f("twiddle"),
+                     (const double *)e->f("mean64"), (const double *)e->f("std64"), c.mvn_mode, c.n_fft, c.hop_length,
+                     c.win_length, c.n_mels, b->featbuf, b->es);
+  }
+  if (rc == SC_OK && g->P.n_conv) rc = encode_launch(b, g->P);
+  if (rc == SC_OK) rc = project_rows(b, *g);
+  (void)hipEventRecord(b->ev_group[g->slot], b->es);
+  if (b->es == b->stream) b->gen_ordered = std::max(b->gen_ordered, g->gen);
+  b->es = b->stream;
+  return rc;
+}
+
+int launch_pending_groups(sc_streams *b) {
+  for (EncGroup *g : b->groups)
+    if (!g->launched) RC_TRY(launch_group(b, g));
+  return SC_OK;
+}
+
+// ---- the tick engine ------------------------------------------------------------------------------------------------
+// _decode_one_block's epilogue for a stream whose step loop has ended: rewind (beam_search.py:827-836), back to the
+// stream state; a non-final block advances the schedule (:619-621)
+void finish_block(sc_streams *b, int s) {
+  Run &r = b->run[s];
+  const bool rw = r.pidx > 1 && r.pvalid;
+  const bool r2 = rw && r.took;   // live state is a non-accepted H_out: go back to its H_in
+  if (r2) {
+    r.cur = 1 - r.cur;
+    r.L -= 1;
+    r.nhyp = r.nhp;
+    r.has = r.hasp;
+  }
+  if (rw) { r.pidx -= 1; r.pvalid = false; }
+  St &x = b->st[s];
+  x.cur = r.cur; x.L = r.L; x.nhyp = r.nhyp; x.has_ctc = r.has;
+  x.process_idx = r.pidx; x.prev_valid = r.pvalid;
+  x.output_index = r.out;
+  x.n_steps_total += r.nsteps;
+  if (!r.fin) x.processed_block += 1;
+  r.inblk = false;
+}
+
+void fault_stream(sc_streams *b, int s, int code, const std::string &msg) {
+  b->job[s].fault = code;
+  b->fault_msg[s] = msg;
+  b->run[s] = Run();
+  b->bq[s].clear();
+}
+
+// idle streams whose next block is ready start it: extend_scorers' search-side half (beam_search.py:403-464) -
+// log-softmax of the first block's CTC rows (quirk A1), CTC state extension - and the loop state of the block
+int start_blocks(sc_streams *b) {
+  const int S = b->S;
+  const long gen_ok = std::max(b->gen_done, b->gen_ordered);
+  std::vector<int> starts;
+  for (int s = 0; s < S; ++s)
+    if (!b->run[s].inblk && !b->bq[s].empty() && b->bq[s].front().gen <= gen_ok) starts.push_back(s);
+  if (starts.empty()) return SC_OK;
   if (!b->decode_prepared) {
     b->decode_prepared = true;
     RC_TRY(prepare_decode(b));
   }
-  // block-start ctrl rows (own pinned buffer: every earlier use was followed by a flag read-back sync)
-  memset(b->ctrl0_host, 0, (size_t)S * 8 * sizeof(int32_t));
-  for (int i = 0; i < n; ++i) {
-    int32_t *r = b->ctrl0_host + todo[i].s * 8;
-    r[0] = 1; r[1] = cur[i]; r[2] = fin[i]; r[3] = Ttab[i]; r[4] = L[i]; r[5] = nhyp[i]; r[6] = has[i]; r[7] = told[i];
-  }
-  HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrl0_host, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  RC_TRY(sc_ctc_extend_state(&b->sb, b->stream));
-  for (int i = 0; i < n; ++i) {
-    St &x = b->st[todo[i].s];
-    x.T_ctc = Ttab[i];
-    x.T_kv = std::max(T[i], tkv[i]);
+  b->bs_i = (b->bs_i + 1) % N_RING;
+  int32_t *ctrl0 = b->bs_host + (size_t)b->bs_i * b->bs_cap, *lsm = ctrl0 + (size_t)S * 8;
+  memset(ctrl0, 0, (size_t)S * 8 * sizeof(int32_t));
+  int n_lsm = 0;
+  for (int s : starts) {
+    const Blk k = b->bq[s].front();
+    b->bq[s].pop_front();
+    St &x = b->st[s];
+    Run &r = b->run[s];
+    r = Run();
+    r.inblk = r.live = true;
+    r.T = k.T; r.fin = k.fin;
+    r.cur = x.cur; r.L = x.L; r.nhyp = x.nhyp; r.has = x.has_ctc; r.pidx = x.process_idx; r.pvalid = x.prev_valid;
+    const int told = x.T_ctc;
+    r.Tc = std::max(k.T, told);   // the CTC table never shrinks (stale table after reset())
+    if (k.T > told && told == 0)  // quirk A1: only the rows of the stream's first block are log-softmaxed
+      for (int t = 0; t < k.T && n_lsm < (int)(b->bs_cap - (size_t)S * 8); ++t) lsm[n_lsm++] = s * b->TCAP + t;
+    int32_t *c = ctrl0 + s * 8;
+    c[0] = 1; c[1] = r.cur; c[2] = r.fin; c[3] = r.Tc; c[4] = r.L; c[5] = r.nhyp; c[6] = r.has; c[7] = told;
+    x.T_ctc = r.Tc;
+    x.T_kv = std::max(k.T, x.T_kv);
     x.output_index = 0;
-    nhyp_prev[i] = nhyp[i];
-    has_prev[i] = has[i];
+    r.nhp = r.nhyp; r.hasp = r.has;
+    b->dec_blocks++;
   }
+  HIP_TRY(hipMemcpyAsync(b->ctrlmap, ctrl0, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  if (n_lsm) {
+    int32_t *ld = b->bs_dev + (size_t)b->bs_i * b->bs_cap;
+    HIP_TRY(hipMemcpyAsync(ld, lsm, (size_t)n_lsm * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    RC_TRY(sc_log_softmax_rows(const_cast<float *>(b->sb.ctcx), ld, n_lsm, b->cfg.vocab_size, b->stream));
+  }
+  RC_TRY(sc_ctc_extend_state(&b->sb, b->stream));
+  return SC_OK;
+}
+
+// One tick.  *progress: a block was started or finished, or a decode step ran.  Nothing to do -> *progress = false.
+int engine_tick(sc_streams *b, bool *progress) {
+  const int S = b->S, W = b->W, Ld = b->cfg.dec_layers;
+  *progress = false;
+  RC_TRY(retire_groups(b));
+  RC_TRY(start_blocks(b));
+  // streams whose step loop has ended (stop flags of the previous tick, or process_idx at its bound: :701)
+  std::vector<int> active;
+  for (int s = 0; s < S; ++s) {
+    Run &r = b->run[s];
+    if (!r.inblk) continue;
+    const bool act = r.live && r.pidx < b->max_length;
+    if (act && r.L + 1 > b->LCAP) {   // the stream leaves the loop here and is reset when its chunk is reported
+      fault_stream(b, s, SC_ERR_CAPACITY, "max_tokens exceeded");
+      *progress = true;
+      continue;
+    }
+    if (!act) {
+      finish_block(b, s);
+      *progress = true;
+      continue;
+    }
+    active.push_back(s);
+  }
+  if (active.empty()) {
+    if (*progress) return SC_OK;
+    // nobody is decoding: a block that waits for its encoder group is ordered behind it ON THE DEVICE
+    long need = 0;
+    for (int s = 0; s < S; ++s)
+      if (!b->run[s].inblk && !b->bq[s].empty() && (need == 0 || b->bq[s].front().gen < need)) need = b->bq[s].front().gen;
+    if (need > std::max(b->gen_done, b->gen_ordered)) {
+      RC_TRY(launch_pending_groups(b));
+      if (b->stream_enc) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_group[need % N_ARENA], 0));
+      b->gen_ordered = std::max(b->gen_ordered, need);
+      *progress = true;
+    }
+    return SC_OK;
+  }
+  *progress = true;
+  const auto tp0 = std::chrono::steady_clock::now();
+  set_rowmap(b, active);
+  b->scan_long = false;   // the graph with the T-parallel scan only when a stream's table is long enough for it
   int32_t *ctrl = b->ctrl_host();
   memset(ctrl, 0, (size_t)S * 8 * sizeof(int32_t));
-  // ---- step loop (:701-821)
-  // Device-side step control (opt-in, sc_streams_set_speculation): sc_step_advance behind every step derives the
-  // next ctrl rows on the device, so iteration k+1 can be enqueued BEFORE the host has read the stop flags of
-  // iteration k ("speculated": same compaction bucket, the streams that stop in k are inactive in k+1 by their device
-  // ctrl row); the host reads the flags of k (ring slot L & 1) while k+1 runs.  Not speculated: a step after which a
-  // stream would hit max_length / max_tokens (the host decides those), fewer than two live streams (the likely last
-  // iteration of a round would run for nothing), buckets that can still shrink, graphs off.  Measured at 128 streams:
-  // 3050-3071 with, 3052-3065 audio-s/s without - the host turnaround is not on the critical path - hence off.
-  std::vector<int> active;
-  bool inflight = false;   // iteration `iter` has already been enqueued
-  long iter = 0;
-  while (true) {
-    active.clear();
-    bool any = false;
-    for (int i = 0; i < n; ++i) {
-      const bool act = live[i] && pidx[i] < b->max_length;
-      live[i] = act;
-      if (act && L[i] + 1 > b->LCAP) {   // the stream leaves the loop here and is reset by push()
-        faults.push_back({todo[i].s, SC_ERR_CAPACITY, "max_tokens exceeded"});
-        live[i] = 0;
-        continue;
-      }
-      if (act) { any = true; active.push_back(todo[i].s); }
-    }
-    if (!any) {
-      if (inflight) b->spec_wasted++;   // runs with every stream inactive
-      break;
-    }
-    const auto tp0 = std::chrono::steady_clock::now();
-    std::sort(active.begin(), active.end());
-    set_rowmap(b, active);
-    b->scan_long = false;   // the graph with the T-parallel scan only when a stream's table is long enough for it
-    for (int i = 0; i < n && b->scan_split_min > 0; ++i)
-      if (live[i] && Ttab[i] - std::max(L[i] - 1, 1) >= b->scan_split_min) b->scan_long = true;
-    if (!inflight) {
-      for (int i = 0; i < n; ++i) {
-        int32_t *r = ctrl + todo[i].s * 8;
-        r[0] = live[i]; r[1] = cur[i]; r[2] = fin[i]; r[3] = T[i]; r[4] = L[i]; r[5] = nhyp[i]; r[6] = has[i]; r[7] = Ttab[i];
-      }
-      // the encoder stage of this push fills the CUs that the thinned-out step loop leaves idle
-      if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
-      if (b->rm_dirty) {   // one copy command for both (nothing is in flight here: the pinned image is free)
-        memcpy(b->ctrlmap_host + S * 8, b->rm_host[b->rm_idx], (size_t)S * W * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)(S * 8 + S * W) * sizeof(int32_t), hipMemcpyHostToDevice,
-                               b->stream));
-        b->rm_dirty = false;
-      } else {
-        RC_TRY(upload_ctrl(b));
-      }
-      RC_TRY(decode_step_launch(b));
-      HIP_TRY(hipEventRecord(b->ev_iter[iter & 1], b->stream));
-    }
-    for (int i = 0; i < n; ++i)
-      if (live[i]) b->xattn_rows[b->n_rows_step > SC_FUSED_MAX_ROWS ? 0 : 1] += (long)T[i] * Ld;   // K|V rows the cross-attention reads this step (bench roofline)
-    // (speculating at every size measured 2 % SLOWER than not at all: the compaction bucket then follows the active
-    // set one iteration late, which costs what the hidden host turnaround saves - so only where the bucket cannot
-    // shrink much any more: the tail of the step loop (at most 8 streams))
-    bool spec = b->speculate && b->use_graphs && active.size() >= 2 &&
-                (int)active.size() <= std::max(b->row_bucket, std::min(8, S / 4));
-    for (int i = 0; i < n && spec; ++i)
-      if (live[i] && (pidx[i] + 1 >= b->max_length || L[i] + 2 > b->LCAP)) spec = false;
-    if (spec) {   // iteration iter + 1, assuming nothing about iter's outcome
-      if (b->pend->valid && (int)active.size() <= b->enc_start_thr) RC_TRY(launch_encoder(b));
-      if (b->rm_dirty) RC_TRY(upload_rowmap(b));
-      RC_TRY(decode_step_launch(b));
-      HIP_TRY(hipEventRecord(b->ev_iter[(iter + 1) & 1], b->stream));
-      b->spec_launched++;
-    }
-    // the stop flags live in host-mapped pinned memory (the advance kernel stores them there: no copy command)
-    const auto tp1 = std::chrono::steady_clock::now();
-    HIP_TRY(hipEventSynchronize(b->ev_iter[iter & 1]));
-    const auto tp2 = std::chrono::steady_clock::now();
-    b->dec_steps++;
-    b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
-    b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
-    {
-      const int bk = std::min(16, (int)((long)b->n_rows_step * 16 / std::max(1, S * W)));
-      b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
-      b->n_bucket[bk] += 1;
-    }
-    inflight = spec;
-    iter++;
-    for (int i = 0; i < n; ++i) {
-      if (!live[i]) continue;
-      // with the device-side step control: the ring slot of the step that ran at this length
-      const int f = b->flags_host[(b->speculate ? (L[i] & 1) * S : 0) + todo[i].s];
-      const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
-      out_idx[i] += 1;
-      nsteps[i] += 1;
-      const bool stop_eos = f_any && (!fin[i] || f_best);
-      const bool stop_bbd = b->use_bbd && !stop_eos && f_rep && !fin[i];
-      const bool stop_all = !stop_eos && !stop_bbd && f_all && fin[i];
-      const bool accept = !(stop_eos || stop_bbd || stop_all);
-      const bool take = stop_eos || stop_all || accept;
-      if (stop_bbd) out_idx[i] -= 1;
-      const int nh_out = std::min(W, nhyp[i] * W);
-      if (take) {
-        nhyp_prev[i] = nhyp[i];
-        has_prev[i] = has[i];
-        cur[i] = 1 - cur[i];
-        L[i] += 1;
-        nhyp[i] = nh_out;
-        has[i] = 1;
-      }
-      if (stop_eos || stop_all) took_out[i] = 1;
-      live[i] = accept;
-      if (accept) {
-        pvalid[i] = 1;   // prev_hyps = copy(H_out)
-        pidx[i] += 1;    // process_idx += 1
-      }
-    }
+  for (int s : active) {
+    const Run &r = b->run[s];
+    if (b->scan_split_min > 0 && r.Tc - std::max(r.L - 1, 1) >= b->scan_split_min) b->scan_long = true;
+    int32_t *c = ctrl + s * 8;
+    c[0] = 1; c[1] = r.cur; c[2] = r.fin; c[3] = r.T; c[4] = r.L; c[5] = r.nhyp; c[6] = r.has; c[7] = r.Tc;
   }
-  // ---- rewind (:827-836)
-  for (int i = 0; i < n; ++i) {
-    const bool rw = pidx[i] > 1 && pvalid[i];
-    const bool r2 = rw && took_out[i];   // live state is a non-accepted H_out: go back to its H_in
-    if (r2) {
-      cur[i] = 1 - cur[i];
-      L[i] -= 1;
-      nhyp[i] = nhyp_prev[i];
-      has[i] = has_prev[i];
+  // sc_push: the planned encoder stage fills the CUs that the thinned-out step loop leaves idle
+  if ((int)active.size() <= b->enc_start_thr) RC_TRY(launch_pending_groups(b));
+  if (b->rm_dirty) {   // one copy command for ctrl rows + rowmap (nothing is in flight here: the pinned image is free)
+    memcpy(b->ctrlmap_host + S * 8, b->rm_host[b->rm_idx], (size_t)S * W * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)(S * 8 + S * W) * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    b->rm_dirty = false;
+  } else {
+    HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  }
+  RC_TRY(decode_step_launch(b));
+  HIP_TRY(hipEventRecord(b->ev_iter[b->iter & 1], b->stream));
+  const bool fused = sc_decode_step_form(&b->sb) != 0;
+  for (int s : active) b->xattn_rows[fused ? 1 : 0] += (long)b->run[s].T * Ld;   // K|V rows the cross-attention reads (bench roofline)
+  const auto tp1 = std::chrono::steady_clock::now();
+  HIP_TRY(hipEventSynchronize(b->ev_iter[b->iter & 1]));   // the stop flags live in host-mapped pinned memory
+  const auto tp2 = std::chrono::steady_clock::now();
+  b->iter++;
+  b->dec_steps++;
+  b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
+  b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
+  {
+    const int bk = std::min(16, (int)((long)b->n_rows_step * 16 / std::max(1, S * W)));
+    b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
+    b->n_bucket[bk] += 1;
+  }
+  // ---- the accept / stop rules of the step loop (:759-821)
+  for (int s : active) {
+    Run &r = b->run[s];
+    const int f = b->flags_host[s];
+    const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
+    r.out += 1;
+    r.nsteps += 1;
+    const bool stop_eos = f_any && (!r.fin || f_best);
+    const bool stop_bbd = b->use_bbd && !stop_eos && f_rep && !r.fin;
+    const bool stop_all = !stop_eos && !stop_bbd && f_all && r.fin;
+    const bool accept = !(stop_eos || stop_bbd || stop_all);
+    const bool take = stop_eos || stop_all || accept;
+    if (stop_bbd) r.out -= 1;
+    if (take) {
+      r.nhp = r.nhyp;
+      r.hasp = r.has;
+      r.cur = 1 - r.cur;
+      r.L += 1;
+      r.nhyp = std::min(W, r.nhyp * W);
+      r.has = true;
     }
-    if (rw) { pidx[i] -= 1; pvalid[i] = 0; }
-    St &x = b->st[todo[i].s];
-    x.cur = cur[i]; x.L = L[i]; x.nhyp = nhyp[i]; x.has_ctc = has[i];
-    x.process_idx = pidx[i]; x.prev_valid = pvalid[i];
-    x.output_index = out_idx[i];
-    x.n_steps_total += nsteps[i];
+    if (stop_eos || stop_all) r.took = true;
+    r.live = accept;
+    if (accept) {
+      r.pvalid = true;   // prev_hyps = copy(H_out)
+      r.pidx += 1;       // process_idx += 1
+    }
   }
   return SC_OK;
 }
 
-// t_old (optional): encoder frames every stream had BEFORE this push's encoder stage, which may still be running on
-// the encoder stream: a block that only sees those frames does not wait for it
-int stage_decode(sc_streams *b, const std::map<int, int> &feat_new, const std::map<int, bool> &finals,
-                 std::vector<StreamFault> &faults, const std::vector<int> *t_old = nullptr) {
-  // decode schedule (beam_search.py:590-634), rounds of lock-step blocks
-  const sc_config &c = b->cfg;
-  std::map<int, bool> done_final;
-  while (true) {
-    std::vector<Todo> todo;
-    for (auto &kv : feat_new) {
-      const int s = kv.first;
-      bool faulted = false;
-      for (auto &f : faults) faulted = faulted || f.stream == s;
-      if (faulted || done_final.count(s)) continue;
-      St &st = b->st[s];
-      const int cur_end = c.block_size - c.look_ahead + c.hop_size * st.processed_block;
-      const int t_avail = st.T_enc;
-      if (t_avail > 0 && cur_end < t_avail) todo.push_back({s, cur_end, false});
-      else if (finals.at(s) && t_avail > 0) {
-        todo.push_back({s, t_avail, true});
-        done_final[s] = true;
-      }
-    }
-    if (todo.empty()) break;
-    if (b->enc_pending || b->pend->valid) {
-      bool needs_new = t_old == nullptr;
-      for (auto &t : todo) needs_new = needs_new || t.T > (*t_old)[t.s];
-      if (needs_new) {   // a block of this round sees frames of this push: order the decode stream behind the encoder
-        RC_TRY(launch_encoder(b));
-        if (b->enc_pending) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_enc_done, 0));
-        b->enc_pending = false;
-      }
-    }
-    RC_TRY(decode_blocks(b, todo, faults));
-    for (auto &t : todo)
-      if (!t.fin) b->st[t.s].processed_block += 1;
-  }
-  return SC_OK;
+// a stream's outstanding chunk is complete: all of its blocks are decoded and its encoder stage has finished
+inline bool chunk_decoded(const sc_streams *b, int s) { return !b->run[s].inblk && b->bq[s].empty(); }
+inline bool chunk_complete(const sc_streams *b, int s) {
+  const Job &j = b->job[s];
+  return j.open && (j.fault != 0 || (chunk_decoded(b, s) && j.gen <= b->gen_done));
 }
 
-int stage_encode(sc_streams *b, const std::vector<Chunk> &chunks, std::map<int, int> &feat_new, std::map<int, bool> &finals,
-                 std::vector<int> &has_out) {
+// ---- admission ------------------------------------------------------------------------------------------------------
+struct Chunk { int s; const float *host; long n; bool fin; int pos; };
+
+// apply_frontend + forward_infer planning of one group, pure host work: stages the host input,
+// advances the host mirrors, fills the group's job tables.  Throws StreamFault for per-stream failures.
+void plan_group(sc_streams *b, const std::vector<Chunk> &chunks, bool features, EncGroup &g, std::map<int, int> &feat_new,
+                std::map<int, bool> &finals, std::vector<int> &has_out) {
   const sc_config &c = b->cfg;
-  std::vector<int32_t> fe_jobs;
-  int n_fe = 0, max_keep = 0;
+  float *stage = g.stage_slot >= 0 ? b->stage_host + (size_t)g.stage_slot * b->stage_cap : nullptr;
   for (size_t k = 0; k < chunks.size(); ++k) {
     const Chunk &ch = chunks[k];
     St &st = b->st[ch.s];
     finals[ch.s] = ch.fin;
+    if (features) {
+      // 2-D (T, n_mels) already-normalised features (speech2text_streaming.py:438-449): appended to the feature buffer
+      const int nbuf = st.enc_started ? st.nfeat : 0;
+      if (ch.n > b->max_feat_new || nbuf + ch.n > b->FCAP)
+        throw StreamFault{ch.s, SC_ERR_CAPACITY, "feature frames of one call exceed the batch's capacity (max_chunk_samples)"};
+      if (ch.n > 0) {
+        const size_t cnt = (size_t)ch.n * c.n_mels;
+        memcpy(stage + g.stage_floats, ch.host, cnt * sizeof(float));
+        g.copy_jobs.insert(g.copy_jobs.end(), {(long long)g.stage_floats,
+                                               (long long)(((size_t)(st.fpp * b->S + ch.s) * b->FCAP + nbuf) * c.n_mels), (long long)cnt});
+        g.stage_floats += cnt;
+      }
+      feat_new[ch.s] = (int)ch.n;
+      has_out[k] = 1;
+      continue;
+    }
     if (st.pcm_end + ch.n > b->PCAP) throw StreamFault{ch.s, SC_ERR_CAPACITY, "pcm buffer capacity exceeded"};
-    if (ch.n > 0 && ch.pcm)
-      if (hipMemcpyAsync(b->pcm + (long)ch.s * b->PCAP + st.pcm_end, ch.pcm, ch.n * sizeof(float), hipMemcpyHostToDevice,
-                         b->es) != hipSuccess)
-        throw StreamFault{ch.s, SC_ERR_LAUNCH, "copy of the PCM chunk failed"};
+    if (ch.n > 0 && ch.host) {
+      if (ch.n > b->max_chunk + 16 * c.hop_length)
+        throw StreamFault{ch.s, SC_ERR_CAPACITY, "chunk is longer than max_chunk_samples allows"};
+      memcpy(stage + g.stage_floats, ch.host, (size_t)ch.n * sizeof(float));
+      g.copy_jobs.insert(g.copy_jobs.end(), {(long long)g.stage_floats, (long long)ch.s * b->PCAP + st.pcm_end, (long long)ch.n});
+      g.stage_floats += (size_t)ch.n;
+    }
     st.pcm_end += ch.n;
     FePlan p = plan_frontend(c, st, ch.fin);
     if (!p.emit) continue;
     if (p.n > b->max_feat_new) throw StreamFault{ch.s, SC_ERR_CAPACITY, "chunk produces more feature frames than max_chunk_samples allows"};
     const int nbuf = st.enc_started ? st.nfeat : 0;
     const int dst_row0 = (st.fpp * b->S + ch.s) * b->FCAP + nbuf;
-    fe_jobs.insert(fe_jobs.end(), {ch.s, (int)p.seg_start, (int)p.seg_len, (int)p.eff_len, p.lo, p.n, dst_row0, 0});
-    ++n_fe;
-    max_keep = std::max(max_keep, p.n);
+    g.fe_jobs.insert(g.fe_jobs.end(), {ch.s, (int)p.seg_start, (int)p.seg_len, (int)p.eff_len, p.lo, p.n, dst_row0, 0});
+    ++g.n_fe;
+    g.max_keep = std::max(g.max_keep, p.n);
     feat_new[ch.s] = p.n;
     has_out[k] = 1;
   }
   // plan the encoder BEFORE anything that changes device state is launched: a per-stream fault thrown by the
-  // planning leaves the device untouched (the PCM copies above only append behind pcm_end)
-  EncPlan P;
+  // planning leaves the device untouched (the staged input only appends behind pcm_end / the buffered features)
   std::vector<int> enc_streams;
   for (auto &kv : feat_new) {
     St &st = b->st[kv.first];
     if (!st.started) st.started = true;   // running_hyps = [initial hypothesis]
     if (kv.second >= 3) enc_streams.push_back(kv.first);   // n < 3: encoder skipped, frames discarded (:551-559)
   }
-  if (!enc_streams.empty()) encode_plan(b, enc_streams, feat_new, finals, P);
-  PendingEnc &pe = *b->pend;
-  pe.valid = n_fe > 0 || P.n_conv > 0;
-  pe.fe_jobs = std::move(fe_jobs);
-  pe.n_fe = n_fe;
-  pe.max_keep = max_keep;
-  pe.P = std::move(P);
+  if (!enc_streams.empty()) encode_plan(b, enc_streams, feat_new, finals, g.P);
+}
+
+// Admit the chunks as ONE group: plan (per-stream faults drop that stream's chunk only), queue the decode blocks the
+// new frames make ready (beam_search.py:590-634), open the jobs.  launch_now: issue the group's encoder stage at once
+// (sc_submit); otherwise the tick loop launches it when the decode loop has thinned out (sc_push).
+int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool launch_now, std::vector<int> *has_out_by_pos) {
+  const sc_config &c = b->cfg;
+  RC_TRY(retire_groups(b));
+  const long gen = b->gen_next;
+  const int slot = (int)(gen % N_ARENA);
+  if (b->slot_gen[slot]) RC_TRY(wait_group(b, b->slot_gen[slot]));   // N_ARENA groups in flight: wait for the oldest
+  bool host_input = false;
+  for (auto &ch : chunks) host_input = host_input || (ch.host && ch.n > 0);
+  int sslot = -1;
+  if (host_input) {
+    sslot = b->stage_next;
+    b->stage_next = (b->stage_next + 1) % N_STAGE;
+    if (b->stage_busy[sslot]) HIP_TRY(hipEventSynchronize(b->ev_stage[sslot]));
+    b->stage_busy[sslot] = false;
+  }
+  EncGroup *g = new EncGroup;
+  std::map<int, int> feat_new;
+  std::map<int, bool> finals;
+  std::vector<int> has_out;
+  std::vector<St> snap;
+  while (true) {
+    if (!features)
+      for (auto &ch : chunks) {   // compaction moves device data: settle it before the snapshot
+        St &st = b->st[ch.s];
+        if (st.pcm_end + ch.n > b->PCAP) {
+          const int rc = compact_pcm(b, ch.s);
+          if (rc != SC_OK) { delete g; return rc; }
+        }
+      }
+    snap = b->st;
+    *g = EncGroup();
+    g->gen = gen; g->slot = slot; g->stage_slot = sslot; g->features = features;
+    feat_new.clear();
+    finals.clear();
+    has_out.assign(chunks.size(), 0);
+    try {
+      plan_group(b, chunks, features, *g, feat_new, finals, has_out);
+      break;
+    } catch (const StreamFault &f) {
+      b->st = snap;   // planning is pure host work that precedes every launch: undo = restore the mirrors
+      for (size_t k = 0; k < chunks.size(); ++k)
+        if (chunks[k].s == f.stream) {
+          chunks.erase(chunks.begin() + k);
+          break;
+        }
+      b->job[f.stream] = Job();
+      b->job[f.stream].open = true;
+      b->n_open++;
+      fault_stream(b, f.stream, f.code, f.msg);
+      if (chunks.empty()) { *g = EncGroup(); break; }
+    }
+  }
+  // decode schedule (beam_search.py:590-634) as per-stream queues; a block that sees frames of this group waits for it
+  for (auto &kv : feat_new) {
+    const int s = kv.first;
+    St &st = b->st[s];
+    std::deque<Blk> &q = b->bq[s];
+    int pb = st.processed_block + (b->run[s].inblk && !b->run[s].fin ? 1 : 0);
+    for (auto &k : q) pb += k.fin ? 0 : 1;
+    const int t_avail = st.T_enc, t_old = snap[s].T_enc;
+    while (t_avail > 0) {
+      const int cur_end = c.block_size - c.look_ahead + c.hop_size * pb;
+      if (!(cur_end < t_avail)) break;
+      q.push_back({cur_end, false, cur_end > t_old ? gen : 0});
+      ++pb;
+    }
+    if (finals.at(s) && t_avail > 0) q.push_back({t_avail, true, t_avail > t_old ? gen : 0});
+  }
+  // eager projections: CTC rows / cross-attention K|V rows of every frame this group emits
+  for (auto &ch : chunks) {
+    St &st = b->st[ch.s];
+    const int t0 = snap[ch.s].T_enc, t1 = st.T_enc;
+    if (t1 <= t0) continue;
+    const int c0 = std::max(t0, st.T_proj), k0 = std::max(t0, st.T_projkv);
+    g->same_rows = g->same_rows && c0 == k0;
+    for (int t = c0; t < t1; ++t) g->ctc_rows.push_back(ch.s * b->TCAP + t);
+    for (int t = k0; t < t1; ++t) {
+      g->kv_src.push_back(ch.s * b->TCAP + t);
+      g->kv_dst.push_back(ch.s * c.dec_layers * b->TCAP + t);
+    }
+    st.T_proj = std::max(st.T_proj, t1);
+    st.T_projkv = std::max(st.T_projkv, t1);
+  }
+  const bool launches = !g->empty();
+  for (size_t k = 0; k < chunks.size(); ++k) {
+    Job &j = b->job[chunks[k].s];
+    j = Job();
+    j.open = true;
+    j.has_out = has_out[k];
+    j.gen = launches ? gen : 0;
+    b->n_open++;
+    if (has_out_by_pos) (*has_out_by_pos)[chunks[k].pos] = has_out[k];
+  }
+  if (!launches) {
+    delete g;
+    return SC_OK;
+  }
+  if (sslot >= 0 && !g->copy_jobs.empty()) b->stage_busy[sslot] = true;
+  b->gen_next++;
+  b->slot_gen[slot] = gen;
+  b->groups.push_back(g);
+  if (launch_now) RC_TRY(launch_group(b, g));
   return SC_OK;
 }
 
-// issue the planned frontend + encoder launches (on the encoder stream when there is one)
-int launch_encoder(sc_streams *b) {
-  PendingEnc &pe = *b->pend;
-  if (!pe.valid) return SC_OK;
-  pe.valid = false;
-  const sc_config &c = b->cfg;
-  sc_engine *e = b->eng;
-  b->es = b->stream_enc ? b->stream_enc : b->stream;
-  int rc = SC_OK;
-  if (pe.n_fe) {
-    const int32_t *jobs;
-    rc = b->itensor(pe.fe_jobs, &jobs);
-    if (rc == SC_OK)
-      rc = sc_logmel(b->pcm, (int)b->PCAP, jobs, pe.n_fe, pe.max_keep, e->f("window"), e->f("mel_fb"), e->f("twiddle"),
-                     (const double *)e->f("mean64"), (const double *)e->f("std64"), c.mvn_mode, c.n_fft, c.hop_length,
-                     c.win_length, c.n_mels, b->featbuf, b->es);
-  }
-  if (rc == SC_OK && pe.P.n_conv) rc = encode_launch(b, pe.P);
-  if (b->stream_enc) {
-    (void)hipEventRecord(b->ev_enc_done, b->stream_enc);
-    b->enc_pending = true;
-  }
-  b->es = b->stream;
+// a call failed half-way (launch error, exhausted arena): settle the device and refuse further work on the handle
+int poison(sc_streams *b, int rc) {
+  (void)hipStreamSynchronize(b->stream);
+  if (b->stream_enc) (void)hipStreamSynchronize(b->stream_enc);
+  (void)hipGetLastError();
+  b->poisoned = true;
   return rc;
+}
+
+#define SC_API_BEGIN try {
+#define SC_API_END                                                            \
+  } catch (const std::bad_alloc &) {                                         \
+    sc_set_error("%s: out of host memory", __func__);                        \
+    return SC_ERR_ARG;                                                       \
+  } catch (const std::exception &ex) {                                       \
+    sc_set_error("%s: %s", __func__, ex.what());                             \
+    return SC_ERR_ARG;                                                       \
+  } catch (...) {                                                            \
+    sc_set_error("%s: unexpected exception", __func__);                      \
+    return SC_ERR_ARG;                                                       \
+  }
+
+int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n, const char *what) {
+  std::vector<char> seen(b->S, 0);
+  for (int i = 0; i < n; ++i) {
+    if (stream_ids[i] < 0 || stream_ids[i] >= b->S || counts[i] < 0) {
+      sc_set_error("%s: stream id / count out of range (entry %d)", what, i);
+      return SC_ERR_ARG;
+    }
+    if (seen[stream_ids[i]]) {
+      sc_set_error("%s: stream %d is listed twice (one chunk per stream and call)", what, stream_ids[i]);
+      return SC_ERR_ARG;
+    }
+    seen[stream_ids[i]] = 1;
+    if (b->job[stream_ids[i]].open) {
+      sc_set_error("%s: stream %d still has a chunk outstanding (sc_poll reports it)", what, stream_ids[i]);
+      return SC_ERR_ARG;
+    }
+  }
+  return SC_OK;
 }
 
 }  // namespace
@@ -1020,19 +1301,25 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
 // sc_config, int32 n, then n x { int32 name_len, name, int32 dtype, int64 numel, data }
 extern "C" int sc_engine_load(const char *path, int device, sc_engine **out) {
   SC_CHECK_ARG(path && out, "null");
+  SC_API_BEGIN
   FILE *fp = fopen(path, "rb");
   if (!fp) { sc_set_error("sc_engine_load: cannot open %s", path); return SC_ERR_ARG; }
-  auto bad = [&](const char *m) { sc_set_error("sc_engine_load: %s (%s)", m, path); fclose(fp); return SC_ERR_ARG; };
+  std::vector<void *> ptrs;
+  auto bad = [&](const char *m) {
+    sc_set_error("sc_engine_load: %s (%s)", m, path);
+    fclose(fp);
+    for (void *p : ptrs) (void)hipFree(p);   // tensors uploaded so far
+    return SC_ERR_ARG;
+  };
   char magic[8];
   int32_t csz = 0, n = 0;
   sc_config cfg{};
   if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "SCPK1\0\0\0", 8) != 0) return bad("not a packed model file");
   if (fread(&csz, 4, 1, fp) != 1 || csz != (int32_t)sizeof(sc_config)) return bad("config size mismatch");
-  if (fread(&cfg, sizeof cfg, 1, fp) != 1 || fread(&n, 4, 1, fp) != 1 || n <= 0) return bad("truncated header");
+  if (fread(&cfg, sizeof cfg, 1, fp) != 1 || fread(&n, 4, 1, fp) != 1 || n <= 0 || n > 100000) return bad("truncated header");
   if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
   std::vector<std::string> names(n);
   std::vector<sc_named_tensor> tens(n);
-  std::vector<void *> ptrs;
   std::vector<char> buf;
   for (int i = 0; i < n; ++i) {
     int32_t nl = 0, dt = 0;
@@ -1041,6 +1328,7 @@ extern "C" int sc_engine_load(const char *path, int device, sc_engine **out) {
     names[i].resize(nl);
     if (fread(&names[i][0], 1, nl, fp) != (size_t)nl || fread(&dt, 4, 1, fp) != 1 || fread(&numel, 8, 1, fp) != 1)
       return bad("truncated tensor header");
+    if (dt < 0 || dt > 2 || numel < 0 || numel > ((int64_t)1 << 33)) return bad("bad tensor dtype / size");
     const size_t bytes = (size_t)numel * (dt == 1 ? 8 : dt == 2 ? 2 : 4);
     buf.resize(bytes);
     if (bytes && fread(buf.data(), 1, bytes, fp) != bytes) return bad("truncated tensor data");
@@ -1058,6 +1346,7 @@ extern "C" int sc_engine_load(const char *path, int device, sc_engine **out) {
   }
   for (auto &kv : (*out)->t) kv.second.owned = true;
   return SC_OK;
+  SC_API_END
 }
 
 extern "C" void sc_engine_destroy(sc_engine *e) { delete e; }
@@ -1121,7 +1410,17 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(b->ws_ffh, m_enc * F);
   A(b->jobs_ctx, (size_t)S * 4);
   A(b->ctrlmap, (size_t)S * 8 + n);
-  A(b->arena_dev, b->arena_cap);
+  // job-table arena: one slot per encoder group in flight; the largest tables are the conv2 row gather
+  // (frames x conv_freq2 per stream) and the per-frame row lists
+  b->slot_cap = (((size_t)S * ((size_t)b->max_t2 * (c.conv_freq2 + 12) + 512) + 8192) + 63) & ~size_t(63);
+  A(b->arena_dev, b->slot_cap * N_ARENA);
+  b->bs_cap = (size_t)S * 8 + (size_t)S * c.block_size;
+  A(b->bs_dev, b->bs_cap * N_RING);
+  b->stage_cap = (size_t)S * std::max<size_t>((size_t)b->max_chunk + 16 * c.hop_length, (size_t)b->max_feat_new * c.n_mels);
+  A(b->stage_dev, b->stage_cap * N_STAGE);
+  b->pack_cap = n * (2 * (size_t)b->LCAP + 8);
+  A(b->pack_dev, b->pack_cap);
+  A(b->pjobs_dev, n * 4);
   sc_search &sb = b->sb;
   sb.S = S; sb.W = W; sb.K = K; sb.V = V; sb.d = d; sb.H = c.dec_heads; sb.F = F; sb.n_layers = c.dec_layers;
   sb.TCAP = b->TCAP; sb.LCAP = b->LCAP; sb.xchunk = 256; sb.blank = c.blank_id; sb.eos = c.eos_id; sb.sos = c.sos_id;
@@ -1146,7 +1445,6 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(sb.ctc_r, (size_t)2 * S * b->TCAP * 2 * W);
   A(sb.ctc_s, 2 * n);
   A(sb.ctc_rnew, (size_t)S * b->TCAP * 2 * W * K);
-  A(b->flags_dev, (size_t)S);   // (sb.flags: set per step - flags_dev, or the host-mapped array itself)
   A(sb.dx, n * d); A(sb.dxn, n * d); A(sb.dqkv, n * 3 * d); A(sb.datt, n * d); A(sb.dq, n * d); A(sb.dffh, n * F);
   A(sb.logits, n * V); A(sb.logp, n * V);
   A(sb.pre_ids, n * K); A(sb.psi, n * K); A(sb.psi_eos, n);
@@ -1185,7 +1483,6 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   sb.layers = e->dec.data();
   (void)sc_set_stream_workspace(b->stream, b->ws, (size_t)128 << 20);
   b->es = b->stream;
-  b->pend = new PendingEnc;
   {
     // The encoder stage starts when at most 7 % of the streams are still in the step loop (small batches: at once).
     // Measured at 128 streams (profiles/r02_encoder_overlap_sweep.txt): serial 33.4 ms per chunk step; started with
@@ -1209,8 +1506,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
       } else {
         er = hipStreamCreateWithPriority(&b->stream_enc, hipStreamNonBlocking, 0);
       }
-      if (er == hipSuccess && hipMalloc(&b->ws_enc, (size_t)128 << 20) == hipSuccess &&
-          hipEventCreateWithFlags(&b->ev_enc_done, hipEventDisableTiming) == hipSuccess) {
+      if (er == hipSuccess && hipMalloc(&b->ws_enc, (size_t)128 << 20) == hipSuccess) {
         b->owned.push_back(b->ws_enc);
         (void)sc_set_stream_workspace(b->stream_enc, b->ws_enc, (size_t)128 << 20);
       } else {
@@ -1221,13 +1517,15 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     }
   }
   const size_t cm = ((size_t)S * 8 + n) * sizeof(int32_t);
-  if (hipHostMalloc((void **)&b->ctrlmap_host, cm) != hipSuccess || hipHostMalloc((void **)&b->ctrl0_host, (size_t)S * 32) != hipSuccess ||
-      hipHostMalloc((void **)&b->flags_host, (size_t)S * 8) != hipSuccess ||
-      hipHostMalloc((void **)&b->rm_host[0], n * sizeof(int32_t)) != hipSuccess ||
-      hipHostMalloc((void **)&b->rm_host[1], n * sizeof(int32_t)) != hipSuccess ||
-      hipEventCreateWithFlags(&b->ev_iter[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&b->ev_iter[1], hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc((void **)&b->arena_host, b->arena_cap * 4) != hipSuccess) {
+  bool ok = b->halloc(&b->ctrlmap_host, (size_t)S * 8 + n) == SC_OK && b->halloc(&b->flags_host, (size_t)S * 2) == SC_OK &&
+            b->halloc(&b->rm_host[0], n) == SC_OK && b->halloc(&b->rm_host[1], n) == SC_OK &&
+            b->halloc(&b->arena_host, b->slot_cap * N_ARENA) == SC_OK && b->halloc(&b->bs_host, b->bs_cap * N_RING) == SC_OK &&
+            b->halloc(&b->stage_host, b->stage_cap * N_STAGE) == SC_OK && b->halloc(&b->pack_host, b->pack_cap) == SC_OK &&
+            b->halloc(&b->pjobs_host, n * 4) == SC_OK;
+  for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_iter[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < N_ARENA && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_group[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < N_STAGE && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     sc_set_error("sc_streams_create: pinned host allocation failed");
     delete b;
     return SC_ERR_LAUNCH;
@@ -1243,7 +1541,6 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     b->ring_dev = (int32_t *)dv;
     sb.flags = b->ring_dev;
   }
-  if (const char *sp = sc_hook("SC_SPECULATE")) b->speculate = atoi(sp) != 0;   // tests / A-B runs
   if (const char *sp = sc_hook("SC_SCAN_SPLIT_MIN")) b->scan_split_min = atoi(sp);   // tests: 0 = never, small = always
   memset(b->ctrlmap_host, 0, cm);
   for (size_t i = 0; i < n; ++i) b->rm_host[0][i] = b->rm_host[1][i] = (int32_t)i;
@@ -1255,6 +1552,10 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   if (const char *rb = sc_hook("SC_ROW_BUCKETS")) b->row_bucket = std::max(1, S / std::max(1, atoi(rb)));   // tools: sweep
   b->n_rows_step = S * W;
   b->st.assign(S, St());
+  b->run.assign(S, Run());
+  b->bq.assign(S, std::deque<Blk>());
+  b->job.assign(S, Job());
+  b->fault_msg.assign(S, std::string());
   for (int s = 0; s < S; ++s) init_hyp(b, s);
   *out = b;
   return SC_OK;
@@ -1263,12 +1564,14 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
 extern "C" void sc_streams_destroy(sc_streams *b) {
   if (b) {
     (void)hipStreamSynchronize(b->stream);
+    if (b->stream_enc) (void)hipStreamSynchronize(b->stream_enc);
     delete b;
   }
 }
 
 extern "C" int sc_reset(sc_streams *b, int stream) {
   SC_CHECK_ARG(b && stream >= 0 && stream < b->S, "stream out of range");
+  SC_CHECK_ARG(!b->job[stream].open, "the stream has a chunk outstanding (sc_poll reports it first)");
   reset_stream(b, stream);
   return SC_OK;
 }
@@ -1281,100 +1584,83 @@ extern "C" float *sc_streams_pcm(sc_streams *b, long *capacity) {
   return b->pcm;
 }
 
+namespace {
+
+// report a complete chunk: status, reset of a failed stream, job closed
+int report_chunk(sc_streams *b, int s) {
+  Job &j = b->job[s];
+  const int status = j.fault ? j.fault : j.has_out;
+  if (j.fault) reset_stream(b, s);   // (fault_msg[s] keeps the message: sc_stream_last_error)
+  j = Job();
+  b->n_open--;
+  return status;
+}
+
+// tick until every listed stream's chunk is decoded (sc_push, sc_push_features)
+int run_to_completion(sc_streams *b, const std::vector<int> &streams) {
+  while (true) {
+    bool all = true;
+    for (int s : streams) all = all && (b->job[s].fault != 0 || chunk_decoded(b, s));
+    if (all) return SC_OK;
+    bool progress = false;
+    RC_TRY(engine_tick(b, &progress));
+    if (!progress) {
+      sc_set_error("decode schedule stalled (internal error)");
+      return SC_ERR_LAUNCH;
+    }
+  }
+}
+
+int push_impl(sc_streams *b, const int *stream_ids, const float *const *host, const int *counts, const uint8_t *is_final,
+              int n, int *status, bool features, const char *what) {
+  if (b->poisoned) {
+    sc_set_error("%s: the handle was left inconsistent by an earlier failed call; destroy it", what);
+    return SC_ERR_LAUNCH;
+  }
+  HIP_TRY(hipSetDevice(b->eng->device));
+  RC_TRY(check_chunks(b, stream_ids, counts, n, what));
+  std::vector<Chunk> chunks;
+  std::vector<int> streams, has_out(n, 0);
+  for (int i = 0; i < n; ++i) {
+    chunks.push_back({stream_ids[i], host ? host[i] : nullptr, counts[i], is_final[i] != 0, i});
+    streams.push_back(stream_ids[i]);
+    if (status) status[i] = 0;
+  }
+  if (n == 0) return SC_OK;
+  int rc = admit(b, chunks, features, /*launch_now=*/false, &has_out);
+  if (rc == SC_OK) rc = run_to_completion(b, streams);
+  if (rc == SC_OK) rc = launch_pending_groups(b);   // (if no decode iteration got to it)
+  if (rc != SC_OK) return poison(b, rc);
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->stream_enc) HIP_TRY(hipStreamSynchronize(b->stream_enc));
+  RC_TRY(retire_groups(b));
+  std::string msgs;
+  for (int i = 0; i < n; ++i) {
+    const int s = stream_ids[i];
+    const bool failed = b->job[s].fault != 0;
+    const int st = report_chunk(b, s);
+    if (status) status[i] = st;
+    if (failed) msgs += (msgs.empty() ? "" : "; ") + std::string("stream ") + std::to_string(s) + ": " + b->fault_msg[s];
+  }
+  if (!msgs.empty()) sc_set_error("%s", msgs.c_str());
+  return SC_OK;
+}
+
+}  // namespace
+
 // One chunk step (Speech2TextStreaming.__call__ for raw audio, for the listed streams at once).
 // pcm[i] == NULL: the samples are already resident in the stream's device PCM buffer (sc_streams_pcm) behind
 // what it has received so far - only the count is taken.  status[i] (HOST out): 1 = the call produced output,
 // 0 = the reference's early `return []` (speech2text_streaming.py:432-433), < 0 = this stream failed
 // (SC_ERR_CAPACITY: a capacity limit; SC_ERR_INPUT: an input the reference itself raises on, A3) - it has been
-// reset, sc_last_error() holds the message, and every other stream of the call is decoded as if it had not been
-// there.  Returns SC_OK unless the call as a whole failed.
+// reset, sc_stream_last_error() holds its message (sc_last_error() all messages of the call), and every other stream
+// of the call is decoded as if it had not been there.  Returns SC_OK unless the call as a whole failed.
 extern "C" int sc_push(sc_streams *b, const int *stream_ids, const float *const *pcm, const int *n_samples,
                        const uint8_t *is_final, int n, int *status) {
   SC_CHECK_ARG(b && stream_ids && n_samples && is_final && n >= 0, "null");
-  HIP_TRY(hipSetDevice(b->eng->device));
-  std::vector<Chunk> chunks;
-  std::vector<int> pos;   // index in the caller's arrays
-  for (int i = 0; i < n; ++i) {
-    SC_CHECK_ARG(stream_ids[i] >= 0 && stream_ids[i] < b->S && n_samples[i] >= 0, "stream id / sample count out of range");
-    chunks.push_back({stream_ids[i], pcm ? pcm[i] : nullptr, n_samples[i], is_final[i] != 0});
-    pos.push_back(i);
-    if (status) status[i] = 0;
-  }
-  b->arena_off = 0;
-  std::vector<StreamFault> faults;
-  std::map<int, int> feat_new;
-  std::map<int, bool> finals;
-  std::vector<int> has_out, t_old;
-  while (true) {
-    for (auto &ch : chunks) {   // compaction moves device data: settle it before the snapshot
-      St &st = b->st[ch.s];
-      if (st.pcm_end + ch.n > b->PCAP) RC_TRY(compact_pcm(b, ch.s));
-    }
-    std::vector<St> snap = b->st;
-    feat_new.clear();
-    finals.clear();
-    has_out.assign(chunks.size(), 0);
-    try {
-      b->es = b->stream_enc ? b->stream_enc : b->stream;   // (the PCM chunks are copied on the encoder's stream)
-      const int rc_enc = stage_encode(b, chunks, feat_new, finals, has_out);
-      b->es = b->stream;
-      if (rc_enc != SC_OK) return rc_enc;
-      if (!b->stream_enc) RC_TRY(launch_encoder(b));        // one stream: encoder first, as the reference does
-      t_old.assign(b->S, 0);
-      for (int s = 0; s < b->S; ++s) t_old[s] = snap[s].T_enc;
-      break;
-    } catch (const StreamFault &f) {
-      b->es = b->stream;
-      b->st = snap;   // planning is pure host work that precedes every launch: undo = restore the mirrors
-      b->arena_off = 0;
-      faults.push_back(f);
-      for (size_t k = 0; k < chunks.size(); ++k)
-        if (chunks[k].s == f.stream) {
-          chunks.erase(chunks.begin() + k);
-          pos.erase(pos.begin() + k);
-          break;
-        }
-      if (chunks.empty()) break;
-    }
-  }
-  if (!chunks.empty()) RC_TRY(stage_decode(b, feat_new, finals, faults, &t_old));
-  RC_TRY(launch_encoder(b));   // (if no decode iteration got to it)
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  if (b->stream_enc) HIP_TRY(hipStreamSynchronize(b->stream_enc));
-  b->enc_pending = false;
-  if (status)
-    for (size_t k = 0; k < chunks.size(); ++k) status[pos[k]] = has_out[k];
-  for (auto &f : faults) {
-    reset_stream(b, f.stream);
-    sc_set_error("stream %d: %s", f.stream, f.msg.c_str());
-    if (status)
-      for (int i = 0; i < n; ++i)
-        if (stream_ids[i] == f.stream) status[i] = f.code;
-  }
-  return SC_OK;
-}
-
-// live hypotheses of a stream, best first: ids / xpos [nbest][max_len] (row-major, caller-allocated), lens[nbest],
-// scores / score_dec / score_ctc [nbest] (any of them may be NULL).  Returns the number of hypotheses written
-// (<= nbest), or a negative error.
-extern "C" int sc_get_hyps(sc_streams *b, int stream, int nbest, int max_len, int32_t *ids, int32_t *xpos, int *lens,
-                           double *scores, double *score_dec, double *score_ctc) {
-  SC_CHECK_ARG(b && stream >= 0 && stream < b->S && nbest >= 0 && max_len >= 0, "bad arguments");
-  const St &st = b->st[stream];
-  if (!st.started) return 0;
-  const int n = std::min(nbest, st.nhyp), L = st.L;
-  SC_CHECK_ARG(ids == nullptr || max_len >= L, "max_len is smaller than the hypotheses");
-  const sc_search &sb = b->sb;
-  const size_t o = ((size_t)st.cur * b->S + stream) * b->W;
-  for (int i = 0; i < n; ++i) {
-    if (ids) HIP_TRY(hipMemcpy(ids + (size_t)i * max_len, sb.yseq + (o + i) * b->LCAP, (size_t)L * 4, hipMemcpyDeviceToHost));
-    if (xpos) HIP_TRY(hipMemcpy(xpos + (size_t)i * max_len, sb.xpos + (o + i) * b->LCAP, (size_t)L * 4, hipMemcpyDeviceToHost));
-    if (lens) lens[i] = L;
-  }
-  if (scores && n) HIP_TRY(hipMemcpy(scores, sb.score + o, (size_t)n * 8, hipMemcpyDeviceToHost));
-  if (score_dec && n) HIP_TRY(hipMemcpy(score_dec, sb.sc_dec + o, (size_t)n * 8, hipMemcpyDeviceToHost));
-  if (score_ctc && n) HIP_TRY(hipMemcpy(score_ctc, sb.sc_ctc + o, (size_t)n * 8, hipMemcpyDeviceToHost));
-  return n;
+  SC_API_BEGIN
+  return push_impl(b, stream_ids, pcm, n_samples, is_final, n, status, false, "sc_push");
+  SC_API_END
 }
 
 // 2-D (T, n_mels) already-normalised features instead of PCM (the reference's 2-D / 3-D input path,
@@ -1382,69 +1668,154 @@ extern "C" int sc_get_hyps(sc_streams *b, int stream, int nbest, int max_len, in
 extern "C" int sc_push_features(sc_streams *b, const int *stream_ids, const float *const *feats, const int *n_frames,
                                 const uint8_t *is_final, int n, int *status) {
   SC_CHECK_ARG(b && stream_ids && feats && n_frames && is_final && n >= 0, "null");
-  HIP_TRY(hipSetDevice(b->eng->device));
-  const sc_config &c = b->cfg;
-  struct Item { int s; const float *f; int n; bool fin; int pos; };
-  std::vector<Item> items;
-  for (int i = 0; i < n; ++i) {
-    SC_CHECK_ARG(stream_ids[i] >= 0 && stream_ids[i] < b->S && n_frames[i] >= 0 && feats[i], "bad item");
-    items.push_back({stream_ids[i], feats[i], n_frames[i], is_final[i] != 0, i});
-    if (status) status[i] = 0;
+  for (int i = 0; i < n; ++i) SC_CHECK_ARG(feats[i] || n_frames[i] == 0, "null feature matrix");
+  SC_API_BEGIN
+  return push_impl(b, stream_ids, feats, n_frames, is_final, n, status, true, "sc_push_features");
+  SC_API_END
+}
+
+// Continuous batching, part 1: hand the engine one chunk for each listed stream and return at once.  The chunks are
+// copied (the caller may free them), planned and their encoder stage is issued as ONE group; decoding happens inside
+// sc_poll.  A stream has at most one chunk outstanding: submit its next chunk after sc_poll has reported this one
+// (the reference's session loop is call -> result -> next call, speechcatcher_server.py:359-397).
+extern "C" int sc_submit(sc_streams *b, const int *stream_ids, const float *const *pcm, const int *n_samples,
+                         const uint8_t *is_final, int n) {
+  SC_CHECK_ARG(b && stream_ids && n_samples && is_final && n >= 0, "null");
+  SC_API_BEGIN
+  if (b->poisoned) {
+    sc_set_error("sc_submit: the handle was left inconsistent by an earlier failed call; destroy it");
+    return SC_ERR_LAUNCH;
   }
-  b->arena_off = 0;
-  std::vector<StreamFault> faults;
-  std::map<int, int> feat_new;
-  std::map<int, bool> finals;
-  while (!items.empty()) {
-    std::vector<St> snap = b->st;
-    feat_new.clear();
-    finals.clear();
-    try {
-      for (auto &it : items) {   // capacity of every item BEFORE anything is copied
-        const St &st = b->st[it.s];
-        const int nbuf = st.enc_started ? st.nfeat : 0;
-        if (it.n > b->max_feat_new || nbuf + it.n > b->FCAP)
-          throw StreamFault{it.s, SC_ERR_CAPACITY, "feature frames of one call exceed the batch's capacity (max_chunk_samples)"};
+  HIP_TRY(hipSetDevice(b->eng->device));
+  RC_TRY(check_chunks(b, stream_ids, n_samples, n, "sc_submit"));
+  if (n == 0) return SC_OK;
+  std::vector<Chunk> chunks;
+  for (int i = 0; i < n; ++i) chunks.push_back({stream_ids[i], pcm ? pcm[i] : nullptr, n_samples[i], is_final[i] != 0, i});
+  const int rc = admit(b, chunks, false, /*launch_now=*/true, nullptr);
+  return rc == SC_OK ? SC_OK : poison(b, rc);
+  SC_API_END
+}
+
+// Continuous batching, part 2: run the engine (decode ticks over every stream that is inside a block) until at least
+// min_done outstanding chunks are complete - or none is outstanding - and report up to max_done of them:
+// done_ids[i] = stream, status[i] as in sc_push.  Returns the number reported (0: nothing outstanding), < 0 on error.
+// The hypotheses of a reported stream are those of ITS call (sc_get_hyps / sc_get_hyps_batch) until its next chunk
+// is submitted.  min_done <= 0: report what is complete now without running a tick.
+extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids, int *status) {
+  SC_CHECK_ARG(b && done_ids && max_done > 0, "bad arguments");
+  SC_API_BEGIN
+  if (b->poisoned) {
+    sc_set_error("sc_poll: the handle was left inconsistent by an earlier failed call; destroy it");
+    return SC_ERR_LAUNCH;
+  }
+  HIP_TRY(hipSetDevice(b->eng->device));
+  min_done = std::min(std::min(min_done, max_done), b->n_open);
+  while (true) {
+    int rc = retire_groups(b);
+    if (rc != SC_OK) return poison(b, rc);
+    int n_complete = 0;
+    for (int s = 0; s < b->S; ++s) n_complete += chunk_complete(b, s) ? 1 : 0;
+    if (n_complete >= min_done || b->n_open == 0) break;
+    bool progress = false;
+    rc = engine_tick(b, &progress);
+    if (rc != SC_OK) return poison(b, rc);
+    if (!progress) {
+      // everything is decoded: the missing completions are encoder stages still running
+      long wait_gen = 0;
+      for (int s = 0; s < b->S; ++s)
+        if (b->job[s].open && !b->job[s].fault && chunk_decoded(b, s) && b->job[s].gen > b->gen_done &&
+            (wait_gen == 0 || b->job[s].gen < wait_gen))
+          wait_gen = b->job[s].gen;
+      if (!wait_gen) {
+        sc_set_error("sc_poll: schedule stalled (internal error)");
+        return poison(b, SC_ERR_LAUNCH);
       }
-      EncPlan P;
-      std::vector<int> enc_streams;
-      std::vector<std::pair<const Item *, size_t>> copies;
-      for (auto &it : items) {
-        St &st = b->st[it.s];
-        const int nbuf = st.enc_started ? st.nfeat : 0;
-        copies.push_back({&it, ((size_t)(st.fpp * b->S + it.s) * b->FCAP + nbuf) * c.n_mels});
-        feat_new[it.s] = it.n;
-        finals[it.s] = it.fin;
-        st.started = true;
-        if (it.n >= 3) enc_streams.push_back(it.s);
-      }
-      if (!enc_streams.empty()) encode_plan(b, enc_streams, feat_new, finals, P);
-      for (auto &cp : copies)   // appended rows only
-        if (cp.first->n > 0)
-          HIP_TRY(hipMemcpyAsync(b->featbuf + cp.second, cp.first->f, (size_t)cp.first->n * c.n_mels * sizeof(float),
-                                 hipMemcpyHostToDevice, b->stream));
-      if (P.n_conv) RC_TRY(encode_launch(b, P));
-      break;
-    } catch (const StreamFault &f) {
-      b->st = snap;
-      b->arena_off = 0;
-      faults.push_back(f);
-      for (size_t k = 0; k < items.size(); ++k)
-        if (items[k].s == f.stream) { items.erase(items.begin() + k); break; }
+      rc = launch_pending_groups(b);
+      if (rc == SC_OK) rc = wait_group(b, wait_gen);
+      if (rc != SC_OK) return poison(b, rc);
     }
   }
-  if (!items.empty()) RC_TRY(stage_decode(b, feat_new, finals, faults));
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  if (status)
-    for (auto &it : items) status[it.pos] = 1;
-  for (auto &f : faults) {
-    reset_stream(b, f.stream);
-    sc_set_error("stream %d: %s", f.stream, f.msg.c_str());
-    if (status)
-      for (int i = 0; i < n; ++i)
-        if (stream_ids[i] == f.stream) status[i] = f.code;
+  int n = 0;
+  for (int s = 0; s < b->S && n < max_done; ++s)
+    if (chunk_complete(b, s)) {
+      done_ids[n] = s;
+      const int st = report_chunk(b, s);
+      if (status) status[n] = st;
+      ++n;
+    }
+  return n;
+  SC_API_END
+}
+
+extern "C" int sc_streams_outstanding(const sc_streams *b) { return b ? b->n_open : 0; }
+
+// message of the last failure of this stream (status < 0 from sc_push / sc_poll), "" if none; valid until the
+// stream fails again or the handle is destroyed
+extern "C" const char *sc_stream_last_error(const sc_streams *b, int stream) {
+  if (!b || stream < 0 || stream >= b->S) return "";
+  return b->fault_msg[stream].c_str();
+}
+
+// live hypotheses of a stream, best first: ids / xpos [nbest][max_len] (row-major, caller-allocated), lens[nbest],
+// scores / score_dec / score_ctc [nbest] (any of them may be NULL).  Returns the number of hypotheses written
+// (<= nbest), or a negative error.
+extern "C" int sc_get_hyps(sc_streams *b, int stream, int nbest, int max_len, int32_t *ids, int32_t *xpos, int *lens,
+                           double *scores, double *score_dec, double *score_ctc) {
+  SC_CHECK_ARG(b && stream >= 0 && stream < b->S, "bad arguments");
+  int nh = 0;
+  const int rc = sc_get_hyps_batch(b, &stream, 1, nbest, max_len, ids, xpos, lens, &nh, scores, score_dec, score_ctc);
+  return rc == SC_OK ? nh : rc;
+}
+
+// The same for n streams with ONE pack launch and ONE device-to-host copy (into pinned memory): ids / xpos
+// [n][nbest][max_len], lens / scores / score_dec / score_ctc [n][nbest], n_hyps [n] (any output may be NULL except
+// n_hyps).  What Speech2TextStreaming.__call__ returns for a batch of sessions (speech2text_streaming.py:466-539:
+// every running hypothesis with yseq, xpos, score, scores{decoder, ctc}).
+extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, int nbest, int max_len, int32_t *ids,
+                                 int32_t *xpos, int *lens, int *n_hyps, double *scores, double *score_dec,
+                                 double *score_ctc) {
+  SC_CHECK_ARG(b && stream_ids && n_hyps && n >= 0 && nbest >= 0 && max_len >= 0, "bad arguments");
+  SC_API_BEGIN
+  HIP_TRY(hipSetDevice(b->eng->device));
+  std::vector<int32_t> jobs;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const int s = stream_ids[i];
+    SC_CHECK_ARG(s >= 0 && s < b->S, "stream out of range");
+    SC_CHECK_ARG(!b->run[s].inblk && b->bq[s].empty(), "stream is inside a decode block (its chunk has not been reported yet)");
+    const St &st = b->st[s];
+    const int nh = st.started ? std::min(nbest, st.nhyp) : 0;
+    n_hyps[i] = nh;
+    SC_CHECK_ARG(nh == 0 || (!ids && !xpos) || max_len >= st.L, "max_len is smaller than the hypotheses");
+    for (int h = 0; h < nh; ++h) {
+      jobs.insert(jobs.end(), {(int32_t)(((size_t)st.cur * b->S + s) * b->W + h), st.L, (int32_t)off, 0});
+      off += (size_t)((2 * st.L + 1) & ~1) + 6;
+    }
   }
+  const int m = (int)jobs.size() / 4;
+  if (m == 0) return SC_OK;
+  SC_CHECK_ARG(off <= b->pack_cap, "hypotheses exceed the read-back buffer");
+  memcpy(b->pjobs_host, jobs.data(), jobs.size() * sizeof(int32_t));
+  HIP_TRY(hipMemcpyAsync(b->pjobs_dev, b->pjobs_host, jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  pack_hyps_kernel<<<m, 128, 0, b->stream>>>(b->sb, b->pjobs_dev, b->pack_dev);
+  HIP_TRY(hipMemcpyAsync(b->pack_host, b->pack_dev, off * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    for (int h = 0; h < n_hyps[i]; ++h, ++k) {
+      const int L = jobs[k * 4 + 1];
+      const int32_t *src = b->pack_host + jobs[k * 4 + 2];
+      const size_t o = (size_t)i * nbest + h;
+      if (ids) memcpy(ids + o * max_len, src, (size_t)L * 4);
+      if (xpos) memcpy(xpos + o * max_len, src + L, (size_t)L * 4);
+      if (lens) lens[o] = L;
+      const double *sc = (const double *)(src + ((2 * L + 1) & ~1));
+      if (scores) scores[o] = sc[0];
+      if (score_dec) score_dec[o] = sc[1];
+      if (score_ctc) score_ctc[o] = sc[2];
+    }
   return SC_OK;
+  SC_API_END
 }
 
 // host <-> device copies of a stream's PCM ring and encoder output (tests, bench preload, the drop-in class's
@@ -1529,19 +1900,6 @@ extern "C" int sc_streams_host_times(sc_streams *b, double *launch_s, double *wa
   return SC_OK;
 }
 
-// decode iterations enqueued ahead of their predecessor's stop flags, and how many of those found every stream stopped
-extern "C" int sc_streams_speculation(const sc_streams *b, long *launched, long *wasted) {
-  SC_CHECK_ARG(b, "null");
-  if (launched) *launched = b->spec_launched;
-  if (wasted) *wasted = b->spec_wasted;
-  return SC_OK;
-}
-extern "C" int sc_streams_set_speculation(sc_streams *b, int on) {
-  SC_CHECK_ARG(b, "null");
-  b->speculate = on != 0;   // the decode graphs of the other mode stay cached (graph_key)
-  return SC_OK;
-}
-
 extern "C" int sc_streams_stats(const sc_streams *b, long *enc_calls, long *dec_steps, long *dec_blocks) {
   SC_CHECK_ARG(b, "null");
   if (enc_calls) *enc_calls = b->enc_calls;
@@ -1549,3 +1907,4 @@ extern "C" int sc_streams_stats(const sc_streams *b, long *enc_calls, long *dec_
   if (dec_blocks) *dec_blocks = b->dec_blocks;
   return SC_OK;
 }
+

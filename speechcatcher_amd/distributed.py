@@ -1,7 +1,8 @@
 """Multi-GPU layer of the hot path: streams are independent, so they are
 sharded across ranks (one process per GPU, torch.distributed; backend "nccl"
 is RCCL over xGMI on ROCm) with NO collective in the hot loop.  The only
-exchange of the path is the gather of final token ids at utterance end
+exchange of the path is the gather of the final text (token ids + their
+encoder-frame positions + length + score per stream) at utterance end
 (the reference's equivalent is its per-segment process
 pool, speechcatcher/speechcatcher.py:474-497)."""
 from typing import List, Sequence, Tuple
@@ -17,46 +18,53 @@ def shard_streams(n_streams_total: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
-def pack_hypotheses(hyps: Sequence[Sequence[int]], scores: Sequence[float], max_len: int,
-                    device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Token ids of the best hypothesis of every local stream -> fixed-shape
-    tensors (ids [n, max_len] int32 padded with -1 + length in column 0 of a
-    second tensor, score float64) that a collective can move."""
-    n = len(hyps)
-    ids = torch.full((n, max_len + 1), -1, dtype=torch.int32)
-    for i, h in enumerate(hyps):
-        h = list(h)[:max_len]
-        ids[i, 0] = len(h)
+def pack_hypotheses(ids: Sequence[Sequence[int]], xpos: Sequence[Sequence[int]], scores: Sequence[float], max_len: int,
+                    device) -> torch.Tensor:
+    """Best hypothesis of every local stream -> ONE fixed-shape int32 tensor [n, 3 + 2*max_len] that a collective can
+    move - the payload of SURVEY 8(e): row = [len, score (float64 bits, 2 words), ids[max_len], xpos[max_len]]
+    (token ids and their encoder-frame positions, padded with -1; the positions are the token timestamps,
+    frame / 24 s: speechcatcher.py:48,522)."""
+    n = len(ids)
+    out = torch.full((n, 3 + 2 * max_len), -1, dtype=torch.int32)
+    sc = torch.tensor([float(x) for x in scores], dtype=torch.float64).view(torch.int32).reshape(n, 2) if n else \
+        torch.zeros((0, 2), dtype=torch.int32)
+    out[:, 1:3] = sc
+    for i in range(n):
+        h = [int(t) for t in ids[i]][:max_len]
+        x = [int(t) for t in xpos[i]][:max_len]
+        assert len(h) == len(x), "every token carries a position"
+        out[i, 0] = len(h)
         if h:
-            ids[i, 1:1 + len(h)] = torch.tensor(h, dtype=torch.int32)
-    sc = torch.tensor(list(scores), dtype=torch.float64)
-    return ids.to(device), sc.to(device)
+            out[i, 3:3 + len(h)] = torch.tensor(h, dtype=torch.int32)
+            out[i, 3 + max_len:3 + max_len + len(h)] = torch.tensor(x, dtype=torch.int32)
+    return out.to(device)
 
 
-def gather_final_hypotheses(ids: torch.Tensor, scores: torch.Tensor, n_local_max: int, group=None):
-    """all_gather of the (padded) per-rank results.  Every rank passes tensors
-    of the same shape [n_local_max, L+1] / [n_local_max] (pad rows with
-    length 0).  Returns per global rank the list of (token ids, score)."""
+def unpack_hypotheses(payload: torch.Tensor) -> List[Tuple[List[int], List[int], float]]:
+    """rows of pack_hypotheses -> (token ids, positions, score) per stream (rows with length 0: padding)"""
+    a = payload.cpu()
+    max_len = (a.shape[1] - 3) // 2
+    sc = a[:, 1:3].contiguous().view(torch.float64).reshape(-1)
+    rows = []
+    for i in range(a.shape[0]):
+        n = int(a[i, 0])
+        rows.append((a[i, 3:3 + n].tolist(), a[i, 3 + max_len:3 + max_len + n].tolist(), float(sc[i])))
+    return rows
+
+
+def gather_final_hypotheses(payload: torch.Tensor, n_local_max: int, group=None):
+    """The path's ONE collective: all_gather of the per-rank payloads (RCCL over xGMI with backend "nccl").  Every
+    rank passes [n_local, 3 + 2L]; rows are padded to n_local_max (length 0).  Returns per global rank the list of
+    (token ids, positions, score)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if ids.shape[0] < n_local_max:
-        pad = torch.full((n_local_max - ids.shape[0], ids.shape[1]), -1, dtype=ids.dtype, device=ids.device)
-        pad[:, 0] = 0
-        ids = torch.cat([ids, pad], 0)
-        scores = torch.cat([scores, torch.zeros(n_local_max - scores.shape[0], dtype=scores.dtype, device=scores.device)])
-    out_ids = [torch.empty_like(ids) for _ in range(world)]
-    out_sc = [torch.empty_like(scores) for _ in range(world)]
-    dist.all_gather(out_ids, ids, group=group)
-    dist.all_gather(out_sc, scores, group=group)
-    res: List[List[Tuple[List[int], float]]] = []
-    for r in range(world):
-        rows = []
-        a, s = out_ids[r].cpu(), out_sc[r].cpu()
-        for i in range(a.shape[0]):
-            n = int(a[i, 0])
-            rows.append((a[i, 1:1 + n].tolist(), float(s[i])))
-        res.append(rows)
-    return res
+    if payload.shape[0] < n_local_max:
+        pad = torch.full((n_local_max - payload.shape[0], payload.shape[1]), -1, dtype=payload.dtype, device=payload.device)
+        pad[:, 0:3] = 0
+        payload = torch.cat([payload, pad], 0)
+    out = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(out, payload.contiguous(), group=group)
+    return [unpack_hypotheses(t) for t in out]
 
 
 def max_over_ranks(value: float, device, group=None) -> float:

@@ -1,10 +1,11 @@
-"""The stream-level C ABI of libscasr.so (include/scasr.h: sc_engine_* / sc_streams_* / sc_push / sc_get_hyps /
-sc_reset) behind the interface of ``engine.StreamBatch``: the whole state machine of the decoder - frontend and
+"""The stream-level C ABI of libscasr.so (include/scasr.h: sc_engine_* / sc_streams_* / sc_push / sc_submit / sc_poll /
+sc_get_hyps_batch / sc_reset) behind the interface of ``engine.StreamBatch``: the whole state machine of the decoder - frontend and
 encoder buffering, block schedule, beam-search step loop - runs in C++ (csrc/streams.hip); this file only
 marshals arguments.  It is what ``Speech2TextStreaming`` / ``load_model`` / the scheduler use on a GPU.
 
 ``engine.StreamBatch`` is the same host logic in Python; it stays as the executable specification that runs on the
-CPU spec backend against the reference fixtures (and as the home of the opt-in deferred-stragglers mode).
+CPU spec backend against the reference fixtures.  Continuous batching (a stream's reply is ready when ITS blocks
+are done, early streams start their next chunk while stragglers finish) is ``submit`` / ``poll`` here.
 """
 import ctypes as C
 from typing import Optional, Sequence, Tuple
@@ -133,43 +134,39 @@ class NativeStreamBatch:
     def stats(self):
         a, b, c = C.c_long(), C.c_long(), C.c_long()
         self.lib.sc_streams_stats(self.handle, C.byref(a), C.byref(b), C.byref(c))
-        d, e = C.c_long(), C.c_long()
-        self.lib.sc_streams_speculation(self.handle, C.byref(d), C.byref(e))
-        return {"enc_calls": a.value, "dec_steps": b.value, "dec_blocks": c.value,
-                "spec_launched": d.value, "spec_wasted": e.value}
+        return {"enc_calls": a.value, "dec_steps": b.value, "dec_blocks": c.value}
 
-    def set_speculation(self, on: bool):
-        """decode iterations enqueued ahead of their predecessor's stop flags (default on; results identical)"""
-        _abi.check(self.lib.sc_streams_set_speculation(self.handle, 1 if on else 0), "sc_streams_set_speculation")
+    def _fault(self, s, code):
+        msg = (self.lib.sc_stream_last_error(self.handle, int(s)) or b"").decode()
+        return (RuntimeError if code == _ERR_INPUT else EngineError)(f"stream {s}: {msg}")
+
+    @staticmethod
+    def _marshal(ids, ptrs, counts, finals):
+        n = len(ids)
+        return ((C.c_int32 * n)(*ids), (C.c_void_p * n)(*ptrs), (C.c_int32 * n)(*counts),
+                (C.c_uint8 * n)(*[1 if f else 0 for f in finals]))
 
     def _call(self, fn, ids, ptrs, counts, finals, keep, isolate_faults):
         n = len(ids)
-        a_ids = (C.c_int32 * n)(*ids)
-        a_ptr = (C.c_void_p * n)(*ptrs)
-        a_cnt = (C.c_int32 * n)(*counts)
-        a_fin = (C.c_uint8 * n)(*[1 if f else 0 for f in finals])
+        a_ids, a_ptr, a_cnt, a_fin = self._marshal(ids, ptrs, counts, finals)
         status = (C.c_int32 * n)()
-        _abi.check(getattr(self.lib, fn)(self.handle, a_ids, a_ptr, a_cnt, a_fin, n, status), fn)
+        try:
+            _abi.check(getattr(self.lib, fn)(self.handle, a_ids, a_ptr, a_cnt, a_fin, n, status), fn)
+        except _abi.ScasrError as e:
+            raise EngineError(str(e)) from e
         del keep
         out = {}
         for i, s in enumerate(ids):
             if status[i] >= 0:
                 out[s] = bool(status[i])
                 continue
-            msg = (self.lib.sc_last_error() or b"").decode()
-            exc = (RuntimeError if status[i] == _ERR_INPUT else EngineError)(f"stream {s}: {msg}")
+            exc = self._fault(s, status[i])
             if not isolate_faults:
                 raise exc     # the other streams of the call were decoded; this one has been reset
             out[s] = exc
         return out
 
-    def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]], pcm_resident: bool = False,
-             prefetch=None, isolate_faults: bool = False):
-        """One chunk step: (stream, samples, is_final); with ``pcm_resident`` the tuple carries the sample COUNT
-        and the samples already sit in the device PCM ring (write_pcm).  Returns {stream: has_output}; a stream
-        that failed carries its exception instead when ``isolate_faults`` (else it is raised)."""
-        if prefetch is not None:
-            raise EngineError("prefetch is a mode of the Python engine")
+    def _gather(self, chunks, pcm_resident):
         ids, ptrs, counts, finals, keep = [], [], [], [], []
         for s, samples, fin in chunks:
             ids.append(int(s))
@@ -184,7 +181,88 @@ class NativeStreamBatch:
                 keep.append(a)
                 ptrs.append(a.ctypes.data)
                 counts.append(int(a.shape[0]))
+        return ids, ptrs, counts, finals, keep
+
+    def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]], pcm_resident: bool = False,
+             prefetch=None, isolate_faults: bool = False):
+        """One chunk step: (stream, samples, is_final); with ``pcm_resident`` the tuple carries the sample COUNT
+        and the samples already sit in the device PCM ring (write_pcm).  Returns {stream: has_output}; a stream
+        that failed carries its exception instead when ``isolate_faults`` (else it is raised)."""
+        if prefetch is not None:
+            raise EngineError("prefetch is a mode of the Python engine")
+        ids, ptrs, counts, finals, keep = self._gather(chunks, pcm_resident)
         return self._call("sc_push", ids, ptrs, counts, finals, keep, isolate_faults)
+
+    def push_block(self, stream_ids: np.ndarray, pcm: np.ndarray, finals: Optional[np.ndarray] = None) -> np.ndarray:
+        """sc_push for row i of a contiguous float32 matrix ``pcm`` [n, samples] -> stream ``stream_ids[i]`` without
+        per-chunk Python work (the batched callers: bench, scheduler).  Returns the int32 status array (sc_push)."""
+        n, m = pcm.shape
+        assert pcm.dtype == np.float32 and pcm.flags.c_contiguous and len(stream_ids) == n
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        ptrs = (pcm.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(m * 4)).astype(np.uint64)
+        cnt = np.full(n, m, np.int32)
+        fin = np.zeros(n, np.uint8) if finals is None else np.ascontiguousarray(finals, dtype=np.uint8)
+        status = np.zeros(n, np.int32)
+        _abi.check(self.lib.sc_push(self.handle, ids.ctypes.data_as(_abi.c_int_p), ptrs.ctypes.data_as(C.POINTER(C.c_void_p)),
+                                    cnt.ctypes.data_as(_abi.c_int_p), fin.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                    status.ctypes.data_as(_abi.c_int_p)), "sc_push")
+        return status
+
+    # ---- continuous batching (sc_submit / sc_poll) ---------------------------------------------------
+    def submit(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]], pcm_resident: bool = False):
+        """Hand the engine one chunk per listed stream and return at once (the chunks are copied); their frontend +
+        encoder stage is issued as one group.  A stream's next chunk may be submitted once ``poll`` has reported
+        this one."""
+        ids, ptrs, counts, finals, keep = self._gather(chunks, pcm_resident)
+        a_ids, a_ptr, a_cnt, a_fin = self._marshal(ids, ptrs, counts, finals)
+        try:
+            _abi.check(self.lib.sc_submit(self.handle, a_ids, a_ptr, a_cnt, a_fin, len(ids)), "sc_submit")
+        except _abi.ScasrError as e:
+            raise EngineError(str(e)) from e
+        del keep
+
+    def submit_block(self, stream_ids: np.ndarray, pcm: np.ndarray, finals: Optional[np.ndarray] = None):
+        n, m = pcm.shape
+        assert pcm.dtype == np.float32 and pcm.flags.c_contiguous and len(stream_ids) == n
+        ids = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        ptrs = (pcm.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(m * 4)).astype(np.uint64)
+        cnt = np.full(n, m, np.int32)
+        fin = np.zeros(n, np.uint8) if finals is None else np.ascontiguousarray(finals, dtype=np.uint8)
+        _abi.check(self.lib.sc_submit(self.handle, ids.ctypes.data_as(_abi.c_int_p), ptrs.ctypes.data_as(C.POINTER(C.c_void_p)),
+                                      cnt.ctypes.data_as(_abi.c_int_p), fin.ctypes.data_as(C.POINTER(C.c_uint8)), n), "sc_submit")
+
+    def poll(self, min_done: int = 1, isolate_faults: bool = True):
+        """Run the engine until at least ``min_done`` outstanding chunks are complete (or none is outstanding).
+        Returns {stream: has_output | exception} for the chunks reported by this call."""
+        ids = np.zeros(self.S, np.int32)
+        st = np.zeros(self.S, np.int32)
+        n = self.lib.sc_poll(self.handle, int(min_done), self.S, ids.ctypes.data_as(_abi.c_int_p), st.ctypes.data_as(_abi.c_int_p))
+        if n < 0:
+            _abi.check(n, "sc_poll")
+        out = {}
+        for i in range(n):
+            s = int(ids[i])
+            if st[i] >= 0:
+                out[s] = bool(st[i])
+            else:
+                exc = self._fault(s, int(st[i]))
+                if not isolate_faults:
+                    raise exc
+                out[s] = exc
+        return out
+
+    def poll_ids(self, min_done: int = 1):
+        """``poll`` without Python objects: (stream ids, statuses) as int32 arrays."""
+        ids = np.zeros(self.S, np.int32)
+        st = np.zeros(self.S, np.int32)
+        n = self.lib.sc_poll(self.handle, int(min_done), self.S, ids.ctypes.data_as(_abi.c_int_p), st.ctypes.data_as(_abi.c_int_p))
+        if n < 0:
+            _abi.check(n, "sc_poll")
+        return ids[:n], st[:n]
+
+    @property
+    def outstanding(self) -> int:
+        return int(self.lib.sc_streams_outstanding(self.handle))
 
     def push_features(self, items, isolate_faults: bool = False):
         ids, ptrs, counts, finals, keep = [], [], [], [], []
@@ -205,18 +283,42 @@ class NativeStreamBatch:
         for s in range(self.S):
             self.reset(s)
 
+    def hypotheses_arrays(self, streams: Sequence[int], nbest: Optional[int] = None):
+        """Live hypotheses of the listed streams with ONE device round trip (sc_get_hyps_batch): numpy arrays
+        ids / xpos [n, nbest, Lmax], lens / scores / score_dec / score_ctc [n, nbest], n_hyps [n]."""
+        nb = self.W if nbest is None else int(nbest)
+        sid = np.ascontiguousarray(streams, dtype=np.int32)
+        n = len(sid)
+        lmax = max([1] + [self.st[int(s)].L for s in sid]) if n <= 4 else self.LCAP
+        ids = np.zeros((n, nb, lmax), np.int32)
+        xp = np.zeros((n, nb, lmax), np.int32)
+        lens = np.zeros((n, nb), np.int32)
+        nh = np.zeros(n, np.int32)
+        sc, sd, scc = np.zeros((n, nb)), np.zeros((n, nb)), np.zeros((n, nb))
+        ip, dp = _abi.c_int_p, _abi.c_double_p
+        _abi.check(self.lib.sc_get_hyps_batch(self.handle, sid.ctypes.data_as(ip), n, nb, lmax, ids.ctypes.data_as(ip),
+                                              xp.ctypes.data_as(ip), lens.ctypes.data_as(ip), nh.ctypes.data_as(ip),
+                                              sc.ctypes.data_as(dp), sd.ctypes.data_as(dp), scc.ctypes.data_as(dp)),
+                   "sc_get_hyps_batch")
+        return {"ids": ids, "xpos": xp, "lens": lens, "n_hyps": nh, "score": sc, "score_dec": sd, "score_ctc": scc}
+
+    def hypotheses_batch(self, streams: Sequence[int], nbest: Optional[int] = None):
+        """{stream: [hypothesis dicts, best first]} for the listed streams, one device round trip for all."""
+        a = self.hypotheses_arrays(streams, nbest)
+        out = {}
+        for i, s in enumerate(streams):
+            hy = []
+            for j in range(int(a["n_hyps"][i])):
+                L = int(a["lens"][i, j])
+                hy.append({"yseq": a["ids"][i, j, :L].tolist(), "score": float(a["score"][i, j]),
+                           "score_dec": float(a["score_dec"][i, j]), "score_ctc": float(a["score_ctc"][i, j]),
+                           "xpos": a["xpos"][i, j, :L].tolist()})
+            out[int(s)] = hy
+        return out
+
     def hypotheses(self, s: int):
         """Live hypotheses of stream s: list of dicts (yseq, score, score_dec, score_ctc, xpos), best first."""
-        W, LC = self.W, self.LCAP
-        ids = (C.c_int32 * (W * LC))()
-        xp = (C.c_int32 * (W * LC))()
-        lens = (C.c_int32 * W)()
-        sc, sd, scc = (C.c_double * W)(), (C.c_double * W)(), (C.c_double * W)()
-        n = self.lib.sc_get_hyps(self.handle, int(s), W, LC, ids, xp, lens, sc, sd, scc)
-        if n < 0:
-            _abi.check(n, "sc_get_hyps")
-        return [{"yseq": list(ids[i * LC:i * LC + lens[i]]), "score": float(sc[i]), "score_dec": float(sd[i]),
-                 "score_ctc": float(scc[i]), "xpos": list(xp[i * LC:i * LC + lens[i]])} for i in range(n)]
+        return self.hypotheses_batch([int(s)])[int(s)]
 
     # ---- device-resident audio (bench) and the views of the drop-in class -------------------------------
     def write_pcm(self, s: int, offset: int, samples: np.ndarray):

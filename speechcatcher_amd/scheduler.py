@@ -21,6 +21,8 @@ import numpy as np
 from .engine import StreamBatch
 from .speech2text_streaming import hyps_to_results
 
+EOS_ID = 1023   # hard-coded in the reference's result assembly (speech2text_streaming.py:474,500: SURVEY A4)
+
 
 class ServerBusy(RuntimeError):
     """All stream slots are taken (the reference answers "Server busy",
@@ -45,6 +47,7 @@ class StreamScheduler:
         self._free: Deque[int] = deque(range(batch.S))
         self._slot_of: Dict[int, int] = {}
         self._queue: Dict[int, Deque[Tuple[np.ndarray, bool, bool]]] = {}
+        self._in_flight: Dict[int, Tuple[int, bool, bool]] = {}     # continuous batching: session -> (slot, final, finalize_all)
         self._next_sid = 0
 
     # ---- session lifecycle -------------------------------------------------
@@ -61,6 +64,8 @@ class StreamScheduler:
         return sid
 
     def close(self, sid: int):
+        while sid in self._in_flight:        # its chunk must be reported before the slot can be reset
+            self.pump(1)
         slot = self._slot_of.pop(sid)
         self._queue.pop(sid)
         if self.reset_on_open:
@@ -77,7 +82,43 @@ class StreamScheduler:
         self._queue[sid].append((np.asarray(pcm, dtype=np.float32), bool(is_final), bool(finalize_all)))
 
     def pending(self) -> int:
-        return sum(1 for q in self._queue.values() if q)
+        return sum(1 for sid, q in self._queue.items() if q or sid in self._in_flight)
+
+    def _take_queued(self, skip=()):
+        items, meta = [], {}
+        for sid, q in self._queue.items():
+            if q and sid not in skip:
+                pcm, fin, fa = q.popleft()
+                slot = self._slot_of[sid]
+                items.append((slot, pcm, fin))
+                meta[sid] = (slot, fin, fa)
+        return items, meta
+
+    def _results(self, has: dict, meta: Dict[int, Tuple[int, bool, bool]]) -> Dict[int, list]:
+        """replies of the sessions in `meta` ({session: (slot, is_final, finalize_all)}) whose engine call returned
+        `has[slot]`: ONE device round trip for the hypotheses of all of them (sc_get_hyps_batch)"""
+        out: Dict[int, list] = {}
+        want = [slot for (slot, _, _) in meta.values() if has[slot] is True]
+        arrays = hyps = None
+        if want:
+            if hasattr(self.batch, "hypotheses_arrays"):
+                arrays = self.batch.hypotheses_arrays(want)
+                row = {slot: i for i, slot in enumerate(want)}
+            else:
+                hyps = {slot: self.batch.hypotheses(slot) for slot in want}
+        for sid, (slot, fin, fa) in meta.items():
+            if isinstance(has[slot], Exception):
+                out[sid] = has[slot]          # the engine has reset the stream
+                continue
+            if not has[slot]:
+                out[sid] = []
+            elif arrays is not None:
+                out[sid] = hyps_to_results(_select_hyps(arrays, row[slot], fin, fa), fin, fa, self.token_list, self.result_format)
+            else:
+                out[sid] = hyps_to_results(hyps[slot], fin, fa, self.token_list, self.result_format)
+            if fin and self.reset_after_final:
+                self.batch.reset(slot)
+        return out
 
     def step(self) -> Dict[int, list]:
         """One batched chunk step over every session that has a chunk queued
@@ -91,39 +132,63 @@ class StreamScheduler:
         EXCEPTION OBJECT as its result and its stream is reset; the other sessions of the step
         are decoded as if it had not been there (in the reference an exception ends only that
         client's handler: every client owns a model instance)."""
-        items, meta = [], {}
-        for sid, q in self._queue.items():
-            if q:
-                pcm, fin, fa = q.popleft()
-                slot = self._slot_of[sid]
-                items.append((slot, pcm, fin))
-                meta[sid] = (slot, fin, fa)
+        items, meta = self._take_queued()
         if not items:
             return {}
         has = self.batch.push(items, isolate_faults=True)
-        out = {}
-        for sid, (slot, fin, fa) in meta.items():
-            if isinstance(has[slot], Exception):
-                out[sid] = has[slot]          # the engine has reset the stream
-                continue
-            if not has[slot]:
-                out[sid] = []
-            else:
-                out[sid] = hyps_to_results(self.batch.hypotheses(slot), fin, fa, self.token_list,
-                                           self.result_format)
-            if fin and self.reset_after_final:
-                self.batch.reset(slot)
-        return out
+        return self._results(has, meta)
+
+    # ---- continuous batching ------------------------------------------------------
+    def pump(self, min_done: int = 1) -> Dict[int, list]:
+        """Continuous batching (C++ engine: sc_submit / sc_poll).  Hands the engine the next queued chunk of every
+        session that has none in flight - ONE admission group - and then lets it decode until at least ``min_done``
+        replies are ready.  A session's reply is delivered when ITS decode blocks are done: sessions that finish
+        early are fed again by the next pump() while the stragglers of this group are still decoding, so the streams
+        leave lock-step and every decode iteration runs with (nearly) all of them.  Per session the calls and their
+        results are those of ``step()`` (the reference's session loop: call, reply, next call -
+        speechcatcher_server.py:359-397).  Returns {session: results} of the replies that became ready."""
+        if not hasattr(self.batch, "submit"):
+            return self.step()                      # the Python engine has no resumable decode loop any more
+        items, meta = self._take_queued(skip=self._in_flight)
+        if items:
+            self.batch.submit(items)
+            for sid, m in meta.items():
+                self._in_flight[sid] = m
+        if not self._in_flight:
+            return {}
+        has = self.batch.poll(max(1, min(min_done, len(self._in_flight))), isolate_faults=True)
+        sid_of = {m[0]: sid for sid, m in self._in_flight.items()}
+        done = {sid_of[slot]: self._in_flight.pop(sid_of[slot]) for slot in has}
+        return self._results(has, done)
+
+    @property
+    def n_in_flight(self) -> int:
+        return len(self._in_flight)
 
     def drain(self) -> Dict[int, list]:
         """Run steps until every queue is empty; returns the LAST result of each session."""
         last: Dict[int, list] = {}
         while self.pending():
-            for sid, res in self.step().items():
+            for sid, res in (self.pump() if self._in_flight else self.step()).items():
                 if isinstance(res, Exception):
                     raise res
                 last[sid] = res
         return last
+
+
+def _select_hyps(a: dict, i: int, is_final: bool, finalize_all: bool) -> List[dict]:
+    """hypothesis dicts of row i of ``hypotheses_arrays`` - only those the reference's result assembly looks at
+    (speech2text_streaming.py:469-476: without finalize_all only hypotheses that end in <eos>), so that a partial
+    reply does not turn W x L token ids into Python lists"""
+    out = []
+    for j in range(int(a["n_hyps"][i])):
+        L = int(a["lens"][i, j])
+        if not (is_final and finalize_all) and int(a["ids"][i, j, L - 1]) != EOS_ID:
+            continue
+        out.append({"yseq": a["ids"][i, j, :L].tolist(), "score": float(a["score"][i, j]),
+                    "score_dec": float(a["score_dec"][i, j]), "score_ctc": float(a["score_ctc"][i, j]),
+                    "xpos": a["xpos"][i, j, :L].tolist()})
+    return out
 
 
 def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tuple[int, int]],

@@ -103,13 +103,19 @@ class ServerLoop:
     """Sessions of all connected clients over one ``StreamScheduler``."""
 
     def __init__(self, scheduler: StreamScheduler, vosk_output_format: bool = False,
-                 finalize_update_iters: int = 6, max_partial_iters: int = 42, strict_reference: bool = False):
+                 finalize_update_iters: int = 6, max_partial_iters: int = 42, strict_reference: bool = False,
+                 continuous: bool = False, min_replies: int = 1):
         """``strict_reference``: no stream reset after a finalised utterance nor between clients, exactly like
-        ``recognize_ws`` / ``process_audio_chunk`` (speechcatcher_server.py:270,359-397); the default resets."""
+        ``recognize_ws`` / ``process_audio_chunk`` (speechcatcher_server.py:270,359-397); the default resets.
+        ``continuous``: a step hands the engine the chunks of the sessions that are ready and returns as soon as
+        ``min_replies`` replies are (``StreamScheduler.pump``): every client is answered when ITS chunk is decoded
+        and may send the next one at once, instead of all clients waiting for the slowest stream of a batch -
+        the reference's per-client handler loop (:359-397), same calls and replies per session."""
         assert scheduler.result_format == "espnet", "sessions need token positions: result_format='espnet'"
         if strict_reference:
             scheduler.reset_after_final = scheduler.reset_on_open = False
         self.sch = scheduler
+        self.continuous, self.min_replies = continuous, min_replies
         self.vosk = vosk_output_format
         self.fui, self.mpi = finalize_update_iters, max_partial_iters
         self.sessions: Dict[int, _Session] = {}
@@ -147,7 +153,7 @@ class ServerLoop:
                     continue
                 if immediate is not None:
                     replies.setdefault(ses.sid, []).append(self._reply(ses, immediate))
-        for sid, results in self.sch.step().items():
+        for sid, results in (self.sch.pump(self.min_replies) if self.continuous else self.sch.step()).items():
             ses = self.sessions[sid]
             if isinstance(results, Exception):
                 # the client's handler dies with the exception in the reference (recognize_ws has no except for

@@ -36,9 +36,9 @@ def _worker(rank, world, port, n_total, ret):
         end = min(pos + 10240, n)
         sb.push([(i, synth.synth_audio(100 + g, n)[pos:end], end >= n) for i, g in enumerate(mine)])
     hyps = [sb.hypotheses(i)[0] for i in range(len(mine))]
-    ids, sc = pack_hypotheses([h["yseq"] for h in hyps], [h["score"] for h in hyps], 256, "cpu")
+    payload = pack_hypotheses([h["yseq"] for h in hyps], [h["xpos"] for h in hyps], [h["score"] for h in hyps], 256, "cpu")
     n_max = -(-n_total // world)
-    allres = gather_final_hypotheses(ids, sc, n_max)
+    allres = gather_final_hypotheses(payload, n_max)
     t = max_over_ranks(float(rank + 1), "cpu")
     dist.barrier()
     dist.destroy_process_group()
@@ -70,5 +70,5 @@ def test_two_rank_sharding_and_gather():
         sb.push([(g, synth.synth_audio(100 + g, n)[pos:end], end >= n) for g in range(n_total)])
     for g in range(n_total):
         h = sb.hypotheses(g)[0]
-        assert flat[g][0] == h["yseq"]
-        assert abs(flat[g][1] - h["score"]) < 1e-4   # batch size changes the CPU GEMM blocking
+        assert flat[g][0] == h["yseq"] and flat[g][1] == h["xpos"]   # ids and their token timestamps (frame positions)
+        assert abs(flat[g][2] - h["score"]) < 1e-4   # batch size changes the CPU GEMM blocking

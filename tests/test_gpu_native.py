@@ -90,17 +90,20 @@ def test_native_capacity_faults_are_isolated():
 
 def test_native_batch_of_distinct_streams_equals_one_by_one():
     """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
-    head-parallel and six-launch layer forms by bucket size, decode iterations enqueued ahead of their predecessor's
-    stop flags) = every stream alone (never speculated: one live stream) = the batch with the speculation off."""
+    head-parallel and six-launch layer forms by bucket size) = every stream alone = the same streams served by
+    CONTINUOUS BATCHING (sc_submit / sc_poll: every stream gets its next chunk as soon as its previous one is
+    reported, so the streams desynchronise and blocks of different chunk steps share decode iterations)."""
     from test_engine_spec import make_batch
     S, chunk, beam = 32, 10240, 5
     lens = [chunk * (2 + (i * 7) % 5) + (i * 1234) % 4000 for i in range(S)]
     audio = [synth.synth_audio(100 + i, n) for i, n in enumerate(lens)]
 
-    def run(streams, speculate=True):
-        sb = make_batch("TINY", 1234, "meanstd", beam, False, n_streams=len(streams), backend="native",
-                        max_frames=400, max_tokens=500, pcm_capacity=1 << 17)
-        sb.set_speculation(speculate)
+    def mk(n):
+        return make_batch("TINY", 1234, "meanstd", beam, False, n_streams=n, backend="native",
+                          max_frames=400, max_tokens=500, pcm_capacity=1 << 17)
+
+    def run(streams):
+        sb = mk(len(streams))
         pos = 0
         while True:
             items = []
@@ -114,21 +117,85 @@ def test_native_batch_of_distinct_streams_equals_one_by_one():
             pos += chunk
         return [sb.hypotheses(slot) for slot in range(len(streams))], sb.stats
 
+    def run_continuous(streams, min_done):
+        sb = mk(len(streams))
+        pos = [0] * len(streams)
+
+        def nxt(slot):
+            i = streams[slot]
+            a, e = pos[slot], min(pos[slot] + chunk, lens[i])
+            pos[slot] = e
+            return (slot, audio[i][a:e], e >= lens[i])
+
+        sb.submit([nxt(slot) for slot in range(len(streams))])
+        n_reports, max_group = 0, 0
+        while sb.outstanding:
+            done = sb.poll(min_done)
+            assert done and not any(isinstance(v, Exception) for v in done.values())
+            n_reports += len(done)
+            max_group = max(max_group, len(done))
+            again = [nxt(slot) for slot in done if pos[slot] < lens[streams[slot]]]
+            if again:
+                sb.submit(again)
+        assert n_reports == sum((lens[i] + chunk - 1) // chunk for i in streams)
+        return sb.hypotheses_batch(list(range(len(streams)))), sb.stats, max_group
+
     batch, st = run(list(range(S)))
-    assert st["spec_launched"] > 0 and st["spec_wasted"] <= st["dec_blocks"], st
-    plain, st0 = run(list(range(S)), speculate=False)
-    assert st0["spec_launched"] == 0 and st0["dec_steps"] == st["dec_steps"]
-    for a, b in zip(batch, plain):
-        assert [(h["yseq"], h["xpos"]) for h in a] == [(h["yseq"], h["xpos"]) for h in b]
-        for x, y in zip(a, b):
-            assert abs(x["score"] - y["score"]) < 1e-3
+    for min_done in (1, 5):
+        cont, stc, max_group = run_continuous(list(range(S)), min_done)
+        assert stc["dec_blocks"] == st["dec_blocks"], (stc, st, max_group)
+        assert stc["dec_steps"] < st["dec_steps"], (stc, st)     # fewer, fuller decode iterations
+        for i in range(S):
+            assert [(h["yseq"], h["xpos"]) for h in cont[i]] == [(h["yseq"], h["xpos"]) for h in batch[i]], i
+            for x, y in zip(cont[i], batch[i]):
+                assert abs(x["score"] - y["score"]) < 1e-3
     for i in range(0, S, 3):
         solo, sts = run([i])
-        assert sts["spec_launched"] == 0
         assert len(solo[0]) == len(batch[i]) > 0
         for x, y in zip(solo[0], batch[i]):
             assert x["yseq"] == y["yseq"] and x["xpos"] == y["xpos"], i
             assert abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(x["score"])), i
+
+
+def test_native_batched_readback_and_argument_checks():
+    """sc_get_hyps_batch (one pack launch + one copy for all streams) = sc_get_hyps stream by stream; push_block =
+    push; the C ABI refuses a stream listed twice, a second chunk for a stream that has one outstanding, and a
+    reset of such a stream; per-stream failure messages do not clobber each other."""
+    import ctypes as C
+    from speechcatcher_amd import _abi
+    from speechcatcher_amd.engine import EngineError
+    from test_engine_spec import make_batch
+    S, chunk = 6, 10240
+    kw = dict(n_streams=S, backend="native", max_frames=400, max_tokens=300, pcm_capacity=1 << 18)
+    sb, sb2 = make_batch("TINY", 1234, "meanstd", 5, False, **kw), make_batch("TINY", 1234, "meanstd", 5, False, **kw)
+    audio = np.stack([synth.synth_audio(40 + s, chunk * 4) for s in range(S)])
+    for k in range(4):
+        sb.push([(s, audio[s, k * chunk:(k + 1) * chunk], False) for s in range(S)])
+        st = sb2.push_block(np.arange(S), np.ascontiguousarray(audio[:, k * chunk:(k + 1) * chunk]))
+        assert (st >= 0).all()
+    one = [sb.hypotheses(s) for s in range(S)]
+    allb = sb2.hypotheses_batch(list(range(S)))
+    assert all(len(one[s]) > 0 and one[s] == allb[s] for s in range(S))
+    arr = sb.hypotheses_arrays([3, 1], nbest=2)
+    assert arr["n_hyps"].tolist() == [2, 2] and arr["ids"][0, 0, :arr["lens"][0, 0]].tolist() == one[3][0]["yseq"]
+    assert arr["xpos"][1, 1, :arr["lens"][1, 1]].tolist() == one[1][1]["xpos"] and arr["score"][1, 0] == one[1][0]["score"]
+    with pytest.raises(EngineError, match="listed twice"):
+        sb.push([(2, audio[2, :chunk], False), (2, audio[2, :chunk], False)])
+    sb.submit([(0, audio[0, :chunk], False)])
+    with pytest.raises(EngineError, match="outstanding"):
+        sb.submit([(0, audio[0, :chunk], False)])
+    with pytest.raises(_abi.ScasrError, match="outstanding"):
+        sb.reset(0)
+    with pytest.raises(_abi.ScasrError, match="decode block|reported"):
+        sb.hypotheses(0)
+    assert sb.poll(1) == {0: True} and sb.outstanding == 0
+    # two streams fail in one call, each keeps its own message
+    sb.reset(1)
+    out = sb.push([(1, synth.synth_audio(1, 700), True), (4, np.zeros(50000, np.float32), False),
+                   (5, audio[5, :chunk], False)], isolate_faults=True)
+    assert isinstance(out[1], RuntimeError) and "3x3" in str(out[1]) and "stream 1" in str(out[1])
+    assert isinstance(out[4], EngineError) and "max_chunk_samples" in str(out[4]) and out[5] is True
+    assert sb.lib.sc_stream_last_error(sb.handle, 5) == b""
 
 
 def test_step_advance_kernel_applies_the_stop_rules():
@@ -176,14 +243,15 @@ def test_step_advance_kernel_applies_the_stop_rules():
                 assert out[s].tolist() == [1, 1 - cur, fin, T, L + 1, min(W, nh * W), 1, tt], (s, f)
 
 
-@pytest.mark.parametrize("seed,bbd,speculate,split", [(0, False, False, None), (1, True, False, None), (2, False, True, None),
-                                                      (3, True, True, "32"), (4, False, False, "32")])
-def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate, split, monkeypatch):
+@pytest.mark.parametrize("seed,bbd,continuous,split", [(0, False, False, None), (1, True, False, None), (2, False, True, None),
+                                                       (3, True, True, "32"), (4, False, False, "32")])
+def test_native_random_sessions_equal_the_python_engine(seed, bbd, continuous, split, monkeypatch):
     """Randomised sessions on 16 stream slots (tiny dims): every push feeds a random subset of the streams with chunks
     of random length (a few hundred samples to 1.5 s), utterances end at random and their slots are reset and reused -
     block schedules, ragged buckets, final calls, resets and the early `return []` calls interleave in ways no fixture
-    covers.  The C++ engine (optionally with the device-side step control) and the Python engine over the same kernels
-    must end every push with the same hypotheses for every stream.  split: the CTC scan of the C++ engine split over T
+    covers.  The C++ engine (sc_push, or continuous: the chunks of a step submitted as two groups and polled one
+    completion at a time) and the Python engine over the same kernels must end every step with the same hypotheses
+    for every stream.  split: the CTC scan of the C++ engine split over T
     from 32 frames on (the Python engine always walks sequentially)."""
     from speechcatcher_amd.hip_backend import HipBackend
     from test_engine_spec import make_batch
@@ -192,7 +260,6 @@ def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate, sp
     S, beam = 16, 5
     kw = dict(n_streams=S, max_frames=400, max_tokens=400, pcm_capacity=1 << 17, strict_reference=False)
     nat = make_batch("TINY", 1234, "meanstd", beam, bbd, backend="native", **kw)
-    nat.set_speculation(speculate)
     pye = make_batch("TINY", 1234, "meanstd", beam, bbd, backend=HipBackend("cuda:0"), device="cuda:0", **kw)
     rng = np.random.default_rng(seed)
     fed = [0] * S            # samples fed to the current utterance of a slot
@@ -211,7 +278,18 @@ def test_native_random_sessions_equal_the_python_engine(seed, bbd, speculate, sp
             fed[s] += n
         if not items:
             continue
-        a = nat.push(items, isolate_faults=True)
+        if continuous:
+            cut = int(rng.integers(0, len(items) + 1))
+            a = {}
+            for part in (items[:cut], items[cut:]):
+                if part:
+                    nat.submit(part)
+                    if rng.random() < 0.5:
+                        a.update(nat.poll(1))
+            while nat.outstanding:
+                a.update(nat.poll(1))
+        else:
+            a = nat.push(items, isolate_faults=True)
         b = pye.push(items, isolate_faults=True)
         for s, _, fin in items:
             fa, fb = isinstance(a[s], Exception), isinstance(b[s], Exception)
@@ -254,10 +332,11 @@ def test_native_xl_batch_equals_python_engine():
         assert all(abs(x["score"] - y["score"]) < 1e-6 for x, y in zip(nat[s], py[s])), s
 
 
-@pytest.mark.parametrize("vosk", [False, True])
-def test_native_server_sessions_equal_private_oracle_sessions(vosk):
+@pytest.mark.parametrize("vosk,continuous", [(False, False), (True, False), (False, True), (True, True)])
+def test_native_server_sessions_equal_private_oracle_sessions(vosk, continuous):
+    """continuous: the server loop over sc_submit / sc_poll - every client is answered as soon as ITS chunk is decoded"""
     from test_server_session import run_sessions_vs_oracle
-    run_sessions_vs_oracle(vosk, backend="native")
+    run_sessions_vs_oracle(vosk, backend="native", continuous=continuous)
 
 
 def test_native_scheduler_and_segment_loop():

@@ -54,14 +54,14 @@ def _pcm16(stream_id, n):
     return np.clip(np.round(synth.synth_audio(stream_id, n) * 32767.0), -32768, 32767).astype(np.int16)
 
 
-def run_sessions_vs_oracle(vosk, backend=None, device="cpu"):
+def run_sessions_vs_oracle(vosk, backend=None, device="cpu", continuous=False):
     from helpers import oracle_model
     from oracle.ref_port import RefPortStreaming, RefServerSession
     fui, mpi, beam = 2, 5, 3
     sb = make_batch("TINY", 1234, "meanstd", beam, True, n_streams=2, backend=backend, device=device, max_frames=400,
                     max_tokens=300, pcm_capacity=1 << 18)
     loop = ServerLoop(StreamScheduler(sb, None, result_format="espnet"), vosk_output_format=vosk,
-                      finalize_update_iters=fui, max_partial_iters=mpi)
+                      finalize_update_iters=fui, max_partial_iters=mpi, continuous=continuous)
     model = oracle_model("TINY", 1234, "meanstd")
     chunk = 10240
     plans = {0: [_pcm16(5, chunk) for _ in range(9)], 1: [_pcm16(6, chunk) for _ in range(7)]}
