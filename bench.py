@@ -48,6 +48,7 @@ from speechcatcher_amd import synth  # noqa: E402
 from speechcatcher_amd.config import XL, SearchConfig  # noqa: E402
 
 CHUNK = 10240
+SERVED_SPARE = 6               # chunks per stream beyond the window (served leg: streams that run ahead of the average)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 # algorithmic work of one stream-hop (10 240 samples of one stream)
@@ -56,10 +57,11 @@ GFLOP_PER_DECODE_STEP = 0.437  # at beam 10
 
 
 def capacities(n_steps_total):
-    """encoder frames / tokens per hypothesis a window of n steps can reach (the reference stops extending a
-    hypothesis at process_idx 500: beam_search.py:701, so 520 tokens always suffice)"""
+    """encoder frames / tokens per hypothesis a window of n steps can reach (the reference's step loop is bounded by
+    process_idx < 500, beam_search.py:701: from then on a hypothesis grows by ONE token per block - the step that
+    reaches the bound is kept, the rewind only takes process_idx back)"""
     hops = (n_steps_total + 2) * CHUNK / 10240.0       # encoder hops (16 frames each) in the window
-    return int(16 * hops) + 64, min(520, int(14 * hops) + 32)
+    return int(16 * hops) + 64, min(int(14 * hops) + 32, 540 + int(hops))
 
 
 FFN_DTYPE = "float32"  # --ffn-dtype float16: fp16 feed-forward weights + fp16 MFMA inputs (configs[4]), never the default
@@ -124,7 +126,7 @@ def n_dec_steps(sb):
     return sum(st.n_steps_total for st in sb.st)
 
 
-def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None):
+def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None, before_timing=None):
     """roll `preroll + warmup` steps untimed (resident audio), then time `steps` steps in `mode`"""
     ids = np.arange(sb.S, dtype=np.int32)
     k0 = preroll + warmup
@@ -139,6 +141,8 @@ def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None):
     if dist is not None:
         dist.barrier()
     steps0 = n_dec_steps(sb)
+    if before_timing:
+        before_timing(sb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if mode == "host":
@@ -154,10 +158,12 @@ def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None):
     return elapsed, dec_steps / max(steps, 1), last
 
 
-def served_window(sb, audio, preroll, warmup, steps, group):
-    """Continuous batching over the same window: after the lock-step pre-roll every stream is served on its own -
-    sc_submit its chunk, sc_poll until replies are ready, read the best hypothesis of the streams that answered
-    (sc_get_hyps_batch), submit THEIR next chunks.  Host PCM in, hypotheses out, as in run_host."""
+def served_window(sb, audio, preroll, warmup, steps, group, before_timing=None):
+    """Continuous batching from the same starting point: after the lock-step pre-roll every stream is served on its
+    own - sc_submit its chunk, sc_poll until replies are ready, read the best hypothesis of the streams that answered
+    (sc_get_hyps_batch), submit THEIR next chunks.  Host PCM in, hypotheses out, as in run_host.  The clock stops
+    when S x steps replies have been delivered (the same amount of audio as the strict window; a stream whose blocks
+    need fewer decode steps gets further than one that needs more - `audio` must hold spare chunks for them)."""
     S = sb.S
     ids = np.arange(S, dtype=np.int32)
     k0 = preroll + warmup
@@ -166,26 +172,36 @@ def served_window(sb, audio, preroll, warmup, steps, group):
     run_host(sb, step_blocks(audio, preroll, k0), ids)
     a3 = audio.reshape(S, -1, CHUNK)
     nxt = np.full(S, k0, np.int64)
-    end = k0 + steps
+    end = a3.shape[1]
     torch.cuda.synchronize()
     steps0 = n_dec_steps(sb)
     iters0 = sb.stats["dec_steps"]
+    if before_timing:
+        before_timing(sb)
     t0 = time.perf_counter()
     sb.submit_block(ids, np.ascontiguousarray(a3[:, k0]))
     nxt += 1
-    n_polls = 0
+    n_polls, n_replies, target = 0, 0, S * steps
+    elapsed = None
     while sb.outstanding:
         done, st = sb.poll_ids(min(group, sb.outstanding))
         assert (st >= 0).all()
         n_polls += 1
         sb.hypotheses_arrays(done, nbest=1)
+        n_replies += len(done)
+        if n_replies >= target:
+            if elapsed is None:
+                elapsed = time.perf_counter() - t0
+                spread = (int(nxt.min()) - k0, int(nxt.max()) - k0)
+                dsh = (n_dec_steps(sb) - steps0) / float(n_replies)
+                iters = (sb.stats["dec_steps"] - iters0) / steps
+            continue          # (drain what is in flight, untimed)
         again = done[nxt[done] < end]
         if len(again):
             sb.submit_block(again, a3[again, nxt[again]])
             nxt[again] += 1
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    return elapsed, (n_dec_steps(sb) - steps0) / float(S) / steps, (sb.stats["dec_steps"] - iters0) / steps, n_polls / steps
+    return elapsed, dsh, iters, n_polls / steps, spread
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -244,7 +260,7 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
     """strict and served throughput with every stream `target_T` encoder frames into its utterance"""
     hops = max(2, (target_T - 24) // 16 + 2)
     preroll, warm = hops - 2, 2
-    total = preroll + warm + steps
+    total = preroll + warm + steps + SERVED_SPARE
     audio = make_audio(streams, total, stream_offset=7000, shared=True)
     out = {"bbd": int(bbd), "steps": steps, "audio": "windows of one seeded noise buffer at per-stream offsets"}
     sb = build_native(w, streams, beam, bbd, total)
@@ -257,7 +273,7 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
     sb.close()
     del sb
     sb = build_native(w, streams, beam, bbd, total)
-    e, dsh, iters, polls = served_window(sb, audio, preroll, warm, steps, group)
+    e, dsh, iters, polls, spread = served_window(sb, audio, preroll, warm, steps, group)
     out["served"] = {"value": round(streams * steps * CHUNK / 16000.0 / e, 2), "ms_per_step_equivalent": round(e / steps * 1e3, 3),
                      "decode_iterations_per_step": round(iters, 2)}
     sb.close()
@@ -322,7 +338,7 @@ def main():
     coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
     window = args.preroll + args.warmup + args.steps
-    total_steps = window + args.roofline_steps
+    total_steps = window + max(args.roofline_steps, SERVED_SPARE)
     w = make_weights(device)
     sb = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
     lib = sb.lib
@@ -341,7 +357,7 @@ def main():
         sb.set_graphs(False)
         sb.take_xattn_rows()
         lib.sc_prof_enable(1)
-        run_host(sb, step_blocks(audio, window, total_steps), np.arange(sb.S, dtype=np.int32))
+        run_host(sb, step_blocks(audio, window, window + args.roofline_steps), np.arange(sb.S, dtype=np.int32))
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
@@ -450,17 +466,17 @@ def main():
 
     served = None
     if not args.no_served and world == 1:
-        sbs = build_native(w, args.streams, args.beam, bool(args.bbd), window)
-        e3, dsh3, iters3, polls3 = served_window(sbs, audio, args.preroll, args.warmup, args.steps, group)
+        sbs = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
+        e3, dsh3, iters3, polls3, spread3 = served_window(sbs, audio, args.preroll, args.warmup, args.steps, group)
         v3 = args.streams * args.steps * CHUNK / 16000.0 / e3
         served = {"value": round(v3, 2), "unit": "audio_s/s", "over_strict": round(v3 / value, 4),
                   "ms_per_step_equivalent": round(e3 / args.steps * 1e3, 3), "poll_min_done": group,
                   "decode_steps_per_hop": round(dsh3, 2), "decode_iterations_per_step": round(iters3, 2),
-                  "polls_per_step": round(polls3, 2),
+                  "polls_per_step": round(polls3, 2), "chunks_per_stream_min_max": list(spread3),
                   "note": "continuous batching (sc_submit / sc_poll), same window and chunks, host PCM in and best hypothesis "
                           "out per reply: a stream's reply is delivered when ITS blocks are done and its next chunk is "
                           "admitted at once (the reference server's session loop, speechcatcher_server.py:359-397); per-call "
-                          "results are those of the strict run; includes the drain of the last stragglers"}
+                          "results are those of the strict run; timed until streams x steps replies have been delivered"}
         sbs.close()
         del sbs
 

@@ -503,6 +503,12 @@ int sc_submit(sc_streams *streams, const int *stream_ids, const float *const *pc
               const uint8_t *is_final, int n);
 int sc_poll(sc_streams *streams, int min_done, int max_done, int *done_ids /*HOST out*/, int *status /*HOST out, may be NULL*/);
 int sc_streams_outstanding(const sc_streams *streams);
+/* sc_submit policy: a chunk's own decode block only sees frames that were there before it (the block schedule runs one
+ * hop behind the encoder, beam_search.py:590-634), so its frontend + encoder stage has a whole chunk period of slack:
+ * the stages of successive admissions are merged and issued as ONE group when it holds min_streams streams (default:
+ * half of the streams) or as soon as a queued decode block needs its frames.  1: every admission is issued at once.
+ * Results do not depend on it. */
+int sc_streams_set_encoder_batch(sc_streams *streams, int min_streams);
 /* message of the stream's last failure (status < 0 from sc_push / sc_poll); "" if it never failed */
 const char *sc_stream_last_error(const sc_streams *streams, int stream);
 /* live hypotheses, best first (BeamState.hypotheses: yseq, xpos, score, scores{decoder, ctc}; hypothesis.py).

@@ -69,6 +69,12 @@ XL = ModelConfig()
 # the `_m` checkpoints (BASELINE configs[0]; their config.yaml is not available offline).  Head dim 64.
 M_DEFAULTS = ModelConfig(d_model=256, enc_heads=4, enc_layers=12, dec_heads=4, dec_layers=6)
 
+# Stand-in for the `_l` checkpoints (BASELINE configs[3], en_streaming_transformer_l): their config.yaml is not available
+# offline and only output_size / attention_heads / num_blocks are read from it (speech2text_streaming.py:215-232).
+# ASSUMED: between the no-config defaults (256 / 4 heads / 12 + 6 blocks) and XL (256 / 8 heads / 30 + 14 blocks) -
+# 256 / 4 heads (head dim 64) / 18 + 8 blocks.  The engine is generic in these three; nothing else varies.
+L_LIKE = ModelConfig(d_model=256, enc_heads=4, enc_layers=18, dec_heads=4, dec_layers=8)
+
 # Small model used for full-tensor golden fixtures.
 TINY = ModelConfig(d_model=64, enc_heads=4, enc_layers=2, dec_heads=4,
                    dec_layers=2, ffn_dim=2048)

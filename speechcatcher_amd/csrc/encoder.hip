@@ -21,7 +21,10 @@ extern "C" int sc_version(void) { return 1; }
 // decode step are launch-bound for a single stream: replay costs one launch).
 // ---------------------------------------------------------------------------
 extern "C" int sc_graph_capture_begin(void *stream) {
-  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+  // Relaxed: only launches on `stream` are recorded and nothing else is policed.  (Thread-local mode invalidates the
+  // capture when the capturing thread makes any "unsafe" call - e.g. a hipFree from a Python destructor that the
+  // garbage collector happens to run between two launches of a captured sequence.)
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
   if (e != hipSuccess) { sc_set_error("sc_graph_capture_begin: %s", hipGetErrorString(e)); return SC_ERR_LAUNCH; }
   return SC_OK;
 }

@@ -130,7 +130,6 @@ struct Job {
   bool open = false;
   int has_out = 0;   // 1: the call produced output, 0: the reference's early `return []`
   int fault = 0;     // SC_ERR_*: the chunk failed, the stream is reset when it is reported
-  long gen = 0;      // encoder group that carries the chunk's frontend / encoder stage (0: nothing was launched)
 };
 
 template <typename T>
@@ -157,8 +156,10 @@ struct EncPlan {
 struct EncGroup {
   long gen = 0;
   bool launched = false, features = false;
+  bool open = false;                         // sc_submit: later admissions may still be merged into this (unlaunched) group
+  bool deferred = false;                     // sc_submit: issued when it is full or when a decode block needs its frames
   int slot = 0;                              // job-table arena slot
-  int stage_slot = -1;                       // pinned staging slot holding the group's host input (-1: none)
+  int stage_slot = -1;                       // pinned staging slot holding the admission's host input (-1: none)
   std::vector<long long> copy_jobs;          // [n][3] staging offset, destination offset, count (floats)
   size_t stage_floats = 0;
   std::vector<int32_t> fe_jobs;
@@ -166,7 +167,8 @@ struct EncGroup {
   EncPlan P;
   std::vector<int32_t> ctc_rows, kv_src, kv_dst;   // eager projections of the frames the group emits
   bool same_rows = true;
-  bool empty() const { return !n_fe && !P.n_conv && copy_jobs.empty(); }
+  std::vector<int> streams;                  // streams with work in this group (each at most once)
+  bool empty() const { return !n_fe && !P.n_conv; }
 };
 
 constexpr int N_ARENA = 8;   // job-table arena slots = encoder groups that can be in flight
@@ -196,6 +198,7 @@ struct sc_streams {
   int step_split_min() const { return (scan_long && n_rows_step <= scan_split_streams * W) ? scan_split_min : 0; }
   int graph_key() const { return n_rows_step * 2 + (step_split_min() > 0 ? 1 : 0); }
   int enc_start_thr = 0;         // sc_push: launch the planned encoder group when at most this many streams are still decoding
+  int enc_batch_min = 0;         // sc_submit: launch the open encoder group when it holds this many streams (sc_streams_set_encoder_batch)
   void *ws = nullptr, *ws_enc = nullptr;
   std::vector<void *> owned, owned_host;
   // device buffers
@@ -224,6 +227,7 @@ struct sc_streams {
   hipEvent_t ev_stage[N_STAGE] = {nullptr};
   bool stage_busy[N_STAGE] = {false};
   int stage_next = 0;
+  long long *cjobs_host = nullptr, *cjobs_dev = nullptr;   // [N_STAGE][S*3] scatter jobs of a staging slot
   // ---- batched hypothesis read-back (sc_get_hyps_batch): pack kernel -> one D2H into pinned memory -------------------
   int32_t *pack_dev = nullptr, *pack_host = nullptr, *pjobs_host = nullptr, *pjobs_dev = nullptr;
   size_t pack_cap = 0;            // int32 elements
@@ -233,6 +237,7 @@ struct sc_streams {
   std::vector<std::deque<Blk>> bq;
   std::vector<Job> job;
   std::vector<std::string> fault_msg;
+  std::vector<long> enc_gen;       // group of the stream's latest encoder stage
   std::deque<EncGroup *> groups;   // planned or in flight, oldest first
   long gen_next = 1, gen_done = 0, gen_ordered = 0;   // groups: issued, known complete, main stream ordered behind
   int n_open = 0;                  // outstanding chunks
@@ -740,7 +745,6 @@ int retire_groups(sc_streams *b) {
     }
     b->gen_done = g->gen;
     b->slot_gen[g->slot] = 0;
-    if (g->stage_slot >= 0) b->stage_busy[g->stage_slot] = false;
     b->groups.pop_front();
     delete g;
   }
@@ -748,8 +752,10 @@ int retire_groups(sc_streams *b) {
 }
 
 // host-blocking wait for the group `gen` (and, the stream being in order, every group before it)
+int launch_pending_groups(sc_streams *b, long upto = -1);
 int wait_group(sc_streams *b, long gen) {
   if (gen <= b->gen_done) return SC_OK;
+  RC_TRY(launch_pending_groups(b, gen));
   const int slot = (int)(gen % N_ARENA);
   HIP_TRY(hipEventSynchronize(b->ev_group[slot]));
   return retire_groups(b);
@@ -792,36 +798,67 @@ int project_rows(sc_streams *b, EncGroup &g) {
   return SC_OK;
 }
 
-// issue a planned group: input copy + scatter, frontend, encoder, projections (on the encoder stream when there is one)
+// host input of an admission -> device, at once: ONE host-to-device copy of the pinned staging slot, one scatter
+// launch to the chunks' places behind what each stream has buffered (PCM ring / feature buffer)
+int stage_copy(sc_streams *b, EncGroup &g) {
+  if (g.copy_jobs.empty()) return SC_OK;
+  hipStream_t es = b->stream_enc ? b->stream_enc : b->stream;
+  const int ss = g.stage_slot;
+  const size_t so = (size_t)ss * b->stage_cap, jo = (size_t)ss * b->S * 3;
+  const int nj = (int)g.copy_jobs.size() / 3;
+  memcpy(b->cjobs_host + jo, g.copy_jobs.data(), g.copy_jobs.size() * sizeof(long long));
+  HIP_TRY(hipMemcpyAsync(b->stage_dev + so, b->stage_host + so, g.stage_floats * sizeof(float), hipMemcpyHostToDevice, es));
+  HIP_TRY(hipMemcpyAsync(b->cjobs_dev + jo, b->cjobs_host + jo, g.copy_jobs.size() * sizeof(long long), hipMemcpyHostToDevice, es));
+  long long mx = 1;
+  for (int j = 0; j < nj; ++j) mx = std::max(mx, g.copy_jobs[j * 3 + 2]);
+  dim3 grid((unsigned)std::min<long long>(64, (mx + 1023) / 1024), nj);
+  scatter_f32_kernel<<<grid, 256, 0, es>>>(b->stage_dev + so, g.features ? b->featbuf : b->pcm, b->cjobs_dev + jo);
+  HIP_TRY(hipEventRecord(b->ev_stage[ss], es));   // the pinned slot is free again behind this
+  b->stage_busy[ss] = true;
+  g.copy_jobs.clear();
+  return SC_OK;
+}
+
+// src (planned after dst, disjoint streams) joins dst: job tables are concatenated, indices into the group-local
+// scratch buffers (conv1 output rows, encoder block slots) are shifted behind dst's
+void merge_group(sc_streams *b, EncGroup &dst, EncGroup &src) {
+  const sc_config &c = b->cfg;
+  const int F1 = c.conv_freq1, R = c.block_size + 2;
+  EncPlan &D = dst.P, &P = src.P;
+  int c1_rows = 0;
+  if (D.n_conv) c1_rows = D.conv_jobs[(D.n_conv - 1) * 4 + 2] + D.conv_jobs[(D.n_conv - 1) * 4 + 3];
+  const int nblk = (int)D.blk_jobs.size() / 6;
+  for (int j = 0; j < P.n_conv; ++j) P.conv_jobs[j * 4 + 2] += c1_rows;
+  for (auto &v : P.a_rows) v += c1_rows * F1;
+  for (size_t j = 0; j < P.sjobs.size(); j += 5) P.sjobs[j] += nblk;
+  for (auto &v : P.emit_src)
+    if (v >= 0) v += nblk * R;
+  auto cat = [](std::vector<int32_t> &a, const std::vector<int32_t> &x) { a.insert(a.end(), x.begin(), x.end()); };
+  cat(D.conv_jobs, P.conv_jobs); cat(D.a_rows, P.a_rows); cat(D.lin_dst, P.lin_dst); cat(D.feat_src, P.feat_src);
+  cat(D.feat_dst, P.feat_dst); cat(D.blk_jobs, P.blk_jobs); cat(D.sjobs, P.sjobs); cat(D.emit_src, P.emit_src);
+  cat(D.emit_dst, P.emit_dst); cat(D.sub_src, P.sub_src); cat(D.sub_dst, P.sub_dst);
+  D.shorts.insert(D.shorts.end(), P.shorts.begin(), P.shorts.end());
+  D.n_conv += P.n_conv;
+  D.max_t1 = std::max(D.max_t1, P.max_t1);
+  cat(dst.fe_jobs, src.fe_jobs);
+  dst.n_fe += src.n_fe;
+  dst.max_keep = std::max(dst.max_keep, src.max_keep);
+  cat(dst.ctc_rows, src.ctc_rows); cat(dst.kv_src, src.kv_src); cat(dst.kv_dst, src.kv_dst);
+  dst.same_rows = dst.same_rows && src.same_rows;
+  dst.streams.insert(dst.streams.end(), src.streams.begin(), src.streams.end());
+}
+
+// issue a planned group: frontend, encoder, projections (on the encoder stream when there is one)
 int launch_group(sc_streams *b, EncGroup *g) {
   if (g->launched) return SC_OK;
   g->launched = true;
+  g->open = false;
   const sc_config &c = b->cfg;
   sc_engine *e = b->eng;
   b->es = b->stream_enc ? b->stream_enc : b->stream;
   b->cur_slot = g->slot;
   b->arena_off = 0;
   int rc = SC_OK;
-  if (!g->copy_jobs.empty()) {
-    // ONE host-to-device copy of the group's input (pinned staging slot), one scatter launch to its places
-    const size_t so = (size_t)g->stage_slot * b->stage_cap;
-    if (hipMemcpyAsync(b->stage_dev + so, b->stage_host + so, g->stage_floats * sizeof(float), hipMemcpyHostToDevice, b->es) != hipSuccess) {
-      sc_set_error("copy of the input chunks failed");
-      rc = SC_ERR_LAUNCH;
-    }
-    std::vector<int32_t> jt(g->copy_jobs.size() * 2);
-    memcpy(jt.data(), g->copy_jobs.data(), jt.size() * sizeof(int32_t));
-    const int32_t *jd = nullptr;
-    if (rc == SC_OK) rc = b->itensor(jt, &jd);
-    if (rc == SC_OK) {
-      const int nj = (int)g->copy_jobs.size() / 3;
-      long long mx = 1;
-      for (int j = 0; j < nj; ++j) mx = std::max(mx, g->copy_jobs[j * 3 + 2]);
-      dim3 grid((unsigned)std::min<long long>(64, (mx + 1023) / 1024), nj);
-      scatter_f32_kernel<<<grid, 256, 0, b->es>>>(b->stage_dev + so, g->features ? b->featbuf : b->pcm, (const long long *)jd);
-      (void)hipEventRecord(b->ev_stage[g->stage_slot], b->es);   // the pinned slot is free again behind this
-    }
-  }
   if (rc == SC_OK && g->n_fe) {
     const int32_t *jobs;
     rc = b->itensor(g->fe_jobs, &jobs);
@@ -838,9 +875,10 @@ int launch_group(sc_streams *b, EncGroup *g) {
   return rc;
 }
 
-int launch_pending_groups(sc_streams *b) {
+// groups are launched in order; upto >= 0: only the groups up to that generation
+int launch_pending_groups(sc_streams *b, long upto) {
   for (EncGroup *g : b->groups)
-    if (!g->launched) RC_TRY(launch_group(b, g));
+    if (!g->launched && (upto < 0 || g->gen <= upto)) RC_TRY(launch_group(b, g));
   return SC_OK;
 }
 
@@ -928,6 +966,17 @@ int engine_tick(sc_streams *b, bool *progress) {
   *progress = false;
   RC_TRY(retire_groups(b));
   RC_TRY(start_blocks(b));
+  {
+    // a queued block that sees frames of a group which has not even been issued (sc_submit defers and merges the
+    // encoder stages of successive admissions): issue it now, it will have completed a few ticks on
+    long need = 0;
+    for (int s = 0; s < S; ++s)
+      if (!b->run[s].inblk && !b->bq[s].empty()) need = std::max(need, b->bq[s].front().gen);
+    long upto = -1;
+    for (EncGroup *g : b->groups)
+      if (!g->launched && g->deferred && g->gen <= need) upto = g->gen;
+    if (upto >= 0) RC_TRY(launch_pending_groups(b, upto));
+  }
   // streams whose step loop has ended (stop flags of the previous tick, or process_idx at its bound: :701)
   std::vector<int> active;
   for (int s = 0; s < S; ++s) {
@@ -953,7 +1002,7 @@ int engine_tick(sc_streams *b, bool *progress) {
     for (int s = 0; s < S; ++s)
       if (!b->run[s].inblk && !b->bq[s].empty() && (need == 0 || b->bq[s].front().gen < need)) need = b->bq[s].front().gen;
     if (need > std::max(b->gen_done, b->gen_ordered)) {
-      RC_TRY(launch_pending_groups(b));
+      RC_TRY(launch_pending_groups(b, need));
       if (b->stream_enc) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_group[need % N_ARENA], 0));
       b->gen_ordered = std::max(b->gen_ordered, need);
       *progress = true;
@@ -973,7 +1022,9 @@ int engine_tick(sc_streams *b, bool *progress) {
     c[0] = 1; c[1] = r.cur; c[2] = r.fin; c[3] = r.T; c[4] = r.L; c[5] = r.nhyp; c[6] = r.has; c[7] = r.Tc;
   }
   // sc_push: the planned encoder stage fills the CUs that the thinned-out step loop leaves idle
-  if ((int)active.size() <= b->enc_start_thr) RC_TRY(launch_pending_groups(b));
+  if ((int)active.size() <= b->enc_start_thr)
+    for (EncGroup *g : b->groups)
+      if (!g->launched && !g->open) RC_TRY(launch_group(b, g));
   if (b->rm_dirty) {   // one copy command for ctrl rows + rowmap (nothing is in flight here: the pinned image is free)
     memcpy(b->ctrlmap_host + S * 8, b->rm_host[b->rm_idx], (size_t)S * W * sizeof(int32_t));
     HIP_TRY(hipMemcpyAsync(b->ctrlmap, b->ctrlmap_host, (size_t)(S * 8 + S * W) * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
@@ -1032,11 +1083,15 @@ int engine_tick(sc_streams *b, bool *progress) {
 inline bool chunk_decoded(const sc_streams *b, int s) { return !b->run[s].inblk && b->bq[s].empty(); }
 inline bool chunk_complete(const sc_streams *b, int s) {
   const Job &j = b->job[s];
-  return j.open && (j.fault != 0 || (chunk_decoded(b, s) && j.gen <= b->gen_done));
+  return j.open && (j.fault != 0 || chunk_decoded(b, s));
 }
 
 // ---- admission ------------------------------------------------------------------------------------------------------
 struct Chunk { int s; const float *host; long n; bool fin; int pos; };
+
+// the group that carries the stream's LATEST encoder stage (its frames are what "the frames that were there before"
+// means for the next admission: a block that only sees those still has to wait for that group)
+inline long st_gen(const sc_streams *b, int s) { return b->enc_gen[s] > b->gen_done ? b->enc_gen[s] : 0; }
 
 // apply_frontend + forward_infer planning of one group, pure host work: stages the host input,
 // advances the host mirrors, fills the group's job tables.  Throws StreamFault for per-stream failures.
@@ -1095,15 +1150,16 @@ void plan_group(sc_streams *b, const std::vector<Chunk> &chunks, bool features, 
   if (!enc_streams.empty()) encode_plan(b, enc_streams, feat_new, finals, g.P);
 }
 
-// Admit the chunks as ONE group: plan (per-stream faults drop that stream's chunk only), queue the decode blocks the
-// new frames make ready (beam_search.py:590-634), open the jobs.  launch_now: issue the group's encoder stage at once
-// (sc_submit); otherwise the tick loop launches it when the decode loop has thinned out (sc_push).
-int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool launch_now, std::vector<int> *has_out_by_pos) {
+// Admit the chunks of one call: plan them (per-stream faults drop that stream's chunk only), copy the host input
+// to the device, queue the decode blocks the new frames make ready (beam_search.py:590-634), open the jobs.
+// sc_push (defer = false): the admission is one encoder group of its own, issued by the tick loop when the decode
+// loop has thinned out.  sc_submit (defer = true): the admission JOINS the open group - the frontend + encoder stages
+// of successive small admissions run as one large batch (a chunk's own decode block only sees frames that were there
+// before it, SURVEY A7, so its encoder stage has a whole chunk period of slack) - which is issued when it holds
+// enc_batch_min streams, or as soon as a queued decode block needs its frames.
+int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, std::vector<int> *has_out_by_pos) {
   const sc_config &c = b->cfg;
   RC_TRY(retire_groups(b));
-  const long gen = b->gen_next;
-  const int slot = (int)(gen % N_ARENA);
-  if (b->slot_gen[slot]) RC_TRY(wait_group(b, b->slot_gen[slot]));   // N_ARENA groups in flight: wait for the oldest
   bool host_input = false;
   for (auto &ch : chunks) host_input = host_input || (ch.host && ch.n > 0);
   int sslot = -1;
@@ -1122,14 +1178,16 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool launch_n
     if (!features)
       for (auto &ch : chunks) {   // compaction moves device data: settle it before the snapshot
         St &st = b->st[ch.s];
-        if (st.pcm_end + ch.n > b->PCAP) {
-          const int rc = compact_pcm(b, ch.s);
+        if (st.pcm_end + ch.n > b->PCAP && st.pcm_start > 0) {
+          int rc = launch_pending_groups(b);   // (a frontend that still has to read the old places)
+          if (rc == SC_OK && b->stream_enc && hipStreamSynchronize(b->stream_enc) != hipSuccess) rc = SC_ERR_LAUNCH;
+          if (rc == SC_OK) rc = compact_pcm(b, ch.s);
           if (rc != SC_OK) { delete g; return rc; }
         }
       }
     snap = b->st;
     *g = EncGroup();
-    g->gen = gen; g->slot = slot; g->stage_slot = sslot; g->features = features;
+    g->stage_slot = sslot; g->features = features; g->deferred = defer;
     feat_new.clear();
     finals.clear();
     has_out.assign(chunks.size(), 0);
@@ -1150,26 +1208,15 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool launch_n
       if (chunks.empty()) { *g = EncGroup(); break; }
     }
   }
-  // decode schedule (beam_search.py:590-634) as per-stream queues; a block that sees frames of this group waits for it
-  for (auto &kv : feat_new) {
-    const int s = kv.first;
-    St &st = b->st[s];
-    std::deque<Blk> &q = b->bq[s];
-    int pb = st.processed_block + (b->run[s].inblk && !b->run[s].fin ? 1 : 0);
-    for (auto &k : q) pb += k.fin ? 0 : 1;
-    const int t_avail = st.T_enc, t_old = snap[s].T_enc;
-    while (t_avail > 0) {
-      const int cur_end = c.block_size - c.look_ahead + c.hop_size * pb;
-      if (!(cur_end < t_avail)) break;
-      q.push_back({cur_end, false, cur_end > t_old ? gen : 0});
-      ++pb;
-    }
-    if (finals.at(s) && t_avail > 0) q.push_back({t_avail, true, t_avail > t_old ? gen : 0});
+  {
+    const int rc = stage_copy(b, *g);
+    if (rc != SC_OK) { delete g; return rc; }
   }
-  // eager projections: CTC rows / cross-attention K|V rows of every frame this group emits
+  // eager projections: CTC rows / cross-attention K|V rows of every frame this admission emits
   for (auto &ch : chunks) {
     St &st = b->st[ch.s];
     const int t0 = snap[ch.s].T_enc, t1 = st.T_enc;
+    if (feat_new.count(ch.s)) g->streams.push_back(ch.s);
     if (t1 <= t0) continue;
     const int c0 = std::max(t0, st.T_proj), k0 = std::max(t0, st.T_projkv);
     g->same_rows = g->same_rows && c0 == k0;
@@ -1181,25 +1228,70 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool launch_n
     st.T_proj = std::max(st.T_proj, t1);
     st.T_projkv = std::max(st.T_projkv, t1);
   }
-  const bool launches = !g->empty();
+  // which group carries the work: the open one (sc_submit; never two admissions of one stream in a group), or a new one
+  long gen = 0;
+  if (!g->empty()) {
+    EncGroup *open = (!b->groups.empty() && b->groups.back()->open && !b->groups.back()->launched) ? b->groups.back() : nullptr;
+    if (open) {
+      bool clash = !defer;
+      for (int s : g->streams) clash = clash || std::find(open->streams.begin(), open->streams.end(), s) != open->streams.end();
+      if (clash) {
+        open->open = false;
+        if (defer) {
+          const int rc = launch_group(b, open);
+          if (rc != SC_OK) { delete g; return rc; }
+        }
+        open = nullptr;
+      }
+    }
+    if (open) {
+      merge_group(b, *open, *g);
+      delete g;
+      g = open;
+    } else {
+      g->gen = b->gen_next++;
+      g->slot = (int)(g->gen % N_ARENA);
+      if (b->slot_gen[g->slot]) {   // N_ARENA groups in flight: wait for the oldest
+        const int rc = wait_group(b, b->slot_gen[g->slot]);
+        if (rc != SC_OK) { delete g; return rc; }
+      }
+      b->slot_gen[g->slot] = g->gen;
+      g->open = defer;
+      b->groups.push_back(g);
+    }
+    gen = g->gen;
+  } else {
+    delete g;
+    g = nullptr;
+  }
+  // decode schedule (beam_search.py:590-634) as per-stream queues; a block that sees frames of this admission waits
+  // for the group that carries it
+  for (auto &kv : feat_new) {
+    const int s = kv.first;
+    St &st = b->st[s];
+    std::deque<Blk> &q = b->bq[s];
+    int pb = st.processed_block + (b->run[s].inblk && !b->run[s].fin ? 1 : 0);
+    for (auto &k : q) pb += k.fin ? 0 : 1;
+    const int t_avail = st.T_enc, t_old = snap[s].T_enc;
+    while (t_avail > 0) {
+      const int cur_end = c.block_size - c.look_ahead + c.hop_size * pb;
+      if (!(cur_end < t_avail)) break;
+      q.push_back({cur_end, false, cur_end > t_old ? gen : st_gen(b, s)});
+      ++pb;
+    }
+    if (finals.at(s) && t_avail > 0) q.push_back({t_avail, true, t_avail > t_old ? gen : st_gen(b, s)});
+  }
+  if (gen)
+    for (int s : g->streams) b->enc_gen[s] = gen;
   for (size_t k = 0; k < chunks.size(); ++k) {
     Job &j = b->job[chunks[k].s];
     j = Job();
     j.open = true;
     j.has_out = has_out[k];
-    j.gen = launches ? gen : 0;
     b->n_open++;
     if (has_out_by_pos) (*has_out_by_pos)[chunks[k].pos] = has_out[k];
   }
-  if (!launches) {
-    delete g;
-    return SC_OK;
-  }
-  if (sslot >= 0 && !g->copy_jobs.empty()) b->stage_busy[sslot] = true;
-  b->gen_next++;
-  b->slot_gen[slot] = gen;
-  b->groups.push_back(g);
-  if (launch_now) RC_TRY(launch_group(b, g));
+  if (g && defer && !g->launched && (int)g->streams.size() >= std::max(1, b->enc_batch_min)) RC_TRY(launch_group(b, g));
   return SC_OK;
 }
 
@@ -1421,6 +1513,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->pack_cap = n * (2 * (size_t)b->LCAP + 8);
   A(b->pack_dev, b->pack_cap);
   A(b->pjobs_dev, n * 4);
+  A(b->cjobs_dev, (size_t)N_STAGE * S * 3);
   sc_search &sb = b->sb;
   sb.S = S; sb.W = W; sb.K = K; sb.V = V; sb.d = d; sb.H = c.dec_heads; sb.F = F; sb.n_layers = c.dec_layers;
   sb.TCAP = b->TCAP; sb.LCAP = b->LCAP; sb.xchunk = 256; sb.blank = c.blank_id; sb.eos = c.eos_id; sb.sos = c.sos_id;
@@ -1521,7 +1614,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
             b->halloc(&b->rm_host[0], n) == SC_OK && b->halloc(&b->rm_host[1], n) == SC_OK &&
             b->halloc(&b->arena_host, b->slot_cap * N_ARENA) == SC_OK && b->halloc(&b->bs_host, b->bs_cap * N_RING) == SC_OK &&
             b->halloc(&b->stage_host, b->stage_cap * N_STAGE) == SC_OK && b->halloc(&b->pack_host, b->pack_cap) == SC_OK &&
-            b->halloc(&b->pjobs_host, n * 4) == SC_OK;
+            b->halloc(&b->pjobs_host, n * 4) == SC_OK && b->halloc(&b->cjobs_host, (size_t)N_STAGE * S * 3) == SC_OK;
   for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_iter[i], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < N_ARENA && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_group[i], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < N_STAGE && ok; ++i) ok = hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming) == hipSuccess;
@@ -1548,6 +1641,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   (void)hipMemcpy(b->ctrlmap + S * 8, b->rm_host[0], n * sizeof(int32_t), hipMemcpyHostToDevice);
   b->rowmap_key.resize(S);
   for (int s = 0; s < S; ++s) b->rowmap_key[s] = s;
+  b->enc_batch_min = std::max(1, S / 2);
   b->row_bucket = std::max(1, S / 32);   // 32 compaction buckets (graphs): 16 -> 32 measured +1 % at 128 streams, 64 nothing more
   if (const char *rb = sc_hook("SC_ROW_BUCKETS")) b->row_bucket = std::max(1, S / std::max(1, atoi(rb)));   // tools: sweep
   b->n_rows_step = S * W;
@@ -1556,6 +1650,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->bq.assign(S, std::deque<Blk>());
   b->job.assign(S, Job());
   b->fault_msg.assign(S, std::string());
+  b->enc_gen.assign(S, 0);
   for (int s = 0; s < S; ++s) init_hyp(b, s);
   *out = b;
   return SC_OK;
@@ -1720,19 +1815,8 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
     rc = engine_tick(b, &progress);
     if (rc != SC_OK) return poison(b, rc);
     if (!progress) {
-      // everything is decoded: the missing completions are encoder stages still running
-      long wait_gen = 0;
-      for (int s = 0; s < b->S; ++s)
-        if (b->job[s].open && !b->job[s].fault && chunk_decoded(b, s) && b->job[s].gen > b->gen_done &&
-            (wait_gen == 0 || b->job[s].gen < wait_gen))
-          wait_gen = b->job[s].gen;
-      if (!wait_gen) {
-        sc_set_error("sc_poll: schedule stalled (internal error)");
-        return poison(b, SC_ERR_LAUNCH);
-      }
-      rc = launch_pending_groups(b);
-      if (rc == SC_OK) rc = wait_group(b, wait_gen);
-      if (rc != SC_OK) return poison(b, rc);
+      sc_set_error("sc_poll: schedule stalled (internal error)");
+      return poison(b, SC_ERR_LAUNCH);
     }
   }
   int n = 0;
@@ -1748,6 +1832,15 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
 }
 
 extern "C" int sc_streams_outstanding(const sc_streams *b) { return b ? b->n_open : 0; }
+
+// sc_submit policy: the frontend + encoder stages of successive admissions are merged and issued as ONE group when it
+// holds min_streams streams (default: half of the streams), or as soon as a queued decode block needs its frames.
+// 1: every admission is issued at once.  Results do not depend on it.
+extern "C" int sc_streams_set_encoder_batch(sc_streams *b, int min_streams) {
+  SC_CHECK_ARG(b && min_streams >= 1, "bad arguments");
+  b->enc_batch_min = min_streams;
+  return SC_OK;
+}
 
 // message of the last failure of this stream (status < 0 from sc_push / sc_poll), "" if none; valid until the
 // stream fails again or the handle is destroyed
@@ -1825,8 +1918,16 @@ extern "C" int sc_streams_write_pcm(sc_streams *b, int stream, long offset, cons
   HIP_TRY(hipMemcpy(b->pcm + (long)stream * b->PCAP + offset, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   return SC_OK;
 }
+// (reads of encoder-side buffers first settle the encoder groups that sc_submit may still hold back or have in flight)
+static int settle_encoder(sc_streams *b) {
+  RC_TRY(launch_pending_groups(b));
+  if (b->stream_enc) HIP_TRY(hipStreamSynchronize(b->stream_enc));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return retire_groups(b);
+}
 extern "C" long sc_streams_read_pcm_buffer(sc_streams *b, int stream, float *host, long max_n) {
   if (!b || stream < 0 || stream >= b->S) return SC_ERR_ARG;
+  if (settle_encoder(b) != SC_OK) return SC_ERR_LAUNCH;
   const St &st = b->st[stream];
   const long n = std::min<long>(st.pcm_end - st.pcm_start, max_n);
   if (host && n > 0 &&
@@ -1836,6 +1937,7 @@ extern "C" long sc_streams_read_pcm_buffer(sc_streams *b, int stream, float *hos
 }
 extern "C" int sc_streams_read_enc(sc_streams *b, int stream, float *host, int max_frames) {
   if (!b || stream < 0 || stream >= b->S) return SC_ERR_ARG;
+  if (settle_encoder(b) != SC_OK) return SC_ERR_LAUNCH;
   const int T = std::min(b->st[stream].T_enc, max_frames);
   if (host && T > 0 &&
       hipMemcpy(host, b->enc + (size_t)stream * b->TCAP * b->cfg.d_model, (size_t)T * b->cfg.d_model * sizeof(float),

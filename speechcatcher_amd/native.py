@@ -260,6 +260,11 @@ class NativeStreamBatch:
             _abi.check(n, "sc_poll")
         return ids[:n], st[:n]
 
+    def set_encoder_batch(self, min_streams: int):
+        """continuous batching: the encoder stages of successive admissions are issued as one group when it holds this
+        many streams (or as soon as a decode block needs its frames); results do not depend on it"""
+        _abi.check(self.lib.sc_streams_set_encoder_batch(self.handle, int(min_streams)), "sc_streams_set_encoder_batch")
+
     @property
     def outstanding(self) -> int:
         return int(self.lib.sc_streams_outstanding(self.handle))

@@ -48,6 +48,7 @@ class StreamScheduler:
         self._slot_of: Dict[int, int] = {}
         self._queue: Dict[int, Deque[Tuple[np.ndarray, bool, bool]]] = {}
         self._in_flight: Dict[int, Tuple[int, bool, bool]] = {}     # continuous batching: session -> (slot, final, finalize_all)
+        self._stash: Dict[int, list] = {}                           # replies that became ready inside close()
         self._next_sid = 0
 
     # ---- session lifecycle -------------------------------------------------
@@ -64,8 +65,10 @@ class StreamScheduler:
         return sid
 
     def close(self, sid: int):
-        while sid in self._in_flight:        # its chunk must be reported before the slot can be reset
-            self.pump(1)
+        while sid in self._in_flight:        # its chunk must be reported before the slot can be reset;
+            for k, v in self.pump(1, _collect=False).items():   # replies of OTHER sessions wait for their pump()
+                if k != sid:
+                    self._stash[k] = v
         slot = self._slot_of.pop(sid)
         self._queue.pop(sid)
         if self.reset_on_open:
@@ -82,7 +85,7 @@ class StreamScheduler:
         self._queue[sid].append((np.asarray(pcm, dtype=np.float32), bool(is_final), bool(finalize_all)))
 
     def pending(self) -> int:
-        return sum(1 for sid, q in self._queue.items() if q or sid in self._in_flight)
+        return sum(1 for sid, q in self._queue.items() if q or sid in self._in_flight or sid in self._stash)
 
     def _take_queued(self, skip=()):
         items, meta = [], {}
@@ -139,7 +142,7 @@ class StreamScheduler:
         return self._results(has, meta)
 
     # ---- continuous batching ------------------------------------------------------
-    def pump(self, min_done: int = 1) -> Dict[int, list]:
+    def pump(self, min_done: int = 1, _collect: bool = True) -> Dict[int, list]:
         """Continuous batching (C++ engine: sc_submit / sc_poll).  Hands the engine the next queued chunk of every
         session that has none in flight - ONE admission group - and then lets it decode until at least ``min_done``
         replies are ready.  A session's reply is delivered when ITS decode blocks are done: sessions that finish
@@ -154,12 +157,16 @@ class StreamScheduler:
             self.batch.submit(items)
             for sid, m in meta.items():
                 self._in_flight[sid] = m
-        if not self._in_flight:
-            return {}
-        has = self.batch.poll(max(1, min(min_done, len(self._in_flight))), isolate_faults=True)
+        out: Dict[int, list] = {}
+        if _collect and self._stash:
+            out, self._stash = self._stash, {}
+        if not self._in_flight or len(out) >= min_done:
+            return out
+        has = self.batch.poll(max(1, min(min_done - len(out), len(self._in_flight))), isolate_faults=True)
         sid_of = {m[0]: sid for sid, m in self._in_flight.items()}
         done = {sid_of[slot]: self._in_flight.pop(sid_of[slot]) for slot in has}
-        return self._results(has, done)
+        out.update(self._results(has, done))
+        return out
 
     @property
     def n_in_flight(self) -> int:

@@ -5,10 +5,10 @@ import numpy as np
 import torch
 
 from speechcatcher_amd import synth
-from speechcatcher_amd.config import MICRO, TINY, XL
+from speechcatcher_amd.config import L_LIKE, MICRO, TINY, XL
 from speechcatcher_amd.mel import melscale_fbanks_slaney
 
-CFGS = {"TINY": TINY, "XL": XL, "MICRO": MICRO}
+CFGS = {"TINY": TINY, "XL": XL, "MICRO": MICRO, "L_LIKE": L_LIKE}
 
 
 @functools.lru_cache(maxsize=4)

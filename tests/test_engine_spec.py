@@ -14,7 +14,8 @@ from speechcatcher_amd.config import TINY, XL, SearchConfig
 from speechcatcher_amd.engine import StreamBatch
 from speechcatcher_amd.weights import PackedWeights
 
-CFGS = {"TINY": TINY, "XL": XL}
+from speechcatcher_amd.config import L_LIKE, M_DEFAULTS  # noqa: E402
+CFGS = {"TINY": TINY, "XL": XL, "L_LIKE": L_LIKE, "M_DEFAULTS": M_DEFAULTS}
 
 
 def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", ffn_dtype="float32", **kw):

@@ -1,0 +1,168 @@
+"""The C++ engine (the thing bench.py times) at BASELINE.json's sizes: configs[2] (XL dims, 128 streams, beam 10),
+the per-GPU share of configs[4] (256 streams, fp16 feed-forward + fp16 K|V caches, graphs on, token positions),
+a stand-in for configs[3] (`_l` dims are not available offline: config.L_LIKE, 128 streams) and the 2-D feature
+input of the reference API (speech2text_streaming.py:438-449) - through the stream-level C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from speechcatcher_amd import synth
+from test_engine_spec import make_batch
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 10240
+
+
+def _same(a, b, tol, what):
+    assert len(a) == len(b) > 0, what
+    for x, y in zip(a, b):
+        assert x["yseq"] == y["yseq"] and x["xpos"] == y["xpos"], what
+        assert abs(x["score"] - y["score"]) <= tol * max(1.0, abs(y["score"]) * 1e-2), (what, x["score"], y["score"])
+
+
+def _feed(sb, audio, n_steps, rows=None):
+    rows = list(range(sb.S)) if rows is None else rows
+    ids = np.arange(len(rows), dtype=np.int32)
+    for k in range(n_steps):
+        st = sb.push_block(ids, np.ascontiguousarray(audio[rows, k * CHUNK:(k + 1) * CHUNK]))
+        assert (st >= 0).all()
+
+
+def test_xl_128_streams_native_equals_python_engine_solo_runs_and_continuous_batching():
+    """BASELINE configs[2] on the product engine: 128 streams x 8 chunk steps (5 decode blocks each).  Every stream's
+    hypotheses (ids and positions exact, scores <= 1e-3) equal those of the Python engine over the same kernels, of
+    solo runs, of its duplicate elsewhere in the batch, and of the same streams served by continuous batching; the
+    encoder ran beside the decode loop and (nearly) every compaction bucket was used."""
+    from speechcatcher_amd.hip_backend import HipBackend
+    S, n, beam = 128, 8, 10
+    audio = np.stack([synth.synth_audio(500 + (s if s < 120 else s - 120), CHUNK * n) for s in range(S)])   # 120..127 = 0..7
+    kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+    nat = make_batch("XL", 1234, "meanstd", beam, False, backend="native", **kw)
+    sec, it = (C.c_double * 17)(), (C.c_long * 17)()
+    _feed(nat, audio, n)
+    nat.lib.sc_streams_bucket_times(nat.handle, sec, it)
+    assert sum(1 for k in range(17) if it[k]) >= 15, list(it)          # the ragged step loop went through the buckets
+    assert nat.stats["enc_calls"] == n - 2 and nat.stats["dec_blocks"] == S * (n - 3)
+    got = nat.hypotheses_batch(list(range(S)))
+    assert all(len(got[s]) == beam and len(got[s][0]["yseq"]) > 10 for s in range(S))
+    for s in range(8):
+        _same(got[120 + s], got[s], 1e-6, f"duplicate of stream {s}")
+    # continuous batching: same streams, every reply followed by that stream's next chunk
+    cont = make_batch("XL", 1234, "meanstd", beam, False, backend="native", **kw)
+    nxt = np.zeros(S, np.int64)
+    a3 = audio.reshape(S, n, CHUNK)
+    cont.submit_block(np.arange(S, dtype=np.int32), np.ascontiguousarray(a3[:, 0]))
+    nxt += 1
+    while cont.outstanding:
+        done, st = cont.poll_ids(16)
+        assert (st >= 0).all()
+        again = done[nxt[done] < n]
+        if len(again):
+            cont.submit_block(again, a3[again, nxt[again]])
+            nxt[again] += 1
+    assert cont.stats["dec_blocks"] == nat.stats["dec_blocks"] and cont.stats["dec_steps"] < nat.stats["dec_steps"]
+    gc_ = cont.hypotheses_batch(list(range(S)))
+    for s in range(S):
+        _same(gc_[s], got[s], 1e-3, f"continuous batching, stream {s}")
+    cont.close()
+    # solo runs of three streams
+    for s in (0, 50, 127):
+        solo = make_batch("XL", 1234, "meanstd", beam, False, backend="native", **dict(kw, n_streams=1))
+        _feed(solo, audio, n, rows=[s])
+        _same(solo.hypotheses(0), got[s], 1e-3, f"solo run of stream {s}")
+        solo.close()
+    nat.close()
+    # the Python engine over the same kernels
+    pye = make_batch("XL", 1234, "meanstd", beam, False, backend=HipBackend("cuda:0"), device="cuda:0", **kw)
+    for k in range(n):
+        pye.push([(s, audio[s, k * CHUNK:(k + 1) * CHUNK], False) for s in range(S)])
+    for s in range(S):
+        _same(pye.hypotheses(s), got[s], 1e-3, f"python engine, stream {s}")
+
+
+def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
+    """Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward weights / MFMA inputs and fp16 K|V caches
+    (hipGraph replay on, token positions read back) against the fp32 engine on the same audio: the best hypothesis of
+    every stream keeps its token ids AND positions; the full beams agree for nearly all streams (fp16 rounding may
+    reorder hypotheses whose fp32 scores are closer than its error)."""
+    S, n, beam = 256, 7, 10
+    audio = np.stack([synth.synth_audio(900 + s, CHUNK * n) for s in range(S)])
+    kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+    out = {}
+    for mode in ("float32", "float16"):
+        sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", ffn_dtype=mode, kv_dtype=mode, **kw)
+        _feed(sb, audio, n)
+        out[mode] = sb.hypotheses_arrays(list(range(S)))
+        sb.close()
+    a, b = out["float32"], out["float16"]
+    assert (a["n_hyps"] == beam).all() and (b["n_hyps"] == beam).all()
+    assert (a["lens"][:, 0] == b["lens"][:, 0]).all() and a["lens"][:, 0].min() > 10
+    L = a["ids"].shape[2]
+    mask = np.arange(L)[None, :] < a["lens"][:, 0][:, None]
+    assert (np.where(mask, a["ids"][:, 0], 0) == np.where(mask, b["ids"][:, 0], 0)).all(), "best hypothesis: token ids"
+    assert (np.where(mask, a["xpos"][:, 0], 0) == np.where(mask, b["xpos"][:, 0], 0)).all(), "best hypothesis: positions"
+    assert np.abs(a["score"][:, 0] - b["score"][:, 0]).max() < 0.5
+    same_beam = sum(1 for s in range(S) if (a["lens"][s] == b["lens"][s]).all() and
+                    all((a["ids"][s, j, :a["lens"][s, j]] == b["ids"][s, j, :a["lens"][s, j]]).all() for j in range(beam)))
+    assert same_beam >= int(0.9 * S), same_beam
+
+
+def test_l_like_dims_128_streams_equal_solo_oracle_runs():
+    """Stand-in for BASELINE configs[3] (`_l` dims assumed: config.L_LIKE = 256 / 4 heads of 64 / 18 + 8 blocks) at its
+    per-GPU batch: 128 streams, beam 10; three of them against the oracle run alone on the same audio."""
+    from helpers import oracle_model, run_oracle_stream
+    S, n, beam = 128, 7, 10
+    audio = np.stack([synth.synth_audio(700 + s, CHUNK * n) for s in range(S)])
+    sb = make_batch("L_LIKE", 1234, "meanstd", beam, False, n_streams=S, backend="native", max_frames=200, max_tokens=160,
+                    pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+    for k in range(n):
+        fin = np.full(S, 1 if k == n - 1 else 0, np.uint8)
+        st = sb.push_block(np.arange(S, dtype=np.int32), np.ascontiguousarray(audio[:, k * CHUNK:(k + 1) * CHUNK]), fin)
+        assert (st >= 0).all()
+    got = sb.hypotheses_batch(list(range(S)))
+    model = oracle_model("L_LIKE", 1234, "meanstd")
+    for s in (3, 64, 125):
+        ora, _, _, _ = run_oracle_stream(model, audio[s], CHUNK, beam, False)
+        ref = ora.running_hyps
+        assert sorted(tuple(h["yseq"]) for h in got[s]) == sorted(tuple(h.yseq) for h in ref), s
+        assert got[s][0]["yseq"] == list(ref[0].yseq) and got[s][0]["xpos"] == list(ref[0].xpos), s
+        assert abs(got[s][0]["score"] - ref[0].score) < 2e-3, (s, got[s][0]["score"], ref[0].score)
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "XL"])
+def test_feature_input_on_the_native_engine_matches_oracle(cfg_name):
+    """2-D (T, 80) feature matrices instead of PCM (speech2text_streaming.py:438-449: normalised, then used) through
+    sc_push_features, two streams with different splits in one batch, against the oracle fed the same features."""
+    import torch
+    from helpers import oracle_model
+    from oracle.ref_port import RefPortStreaming
+    model = oracle_model(cfg_name, 1234, "meanstd")
+    g = torch.Generator().manual_seed(5)
+    feats = [(torch.randn(150, 80, generator=g) * 2.0 - 8.0).numpy().astype(np.float32) for _ in range(2)]
+    splits = [((0, 70), (70, 150)), ((0, 90), (90, 150))]
+    sb = make_batch(cfg_name, 1234, "meanstd", 5, False, n_streams=3, backend="native", max_frames=128, max_tokens=200,
+                    pcm_capacity=1 << 14, max_chunk_samples=32768)
+    oras = [RefPortStreaming(model, beam_size=5) for _ in range(2)]
+    for part in range(2):
+        items = []
+        for i in range(2):
+            a, b = splits[i][part]
+            fin = b == 150
+            oras[i](torch.from_numpy(feats[i][a:b]), is_final=fin, finalize_all=fin)
+            norm = ((feats[i][a:b] - model.mean) / model.std).astype(np.float32)
+            items.append((2 * i, norm, fin))                      # streams 0 and 2; stream 1 stays idle
+        out = sb.push_features(items)
+        assert all(out[s] is True for s, _, _ in items)
+    for i in range(2):
+        got, ref = sb.hypotheses(2 * i), oras[i].running_hyps
+        assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref], i
+        assert [h["xpos"] for h in got] == [list(h.xpos) for h in ref], i
+        np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=5e-3 if cfg_name == "XL" else 2e-3)
+    assert sb.hypotheses(1) == [] or len(sb.hypotheses(1)[0]["yseq"]) == 1
+    # a feature matrix that does not fit fails that stream only
+    from speechcatcher_amd.engine import EngineError
+    big = np.zeros((400, 80), np.float32)
+    out = sb.push_features([(1, big, False)], isolate_faults=True)
+    assert isinstance(out[1], EngineError)

@@ -329,7 +329,9 @@ def test_native_xl_batch_equals_python_engine():
     py = run(HipBackend("cuda:0"), "cuda:0")
     for s in range(S):
         assert [h["yseq"] for h in nat[s]] == [h["yseq"] for h in py[s]], s
-        assert all(abs(x["score"] - y["score"]) < 1e-6 for x, y in zip(nat[s], py[s])), s
+        # (not bit-equal: the C++ engine projects the CTC / cross-attention K|V rows inside the encoder stage, in other
+        # GEMM batches - another split-K summation order - than the Python engine does at block start)
+        assert all(abs(x["score"] - y["score"]) < 5e-4 for x, y in zip(nat[s], py[s])), s
 
 
 @pytest.mark.parametrize("vosk,continuous", [(False, False), (True, False), (False, True), (True, True)])

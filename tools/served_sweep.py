@@ -1,0 +1,43 @@
+"""Continuous batching (sc_submit / sc_poll) at 128 streams: throughput against the number of replies sc_poll waits for
+(= the size of the next admission group), with the decode iterations by compaction bucket.
+    gpurun -- 'python tools/served_sweep.py 4 8 16 32 e1 e64'      (eN: encoder batch of N streams)"""
+import ctypes as C
+import sys
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+
+groups = [int(a) for a in sys.argv[1:] if not a.startswith("e")] or [8, 16, 32]
+encb = [int(a[1:]) for a in sys.argv[1:] if a.startswith("e")] or [64]
+S, pre, warm, steps = 128, 21, 5, 20
+w = bench.make_weights("cuda:0")
+total = pre + warm + steps + bench.SERVED_SPARE
+audio = bench.make_audio(S, total)
+def clear(sb):
+    sec, it = (C.c_double * 17)(), (C.c_long * 17)()
+    sb.lib.sc_streams_bucket_times(sb.handle, sec, it)
+    a, b = C.c_double(), C.c_double()
+    sb.lib.sc_streams_host_times(sb.handle, C.byref(a), C.byref(b))
+
+
+def hist(sb):
+    sec, it = (C.c_double * 17)(), (C.c_long * 17)()
+    sb.lib.sc_streams_bucket_times(sb.handle, sec, it)
+    a, b = C.c_double(), C.c_double()
+    sb.lib.sc_streams_host_times(sb.handle, C.byref(a), C.byref(b))
+    tot = sum(it)
+    return (" ".join(f"{k}:{it[k] / steps:.1f}x{sec[k] / max(it[k], 1) * 1e3:.2f}" for k in range(17) if it[k]) +
+            f" | loop {sum(sec) / steps * 1e3:.2f} ms/step (issue {a.value / steps * 1e3:.2f}, wait {b.value / steps * 1e3:.2f}), {tot / steps:.1f} it/step")
+
+
+sb = bench.build_native(w, S, 10, False, total)
+e, dsh, _ = bench.timed_window(sb, audio, pre, warm, steps, "host", before_timing=clear)
+print(f"strict: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step  {dsh:.2f} decode steps/hop\n    bucket:iterations per step x ms  {hist(sb)}", flush=True)
+sb.close()
+for g, eb in [(g, eb) for eb in encb for g in groups]:
+    sb = bench.build_native(w, S, 10, False, total)
+    sb.set_encoder_batch(eb)
+    e, dsh, iters, polls, spread = bench.served_window(sb, audio, pre, warm, steps, g, before_timing=clear)
+    print(f"group {g:3d} encoder batch {eb:3d}: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step-eq  {iters:5.2f} iterations/step  "
+          f"{polls:.1f} polls/step  spread {spread}\n    bucket:iterations per step x ms  {hist(sb)}", flush=True)
+    sb.close()
