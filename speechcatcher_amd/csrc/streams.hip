@@ -242,6 +242,10 @@ struct sc_streams {
   long gen_next = 1, gen_done = 0, gen_ordered = 0;   // groups: issued, known complete, main stream ordered behind
   int n_open = 0;                  // outstanding chunks
   long iter = 0;
+  bool inflight = false;           // a decode step has been enqueued and not collected yet (between two sc_poll calls)
+  std::vector<int> tick_active;    // ... for these streams
+  std::chrono::steady_clock::time_point tick_t0, tick_t1;
+  hipStream_t stream_rb = nullptr; // hypothesis read-back (sc_get_hyps_batch) beside an enqueued decode step
   bool poisoned = false;           // a call failed half-way: device and host state may disagree
   std::vector<int> rowmap_key;
   int row_bucket = 1, n_rows_step = 0;
@@ -271,6 +275,7 @@ struct sc_streams {
     for (EncGroup *g : groups) delete g;
     for (void *p : owned) (void)hipFree(p);
     for (void *p : owned_host) (void)hipHostFree(p);
+    if (stream_rb) (void)hipStreamDestroy(stream_rb);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -960,10 +965,16 @@ int start_blocks(sc_streams *b) {
   return SC_OK;
 }
 
-// One tick.  *progress: a block was started or finished, or a decode step ran.  Nothing to do -> *progress = false.
-int engine_tick(sc_streams *b, bool *progress) {
+// One tick = issue (start the ready blocks, close the ended ones, enqueue ONE beam-search step for every stream that is
+// inside a block) + collect (wait for the step, read its stop flags, apply the accept / stop rules).  sc_poll returns
+// to its caller BETWEEN the two: the device runs the step while the host handles the replies of the streams that
+// finished (read-back on the read-back stream, the next chunks' admission on the encoder stream).
+// *progress: a block was started or finished, or a step was enqueued.  Nothing to do -> *progress = false.
+int tick_collect(sc_streams *b);
+int tick_issue(sc_streams *b, bool *progress) {
   const int S = b->S, W = b->W, Ld = b->cfg.dec_layers;
   *progress = false;
+  if (b->inflight) RC_TRY(tick_collect(b));
   RC_TRY(retire_groups(b));
   RC_TRY(start_blocks(b));
   {
@@ -978,7 +989,8 @@ int engine_tick(sc_streams *b, bool *progress) {
     if (upto >= 0) RC_TRY(launch_pending_groups(b, upto));
   }
   // streams whose step loop has ended (stop flags of the previous tick, or process_idx at its bound: :701)
-  std::vector<int> active;
+  std::vector<int> &active = b->tick_active;
+  active.clear();
   for (int s = 0; s < S; ++s) {
     Run &r = b->run[s];
     if (!r.inblk) continue;
@@ -1010,7 +1022,7 @@ int engine_tick(sc_streams *b, bool *progress) {
     return SC_OK;
   }
   *progress = true;
-  const auto tp0 = std::chrono::steady_clock::now();
+  b->tick_t0 = std::chrono::steady_clock::now();
   set_rowmap(b, active);
   b->scan_long = false;   // the graph with the T-parallel scan only when a stream's table is long enough for it
   int32_t *ctrl = b->ctrl_host();
@@ -1036,20 +1048,29 @@ int engine_tick(sc_streams *b, bool *progress) {
   HIP_TRY(hipEventRecord(b->ev_iter[b->iter & 1], b->stream));
   const bool fused = sc_decode_step_form(&b->sb) != 0;
   for (int s : active) b->xattn_rows[fused ? 1 : 0] += (long)b->run[s].T * Ld;   // K|V rows the cross-attention reads (bench roofline)
-  const auto tp1 = std::chrono::steady_clock::now();
+  b->tick_t1 = std::chrono::steady_clock::now();
+  b->inflight = true;
+  return SC_OK;
+}
+
+int tick_collect(sc_streams *b) {
+  if (!b->inflight) return SC_OK;
+  const int S = b->S, W = b->W;
+  b->inflight = false;
+  const auto tpw = std::chrono::steady_clock::now();
   HIP_TRY(hipEventSynchronize(b->ev_iter[b->iter & 1]));   // the stop flags live in host-mapped pinned memory
   const auto tp2 = std::chrono::steady_clock::now();
   b->iter++;
   b->dec_steps++;
-  b->t_launch += std::chrono::duration<double>(tp1 - tp0).count();
-  b->t_wait += std::chrono::duration<double>(tp2 - tp1).count();
+  b->t_launch += std::chrono::duration<double>(b->tick_t1 - b->tick_t0).count();
+  b->t_wait += std::chrono::duration<double>(tp2 - tpw).count();
   {
     const int bk = std::min(16, (int)((long)b->n_rows_step * 16 / std::max(1, S * W)));
-    b->t_bucket[bk] += std::chrono::duration<double>(tp2 - tp0).count();
+    b->t_bucket[bk] += std::chrono::duration<double>(tp2 - b->tick_t0).count();
     b->n_bucket[bk] += 1;
   }
   // ---- the accept / stop rules of the step loop (:759-821)
-  for (int s : active) {
+  for (int s : b->tick_active) {
     Run &r = b->run[s];
     const int f = b->flags_host[s];
     const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
@@ -1077,6 +1098,11 @@ int engine_tick(sc_streams *b, bool *progress) {
     }
   }
   return SC_OK;
+}
+
+int engine_tick(sc_streams *b, bool *progress) {
+  RC_TRY(tick_issue(b, progress));
+  return tick_collect(b);
 }
 
 // a stream's outstanding chunk is complete: all of its blocks are decoded and its encoder stage has finished
@@ -1300,6 +1326,7 @@ int poison(sc_streams *b, int rc) {
   (void)hipStreamSynchronize(b->stream);
   if (b->stream_enc) (void)hipStreamSynchronize(b->stream_enc);
   (void)hipGetLastError();
+  b->inflight = false;
   b->poisoned = true;
   return rc;
 }
@@ -1483,6 +1510,11 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   int rc = SC_OK;
 #define A(ptr, count) if (rc == SC_OK) rc = b->alloc(&ptr, (size_t)(count))
   if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, -1) != hipSuccess) {
+    sc_set_error("sc_streams_create: hipStreamCreate failed");
+    delete b;
+    return SC_ERR_LAUNCH;
+  }
+  if (hipStreamCreateWithPriority(&b->stream_rb, hipStreamNonBlocking, -1) != hipSuccess) {
     sc_set_error("sc_streams_create: hipStreamCreate failed");
     delete b;
     return SC_ERR_LAUNCH;
@@ -1805,16 +1837,26 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
   }
   HIP_TRY(hipSetDevice(b->eng->device));
   min_done = std::min(std::min(min_done, max_done), b->n_open);
+  int stalled = 0;
   while (true) {
-    int rc = retire_groups(b);
+    int rc = tick_collect(b);   // the step enqueued by the previous call (or iteration)
+    if (rc == SC_OK) rc = retire_groups(b);
     if (rc != SC_OK) return poison(b, rc);
     int n_complete = 0;
     for (int s = 0; s < b->S; ++s) n_complete += chunk_complete(b, s) ? 1 : 0;
-    if (n_complete >= min_done || b->n_open == 0) break;
+    const bool enough = n_complete >= min_done || b->n_open == 0;
+    // the next step is enqueued BEFORE the replies go back to the caller: the device decodes the streams that are still
+    // inside their blocks while the host reads the finished streams' hypotheses and admits their next chunks
     bool progress = false;
-    rc = engine_tick(b, &progress);
-    if (rc != SC_OK) return poison(b, rc);
-    if (!progress) {
+    if (b->n_open > n_complete || !enough) {
+      do {   // (a tick that only started / closed blocks enqueues nothing: go on until a step is in flight or all is idle)
+        rc = tick_issue(b, &progress);
+        if (rc != SC_OK) return poison(b, rc);
+      } while (progress && !b->inflight);
+    }
+    if (enough) break;
+    if (b->inflight || progress) stalled = 0;
+    else if (++stalled > 1) {   // (once: blocks that were closed without a step change the count above)
       sc_set_error("sc_poll: schedule stalled (internal error)");
       return poison(b, SC_ERR_LAUNCH);
     }
@@ -1889,10 +1931,12 @@ extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, in
   if (m == 0) return SC_OK;
   SC_CHECK_ARG(off <= b->pack_cap, "hypotheses exceed the read-back buffer");
   memcpy(b->pjobs_host, jobs.data(), jobs.size() * sizeof(int32_t));
-  HIP_TRY(hipMemcpyAsync(b->pjobs_dev, b->pjobs_host, jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  pack_hyps_kernel<<<m, 128, 0, b->stream>>>(b->sb, b->pjobs_dev, b->pack_dev);
-  HIP_TRY(hipMemcpyAsync(b->pack_host, b->pack_dev, off * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  // on the read-back stream: a decode step of OTHER streams may be in flight on the batch's stream (sc_poll); the
+  // listed streams' last steps have been collected (host-synchronised) by then
+  HIP_TRY(hipMemcpyAsync(b->pjobs_dev, b->pjobs_host, jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream_rb));
+  pack_hyps_kernel<<<m, 128, 0, b->stream_rb>>>(b->sb, b->pjobs_dev, b->pack_dev);
+  HIP_TRY(hipMemcpyAsync(b->pack_host, b->pack_dev, off * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream_rb));
+  HIP_TRY(hipStreamSynchronize(b->stream_rb));
   int k = 0;
   for (int i = 0; i < n; ++i)
     for (int h = 0; h < n_hyps[i]; ++h, ++k) {
@@ -1920,6 +1964,7 @@ extern "C" int sc_streams_write_pcm(sc_streams *b, int stream, long offset, cons
 }
 // (reads of encoder-side buffers first settle the encoder groups that sc_submit may still hold back or have in flight)
 static int settle_encoder(sc_streams *b) {
+  RC_TRY(tick_collect(b));
   RC_TRY(launch_pending_groups(b));
   if (b->stream_enc) HIP_TRY(hipStreamSynchronize(b->stream_enc));
   HIP_TRY(hipStreamSynchronize(b->stream));
