@@ -48,7 +48,7 @@ from speechcatcher_amd import synth  # noqa: E402
 from speechcatcher_amd.config import XL, SearchConfig  # noqa: E402
 
 CHUNK = 10240
-SERVED_SPARE = 6               # chunks per stream beyond the window (served leg: streams that run ahead of the average)
+SERVED_SPARE = 8               # chunks per stream beyond the window (served leg: streams that run ahead of the average)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E ~8 TB/s
 # algorithmic work of one stream-hop (10 240 samples of one stream)
@@ -126,17 +126,18 @@ def n_dec_steps(sb):
     return sum(st.n_steps_total for st in sb.st)
 
 
-def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None, before_timing=None):
-    """roll `preroll + warmup` steps untimed (resident audio), then time `steps` steps in `mode`"""
-    ids = np.arange(sb.S, dtype=np.int32)
-    k0 = preroll + warmup
-    preload_audio(sb, audio, k0 + (steps if mode == "resident" else 0))
+def roll(sb, audio, preroll):
+    """the untimed pre-roll: `preroll` lock-step chunk steps on resident audio"""
+    preload_audio(sb, audio, preroll)
     run_resident(sb, preroll)
-    if mode == "host":      # warm-up in the timed mode (staging buffers, pack kernel, graphs of the window's buckets)
-        run_host(sb, step_blocks(audio, preroll, k0), ids)
-    else:
-        run_resident(sb, warmup)
-    blocks = step_blocks(audio, k0, k0 + steps) if mode == "host" else None
+    torch.cuda.synchronize()
+
+
+def strict_window(sb, audio, k0, steps, dist=None, before_timing=None):
+    """STRICT lock-step: `steps` batched sc_push calls (chunks k0.. of every stream), every block completes inside its
+    call; host PCM in, best hypothesis of every stream out after every call."""
+    ids = np.arange(sb.S, dtype=np.int32)
+    blocks = step_blocks(audio, k0, k0 + steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -145,63 +146,75 @@ def timed_window(sb, audio, preroll, warmup, steps, mode, dist=None, before_timi
         before_timing(sb)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if mode == "host":
-        last = run_host(sb, blocks, ids)
-    else:
-        run_resident(sb, steps)
-        last = None
+    last = run_host(sb, blocks, ids)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    dec_steps = (n_dec_steps(sb) - steps0) / float(sb.S)
-    return elapsed, dec_steps / max(steps, 1), last
+    return elapsed, (n_dec_steps(sb) - steps0) / float(sb.S) / max(steps, 1), last
 
 
-def served_window(sb, audio, preroll, warmup, steps, group, before_timing=None):
-    """Continuous batching from the same starting point: after the lock-step pre-roll every stream is served on its
-    own - sc_submit its chunk, sc_poll until replies are ready, read the best hypothesis of the streams that answered
-    (sc_get_hyps_batch), submit THEIR next chunks.  Host PCM in, hypotheses out, as in run_host.  The clock stops
-    when S x steps replies have been delivered (the same amount of audio as the strict window; a stream whose blocks
-    need fewer decode steps gets further than one that needs more - `audio` must hold spare chunks for them)."""
+def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None):
+    """CONTINUOUS batching, closed loop: every stream is served on its own - sc_submit its chunk, sc_poll until replies
+    are ready, read the best hypothesis of the streams that answered (sc_get_hyps_batch), submit THEIR next chunks
+    (stream i continues at chunk nxt[i] of a3 [S][chunks][CHUNK]).  boundary: host PCM in (pinned staging, one H2D
+    per admission) and hypotheses out per reply; False: chunks already resident in the device PCM ring, no read-back.
+    The clock stops when S x steps replies have been delivered - `steps` chunk steps' worth of audio; a stream whose
+    blocks need fewer decode steps gets further than one that needs more (a3 must hold spare chunks).  What is in
+    flight then is drained untimed."""
     S = sb.S
-    ids = np.arange(S, dtype=np.int32)
-    k0 = preroll + warmup
-    preload_audio(sb, audio, preroll)
-    run_resident(sb, preroll)
-    run_host(sb, step_blocks(audio, preroll, k0), ids)
-    a3 = audio.reshape(S, -1, CHUNK)
-    nxt = np.full(S, k0, np.int64)
     end = a3.shape[1]
+    k_start = nxt.copy()
     torch.cuda.synchronize()
-    steps0 = n_dec_steps(sb)
-    iters0 = sb.stats["dec_steps"]
+    if dist is not None:
+        dist.barrier()
+    steps0, iters0 = n_dec_steps(sb), sb.stats["dec_steps"]
     if before_timing:
         before_timing(sb)
+
+    def submit(streams):
+        streams = streams[nxt[streams] < end]
+        if len(streams):
+            if boundary:
+                sb.submit_block(streams, a3[streams, nxt[streams]])
+            else:
+                sb.submit([(int(i), CHUNK, False) for i in streams], pcm_resident=True)
+            nxt[streams] += 1
+
     t0 = time.perf_counter()
-    sb.submit_block(ids, np.ascontiguousarray(a3[:, k0]))
-    nxt += 1
-    n_polls, n_replies, target = 0, 0, S * steps
-    elapsed = None
+    submit(np.arange(S, dtype=np.int32))
+    n_polls, n_replies, target, res = 0, 0, S * steps, None
     while sb.outstanding:
         done, st = sb.poll_ids(min(group, sb.outstanding))
         assert (st >= 0).all()
         n_polls += 1
-        sb.hypotheses_arrays(done, nbest=1)
+        if boundary:
+            sb.hypotheses_arrays(done, nbest=1)
         n_replies += len(done)
         if n_replies >= target:
-            if elapsed is None:
+            if res is None:
+                torch.cuda.synchronize()
                 elapsed = time.perf_counter() - t0
-                spread = (int(nxt.min()) - k0, int(nxt.max()) - k0)
-                dsh = (n_dec_steps(sb) - steps0) / float(n_replies)
-                iters = (sb.stats["dec_steps"] - iters0) / steps
+                if at_target:
+                    at_target()
+                adv = nxt - k_start
+                res = {"elapsed": elapsed, "dec_steps_per_hop": (n_dec_steps(sb) - steps0) / float(n_replies),
+                       "iterations_per_step": (sb.stats["dec_steps"] - iters0) / float(steps), "polls_per_step": n_polls / float(steps),
+                       "chunks_per_stream_min_max": [int(adv.min()), int(adv.max())]}
             continue          # (drain what is in flight, untimed)
-        again = done[nxt[done] < end]
-        if len(again):
-            sb.submit_block(again, a3[again, nxt[again]])
-            nxt[again] += 1
+        submit(done)
     torch.cuda.synchronize()
-    return elapsed, dsh, iters, n_polls / steps, spread
+    if dist is not None:
+        dist.barrier()
+    assert res is not None, "the streams ran out of audio before the target number of replies"
+    return res
+
+
+def state_of(sb):
+    a = sb.hypotheses_arrays(list(range(sb.S)), nbest=1)
+    T = [st.T_enc for st in sb.st]
+    return {"encoder_frames_T": [min(T), max(T)], "tokens_L": [int(a["lens"].min()), int(a["lens"].max())],
+            "process_idx": [min(st.process_idx for st in sb.st), max(st.process_idx for st in sb.st)]}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -256,26 +269,45 @@ def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
                                                 "12-15 steps in its 10 s budget: +-10 %"}}
 
 
+def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True):
+    """one fresh batch: pre-roll (lock-step, resident audio, untimed), warm-up in the timed mode, then the timed leg"""
+    sb = build_native(w, streams, beam, bbd, total)
+    roll(sb, audio, preroll)
+    k0 = preroll + warmup
+    a3 = audio.reshape(streams, -1, CHUNK)
+    if mode == "strict":
+        run_host(sb, step_blocks(audio, preroll, k0), np.arange(streams, dtype=np.int32))
+        e, dsh, _ = strict_window(sb, audio, k0, steps, dist)
+        out = {"elapsed": e, "dec_steps_per_hop": dsh}
+    else:
+        nxt = np.full(streams, preroll, np.int64)
+        if not boundary:
+            preload_audio(sb, audio, a3.shape[1])
+        if warmup > 0:
+            serve(sb, a3, nxt, warmup, group, boundary=boundary)
+        out = serve(sb, a3, nxt, steps, group, dist, boundary=boundary)
+        out["next_chunk"] = nxt
+    out["value"] = streams * steps * CHUNK / 16000.0 / out["elapsed"]
+    return sb, out
+
+
 def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
-    """strict and served throughput with every stream `target_T` encoder frames into its utterance"""
+    """continuous and strict throughput with every stream about `target_T` encoder frames into its utterance"""
     hops = max(2, (target_T - 24) // 16 + 2)
     preroll, warm = hops - 2, 2
     total = preroll + warm + steps + SERVED_SPARE
     audio = make_audio(streams, total, stream_offset=7000, shared=True)
     out = {"bbd": int(bbd), "steps": steps, "audio": "windows of one seeded noise buffer at per-stream offsets"}
-    sb = build_native(w, streams, beam, bbd, total)
-    e, dsh, last = timed_window(sb, audio, preroll, warm, steps, "host")
-    T = [st.T_enc for st in sb.st]
-    out.update({"value": round(streams * steps * CHUNK / 16000.0 / e, 2), "unit": "audio_s/s",
-                "ms_per_step": round(e / steps * 1e3, 3), "decode_steps_per_hop": round(dsh, 2),
-                "encoder_frames_T": [min(T), max(T)], "tokens_L": [int(last["lens"].min()), int(last["lens"].max())],
-                "process_idx": [min(st.process_idx for st in sb.st), max(st.process_idx for st in sb.st)]})
+    sb, r = measure(w, audio, streams, beam, bbd, preroll, warm, steps, group, "continuous", total)
+    out.update({"value": round(r["value"], 2), "unit": "audio_s/s", "ms_per_step_equivalent": round(r["elapsed"] / steps * 1e3, 3),
+                "decode_steps_per_hop": round(r["dec_steps_per_hop"], 2),
+                "decode_iterations_per_step": round(r["iterations_per_step"], 2)})
+    out.update(state_of(sb))
     sb.close()
     del sb
-    sb = build_native(w, streams, beam, bbd, total)
-    e, dsh, iters, polls, spread = served_window(sb, audio, preroll, warm, steps, group)
-    out["served"] = {"value": round(streams * steps * CHUNK / 16000.0 / e, 2), "ms_per_step_equivalent": round(e / steps * 1e3, 3),
-                     "decode_iterations_per_step": round(iters, 2)}
+    sb, r = measure(w, audio, streams, beam, bbd, preroll, warm, steps, group, "strict", total)
+    out["strict_lock_step"] = {"value": round(r["value"], 2), "ms_per_step": round(r["elapsed"] / steps * 1e3, 3),
+                               "decode_steps_per_hop": round(r["dec_steps_per_hop"], 2)}
     sb.close()
     del sb, audio
     return out
@@ -287,8 +319,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preroll", type=int, default=21,
-                    help="untimed chunk steps in front of the warm-up: the timed window then sits in the middle of SURVEY "
-                         "8(d)'s 60 s utterance (hops 27-46 with --warmup 5 --steps 20) instead of at its cheap beginning")
+                    help="untimed lock-step chunk steps in front of the warm-up: the timed window then sits in the middle of "
+                         "SURVEY 8(d)'s 60 s utterance (hops 26-45 with --warmup 5 --steps 20) instead of at its cheap beginning")
+    ap.add_argument("--mode", choices=["continuous", "strict"], default="continuous",
+                    help="continuous: every stream is served on its own through sc_submit / sc_poll (continuous batching: a "
+                         "reply is delivered when ITS blocks are decoded - the reference's concurrency model, one independent "
+                         "call loop per stream); strict: one batched sc_push per chunk step, every stream waits for the slowest "
+                         "one of the batch.  Per call the results are the same.  The other mode is reported as an extra key")
     ap.add_argument("--streams", type=int, default=128, help="streams per GPU")
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
@@ -296,11 +333,11 @@ def main():
                     help="samples per chunk step (10240 = 640 ms = one encoder hop; also 8192 = CLI default, 25600 = block size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
-    ap.add_argument("--no-served", action="store_true", help="skip the continuous-batching (sc_submit / sc_poll) leg")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the leg of the mode that is not the headline")
     ap.add_argument("--no-resident", action="store_true", help="skip the resident-audio / no-read-back leg")
     ap.add_argument("--no-long-context", action="store_true", help="skip the T ~ 1000 / T ~ 4500 legs")
-    ap.add_argument("--served-group", type=int, default=0,
-                    help="sc_poll returns when at least this many replies are ready (0: streams / 8)")
+    ap.add_argument("--poll-group", type=int, default=0,
+                    help="continuous: sc_poll returns when at least this many replies are ready (0: streams / 16)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the hot kernels")
     ap.add_argument("--kv-dtype", choices=["float32", "float16"], default="float32",
@@ -314,7 +351,8 @@ def main():
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
     FFN_DTYPE = args.ffn_dtype
-    group = args.served_group or max(1, args.streams // 8)
+    group = args.poll_group or max(1, args.streams // 16)
+    S = args.streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -337,18 +375,19 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
 
-    window = args.preroll + args.warmup + args.steps
-    total_steps = window + max(args.roofline_steps, SERVED_SPARE)
+    k0 = args.preroll + args.warmup
+    total_steps = k0 + args.steps + args.roofline_steps + SERVED_SPARE
     w = make_weights(device)
-    sb = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
+    audio = make_audio(S, total_steps, stream_offset=rank * S)
+    a3 = audio.reshape(S, -1, CHUNK)
+    sb, head = measure(w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, args.mode,
+                       total_steps, dist)
     lib = sb.lib
-    audio = make_audio(args.streams, total_steps, stream_offset=rank * args.streams)
-    elapsed, dec_steps_per_hop, last = timed_window(sb, audio, args.preroll, args.warmup, args.steps, "host", dist)
-    T_now = [st.T_enc for st in sb.st]
-    L_now = [int(last["lens"].min()), int(last["lens"].max())]
+    elapsed, dec_steps_per_hop = head["elapsed"], head["dec_steps_per_hop"]
+    state = state_of(sb)
 
-    # Roofline leg: the SAME workload continues for a few more steps with hipGraph replay switched off, so that
-    # every launch of the hot kernels can be bracketed by HIP events on its launch stream.
+    # Roofline leg: the SAME workload continues in the SAME mode for a few more steps with hipGraph replay switched
+    # off, so that every launch of the hot kernels can be bracketed by HIP events on its launch stream.
     NK = 12   # scasr.h: SC_PROF_KINDS
     ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
@@ -357,7 +396,12 @@ def main():
         sb.set_graphs(False)
         sb.take_xattn_rows()
         lib.sc_prof_enable(1)
-        run_host(sb, step_blocks(audio, window, window + args.roofline_steps), np.arange(sb.S, dtype=np.int32))
+        if args.mode == "strict":
+            run_host(sb, step_blocks(audio, k0 + args.steps, k0 + args.steps + args.roofline_steps), np.arange(S, dtype=np.int32))
+        else:
+            # (the per-launch timing stops with the last timed reply: the untimed drain of the stragglers runs at small
+            # compaction buckets that the steady state never sees)
+            serve(sb, a3, head["next_chunk"], args.roofline_steps, group, at_target=lambda: lib.sc_prof_enable(0))
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
@@ -374,20 +418,19 @@ def main():
         elapsed = float(t.item())
         # the path's single collective: gather of the final text (token ids + positions + length + score)
         from speechcatcher_amd.distributed import gather_final_hypotheses, pack_hypotheses
-        a = sb.hypotheses_arrays(list(range(args.streams)), nbest=1)
+        a = sb.hypotheses_arrays(list(range(S)), nbest=1)
         n1 = a["lens"][:, 0]
-        payload = pack_hypotheses([a["ids"][i, 0, :n1[i]] for i in range(args.streams)],
-                                  [a["xpos"][i, 0, :n1[i]] for i in range(args.streams)],
-                                  a["score"][:, 0], 520, coll_device)
-        gathered = gather_final_hypotheses(payload, args.streams)
-        assert len(gathered) == world and len(gathered[0]) == args.streams
+        payload = pack_hypotheses([a["ids"][i, 0, :n1[i]] for i in range(S)], [a["xpos"][i, 0, :n1[i]] for i in range(S)],
+                                  a["score"][:, 0], 640, coll_device)
+        gathered = gather_final_hypotheses(payload, S)
+        assert len(gathered) == world and len(gathered[0]) == S
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    audio_s = world * args.streams * args.steps * CHUNK / 16000.0
+    audio_s = world * S * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
@@ -453,50 +496,47 @@ def main():
     sb.close()
     del sb
 
-    resident = None
-    if not args.no_resident and world == 1:
-        sbr = build_native(w, args.streams, args.beam, bool(args.bbd), window)
-        e2, _, _ = timed_window(sbr, audio, args.preroll, args.warmup, args.steps, "resident")
-        v2 = args.streams * args.steps * CHUNK / 16000.0 / e2
-        resident = {"value": round(v2, 2), "unit": "audio_s/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                    "headline_over_this": round(value / v2, 4),
-                    "note": "same window, audio resident in HBM (sc_push with NULL pcm), no hypothesis read-back"}
-        sbr.close()
-        del sbr
+    def leg(mode, boundary=True):
+        sbx, r = measure(w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, mode, total_steps,
+                         boundary=boundary)
+        sbx.close()
+        o = {"value": round(r["value"], 2), "unit": "audio_s/s", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
+             "decode_steps_per_hop": round(r["dec_steps_per_hop"], 2)}
+        if mode == "continuous":
+            o.update({"decode_iterations_per_step": round(r["iterations_per_step"], 2), "polls_per_step": round(r["polls_per_step"], 2),
+                      "chunks_per_stream_min_max": r["chunks_per_stream_min_max"]})
+        return o
 
-    served = None
-    if not args.no_served and world == 1:
-        sbs = build_native(w, args.streams, args.beam, bool(args.bbd), total_steps)
-        e3, dsh3, iters3, polls3, spread3 = served_window(sbs, audio, args.preroll, args.warmup, args.steps, group)
-        v3 = args.streams * args.steps * CHUNK / 16000.0 / e3
-        served = {"value": round(v3, 2), "unit": "audio_s/s", "over_strict": round(v3 / value, 4),
-                  "ms_per_step_equivalent": round(e3 / args.steps * 1e3, 3), "poll_min_done": group,
-                  "decode_steps_per_hop": round(dsh3, 2), "decode_iterations_per_step": round(iters3, 2),
-                  "polls_per_step": round(polls3, 2), "chunks_per_stream_min_max": list(spread3),
-                  "note": "continuous batching (sc_submit / sc_poll), same window and chunks, host PCM in and best hypothesis "
-                          "out per reply: a stream's reply is delivered when ITS blocks are done and its next chunk is "
-                          "admitted at once (the reference server's session loop, speechcatcher_server.py:359-397); per-call "
-                          "results are those of the strict run; timed until streams x steps replies have been delivered"}
-        sbs.close()
-        del sbs
+    resident = None
+    if not args.no_resident and world == 1 and args.mode == "continuous":
+        resident = leg("continuous", boundary=False)
+        resident["headline_over_this"] = round(value / resident["value"], 4)
+        resident["note"] = "same window and mode, audio resident in HBM (sc_submit with NULL pcm), no hypothesis read-back"
+
+    other = None
+    if not args.no_other_mode and world == 1:
+        om = "strict" if args.mode == "continuous" else "continuous"
+        other = leg(om)
+        other["headline_over_this"] = round(value / other["value"], 4)
+        other["note"] = ("STRICT lock-step: one batched sc_push per chunk step (host PCM in, hypotheses out), every block "
+                         "completes inside its call, every stream waits for the slowest stream of the batch" if om == "strict" else
+                         "continuous batching through sc_submit / sc_poll, same window")
 
     single = None
     if not args.no_single_stream and world == 1:
-        sb1 = build_native(w, 1, args.beam, bool(args.bbd), window)
-        e1, _, _ = timed_window(sb1, audio[:1], args.preroll, args.warmup, args.steps, "host")
-        hop_s = CHUNK / 16000.0
-        single = {"ms_per_hop": round(e1 / args.steps * 1e3, 3), "rtf": round(e1 / (args.steps * hop_s), 5),
-                  "x_realtime": round(args.steps * hop_s / e1, 1)}
+        sb1, r1 = measure(w, audio[:1], 1, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, 1, "strict", total_steps)
         sb1.close()
-        del sb1
-    del audio
+        hop_s = CHUNK / 16000.0
+        single = {"ms_per_hop": round(r1["elapsed"] / args.steps * 1e3, 3), "rtf": round(r1["elapsed"] / (args.steps * hop_s), 5),
+                  "x_realtime": round(args.steps * hop_s / r1["elapsed"], 1)}
+    del audio, a3
 
     long_ctx = None
     if not args.no_long_context and world == 1 and CHUNK == 10240:
         long_ctx = {}
         try:
-            long_ctx["T1000"] = long_context_leg(w, args.streams, args.beam, 1000, False, 8, group)
-            long_ctx["T4500"] = long_context_leg(w, args.streams, args.beam, 4500, True, 6, group)
+            long_ctx["T1000"] = long_context_leg(w, S, args.beam, 1000, False, 8, group)
+            long_ctx["T4500"] = long_context_leg(w, S, args.beam, 4500, True, 6, group)
             long_ctx["note"] = ("T1000: search without block-boundary detection like the headline (hypotheses near the "
                                 "reference's 500-step bound); T4500 = a 180 s CLI segment, with block-boundary detection "
                                 "(the reference CLI's default): without it every stream has hit the 500-step bound by then")
@@ -510,7 +550,11 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
 
-    k0 = args.preroll + args.warmup
+    semantics = ("continuous batching: every stream is called, answers and is called again on its own (sc_submit / sc_poll) - a "
+                 "reply is delivered when ITS decode blocks are done, exactly one chunk per stream outstanding (the reference's "
+                 "concurrency model: one independent call loop per stream, speechcatcher_server.py:331-397); per call the "
+                 "results are those of the strict lock-step run" if args.mode == "continuous" else
+                 "strict lock-step: one batched call per chunk step, every block completes inside its call")
     out = {
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",
         "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -521,22 +565,30 @@ def main():
                                                          ("fp16 feed-forward weights and MFMA inputs (fp32 accumulation)"
                                                           if FFN_DTYPE != "float32" else "")) if x)),
         "data": "synthetic",
-        "config": {"workload": f"de_streaming_transformer_xl dims, {args.streams} concurrent synthetic streams/GPU "
+        "config": {"workload": f"de_streaming_transformer_xl dims, {S} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk {CHUNK} samples, bbd {args.bbd}",
-                   "streams_per_gpu": args.streams, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
-                   "semantics": "strict lock-step: every block completes inside its chunk step (the reference's per-call results)",
-                   "boundary": "inside the timed region: host PCM chunks in (pinned staging, one H2D per step), best "
-                               "hypothesis of every stream out (token ids + positions + scores, one D2H per step)",
-                   "window": f"chunk steps {k0}..{k0 + args.steps - 1} of every stream ({args.preroll} pre-roll + {args.warmup} warm-up "
-                             f"steps untimed): T = {min(T_now)}..{max(T_now)} encoder frames and {L_now[0]}..{L_now[1]} tokens per "
-                             "hypothesis at the end of the window",
-                   "engine": "C++ (sc_push + sc_get_hyps_batch, csrc/streams.hip)",
+                   "streams_per_gpu": S, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
+                   "mode": args.mode, "semantics": semantics,
+                   "step": (f"one step = one {CHUNK}-sample chunk of EVERY stream = {S} calls / replies; the clock stops when "
+                            f"{S} x steps replies have been delivered" if args.mode == "continuous" else
+                            f"one step = one batched call with a {CHUNK}-sample chunk of every stream"),
+                   "boundary": "inside the timed region: host PCM chunks in (pinned staging, one H2D per admission), best "
+                               "hypothesis of every answering stream out (token ids + positions + scores, one D2H per reply batch)",
+                   "window": f"chunks {k0}.. of every stream ({args.preroll} lock-step pre-roll + {args.warmup} warm-up steps untimed), "
+                             f"at the end of the window: T = {state['encoder_frames_T'][0]}..{state['encoder_frames_T'][1]} encoder "
+                             f"frames, {state['tokens_L'][0]}..{state['tokens_L'][1]} tokens per hypothesis",
+                   "engine": "C++ (sc_submit / sc_poll / sc_get_hyps_batch, csrc/streams.hip)" if args.mode == "continuous" else
+                             "C++ (sc_push + sc_get_hyps_batch, csrc/streams.hip)",
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
-        "chunk_steps_per_s": round(world * args.streams * args.steps / elapsed, 2),
+        "chunk_steps_per_s": round(world * S * args.steps / elapsed, 2),
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
-        "resident_no_readback": resident, "served": served, "long_context": long_ctx,
+        "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
+        "long_context": long_ctx,
     }
+    if args.mode == "continuous":
+        out["continuous"] = {k: head[k] for k in ("iterations_per_step", "polls_per_step", "chunks_per_stream_min_max")}
+        out["continuous"]["poll_min_done"] = group
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -474,7 +474,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), SC_DIST_BACKEND="gloo", SC_BENCH_SINGLE_DEVICE="1")
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--streams", "8", "--steps", "3",
-                                       "--warmup", "2", "--roofline-steps", "0", "--no-cpu-baseline"], env=env,
+                                       "--warmup", "2", "--preroll", "3", "--roofline-steps", "0", "--no-cpu-baseline", "--no-long-context"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]

@@ -11,7 +11,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
-ARGS="--no-cpu-baseline --no-single-stream --no-served --no-resident --no-long-context"
+ARGS="--no-cpu-baseline --no-single-stream --no-other-mode --no-resident --no-long-context"
 rm -rf /tmp/pk; rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pk -- python3 bench.py $ARGS > gpurun_out/${TAG}_prof_kernel.log 2>&1
 python tools/rocpd_stats.py $(find /tmp/pk -name "*.db" | head -1) gpurun_out/${TAG}_bench_default_kernel_stats.csv > /dev/null
 rm -rf /tmp/pf; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/pf -- python3 bench.py $ARGS --steps 6 --roofline-steps 0 > gpurun_out/${TAG}_prof_fetch.log 2>&1

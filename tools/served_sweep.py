@@ -5,13 +5,15 @@ import ctypes as C
 import sys
 
 sys.path.insert(0, ".")
+import numpy as np  # noqa: E402
+
 import bench  # noqa: E402
 
 groups = [int(a) for a in sys.argv[1:] if not a.startswith("e")] or [8, 16, 32]
 encb = [int(a[1:]) for a in sys.argv[1:] if a.startswith("e")] or [64]
 S, pre, warm, steps = 128, 21, 5, 20
 w = bench.make_weights("cuda:0")
-total = pre + warm + steps + bench.SERVED_SPARE
+total = pre + warm + steps + bench.SERVED_SPARE + 2
 audio = bench.make_audio(S, total)
 def clear(sb):
     sec, it = (C.c_double * 17)(), (C.c_long * 17)()
@@ -30,14 +32,29 @@ def hist(sb):
             f" | loop {sum(sec) / steps * 1e3:.2f} ms/step (issue {a.value / steps * 1e3:.2f}, wait {b.value / steps * 1e3:.2f}), {tot / steps:.1f} it/step")
 
 
-sb = bench.build_native(w, S, 10, False, total)
-e, dsh, _ = bench.timed_window(sb, audio, pre, warm, steps, "host", before_timing=clear)
-print(f"strict: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step  {dsh:.2f} decode steps/hop\n    bucket:iterations per step x ms  {hist(sb)}", flush=True)
-sb.close()
-for g, eb in [(g, eb) for eb in encb for g in groups]:
+a3 = audio.reshape(S, -1, bench.CHUNK)
+
+
+def run(mode, g=8, eb=64):
     sb = bench.build_native(w, S, 10, False, total)
     sb.set_encoder_batch(eb)
-    e, dsh, iters, polls, spread = bench.served_window(sb, audio, pre, warm, steps, g, before_timing=clear)
-    print(f"group {g:3d} encoder batch {eb:3d}: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step-eq  {iters:5.2f} iterations/step  "
-          f"{polls:.1f} polls/step  spread {spread}\n    bucket:iterations per step x ms  {hist(sb)}", flush=True)
+    bench.roll(sb, audio, pre)
+    if mode == "strict":
+        bench.run_host(sb, bench.step_blocks(audio, pre, pre + warm), np.arange(S, dtype=np.int32))
+        e, dsh, _ = bench.strict_window(sb, audio, pre + warm, steps, before_timing=clear)
+        print(f"strict: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step  {dsh:.2f} decode steps/hop\n"
+              f"    bucket:iterations per step x ms  {hist(sb)}", flush=True)
+    else:
+        nxt = np.full(S, pre, np.int64)
+        bench.serve(sb, a3, nxt, warm, g)
+        r = bench.serve(sb, a3, nxt, steps, g, before_timing=clear)
+        e = r["elapsed"]
+        print(f"group {g:3d} encoder batch {eb:3d}: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step-eq  "
+              f"{r['iterations_per_step']:5.2f} iterations/step  {r['polls_per_step']:.1f} polls/step  spread {r['chunks_per_stream_min_max']}\n"
+              f"    bucket:iterations per step x ms  {hist(sb)}", flush=True)
     sb.close()
+
+
+run("strict")
+for g, eb in [(g, eb) for eb in encb for g in groups]:
+    run("continuous", g, eb)
