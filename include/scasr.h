@@ -86,7 +86,7 @@ typedef struct sc_dec_layer {
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
 typedef struct sc_search {
-  int32_t S, W, K, V, d, H, F, n_layers, TCAP, LCAP, xchunk;
+  int32_t S, W, K, V, d, H, F, n_layers, TCAP, LCAP;
   int32_t blank, eos, sos;
   float w_dec, w_ctc, ln_eps;
   const int32_t *ctrl; /* [S][8] */
@@ -107,7 +107,6 @@ typedef struct sc_search {
   int32_t *cand_tok;      /* [S*W][W] */
   float *cand_ctc;        /* [S*W][W] */
   int32_t *sel;           /* [S][W][2] (parent hypothesis, candidate index) */
-  float *xpart;           /* [S*W*H*nchunk][dk+2] cross-attention partials */
   const float *embed, *pe, *dec_norm_g, *dec_norm_b, *out_w, *out_b;
   const sc_dec_layer *layers; /* HOST array [n_layers] */
   /* Ragged-batch compaction of the dense decoder kernels (GEMMs, row panels,
@@ -124,18 +123,13 @@ typedef struct sc_search {
   float *ph1, *ph2, *ffn_part;
   int32_t max_ffn_part;
   /* column-major copy of the CTC table [S][V][tct] (tct = TCAP rounded up to a multiple of 4), maintained by
-   * sc_ctc_extend_state and streamed by sc_ctc_prefix_scan; NULL: the scan gathers from ctcx */
+   * sc_ctc_extend_state and streamed by sc_ctc_prefix_scan (required) */
   int32_t tct;
   float *ctcxT;
   /* 1: the K|V caches ckv / skv hold IEEE fp16 elements (same element offsets, half the bytes); attention
    * arithmetic, softmax and everything else stay fp32.  Written through sc_kv_rows_to_half (cross) and by the
    * self-attention kernels (self); read by the single-pass attention kernels. */
   int32_t kv_half;
-  /* persistent stream-cluster decoder (sc_dec_cluster_layers): DEVICE copy of `layers`, one barrier counter per
-   * stream [S], one error word; NULL: not used */
-  const sc_dec_layer *layers_dev;
-  uint32_t *cbar;
-  int32_t *cl_err;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -361,12 +355,6 @@ int sc_decode_step(const sc_search *sb, void *stream);
 /* ... with the CTC prefix scan of streams that have >= scan_split_min frames to walk split over T
  * (sc_ctc_prefix_scan_split; 0: never) */
 int sc_decode_step_ex(const sc_search *sb, int scan_split_min, void *stream);
-/* device-side step control behind sc_decode_step: the accept / stop rules of the step loop (beam_search.py:759-821)
- * applied to every active stream's ctrl row IN PLACE (accepted: CUR flipped, L+1, NHYP = min(W, NHYP*W), HAS = 1;
- * stopped: ACTIVE = 0), and the step's stop flags copied to ring[(L & 1) * S + s] (ring: device-visible int32[2][S],
- * L = the token count of the step that produced them).  Lets a host enqueue step i+1 before reading step i. */
-int sc_step_advance(const sc_search *sb, int use_bbd, int32_t *ring, void *stream);
-
 /* ---- head-parallel decoder layers: 3 launches per layer (decoder_layer.py:80-132) --------------------
  * The residual stream x ping-pongs between two [S*W][d] buffers (x_in != x_out in every call): sibling
  * workgroups read x_in while the owner of a row writes x_out.  Grid (stream, head) for the two attention
@@ -387,18 +375,6 @@ int sc_dec_layer_cross(const sc_search *sb, int layer, const float *x_in, float 
  * feed_forward.py:48-50) as partial sums ffn_part[z][row], z < *n_part (HOST out; <= max_part). */
 int sc_dec_layer_ffn(const sc_search *sb, int layer, const float *x_in, float *x_out, float *ffn_part,
                      int max_part, int *n_part /*HOST*/, void *stream);
-/* ALL decoder layers of one step in ONE launch for small compaction buckets (at most sc_dec_cluster_max_streams()
- * streams): the H workgroups of a stream stay resident and walk the layers together, ordered by a system-scope
- * cluster barrier per stream; per-head partial products travel with 16-byte system-scope accesses
- * (csrc/decoder_cluster.hip).  Leaves x (before the last feed-forward's residual) in x_out and the last layer's
- * feed-forward partial sums in sb->ffn_part[h], h < H: follow with sc_dec_output_logits(sb, x_out, other, ffn_part, H).
- * dev_layers: DEVICE copy of sb->layers; cbar [S] (zeroed by this call), err [1] (set to 1 if a barrier timed out). */
-int sc_dec_cluster_supported(int d, int H, int W, int F);
-int sc_dec_cluster_max_streams(void);
-/* profiling aid (SC_TEST_HOOKS=1 SC_CLUSTER_DBG=1): shader-clock stamps of one workgroup at the phase boundaries of the last launch */
-int sc_dec_cluster_debug(long long *host_out, int n);
-int sc_dec_cluster_layers(const sc_search *sb, const sc_dec_layer *dev_layers, float *x_out, unsigned *cbar, int *err,
-                          void *stream);
 /* tail: x = x_in + b2[last] + sum_z ffn_part -> x_out; logits = after_norm(x) . out_w^T + out_b
  * (transformer_decoder.py:243-249); needs sb->out_w_q. */
 int sc_dec_output_logits(const sc_search *sb, const float *x_in, float *x_out, const float *ffn_part,

@@ -31,7 +31,6 @@ def _rows(t2d, rows):
 
 class SpecBackend:
     fused_layers = True    # decode_step(): head-parallel layer ops when the batch has their buffers
-    cluster_layers = False  # ... the experimental persistent stream-cluster op (tests switch it on with SC_DEC_CLUSTER=1)
 
     name = "spec"
 
@@ -514,30 +513,6 @@ class SpecBackend:
         sb.ffn_part[0, r] = hid @ lw["w2"].t()
         return 1
 
-    CLUSTER_MAX_STREAMS = 16    # sc_dec_cluster_max_streams
-
-    def cluster_decoder(self, sb) -> bool:
-        """sc_decode_step's choice of the persistent stream-cluster kernel (csrc/decoder_cluster.hip)."""
-        cfg = sb.cfg
-        return (getattr(sb, "cbar", None) is not None and self.cluster_layers and sb.W <= 10 and cfg.dec_heads <= 8
-                and cfg.ffn_dim % (32 * cfg.dec_heads) == 0 and int(sb.n_rows_step) // sb.W <= self.CLUSTER_MAX_STREAMS)
-
-    def dec_cluster_layers(self, sb, xout):
-        """sc_dec_cluster_layers: all decoder layers of the step; x before the last feed-forward's residual -> xout,
-        the last layer's feed-forward partial sums -> sb.ffn_part (the spec writes ONE slot: returns 1)."""
-        n_layers = len(sb.w.dec)
-        xa, xb, npart = torch.empty_like(sb.dx), torch.empty_like(sb.dx), 0
-        xa.copy_(sb.dx)
-        xb.copy_(sb.dxn)
-        for li in range(n_layers):
-            SpecBackend.dec_layer_self(self, sb, li, xa, xb, npart)
-            SpecBackend.dec_layer_cross(self, sb, li, xb, xa)
-            npart = SpecBackend.dec_layer_ffn(self, sb, li, xa, xb)
-            xa, xb = xb, xa
-        r = sb.rowmap[:int(sb.n_rows_step)].to(torch.long)
-        xout[r] = xa[r]
-        return npart
-
     def dec_output_logits(self, sb, xin, xout, npart):
         """sc_dec_output_logits: residual + feed-forward partial sums + b2 -> xout; after_norm, output layer
         (transformer_decoder.py:243-249)."""
@@ -720,10 +695,7 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
-        if self.cluster_decoder(sb):
-            npart = self.dec_cluster_layers(sb, sb.dxn)
-            self.dec_output_logits(sb, sb.dxn, sb.dx, npart)
-        elif getattr(sb, "ph1", None) is not None and self.fused_layers:
+        if getattr(sb, "ph1", None) is not None and self.fused_layers:
             # head-parallel layer kernels, 3 ops per layer (sc_decode_step takes this path for the same models)
             xa, xb, npart = sb.dx, sb.dxn, 0
             for li in range(len(w.dec)):

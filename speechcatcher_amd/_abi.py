@@ -38,16 +38,15 @@ class DecLayer(C.Structure):
 class Search(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("S", "W", "K", "V", "d", "H", "F", "n_layers", "TCAP", "LCAP",
-                                  "xchunk", "blank", "eos", "sos")]
+                                  "blank", "eos", "sos")]
         + [(n, C.c_float) for n in ("w_dec", "w_ctc", "ln_eps")]
         + [(n, vp) for n in ("ctrl", "flags", "ctcx", "ckv", "skv", "yseq", "xpos", "anc", "score",
                              "sc_dec", "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv",
                              "datt", "dq", "dffh", "logits", "logp", "pre_ids", "psi", "psi_eos",
-                             "cand_score", "cand_tok", "cand_ctc", "sel", "xpart", "embed", "pe",
+                             "cand_score", "cand_tok", "cand_ctc", "sel", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
-           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32),
-           ("layers_dev", vp), ("cbar", vp), ("cl_err", vp)]
+           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32)]
     )
 
 
@@ -135,7 +134,6 @@ _SIGS = {
     "sc_fuse_topw": (C.c_int, [vp, vp]),
     "sc_beam_prune": (C.c_int, [vp, vp]),
     "sc_ctc_gather_state": (C.c_int, [vp, vp]),
-    "sc_step_advance": (C.c_int, [vp, C.c_int, vp, vp]),
     "sc_decode_step": (C.c_int, [vp, vp]),
     "sc_decode_step_ex": (C.c_int, [vp, C.c_int, vp]),
     "sc_ctc_prefix_scan_split": (C.c_int, [vp, C.c_int, vp]),
@@ -144,10 +142,6 @@ _SIGS = {
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
-    "sc_dec_cluster_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "sc_dec_cluster_max_streams": (C.c_int, []),
-    "sc_dec_cluster_debug": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
-    "sc_dec_cluster_layers": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     # stream-level API
     "sc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(NamedTensor), C.c_int, C.c_int, C.POINTER(vp)]),
     "sc_engine_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),

@@ -41,7 +41,7 @@ struct ProfScope { bool on; hipEvent_t a, b; hipStream_t st; };
 ProfScope sc_prof_begin(hipStream_t st);
 void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 
-// search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel, 2 cluster)
+// search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel)
 int sc_decode_step_form(const sc_search *sb);
 
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)

@@ -112,91 +112,6 @@ extern "C" int sc_dec_embed(const sc_search *sbp, void *stream) {
 }
 
 // ---------------------------------------------------------------------------
-// decoder self-attention: one wave per (stream, hyp, head).  Lanes stride the
-// L cached positions (ancestor-table gather), online softmax per lane, then a
-// cross-lane merge through LDS.
-// ---------------------------------------------------------------------------
-template <int DK>
-__global__ __launch_bounds__(256) void dec_self_attn_kernel(sc_search sb, int li) {
-  __shared__ float part[4][64][DK + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;
-  const int H = sb.H, d = sb.d, W = sb.W;
-  if (unit >= sb.S * W * H) return;
-  const int row = unit / H, head = unit % H;
-  const int s = row / W, h = row % W;
-  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
-  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
-  const float *qkv = sb.dqkv + (long)row * 3 * d + head * DK;
-  float *skv = sb.skv + ((long)s * sb.n_layers + li) * sb.LCAP * W * 2 * d;
-  // append this token's K|V row at (position L-1, slot h)
-  if (lane < DK) {
-    float *dst = skv + ((long)(L - 1) * W + h) * 2 * d + head * DK;
-    dst[lane] = qkv[d + lane];
-    dst[d + lane] = qkv[2 * d + lane];
-  }
-  float q[DK];
-#pragma unroll
-  for (int c = 0; c < DK; c += 4) {
-    float4 t = reinterpret_cast<const float4 *>(qkv)[c / 4];
-    q[c] = t.x; q[c + 1] = t.y; q[c + 2] = t.z; q[c + 3] = t.w;
-  }
-  const int *anc = ANC(cur, s);
-  const float scale = sqrtf((float)DK);
-  float m = -INFINITY, l = 0.f;
-  float acc[DK];
-#pragma unroll
-  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
-  for (int p = lane; p < L; p += 64) {
-    const float *kr, *vr;
-    if (p == L - 1) {
-      kr = qkv + d;
-      vr = qkv + 2 * d;
-    } else {
-      const int slot = anc[(long)p * W + h];
-      kr = skv + ((long)p * W + slot) * 2 * d + head * DK;
-      vr = kr + d;
-    }
-    float sdot = 0.f;
-#pragma unroll
-    for (int c = 0; c < DK; c += 4) {
-      float4 k4 = reinterpret_cast<const float4 *>(kr)[c / 4];
-      sdot = fmaf(q[c], k4.x, sdot);
-      sdot = fmaf(q[c + 1], k4.y, sdot);
-      sdot = fmaf(q[c + 2], k4.z, sdot);
-      sdot = fmaf(q[c + 3], k4.w, sdot);
-    }
-    sdot = sdot / scale;
-    const float mn = fmaxf(m, sdot);
-    const float corr = expf(m - mn), pe = expf(sdot - mn);
-    l = l * corr + pe;
-#pragma unroll
-    for (int c = 0; c < DK; c += 4) {
-      float4 v4 = reinterpret_cast<const float4 *>(vr)[c / 4];
-      acc[c] = acc[c] * corr + pe * v4.x;
-      acc[c + 1] = acc[c + 1] * corr + pe * v4.y;
-      acc[c + 2] = acc[c + 2] * corr + pe * v4.z;
-      acc[c + 3] = acc[c + 3] * corr + pe * v4.w;
-    }
-    m = mn;
-  }
-  // merge the 64 per-lane partials (lanes with no position have l = 0)
-  const float M = wave_max(m);
-  const float sc = (l > 0.f) ? expf(m - M) : 0.f;
-  const float Lt = wave_sum(l * sc);
-#pragma unroll
-  for (int c = 0; c < DK; ++c) part[wave][lane][c] = acc[c] * sc;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (lane < DK) {
-    float o = 0.f;
-    for (int j = 0; j < 64; ++j) o += part[wave][j][lane];
-    sb.datt[(long)row * d + head * DK + lane] = o / Lt;
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Single-pass ("flash decoding") attention of the decoder, shared by the self-
 // and the cross-attention: one workgroup per (stream, head) serves ALL
 // hypotheses of the stream.
@@ -374,202 +289,33 @@ extern "C" int sc_dec_self_attn(const sc_search *sbp, int layer, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
   const int dk = sb.d / sb.H;
-  const int grid = cdiv(sb.S * sb.W * sb.H, 4);
   hipStream_t st = (hipStream_t)stream;
-  const char *mode = sc_hook("SC_SELF_ATTN");   // test / A-B hook: "legacy"
-  const bool legacy = mode && mode[0] == 'l';
-  if (!legacy && sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024) {
-    ProfScope prof = sc_prof_begin(st);
-    if (dk == 64) launch_attn_flash<64, true>(sb, layer, st);
-    else if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
-    else launch_attn_flash<16, true>(sb, layer, st);
-    sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);   // traffic depends on device-side state (L, ancestors)
-    SC_CHECK_LAUNCH();
-    return SC_OK;
-  }
-  SC_CHECK_ARG(!sb.kv_half, "half-precision K|V caches need the single-pass attention kernels");
-  if (dk == 32) dec_self_attn_kernel<32><<<grid, 256, 0, st>>>(sb, layer);
-  else if (dk == 16) dec_self_attn_kernel<16><<<grid, 256, 0, st>>>(sb, layer);
-  else { sc_set_error("sc_dec_self_attn: unsupported head dim %d", dk); return SC_ERR_ARG; }
+  SC_CHECK_ARG(sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, true) <= 64 * 1024,
+               "unsupported head dim / beam width");
+  ProfScope prof = sc_prof_begin(st);
+  if (dk == 64) launch_attn_flash<64, true>(sb, layer, st);
+  else if (dk == 32) launch_attn_flash<32, true>(sb, layer, st);
+  else launch_attn_flash<16, true>(sb, layer, st);
+  sc_prof_end(prof, SC_PROF_ATTN_SELF, 0.0, 0.0);   // traffic depends on device-side state (L, ancestors)
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
 
-// ---------------------------------------------------------------------------
-// decoder cross-attention, flash-decoding style.  Grid (chunk, head, stream):
-// one workgroup reads 256 encoder frames of K|V ONCE for all W hypotheses of
-// the stream; a second kernel merges the per-chunk partials.
-// ---------------------------------------------------------------------------
-// SEQ = true: one workgroup per (stream, head) walks all 256-frame chunks itself
-// and writes the final context (used when S*H workgroups already fill the chip:
-// no partials, no merge launch).  SEQ = false: grid.x = chunks, partials merged
-// by dec_cross_attn_merge_kernel (single-stream latency path).
-template <int DK, bool SEQ>
-__global__ __launch_bounds__(256) void dec_cross_attn_part_kernel(sc_search sb, int li) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int head = blockIdx.y, s = blockIdx.z;
-  if (!CTRL(s, SC_C_ACTIVE)) return;
-  const int T = CTRL(s, SC_C_T), nh = CTRL(s, SC_C_NHYP);
-  const int W = sb.W, d = sb.d, H = sb.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float *qs = smem;                  // [W][DK]
-  float *sc = qs + W * DK;           // [W][256]
-  float *Vs = sc + W * 256;          // [256][DK+1]
-  float *mw = Vs + 256 * (DK + 1);   // [W]
-  float *lw = mw + W;                // [W]
-  float *rm = lw + W;                // [W]      running max      (SEQ)
-  float *rl = rm + W;                // [W]      running sum      (SEQ)
-  float *racc = rl + W;              // [W][DK]  running context  (SEQ)
-  if (!SEQ && (int)blockIdx.x * 256 >= T) return;
-  for (int e = tid; e < nh * DK; e += 256) {
-    int w = e / DK, c = e % DK;
-    qs[e] = sb.dq[((long)s * W + w) * d + head * DK + c];
-    if (SEQ) racc[e] = 0.f;
-  }
-  if (SEQ && tid < nh) { rm[tid] = -INFINITY; rl[tid] = 0.f; }
-  __syncthreads();
-  const float scale = sqrtf((float)DK);
-  const int nch = cdiv(sb.TCAP, 256);
-  const int chunk_beg = SEQ ? 0 : blockIdx.x, chunk_end = SEQ ? cdiv(T, 256) : blockIdx.x + 1;
-  for (int chunk = chunk_beg; chunk < chunk_end; ++chunk) {
-    const int f = chunk * 256 + tid;
-    const bool valid = f < T;
-    const float *kv = sb.ckv + (((long)s * sb.n_layers + li) * sb.TCAP + (valid ? f : 0)) * 2 * d + head * DK;
-    float k[DK];
-#pragma unroll
-    for (int c = 0; c < DK; c += 4) {
-      float4 t = reinterpret_cast<const float4 *>(kv)[c / 4];
-      k[c] = t.x; k[c + 1] = t.y; k[c + 2] = t.z; k[c + 3] = t.w;
-    }
-#pragma unroll
-    for (int c = 0; c < DK; c += 4) {
-      float4 t = reinterpret_cast<const float4 *>(kv + d)[c / 4];
-      Vs[tid * (DK + 1) + c] = t.x;
-      Vs[tid * (DK + 1) + c + 1] = t.y;
-      Vs[tid * (DK + 1) + c + 2] = t.z;
-      Vs[tid * (DK + 1) + c + 3] = t.w;
-    }
-    for (int w = 0; w < nh; ++w) {
-      float sdot = 0.f;
-#pragma unroll
-      for (int c = 0; c < DK; ++c) sdot = fmaf(qs[w * DK + c], k[c], sdot);
-      sc[w * 256 + tid] = valid ? sdot / scale : -INFINITY;
-    }
-    __syncthreads();
-    // softmax statistics of this chunk: wave wv owns hypotheses wv, wv+4, ...
-    for (int w = wave; w < nh; w += 4) {
-      float v0 = sc[w * 256 + lane], v1 = sc[w * 256 + lane + 64];
-      float v2 = sc[w * 256 + lane + 128], v3 = sc[w * 256 + lane + 192];
-      float m = wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-      float p0 = expf(v0 - m), p1 = expf(v1 - m), p2 = expf(v2 - m), p3 = expf(v3 - m);
-      float l = wave_sum((p0 + p1) + (p2 + p3));
-      sc[w * 256 + lane] = p0;
-      sc[w * 256 + lane + 64] = p1;
-      sc[w * 256 + lane + 128] = p2;
-      sc[w * 256 + lane + 192] = p3;
-      if (lane == 0) { mw[w] = m; lw[w] = l; }
-    }
-    __syncthreads();
-    for (int o = tid; o < nh * DK; o += 256) {
-      const int w = o / DK, c = o % DK;
-      float acc = 0.f;
-      const float *pw = sc + w * 256;
-      for (int t = 0; t < 256; ++t) acc = fmaf(pw[t], Vs[t * (DK + 1) + c], acc);
-      if (SEQ) {
-        const float M = fmaxf(rm[w], mw[w]);
-        racc[o] = racc[o] * expf(rm[w] - M) + acc * expf(mw[w] - M);
-      } else {
-        float *dst = sb.xpart + ((((long)s * W + w) * H + head) * nch + chunk) * (DK + 2);
-        dst[c] = acc;
-        if (c == 0) { dst[DK] = mw[w]; dst[DK + 1] = lw[w]; }
-      }
-    }
-    if (SEQ) {
-      __syncthreads();
-      if (tid < nh) {
-        const float M = fmaxf(rm[tid], mw[tid]);
-        rl[tid] = rl[tid] * expf(rm[tid] - M) + lw[tid] * expf(mw[tid] - M);
-        rm[tid] = M;
-      }
-      __syncthreads();
-    }
-  }
-  if (SEQ) {
-    for (int o = tid; o < nh * DK; o += 256) {
-      const int w = o / DK, c = o % DK;
-      sb.datt[((long)s * W + w) * d + head * DK + c] = racc[o] / rl[w];
-    }
-  }
-}
-
-template <int DK>
-__global__ void dec_cross_attn_merge_kernel(sc_search sb) {
-  const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
-  if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
-  const int T = CTRL(s, SC_C_T);
-  const int nch_all = cdiv(sb.TCAP, 256), nch = cdiv(T, 256);
-  for (int o = threadIdx.x; o < sb.H * DK; o += blockDim.x) {
-    const int head = o / DK, c = o % DK;
-    const float *p = sb.xpart + (((long)row * sb.H + head) * nch_all) * (DK + 2);
-    float M = -INFINITY;
-    for (int j = 0; j < nch; ++j) M = fmaxf(M, p[j * (DK + 2) + DK]);
-    float num = 0.f, den = 0.f;
-    for (int j = 0; j < nch; ++j) {
-      float e = expf(p[j * (DK + 2) + DK] - M);
-      num += p[j * (DK + 2) + c] * e;
-      den += p[j * (DK + 2) + DK + 1] * e;
-    }
-    sb.datt[(long)row * sb.d + head * DK + c] = num / den;
-  }
-}
-
+// decoder cross-attention over the stream's shared encoder K|V: one workgroup per (stream, head) walks all T frames
+// once for all hypotheses (dec_attn_flash_kernel<.., SELF = false>); also the faster form for few streams (measured:
+// 1 / 8 / 16 streams 58.3 / 266.9 / 452.5 vs 58.3 / 260.8 / 433.6 audio-s/s for a split-T + merge pair of launches)
 extern "C" int sc_dec_cross_attn(const sc_search *sbp, int layer, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   const sc_search &sb = *sbp;
-  SC_CHECK_ARG(sb.xchunk == 256, "xchunk must be 256");
   const int dk = sb.d / sb.H;
   hipStream_t st = (hipStream_t)stream;
-  // one workgroup per (stream, head) over all of T.  With the single-pass kernel this is
-  // also the faster form for few streams (measured: 1 / 8 / 16 streams 58.3 / 266.9 / 452.5
-  // vs 58.3 / 260.8 / 433.6 audio-s/s for the split + merge pair); the legacy kernel
-  // pair only splits T when S*H workgroups would not fill the chip.
-  const bool flash_ok = sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, false) <= 64 * 1024;
-  bool seq = flash_ok || sb.S * sb.H >= 192;
-  if (const char *e = sc_hook("SC_XATTN_MODE")) {   // test hook: "seq" / "split"
-    if (e[0] == 's' && e[1] == 'e') seq = true;
-    else if (e[0] == 's' && e[1] == 'p') seq = false;
-  }
-  const char *xm = sc_hook("SC_XATTN_KERNEL");   // test / A-B hook: "legacy"
-  if (seq && !(xm && xm[0] == 'l') && flash_ok) {
-    // one workgroup per (stream, head), single pass, coalesced K/V rows
-    ProfScope prof = sc_prof_begin(st);
-    if (dk == 64) launch_attn_flash<64, false>(sb, layer, st);
-    else if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
-    else launch_attn_flash<16, false>(sb, layer, st);
-    sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
-    SC_CHECK_LAUNCH();
-    return SC_OK;
-  }
-  SC_CHECK_ARG(!sb.kv_half, "half-precision K|V caches need the single-pass attention kernels");
-  dim3 grid(seq ? 1 : cdiv(sb.TCAP, 256), sb.H, sb.S);
-  size_t smem = (size_t)(sb.W * dk + sb.W * 256 + 256 * (dk + 1) + 4 * sb.W + sb.W * dk) * sizeof(float);
-  SC_CHECK_ARG(smem <= 64 * 1024, "beam too wide for the cross-attention LDS tile");
-  if (dk == 32) {
-    if (seq) dec_cross_attn_part_kernel<32, true><<<grid, 256, smem, st>>>(sb, layer);
-    else {
-      dec_cross_attn_part_kernel<32, false><<<grid, 256, smem, st>>>(sb, layer);
-      dec_cross_attn_merge_kernel<32><<<sb.S * sb.W, 256, 0, st>>>(sb);
-    }
-  } else if (dk == 16) {
-    if (seq) dec_cross_attn_part_kernel<16, true><<<grid, 256, smem, st>>>(sb, layer);
-    else {
-      dec_cross_attn_part_kernel<16, false><<<grid, 256, smem, st>>>(sb, layer);
-      dec_cross_attn_merge_kernel<16><<<sb.S * sb.W, 256, 0, st>>>(sb);
-    }
-  } else {
-    sc_set_error("sc_dec_cross_attn: unsupported head dim %d", dk);
-    return SC_ERR_ARG;
-  }
+  SC_CHECK_ARG(sb.W <= 16 && (dk == 64 || dk == 32 || dk == 16) && attn_flash_lds(sb, dk, false) <= 64 * 1024,
+               "unsupported head dim / beam width");
+  ProfScope prof = sc_prof_begin(st);
+  if (dk == 64) launch_attn_flash<64, false>(sb, layer, st);
+  else if (dk == 32) launch_attn_flash<32, false>(sb, layer, st);
+  else launch_attn_flash<16, false>(sb, layer, st);
+  sc_prof_end(prof, SC_PROF_ATTN_CROSS, 0.0, 0.0);  // bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -858,121 +604,11 @@ extern "C" int sc_logsoftmax_topk(const sc_search *sbp, void *stream) {
 // CTC prefix scan (Watanabe Alg. 2): one lane per (hypothesis, candidate),
 // sequential over encoder frames, log-domain, logzero = -1e10.
 // ---------------------------------------------------------------------------
-struct CtcChunk {
-  static constexpr int CH = 16;
-  float xc[CH], xb[CH], pn[CH], pb[CH];
-};
-
-__global__ __launch_bounds__(256) void ctc_prefix_scan_kernel(sc_search sb) {
-  constexpr int CH = CtcChunk::CH;
-  const int s = blockIdx.y;
-  if (!CTRL(s, SC_C_ACTIVE)) return;
-  const int nh = CTRL(s, SC_C_NHYP), K = sb.K, W = sb.W, V = sb.V;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= nh * K) return;
-  const int h = e / K, k = e % K;
-  const int T = SC_CTC_T(s), L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR);
-  const bool has = CTRL(s, SC_C_HAS);
-  const long row = (long)s * W + h;
-  const int c = sb.pre_ids[row * K + k];
-  const int last = YSEQ(cur, s, h)[L - 1];
-  const bool same = (c == last);
-  const float *__restrict__ x = sb.ctcx + (long)s * sb.TCAP * V;
-  const float *__restrict__ rp = CTCR(cur, s);
-  float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
-  const int WK = W * K;
-  const int out_len = L - 1;
-  int start = out_len > 1 ? out_len : 1;
-  if (start > T) start = T;
-  // rows before start-1 are never read again; keep them at logzero
-  for (int t = 0; t < start - 1; ++t) {
-    rn[((long)t * 2) * WK + e] = SC_LOGZERO;
-    rn[((long)t * 2 + 1) * WK + e] = SC_LOGZERO;
-  }
-  float r_n = (out_len == 0) ? x[c] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
-  float r_b = SC_LOGZERO;
-  rn[((long)(start - 1) * 2) * WK + e] = r_n;
-  rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b;
-  // running blank log-prob sum of the initial (state None) hypothesis: sum_{tau < start} x[tau, blank]
-  float cum = 0.f;
-  if (!has)
-    for (int t = 0; t < start; ++t) cum += x[(long)t * V + sb.blank];
-
-  // The recurrence over t is sequential, but everything it READS (the CTC table
-  // column of this candidate, the blank column, the previous prefix's r) is
-  // known in advance: fetch it CH frames at a time, one chunk ahead of the
-  // arithmetic (double buffered, unconditional clamped loads), so the dependent
-  // chain only contains the log-add-exps.
-  auto fetch = [&](CtcChunk &q, int t0) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      int t = t0 + i;
-      t = t < T ? t : T - 1;
-      q.xc[i] = x[(long)t * V + c];
-      q.xb[i] = x[(long)t * V + sb.blank];
-      if (has) {  // wave-uniform
-        q.pn[i] = rp[((long)(t - 1) * 2) * W + h];
-        q.pb[i] = rp[((long)(t - 1) * 2 + 1) * W + h];
-      }
-    }
-  };
-  float pm = r_n, ps = 1.f;  // psi = logsumexp over {phi[t-1] + x[t,c]} and r[start-1][n]
-  auto advance = [&](const CtcChunk &q, int t0) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int t = t0 + i;
-      if (t < T) {
-        const float pn = has ? q.pn[i] : SC_LOGZERO;
-        const float pb = has ? q.pb[i] : cum;     // r_prev[t-1]
-        const float phi = same ? pb : lse2(pn, pb);
-        const float nr_n = lse2(r_n, phi) + q.xc[i];
-        const float nr_b = lse2(r_n, r_b) + q.xb[i];
-        r_n = nr_n;
-        r_b = nr_b;
-        rn[((long)t * 2) * WK + e] = r_n;
-        rn[((long)t * 2 + 1) * WK + e] = r_b;
-        const float v = phi + q.xc[i];
-        if (v > pm) {
-          ps = ps * __expf(pm - v) + 1.f;
-          pm = v;
-        } else {
-          ps += __expf(v - pm);
-        }
-        if (!has) cum += q.xb[i];
-      }
-    }
-  };
-  if (start < T) {
-    CtcChunk qa, qb;
-    int t0 = start;
-    fetch(qa, t0);
-    while (true) {
-      if (t0 + CH < T) fetch(qb, t0 + CH);
-      advance(qa, t0);
-      t0 += CH;
-      if (t0 >= T) break;
-      if (t0 + CH < T) fetch(qa, t0 + CH);
-      advance(qb, t0);
-      t0 += CH;
-      if (t0 >= T) break;
-    }
-  }
-  float psi = pm + logf(ps);
-  // r_prev at the last frame (cum == sum_{tau <= T-1} x[tau, blank] here)
-  const float pn_last = has ? rp[((long)(T - 1) * 2) * W + h] : SC_LOGZERO;
-  const float pb_last = has ? rp[((long)(T - 1) * 2 + 1) * W + h] : cum;
-  const float rsum_last = lse2(pn_last, pb_last);
-  if (c == sb.eos) psi = rsum_last;
-  if (c == sb.blank) psi = SC_LOGZERO;
-  sb.psi[row * K + k] = psi;
-  if (k == 0) sb.psi_eos[row] = rsum_last;
-}
-
-// The same scan over the column-major table copy (sb.ctcxT): every lane streams its candidate's column and the
+// The scan walks the column-major table copy (sb.ctcxT): every lane streams its candidate's column and the
 // blank column with 16-byte loads, 16 frames (4 loads each) ahead of the recurrence, chunks aligned to 16 frames.
 // What remains on the critical path is the recurrence itself: two log-add-exps per frame (~60 cycles), i.e.
-// ~0.025 us per frame instead of the 0.11 us of the row-major gathers (45 us at T = 400; T = 4500 is a 180 s
-// segment of the CLI).
+// ~0.025 us per frame instead of the 0.11 us of gathers from the row-major table (the round-1 kernel: one cache
+// line per lane and frame); 45 us at T = 400; T = 4500 is a 180 s segment of the CLI.
 struct CtcChunkT {
   float4 xc[4], xb[4];
   float pn[16], pb[16];
@@ -1293,13 +929,9 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
 // split_min > 0: streams with at least split_min frames to walk take the T-parallel kernel
 extern "C" int sc_ctc_prefix_scan_split(const sc_search *sbp, int split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
+  SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0, "the prefix scan needs the column-major table copy (sc_search.ctcxT)");
   dim3 grid(cdiv(sbp->W * sbp->K, 256), sbp->S);
-  const bool colmajor = sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0;
-  if (!colmajor) split_min = 0;
-  if (colmajor)
-    ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
-  else
-    ctc_prefix_scan_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp);
+  ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   if (split_min > 0)
     ctc_prefix_scan_tpar_kernel<<<dim3(cdiv(sbp->W * sbp->K, CTC_EB), sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   SC_CHECK_LAUNCH();
@@ -1555,60 +1187,9 @@ static bool dec_fused_ok(const sc_search &sb) {
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
 }
 
-// the persistent stream-cluster kernel (decoder_cluster.hip) runs this bucket: few streams, supported dims, buffers
-// EXPERIMENTAL, off unless the test hook SC_DEC_CLUSTER=1 is set: correct (lock-step parity at XL dims) but slower
-// than the launches it replaces - 83-93 us per layer against 45 us for the three head-parallel launches at 1-8
-// streams (phase timing: tools/cluster_phase_times.py): eight CUs per stream are too few
-// for the feed-forward's 4 MB of weights per layer, which the launched form spreads over 80 workgroups.
-static bool dec_cluster_ok(const sc_search &sb) {
-  const char *e = sc_hook("SC_DEC_CLUSTER");
-  if (!e || atoi(e) == 0) return false;
-  const int nstreams = (sb.rowmap ? sb.n_rows : sb.S * sb.W) / sb.W;
-  return nstreams <= sc_dec_cluster_max_streams() && sc_dec_cluster_supported(sb.d, sb.H, sb.W, sb.F) && sb.layers_dev &&
-         sb.cbar && sb.cl_err && sb.ph1 && sb.ph2 && sb.ffn_part && sb.max_ffn_part >= sb.H && sb.out_w_q &&
-         sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp && sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
-}
-
-// ---------------------------------------------------------------------------
-// Device-side step control (csrc/streams.hip: the host enqueues iteration i+1 before it has read the stop flags of
-// iteration i).  Runs behind sc_decode_step: derives the NEXT ctrl row of every active stream from its stop flags -
-// the accept / stop rules of the step loop (beam_search.py:759-821) - in place: an accepted step flips the buffer
-// side, appends a token (L+1), widens the beam to min(W, nhyp*W) and marks the CTC state as present; a stream that
-// stops becomes inactive (its row is rewritten by the host when its next block starts).  The flags of the step are
-// also published to `ring` (host-mapped, [2][S]: slot = L & 1 of the step that produced them, so the host can read
-// step i while step i+1 is running).
-// ---------------------------------------------------------------------------
-__global__ void step_advance_kernel(sc_search sb, int use_bbd, int32_t *ring) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= sb.S) return;
-  int32_t *c = const_cast<int32_t *>(sb.ctrl) + (long)s * 8;
-  if (!c[SC_C_ACTIVE]) return;
-  const int f = sb.flags[s], L = c[SC_C_L], fin = c[SC_C_FINAL], nh = c[SC_C_NHYP];
-  ring[(L & 1) * sb.S + s] = f;
-  const bool f_any = f & SC_F_ANY_EOS, f_best = f & SC_F_BEST_EOS, f_all = f & SC_F_ALL_EOS, f_rep = f & SC_F_REPEAT;
-  const bool stop_eos = f_any && (!fin || f_best);
-  const bool stop_bbd = use_bbd && !stop_eos && f_rep && !fin;
-  const bool stop_all = !stop_eos && !stop_bbd && f_all && fin;
-  if (stop_eos || stop_bbd || stop_all) {
-    c[SC_C_ACTIVE] = 0;
-  } else {
-    c[SC_C_CUR] = 1 - c[SC_C_CUR];
-    c[SC_C_L] = L + 1;
-    c[SC_C_NHYP] = min(sb.W, nh * sb.W);
-    c[SC_C_HAS] = 1;
-  }
-}
-
-extern "C" int sc_step_advance(const sc_search *sbp, int use_bbd, int32_t *ring, void *stream) {
-  SC_CHECK_ARG(sbp && sbp->ctrl && sbp->flags && ring, "null");
-  step_advance_kernel<<<cdiv(sbp->S, 256), 256, 0, (hipStream_t)stream>>>(*sbp, use_bbd, ring);
-  SC_CHECK_LAUNCH();
-  return SC_OK;
-}
-
 // which form of the decoder layers sc_decode_step runs for this bucket: 0 six launches per layer, 1 head-parallel
-// (3 launches), 2 persistent cluster (streams.hip accounts the cross-attention's K|V traffic by kernel family)
-int sc_decode_step_form(const sc_search *sbp) { return dec_cluster_ok(*sbp) ? 2 : dec_fused_ok(*sbp) ? 1 : 0; }
+// (3 launches) - streams.hip accounts the cross-attention's K|V traffic by kernel family
+int sc_decode_step_form(const sc_search *sbp) { return dec_fused_ok(*sbp) ? 1 : 0; }
 
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) { return sc_decode_step_ex(sbp, 0, stream); }
 
@@ -1617,11 +1198,7 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
-  if (dec_cluster_ok(sb)) {
-    // all layers in one persistent launch; then the tail (feed-forward residual, after_norm, output layer)
-    SC_TRY(sc_dec_cluster_layers(sbp, sb.layers_dev, sb.dxn, sb.cbar, sb.cl_err, stream));
-    SC_TRY(sc_dec_output_logits(sbp, sb.dxn, sb.dx, sb.ffn_part, sb.H, stream));
-  } else if (dec_fused_ok(sb)) {
+  if (dec_fused_ok(sb)) {
     // 3 launches per layer; x ping-pongs dx <-> dxn
     float *xa = sb.dx, *xb = sb.dxn;
     int npart = 0;

@@ -1548,7 +1548,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(b->cjobs_dev, (size_t)N_STAGE * S * 3);
   sc_search &sb = b->sb;
   sb.S = S; sb.W = W; sb.K = K; sb.V = V; sb.d = d; sb.H = c.dec_heads; sb.F = F; sb.n_layers = c.dec_layers;
-  sb.TCAP = b->TCAP; sb.LCAP = b->LCAP; sb.xchunk = 256; sb.blank = c.blank_id; sb.eos = c.eos_id; sb.sos = c.sos_id;
+  sb.TCAP = b->TCAP; sb.LCAP = b->LCAP; sb.blank = c.blank_id; sb.eos = c.eos_id; sb.sos = c.sos_id;
   sb.w_dec = 1.0f - o->ctc_weight; sb.w_ctc = o->ctc_weight; sb.ln_eps = c.ln_eps;
   float *ctcx = nullptr, *ckv = nullptr;
   A(ctcx, (size_t)S * b->TCAP * V);
@@ -1575,22 +1575,11 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(sb.pre_ids, n * K); A(sb.psi, n * K); A(sb.psi_eos, n);
   A(sb.cand_score, n * W); A(sb.cand_tok, n * W); A(sb.cand_ctc, n * W);
   A(sb.sel, n * 2);
-  const int nch = (b->TCAP + 255) / 256;
-  A(sb.xpart, n * c.dec_heads * nch * (d / c.dec_heads + 2));
   if (sc_dec_layer_fused_supported(d, c.dec_heads, W, F) && V % d == 0 && e->dec[0].wqkv_pp && e->f("out_w_q", false)) {
     A(sb.ph1, n * c.dec_heads * d);
     A(sb.ph2, n * c.dec_heads * d);
     A(sb.ffn_part, (size_t)(F / 128) * n * d);
     sb.max_ffn_part = F / 128;
-    if (sc_dec_cluster_supported(d, c.dec_heads, W, F) && rc == SC_OK) {   // persistent stream-cluster decoder
-      sc_dec_layer *ld = nullptr;
-      A(ld, e->dec.size());
-      if (rc == SC_OK && hipMemcpy(ld, e->dec.data(), e->dec.size() * sizeof(sc_dec_layer), hipMemcpyHostToDevice) != hipSuccess)
-        rc = SC_ERR_LAUNCH;
-      sb.layers_dev = ld;
-      A(sb.cbar, (size_t)S);
-      A(sb.cl_err, 1);
-    }
   }
   if (rc == SC_OK && hipMalloc(&b->ws, (size_t)128 << 20) != hipSuccess) rc = SC_ERR_LAUNCH;
   if (rc == SC_OK) b->owned.push_back(b->ws);

@@ -14,6 +14,13 @@ to launch.  It replaces, for S streams at once:
                                              speechcatcher/beam_search/beam_search.py:507-653,655-838
 (paths relative to /root/reference).  SURVEY.md Appendix D/E describe the
 exact buffering arithmetic restated here.
+
+Role: the EXECUTABLE SPECIFICATION of the host logic.  The product engine is the C++
+state machine behind the stream-level C ABI (csrc/streams.hip, speechcatcher_amd/native.py);
+this class runs the same schedule in lock-step, run to completion, on the CPU spec backend
+(oracle/kernel_spec.py) against the reference fixtures - which is how the host logic is
+checked without a GPU - and on the HIP kernels for the per-kernel lock-step parity tests.
+Continuous batching (sc_submit / sc_poll) exists in the C++ engine only.
 """
 import copy
 import math
@@ -186,16 +193,6 @@ class StreamBatch:
         self.n_rows_step = S * W
         self._decode_prepared = False
         self._isolate, self._faults = False, {}
-        # deferred stragglers (opt-in, set_defer_threshold): resumable per-stream decode-loop state
-        self.defer_threshold = 0
-        self.defer_max_lag = 1       # blocks a deferred stream may be behind
-        self._dq: List[List[Tuple[int, bool]]] = [[] for _ in range(S)]   # queued (T, is_final) blocks per stream
-        self._d_inblk = np.zeros(S, bool)
-        self._dq_len = np.zeros(S, np.int64)     # len(self._dq[s]), kept in step for vectorised tests
-        self._d = {k: np.zeros(S, np.int64) for k in ("T", "Tc", "cur", "L", "nhyp", "pidx", "nhp", "out", "nsteps")}
-        self._db = {k: np.zeros(S, bool) for k in ("fin", "has", "pvalid", "live", "took", "hsp")}
-        self._T_proj = np.zeros(S, np.int64)   # rows of the CTC table written so far (deferred path)
-        self._T_projkv = np.zeros(S, np.int64)  # encoder frames already projected to cross-K|V rows (deferred path)
         self.flags = z(S, dtype=i32)
         # pinned host mirrors: the per-step ctrl upload / flag read-back are the
         # only host<->device traffic of the decode loop
@@ -212,8 +209,6 @@ class StreamBatch:
         self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
         self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
         self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
-        self._ctrl0_ring = [torch.zeros(S, 8, dtype=i32, pin_memory=pin) for _ in range(6)]   # deferred path
-        self._ctrl0_ring_i = 0
         self._ctrl_np = self._ctrl_host.numpy()
         # staging arena for the per-call job / row tables
         self._arena_cap = (1 << 22) if pin else 0
@@ -222,10 +217,6 @@ class StreamBatch:
             self._arena_host = torch.zeros(self._arena_cap, dtype=i32, pin_memory=True)
             self._arena_np = self._arena_host.numpy()
             self._arena_dev = torch.zeros(self._arena_cap, dtype=i32, device=dev)
-        self._arena_main = None      # saved main arena while the prefetch stage uses its own (push(prefetch=...))
-        self._arena_pf = None
-        self.stream_enc = None       # second HIP stream: frontend + encoder of the NEXT chunk step
-        self._prefetched = None
         self._flags_np = self._flags_host.numpy()
         n = S * W
         self.dx = z(n, d)
@@ -250,18 +241,11 @@ class StreamBatch:
             self.ph1 = z(n, cfg.dec_heads, d)
             self.ph2 = z(n, cfg.dec_heads, d)
             self.ffn_part = z(F // 128, n, d)
-            self.cbar = z(S, dtype=i32)          # persistent stream-cluster decoder: barrier counters, error word
-            self.cl_err = z(1, dtype=i32)
         else:
-            self.ph1 = self.ph2 = self.ffn_part = self.cbar = self.cl_err = None
-        self.xchunk = 256
-        nch = (self.TCAP + self.xchunk - 1) // self.xchunk
-        self.xpart = z(n * cfg.dec_heads * nch, (d // cfg.dec_heads) + 2)
+            self.ph1 = self.ph2 = self.ffn_part = None
 
         # all device work of this batch runs on one dedicated (non-default) HIP
         # stream, which also makes the decode step capturable as a hipGraph
-        # (high priority: when a prefetched encoder stage runs on the second stream, the
-        # latency-bound decode kernels must not queue behind its large grids)
         self.stream = torch.cuda.Stream(device=dev, priority=-1) if dev.type == "cuda" else None
         if self.stream is not None and hasattr(backend, "bind_stream"):
             backend.bind_stream(self.stream)
@@ -338,19 +322,11 @@ class StreamBatch:
         tests/golden/tiny_reset.json) - and the StreamPositionalEncoding counter of
         the short-segment path keeps counting (A13).  With strict_reference=False
         the stream restarts from a clean state."""
-        if self._prefetched is not None:
-            raise EngineError("reset() while a prefetched chunk step is pending")
         old = self.st[s]
         ns = StreamState()
         if self.strict_reference:
             ns.short_pos = old.short_pos  # A13: counter survives reset()
             ns.T_ctc = old.T_ctc          # stale CTC table (rows stay in self.ctcx)
-        if hasattr(self, "_dq"):
-            self._dq[s] = []
-            self._dq_len[s] = 0
-            self._d_inblk[s] = False
-            self._T_proj[s] = max(int(self._T_proj[s]), old.T_ctc) if self.strict_reference else 0
-            self._T_projkv[s] = 0
         self.st[s] = ns
         if getattr(self, "stream", None) is not None:
             with torch.cuda.stream(self.stream):   # same stream as the kernels that read it
@@ -410,16 +386,9 @@ class StreamBatch:
 
     # ------------------------------------------------------------------
     def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]],
-             pcm_resident: bool = False, prefetch: Optional[Sequence[Tuple[int, Optional[np.ndarray], bool]]] = None,
-             isolate_faults: bool = False):
-        """One chunk step.  ``prefetch`` (GPU only, optional): the chunk step that the
-        NEXT push() call will pass - its frontend + encoder pass is launched on a
-        second HIP stream before this step's decode loop starts, so that the encoder
-        (large MFMA-bound kernels) overlaps the latency-bound decode steps; the next
-        push() then only waits for it.  Results are identical to the serial order:
-        the decode schedule of this step sees the encoder frames of this step only.
-
-        Returns {stream: has_output}.  A stream whose chunk cannot be processed (capacity limit;
+             pcm_resident: bool = False, isolate_faults: bool = False):
+        """One chunk step, run to completion (every block finishes inside the call: the reference's per-call
+        semantics).  Returns {stream: has_output}.  A stream whose chunk cannot be processed (capacity limit;
         a final chunk with fewer than 7 feature frames, on which the reference raises too - A3)
         raises its exception with every stream's state as it was before the call; with
         ``isolate_faults`` that stream alone is reset and its entry in the result is the exception
@@ -430,22 +399,10 @@ class StreamBatch:
             out, feat_new, finals = self._stage_encode_safe(chunks, pcm_resident)
             self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
             return self._finish_faults(out)
-        pf, self._prefetched = self._prefetched, None
-        if pf is not None:
-            if pf["key"] != self._chunk_key(chunks, pcm_resident):
-                raise EngineError("push() does not match the chunk step announced by the previous push(prefetch=...)")
-            out, feat_new, finals = pf["out"], pf["feat_new"], pf["finals"]
-            self.stream.wait_stream(self.stream_enc)
-            self._arena_off = 0
-        else:
-            self._arena_off = 0
-            with torch.cuda.stream(self.stream):
-                out, feat_new, finals = self._stage_encode_safe(chunks, pcm_resident)
-        t_avail = {s: self.st[s].T_enc for s in feat_new}
-        if prefetch is not None:
-            self._launch_prefetch(prefetch, pcm_resident)
+        self._arena_off = 0
         with torch.cuda.stream(self.stream):
-            self._stage_decode(feat_new, finals, t_avail)
+            out, feat_new, finals = self._stage_encode_safe(chunks, pcm_resident)
+            self._stage_decode(feat_new, finals, {s: self.st[s].T_enc for s in feat_new})
         self.stream.synchronize()
         return self._finish_faults(out)
 
@@ -488,33 +445,6 @@ class StreamBatch:
                 chunks = [c for c in chunks if c[0] != f.stream]
                 if not chunks:
                     return {}, {}, {}
-
-    @staticmethod
-    def _chunk_key(chunks, pcm_resident):
-        return tuple((int(s), int(x) if pcm_resident else int(len(x)), bool(f)) for s, x, f in chunks)
-
-    def _launch_prefetch(self, chunks, pcm_resident):
-        if any(f for _, _, f in chunks):
-            raise EngineError("prefetch is for non-final chunk steps")
-        if self.stream_enc is None:
-            self.stream_enc = torch.cuda.Stream(device=self.dev, priority=0)
-            if hasattr(self.be, "bind_stream"):
-                self.be.bind_stream(self.stream_enc)
-            self._arena_pf = {"host": torch.zeros(self._arena_cap, dtype=torch.int32, pin_memory=True),
-                              "dev": torch.zeros(self._arena_cap, dtype=torch.int32, device=self.dev)}
-        # the prefetched stage stages its job tables in its own pinned arena (the main
-        # one is recycled by the decode stage of this step and by the next push)
-        main = (self._arena_host, self._arena_np, self._arena_dev, self._arena_off)
-        self._arena_host, self._arena_dev = self._arena_pf["host"], self._arena_pf["dev"]
-        self._arena_np, self._arena_off = self._arena_host.numpy(), 0
-        try:
-            self.stream_enc.wait_stream(self.stream)   # this step's own encoder stage (if it ran on the main stream)
-            with torch.cuda.stream(self.stream_enc):
-                out, feat_new, finals = self._stage_encode(chunks, pcm_resident)
-        finally:
-            self._arena_host, self._arena_np, self._arena_dev, self._arena_off = main
-        self._prefetched = {"key": self._chunk_key(chunks, pcm_resident), "out": out, "feat_new": feat_new,
-                            "finals": finals}
 
     def _stage_encode(self, chunks, pcm_resident=False):
         """Frontend + encoder of one chunk step for the listed streams: (stream, samples, is_final).
@@ -643,18 +573,9 @@ class StreamBatch:
 
     def _stage_decode(self, feat_new: Dict[int, int], finals: Dict[int, bool], t_avail: Dict[int, int]):
         """Decode schedule of one chunk step.  ``t_avail[s]`` = encoder frames of
-        stream s after THIS step's encoder stage (a prefetched next step may already
-        have appended more frames to the buffer; they belong to the next call)."""
+        stream s after this step's encoder stage."""
         cfg = self.cfg
         if not feat_new:
-            return
-        if self.defer_threshold > 0:
-            t_ph = time.perf_counter()
-            self._enqueue_blocks(feat_new, finals, t_avail)
-            self._tick("enqueue_host", t_ph)
-            t_ph = time.perf_counter()
-            self._decode_deferred(0 if any(finals.values()) else self.defer_threshold)
-            self._tick("decode_total", t_ph)
             return
         # decode schedule (beam_search.py:590-634), rounds of lock-step blocks
         pending = list(feat_new.keys())
@@ -1109,237 +1030,8 @@ class StreamBatch:
             x.n_steps_total += int(nsteps[i])
 
     # ------------------------------------------------------------------
-    # deferred stragglers: the same decode schedule, but the step loop of a chunk step may stop
-    # while a few streams are still inside their block; they resume in the next chunk step's loop
-    # (together with the other streams' next blocks).  Per stream nothing changes - same blocks,
-    # same steps, same order - only WHEN its last steps of a block run.  Lock-step batches spend
-    # most of their decode iterations on a handful of stragglers (bench: 8.5 steps per stream-hop
-    # on average, ~20 per batch); with deferral the iterations per chunk step approach the average.
-    # ------------------------------------------------------------------
-    def set_defer_threshold(self, n_streams: int, max_lag_blocks: int = 1):
-        """Stop a chunk step's decode loop when at most ``n_streams`` streams are still inside
-        a block (0: run every block to completion inside its push - the default and the
-        reference's per-call semantics).  A stream never falls more than ``max_lag_blocks``
-        blocks (= chunk periods of result latency) behind; ``flush()`` / a final chunk /
-        ``hypotheses()`` complete whatever is pending."""
-        self.defer_max_lag = max(1, int(max_lag_blocks))
-        if n_streams <= 0:
-            self.flush()
-        elif self.defer_threshold == 0:
-            for s, st in enumerate(self.st):   # rows projected so far by the run-to-completion path
-                self._T_proj[s] = st.T_ctc
-                self._T_projkv[s] = st.T_kv
-        self.defer_threshold = max(0, int(n_streams))
-
-    def flush(self):
-        """Complete every pending (deferred) block."""
-        if not (self._d_inblk.any() or self._dq_len.any()):
-            return
-        if self.stream is None:
-            self._decode_deferred(0)
-            return
-        with torch.cuda.stream(self.stream):
-            self._decode_deferred(0)
-        self.stream.synchronize()
-
-    def _enqueue_blocks(self, feat_new, finals, t_avail):
-        """The decode schedule of beam_search.py:590-634 as per-stream queues of (T, is_final)."""
-        cfg = self.cfg
-        for s in feat_new:
-            st, q = self.st[s], self._dq[s]
-            pb = st.processed_block + sum(1 for _, f in q if not f) + (1 if self._d_inblk[s] and not self._db["fin"][s] else 0)
-            while t_avail[s] > 0:
-                cur_end = cfg.block_size - cfg.look_ahead + cfg.hop_size * pb
-                if not cur_end < t_avail[s]:
-                    break
-                q.append((cur_end, False))
-                pb += 1
-            if finals[s] and t_avail[s] > 0:
-                q.append((t_avail[s], True))
-            self._dq_len[s] = len(q)
-        # extend_scorers, encoder-side half (:403-464): CTC rows and cross-attention K|V rows of
-        # every frame a queued block will see - they depend on the encoder output only, so they
-        # are projected here for all streams at once (not when a deferred stream starts its block)
-        cfg, be, w = self.cfg, self.be, self.w
-        d, Ld = cfg.d_model, cfg.dec_layers
-        rows, krows, kv0, lsm = [], [], [], []
-        same_rows = True
-        for s in feat_new:
-            q = self._dq[s]
-            if not q:
-                continue
-            t_to = max(t for t, _ in q)
-            if t_to > self.TCAP:
-                raise EngineError("max_frames exceeded")
-            t_from, k_from = int(self._T_proj[s]), int(self._T_projkv[s])
-            same_rows &= t_from == k_from
-            if t_to > t_from:
-                rows.append(s * self.TCAP + _AR[t_from:t_to])
-                if t_from == 0:   # quirk A1: only the rows of the stream's FIRST block are log-softmaxed
-                    first_T = self._d["T"][s] if self._d_inblk[s] else q[0][0]
-                    lsm.append(s * self.TCAP + _AR[0:int(first_T)])
-                self._T_proj[s] = t_to
-            if t_to > k_from:
-                krows.append(s * self.TCAP + _AR[k_from:t_to])
-                kv0.append(s * Ld * self.TCAP + _AR[k_from:t_to])
-                self._T_projkv[s] = t_to
-        ar = None
-        if rows:
-            rows = np.concatenate(rows)
-            ar = self._itensor(rows)
-            m = int(rows.shape[0])
-            be.gemm(self.enc, ar, d, w.ctc_w, w.ctc_b, self.ctcx, ar, cfg.vocab_size, m, cfg.vocab_size, d)
-            if lsm:
-                lr = np.concatenate(lsm)
-                be.log_softmax_rows(self.ctcx, self._itensor(lr), int(lr.size), cfg.vocab_size)
-        if kv0:
-            kv0 = np.concatenate(kv0)
-            if not same_rows or ar is None:
-                ar = self._itensor(np.concatenate(krows))
-            m = int(kv0.shape[0])
-            kvt = self._itensor(kv0)   # one row table for all layers: layer li's rows start li*TCAP rows further
-            self._project_cross_kv(ar, kvt, m)
-
-    def _decode_deferred(self, threshold: int):
-        """Resumable form of _decode_blocks over S-sized state vectors (self._d / self._db)."""
-        be, W = self.be, self.W
-        D, B, inblk = self._d, self._db, self._d_inblk
-        Ld = self.cfg.dec_layers
-        use_bbd = self.search.use_bbd
-        if not self._decode_prepared:
-            self._decode_prepared = True
-            if hasattr(be, "prepare_decode"):
-                self._ctrl_np[:] = 0
-                self._upload_ctrl()
-                be.prepare_decode(self)
-        ctrl = self._ctrl_np
-        while True:
-            # ---- A. idle streams with a queued block start it (extend_scorers, search-side half) ----
-            start = np.nonzero(~inblk & (self._dq_len > 0))[0]
-            if start.size:
-                ids = start
-                self.stats["dec_blocks"] += len(start)
-                blocks = [self._dq[s].pop(0) for s in start]
-                self._dq_len[ids] -= 1
-                xs = [self.st[s] for s in start]
-                D["T"][ids] = [b[0] for b in blocks]
-                B["fin"][ids] = [b[1] for b in blocks]
-                D["cur"][ids] = [x.cur for x in xs]
-                D["L"][ids] = [x.L for x in xs]
-                D["nhyp"][ids] = [x.nhyp for x in xs]
-                B["has"][ids] = [x.has_ctc for x in xs]
-                D["pidx"][ids] = [x.process_idx for x in xs]
-                B["pvalid"][ids] = [x.prev_valid for x in xs]
-                told = np.fromiter((x.T_ctc for x in xs), np.int64, len(xs))
-                D["Tc"][ids] = np.maximum(D["T"][ids], told)      # the CTC table never shrinks (stale table after reset())
-                for x, b in zip(xs, blocks):
-                    if b[0] > x.T_ctc:
-                        x.T_ctc = b[0]
-                    if b[0] > x.T_kv:
-                        x.T_kv = b[0]
-                    x.output_index = 0
-                B["live"][ids], B["took"][ids] = True, False
-                D["nhp"][ids], B["hsp"][ids] = D["nhyp"][ids], B["has"][ids]
-                D["out"][ids] = 0
-                D["nsteps"][ids] = 0
-                inblk[ids] = True
-                # block-start ctrl rows go through a small ring of pinned buffers: two starts can
-                # follow each other without a flag read-back (= stream sync) in between, and the
-                # first iteration of a chunk step is queued behind the encoder stage without waiting
-                self._ctrl0_ring_i = (self._ctrl0_ring_i + 1) % len(self._ctrl0_ring)
-                host0 = self._ctrl0_ring[self._ctrl0_ring_i]
-                ctrl0 = host0.numpy()
-                ctrl0[:] = 0
-                ctrl0[ids] = np.stack([np.ones(len(start), np.int64), D["cur"][ids], B["fin"][ids], D["Tc"][ids],
-                                       D["L"][ids], D["nhyp"][ids], B["has"][ids], told], 1)
-                self.ctrl.copy_(host0, non_blocking=self.stream is not None)
-                be.ctc_extend_state(self)
-            # ---- B. streams whose block ended: rewind (:827-836), back to the stream state ----
-            act = inblk & B["live"] & (D["pidx"] < self.search.max_length)
-            done = np.nonzero(inblk & ~act)[0]
-            if done.size:
-                # rewind, vectorised over the finished streams; one pass of attribute writes
-                pidx, pvalid = D["pidx"][done], B["pvalid"][done]
-                rw = (pidx > 1) & pvalid
-                r2 = rw & B["took"][done]
-                cur = np.where(r2, 1 - D["cur"][done], D["cur"][done]).tolist()
-                L = (D["L"][done] - r2).tolist()
-                nhyp = np.where(r2, D["nhp"][done], D["nhyp"][done]).tolist()
-                has = np.where(r2, B["hsp"][done], B["has"][done]).tolist()
-                pidx, pvalid = (pidx - rw).tolist(), (pvalid & ~rw).tolist()
-                out, nst, fin = D["out"][done].tolist(), D["nsteps"][done].tolist(), B["fin"][done].tolist()
-                for i, s in enumerate(done.tolist()):
-                    x = self.st[s]
-                    x.cur, x.L, x.nhyp, x.has_ctc = cur[i], L[i], nhyp[i], has[i]
-                    x.process_idx, x.prev_valid = pidx[i], pvalid[i]
-                    x.output_index = out[i]
-                    x.n_steps_total += nst[i]
-                    if not fin[i]:
-                        x.processed_block += 1
-                inblk[done] = False
-                continue   # they may have another block queued
-            if not act.any():
-                break
-            n_act = int(np.count_nonzero(act))
-            # ---- D. defer: few streams left, all of them on their newest block, none final ----
-            if threshold > 0 and n_act <= threshold and not (B["fin"] & act).any() and \
-                    not ((self._dq_len >= self.defer_max_lag) & act).any():
-                self.stats["deferred_blocks"] = self.stats.get("deferred_blocks", 0) + n_act
-                break
-            over = (D["L"] + 1 > self.LCAP) & act
-            if over.any():
-                if not self._isolate:
-                    raise EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
-                for i in np.nonzero(over)[0]:
-                    self._faults[int(i)] = EngineError(f"max_tokens exceeded (max_tokens={self.LCAP})")
-                B["live"] &= ~over
-                continue
-            # ---- E. one decode step for the active streams (:701-821); S-sized vectors, masks ----
-            ctrl[:, 0] = act
-            ctrl[:, 1], ctrl[:, 2], ctrl[:, 3], ctrl[:, 4] = D["cur"], B["fin"], D["T"], D["L"]
-            ctrl[:, 5], ctrl[:, 6], ctrl[:, 7] = D["nhyp"], B["has"], D["Tc"]
-            self._set_rowmap(np.nonzero(act)[0])
-            self._upload_ctrl()
-            self.stats["dec_steps"] += 1
-            if "xattn_rows" in self.stats:
-                self.stats["xattn_rows"] += int(D["T"][act].sum()) * Ld
-            t_st = time.perf_counter()
-            be.decode_step(self)
-            self._tick("decode_launch", t_st)
-            t_st = time.perf_counter()
-            f = self._read_flags()
-            self._tick("decode_wait_flags", t_st)
-            fin, nfin = B["fin"], ~B["fin"]
-            f_any, f_best, f_all = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0
-            stop_eos = act & f_any & (nfin | f_best)
-            if use_bbd:
-                stop_bbd = act & ~stop_eos & ((f & F_REPEAT) != 0) & nfin
-                stop_all = act & ~stop_eos & ~stop_bbd & f_all & fin
-                accept = act & ~(stop_eos | stop_bbd | stop_all)
-                D["out"] -= stop_bbd
-            else:
-                stop_all = act & ~stop_eos & f_all & fin
-                accept = act & ~(stop_eos | stop_all)
-            took = stop_eos | stop_all
-            take = took | accept
-            D["out"] += act
-            D["nsteps"] += act
-            np.copyto(D["nhp"], D["nhyp"], where=take)
-            np.copyto(B["hsp"], B["has"], where=take)
-            D["cur"] ^= take                       # flip the ping-pong side
-            D["L"] += take
-            np.copyto(D["nhyp"], np.minimum(W, D["nhyp"] * W), where=take)
-            B["has"] |= take
-            B["took"] |= took
-            B["live"] &= ~act | accept
-            B["pvalid"] |= accept
-            D["pidx"] += accept
-
-    # ------------------------------------------------------------------
     def hypotheses(self, s: int):
         """Live hypotheses of stream s: list of dicts (yseq, score, scores, xpos)."""
-        if self._d_inblk[s] or self._dq_len[s]:
-            self.flush()
         st = self.st[s]
         if not st.started:
             return []

@@ -211,13 +211,13 @@ class HipBackend:
                 setattr(layers[i], name, lw[name].data_ptr() if name in lw else None)
         s = _abi.Search()
         s.S, s.W, s.K, s.V, s.d, s.H, s.F = sb.S, sb.W, sb.K, cfg.vocab_size, cfg.d_model, cfg.dec_heads, cfg.ffn_dim
-        s.n_layers, s.TCAP, s.LCAP, s.xchunk = cfg.dec_layers, sb.TCAP, sb.LCAP, sb.xchunk
+        s.n_layers, s.TCAP, s.LCAP = cfg.dec_layers, sb.TCAP, sb.LCAP
         s.blank, s.eos, s.sos = cfg.blank_id, cfg.eos_id, cfg.sos_id
         s.w_dec, s.w_ctc, s.ln_eps = sb.search.decoder_weight, sb.search.ctc_weight, cfg.ln_eps
         for name in ("ctrl", "flags", "ctcx", "ckv", "skv", "yseq", "xpos", "anc", "score", "sc_dec",
                      "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv", "datt", "dq", "dffh",
                      "logits", "logp", "pre_ids", "psi", "psi_eos", "cand_score", "cand_tok", "cand_ctc",
-                     "sel", "xpart"):
+                     "sel"):
             setattr(s, name, getattr(sb, name).data_ptr())
         s.embed, s.pe = w.embed.data_ptr(), w.pe.data_ptr()
         s.dec_norm_g, s.dec_norm_b = w.dec_norm_g.data_ptr(), w.dec_norm_b.data_ptr()
@@ -231,10 +231,6 @@ class HipBackend:
         if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)
             s.ph1, s.ph2, s.ffn_part = sb.ph1.data_ptr(), sb.ph2.data_ptr(), sb.ffn_part.data_ptr()
             s.max_ffn_part = sb.ffn_part.shape[0]
-            if self.lib.sc_dec_cluster_supported(cfg.d_model, cfg.dec_heads, sb.W, cfg.ffn_dim):
-                raw = bytes(layers)               # device copy of the layer table for the persistent cluster kernel
-                sb._sc_layers_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(sb.dev)
-                s.layers_dev, s.cbar, s.cl_err = sb._sc_layers_dev.data_ptr(), sb.cbar.data_ptr(), sb.cl_err.data_ptr()
         sb._sc_search_struct = (s, layers)
         return s
 
@@ -270,15 +266,6 @@ class HipBackend:
         self._sb_call("sc_dec_layer_ffn", sb, li, _p(xin), _p(xout), _p(sb.ffn_part), int(sb.ffn_part.shape[0]),
                       C.byref(n))
         return int(n.value)
-
-    def dec_cluster_layers(self, sb, xout):
-        """All decoder layers of the step in one persistent launch (csrc/decoder_cluster.hip); returns the number of
-        feed-forward partial-sum slots it left in sb.ffn_part (= heads)."""
-        s = self.search_struct(sb)
-        s.n_rows = int(getattr(sb, "n_rows_step", sb.S * sb.W))
-        self._chk(self.lib.sc_dec_cluster_layers(C.addressof(s), s.layers_dev, _p(xout), s.cbar, s.cl_err, self._stream()),
-                  "sc_dec_cluster_layers")
-        return sb.cfg.dec_heads
 
     def dec_output_logits(self, sb, xin, xout, npart):
         self._sb_call("sc_dec_output_logits", sb, _p(xin), _p(xout), _p(sb.ffn_part), int(npart))

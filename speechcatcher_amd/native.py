@@ -120,16 +120,8 @@ class NativeStreamBatch:
             raise EngineError(str(e)) from e
         self.handle = h
         self.st = _InfoList(self)
-        self.defer_threshold = 0
 
     # ---- StreamBatch interface ---------------------------------------------------------------------
-    def set_defer_threshold(self, n_streams: int, max_lag_blocks: int = 1):
-        if n_streams > 0:
-            raise EngineError("deferred stragglers are a mode of the Python engine (engine.StreamBatch)")
-
-    def flush(self):
-        pass
-
     @property
     def stats(self):
         a, b, c = C.c_long(), C.c_long(), C.c_long()
@@ -184,12 +176,10 @@ class NativeStreamBatch:
         return ids, ptrs, counts, finals, keep
 
     def push(self, chunks: Sequence[Tuple[int, Optional[np.ndarray], bool]], pcm_resident: bool = False,
-             prefetch=None, isolate_faults: bool = False):
+             isolate_faults: bool = False):
         """One chunk step: (stream, samples, is_final); with ``pcm_resident`` the tuple carries the sample COUNT
         and the samples already sit in the device PCM ring (write_pcm).  Returns {stream: has_output}; a stream
         that failed carries its exception instead when ``isolate_faults`` (else it is raised)."""
-        if prefetch is not None:
-            raise EngineError("prefetch is a mode of the Python engine")
         ids, ptrs, counts, finals, keep = self._gather(chunks, pcm_resident)
         return self._call("sc_push", ids, ptrs, counts, finals, keep, isolate_faults)
 

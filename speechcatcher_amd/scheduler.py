@@ -38,9 +38,6 @@ class StreamScheduler:
         go back to the pool as they are); ``ServerLoop(strict_reference=True)`` switches both off to reproduce
         that.  What reset() itself leaves behind is the batch's ``strict_reference`` (StreamBatch.reset)."""
         self.reset_after_final, self.reset_on_open = reset_after_final, reset_on_open
-        # results are reported per chunk, so every block must complete inside its step: the
-        # scheduler always runs the batch in run-to-completion mode (no deferred stragglers)
-        batch.set_defer_threshold(0)
         self.batch = batch
         self.token_list = token_list
         self.result_format = result_format

@@ -9,8 +9,7 @@ from oracle.kernel_spec import SpecBackend
 FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "ffn_ln_proj", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
             "ctx_handoff", "enc_attention", "ctc_extend_state", "dec_embed", "dec_self_attn",
             "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw", "beam_prune",
-            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits",
-            "dec_cluster_layers"]
+            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits"]
 
 
 class LockstepBackend(SpecBackend):
@@ -72,7 +71,6 @@ class LockstepBackend(SpecBackend):
         # head-parallel decoder layers: (sb, li, xin, xout[, npart]) / (sb, xin, xout, npart)
         "dec_layer_self": [3, "skv", "ph1"], "dec_layer_cross": [3, "ph2"], "dec_layer_ffn": [3, "ffn_part"],
         "dec_output_logits": [2, "logits"],
-        "dec_cluster_layers": [1, "skv", "ffn_part"],       # (sb, xout)
     }
     FULL_SYNC = ("logmel", "ctc_extend_state", "dec_embed")
 

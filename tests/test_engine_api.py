@@ -178,34 +178,3 @@ def test_model_blob_round_trip(tmp_path):
         load_model_blob(tmp_path / "bad.scasr")
 
 
-def test_deferred_stragglers_give_identical_hypotheses():
-    """set_defer_threshold: the decode loop of a chunk step may leave a few streams inside
-    their block; they resume in the next step's loop.  Per stream the blocks, steps and
-    results are unchanged - only when the last steps of a block run."""
-    from speechcatcher_amd import synth
-    from test_engine_spec import make_batch
-    S, chunk, steps = 6, 10240, 6
-    audio = [synth.synth_audio(400 + i, chunk * steps) for i in range(S)]
-
-    def run(threshold, final_last, lag=1):
-        sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=S, max_frames=400, max_tokens=500,
-                        pcm_capacity=1 << 17)
-        sb.set_defer_threshold(threshold, max_lag_blocks=lag)
-        for k in range(steps):
-            fin = final_last and k == steps - 1
-            sb.push([(s, audio[s][k * chunk:(k + 1) * chunk], fin) for s in range(S)])
-        hy = [sb.hypotheses(s) for s in range(S)]      # flushes pending blocks
-        return hy, sb
-
-    for final_last, lag in ((False, 1), (True, 1), (False, 2)):
-        ref, sb0 = run(0, final_last)
-        got, sb1 = run(2 * lag, final_last, lag)
-        assert sb1.stats.get("deferred_blocks", 0) > 0, "the test must exercise deferral"
-        assert sb1.stats["dec_steps"] < sb0.stats["dec_steps"]       # fewer batch iterations for the same work
-        assert [st.n_steps_total for st in sb1.st] == [st.n_steps_total for st in sb0.st]
-        assert [st.processed_block for st in sb1.st] == [st.processed_block for st in sb0.st]
-        for s in range(S):
-            assert len(ref[s]) == len(got[s]) > 0
-            for a, b in zip(ref[s], got[s]):
-                assert a["yseq"] == b["yseq"] and a["xpos"] == b["xpos"]
-                assert abs(a["score"] - b["score"]) < 1e-3

@@ -198,51 +198,6 @@ def test_native_batched_readback_and_argument_checks():
     assert sb.lib.sc_stream_last_error(sb.handle, 5) == b""
 
 
-def test_step_advance_kernel_applies_the_stop_rules():
-    """sc_step_advance against the accept / stop rules of the step loop (beam_search.py:759-821) for every
-    combination of stop flags, final flag and block-boundary detection."""
-    import ctypes as C
-    import torch
-    from speechcatcher_amd import _abi
-    lib = _abi.load()
-    S, W = 64, 10
-    g = torch.Generator().manual_seed(3)
-    for use_bbd in (0, 1):
-        ctrl = torch.zeros(S, 8, dtype=torch.int32)
-        ctrl[:, 0] = (torch.arange(S) % 5 != 4).int()           # active
-        ctrl[:, 1] = torch.randint(0, 2, (S,), generator=g).int()   # cur
-        ctrl[:, 2] = (torch.arange(S) // 16 % 2).int()           # final
-        ctrl[:, 3] = 100
-        ctrl[:, 4] = torch.randint(1, 50, (S,), generator=g).int()  # L
-        ctrl[:, 5] = torch.where(torch.arange(S) % 3 == 0, 1, W).int()   # nhyp
-        ctrl[:, 6] = torch.randint(0, 2, (S,), generator=g).int()
-        ctrl[:, 7] = 100
-        flags = (torch.arange(S) % 16).int()                     # every combination of the 4 flag bits
-        sb = _abi.Search()
-        sb.S, sb.W = S, W
-        dc, df = ctrl.cuda(), flags.cuda()
-        ring = torch.full((2, S), -1, dtype=torch.int32, device="cuda:0")
-        sb.ctrl, sb.flags = dc.data_ptr(), df.data_ptr()
-        _abi.check(lib.sc_step_advance(C.byref(sb), use_bbd, ring.data_ptr(), 0), "sc_step_advance")
-        torch.cuda.synchronize()
-        out, rg = dc.cpu(), ring.cpu()
-        for s in range(S):
-            act, cur, fin, T, L, nh, has, tt = (int(v) for v in ctrl[s])
-            f = int(flags[s])
-            if not act:
-                assert out[s].tolist() == ctrl[s].tolist() and int(rg[L & 1, s]) == -1
-                continue
-            assert int(rg[L & 1, s]) == f and int(rg[1 - (L & 1), s]) == -1
-            f_any, f_best, f_all, f_rep = bool(f & 1), bool(f & 2), bool(f & 4), bool(f & 8)
-            stop_eos = f_any and (not fin or f_best)
-            stop_bbd = bool(use_bbd) and not stop_eos and f_rep and not fin
-            stop_all = not stop_eos and not stop_bbd and f_all and bool(fin)
-            if stop_eos or stop_bbd or stop_all:
-                assert out[s].tolist() == [0, cur, fin, T, L, nh, has, tt], (s, f)
-            else:
-                assert out[s].tolist() == [1, 1 - cur, fin, T, L + 1, min(W, nh * W), 1, tt], (s, f)
-
-
 @pytest.mark.parametrize("seed,bbd,continuous,split", [(0, False, False, None), (1, True, False, None), (2, False, True, None),
                                                        (3, True, True, "32"), (4, False, False, "32")])
 def test_native_random_sessions_equal_the_python_engine(seed, bbd, continuous, split, monkeypatch):

@@ -394,28 +394,15 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
 
-def test_engine_with_sequential_cross_attention(hip, monkeypatch):
-    """Large batches use the one-workgroup-per-(stream, head) cross-attention
-    (no partials / merge); force it on a small batch and compare end to end."""
-    monkeypatch.setenv("SC_XATTN_MODE", "seq")
-    from test_engine_spec import run_case
-    run_case("tiny_c10240_b10_bbd0", backend=hip, device="cuda:0")
-    run_case("tiny_c25600_b10_bbd0", backend=hip, device="cuda:0")
-
-
-@pytest.mark.parametrize("layers", ["cluster", "head_parallel", "six_launch"])
+@pytest.mark.parametrize("layers", ["head_parallel", "six_launch"])
 def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
-    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; all three forms of the
-    decoder layers (persistent stream-cluster kernel: buckets of <= 16 streams; 3 launches per layer: small
-    buckets; 6 launches: large ones)."""
+    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; both forms of the
+    decoder layers (3 launches per layer: small buckets; 6 launches: large ones)."""
     from lockstep import LockstepBackend
-    monkeypatch.setenv("SC_DEC_CLUSTER", "1" if layers == "cluster" else "0")
     monkeypatch.setenv("SC_DEC_FUSED", "0" if layers == "six_launch" else "1")
-    monkeypatch.setattr(LockstepBackend, "cluster_layers", layers == "cluster")
     monkeypatch.setattr(LockstepBackend, "fused_layers", layers != "six_launch")
     ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
     _dump(ls, "lockstep_xl_" + layers)
-    assert ("dec_cluster_layers" in ls.calls) == (layers == "cluster")
     assert ("dec_layer_self" in ls.calls) == (layers == "head_parallel")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
@@ -476,8 +463,6 @@ def test_attention_full_batch_variants_lockstep(hip, monkeypatch, dims):
     whole utterance)."""
     from lockstep import LockstepBackend
     monkeypatch.setenv("SC_ATTN_DEEP", "0")
-    monkeypatch.setenv("SC_DEC_CLUSTER", "0")
-    monkeypatch.setattr(LockstepBackend, "cluster_layers", False)
     if dims == "tiny":
         ls = _lockstep_run(hip, "tiny_c10240_b10_bbd0")
         assert ls.calls.get("dec_self_attn", 0) > 0 and ls.calls.get("dec_cross_attn", 0) > 0

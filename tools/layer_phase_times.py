@@ -13,10 +13,9 @@ import bench  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 w = bench.make_weights("cuda:0")
-sb = bench.build_native(w, S, 10, False, 30)
+sb = bench.build_native(w, S, 10, False, 50)
 sb.set_graphs(False)
-bench.preload_audio(sb, 30)
-bench.run_steps(sb, 14)
+bench.roll(sb, bench.make_audio(S, 50), 36)      # (the bench's window: T ~ 600 frames, ~300 tokens)
 torch.cuda.synchronize()
 names = {0: ["touch+partials+x", "LayerNorm", "QKV proj MFMA", "split-K reduce+cache append", "attention walk", "merge", "out-proj MFMA", "store"],
          1: ["touch+partials+x", "LayerNorm", "q proj MFMA", "split-K reduce", "attention walk", "merge", "out-proj MFMA", "store"],
