@@ -75,12 +75,12 @@ def make_weights(device):
     return PackedWeights(sd, XL, device, mean, std, ffn_dtype=FFN_DTYPE)
 
 
-def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None):
+def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None, kv_dtype=None):
     from speechcatcher_amd.native import NativeStreamBatch
     frames, tokens = capacities(n_steps_total)
     return NativeStreamBatch(w, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
                              max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
-                             engine=engine, kv_dtype=KV_DTYPE)
+                             engine=engine, kv_dtype=kv_dtype or KV_DTYPE)
 
 
 def make_audio(n_streams, n_steps, stream_offset=0, shared=False):
@@ -269,9 +269,9 @@ def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
                                                 "12-15 steps in its 10 s budget: +-10 %"}}
 
 
-def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True):
+def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True, kv_dtype=None):
     """one fresh batch: pre-roll (lock-step, resident audio, untimed), warm-up in the timed mode, then the timed leg"""
-    sb = build_native(w, streams, beam, bbd, total)
+    sb = build_native(w, streams, beam, bbd, total, kv_dtype=kv_dtype)
     roll(sb, audio, preroll)
     k0 = preroll + warmup
     a3 = audio.reshape(streams, -1, CHUNK)
@@ -496,9 +496,9 @@ def main():
     sb.close()
     del sb
 
-    def leg(mode, boundary=True):
+    def leg(mode, boundary=True, kv_dtype=None):
         sbx, r = measure(w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, mode, total_steps,
-                         boundary=boundary)
+                         boundary=boundary, kv_dtype=kv_dtype)
         sbx.close()
         o = {"value": round(r["value"], 2), "unit": "audio_s/s", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
              "decode_steps_per_hop": round(r["dec_steps_per_hop"], 2)}
@@ -521,6 +521,14 @@ def main():
         other["note"] = ("STRICT lock-step: one batched sc_push per chunk step (host PCM in, hypotheses out), every block "
                          "completes inside its call, every stream waits for the slowest stream of the batch" if om == "strict" else
                          "continuous batching through sc_submit / sc_poll, same window")
+
+    kv16 = None
+    if not args.no_other_mode and world == 1 and KV_DTYPE == "float32":
+        kv16 = leg(args.mode, kv_dtype="float16")
+        kv16["over_headline"] = round(kv16["value"] / value, 4)
+        kv16["note"] = ("NOT the headline: the same leg with the self- / cross-attention K|V caches STORED in fp16 (arithmetic, softmax and "
+                        "all scores fp32; opt-in `kv_dtype`): tools/fp16_mode_stats.py - 256 streams x 7 chunks, no hypothesis of any "
+                        "stream changes, best scores within 7e-5 of the fp32 run")
 
     single = None
     if not args.no_single_stream and world == 1:
@@ -584,7 +592,7 @@ def main():
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
-        "long_context": long_ctx,
+        "kv_cache_fp16": kv16, "long_context": long_ctx,
     }
     if args.mode == "continuous":
         out["continuous"] = {k: head[k] for k in ("iterations_per_step", "polls_per_step", "chunks_per_stream_min_max")}

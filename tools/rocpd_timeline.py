@@ -16,8 +16,19 @@ def main():
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     scol = [r[1] for r in cur.execute(f"pragma table_info({ks})")]
     name_col = "kernel_name" if "kernel_name" in scol else "display_name"
-    rows = list(cur.execute(f"select s.{name_col}, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id "
-                            f"order by d.start"))
+    kcols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
+    qcol = "queue_id" if "queue_id" in kcols else ("stream_id" if "stream_id" in kcols else None)
+    rows = list(cur.execute(f"select s.{name_col}, d.start, d.end, {('d.' + qcol) if qcol else '0'} from {kd} d "
+                            f"join {ks} s on d.kernel_id = s.id order by d.start"))
+    # only the decode stream's queue (continuous batching: encoder groups run beside it on another stream)
+    dq = [r[3] for r in rows if "dec_embed" in r[0]]
+    if dq:
+        q = max(set(dq), key=dq.count)
+        n_other = sum(1 for r in rows if r[3] != q)
+        rows = [r[:3] for r in rows if r[3] == q]
+        print(f"(decode queue {q}: {len(rows)} kernels; {n_other} kernels on other queues not shown)")
+    else:
+        rows = [r[:3] for r in rows]
     # a decode step starts with dec_embed (six-launch layers) or with the FIRST variant of the head-parallel
     # self-attention layer kernel (last template argument true)
     import re
