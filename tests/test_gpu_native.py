@@ -504,3 +504,48 @@ def test_m_like_dimensions_head_dim_64(engine):
                "score_ctc": [h.scores.get("ctc", 0.0) for h in ref], "process_idx": ora.process_idx}
         check_against_blocks(sb, 0, blk, 5e-3)
         assert len(sb.hypotheses(0)[0]["yseq"]) > 5
+
+
+def test_native_pcm_ring_compaction_and_mixed_push_submit():
+    """A PCM ring that holds only ~3 chunks (the carry-over is moved to the front again and again, also while encoder
+    groups of other streams are pending), every admission issued as its own encoder group (no merging) and then
+    merged groups of all streams, and sc_push calls mixed into a submit / poll session - all equal the plain
+    lock-step run with a large ring."""
+    from test_engine_spec import make_batch
+    S, chunk, n, beam = 6, 10240, 9, 5
+    audio = np.stack([synth.synth_audio(70 + s, chunk * n) for s in range(S)])
+
+    def mk(pcap):
+        return make_batch("TINY", 1234, "meanstd", beam, False, n_streams=S, backend="native", max_frames=400,
+                          max_tokens=400, pcm_capacity=pcap, max_chunk_samples=chunk)
+
+    ref = mk(1 << 18)
+    for k in range(n):
+        ref.push([(s, audio[s, k * chunk:(k + 1) * chunk], k == n - 1) for s in range(S)])
+    want = ref.hypotheses_batch(list(range(S)))
+    for enc_batch in (1, S):
+        sb = mk(3 * chunk + 500)
+        sb.set_encoder_batch(enc_batch)
+        nxt = [0] * S
+
+        def item(s):
+            k = nxt[s]
+            nxt[s] += 1
+            return (s, audio[s, k * chunk:(k + 1) * chunk], k == n - 1)
+
+        sb.submit([item(s) for s in range(0, S, 2)])           # even streams: continuous
+        while any(k < n for k in nxt):
+            odd = [item(s) for s in range(1, S, 2) if nxt[s] < n]
+            if odd:
+                assert all(v is True or v is False for v in sb.push(odd).values())   # odd streams: lock-step calls in between
+            done = sb.poll(1) if sb.outstanding else {}
+            again = [item(s) for s in done if nxt[s] < n]
+            if again:
+                sb.submit(again)
+        while sb.outstanding:
+            sb.poll(1)
+        got = sb.hypotheses_batch(list(range(S)))
+        for s in range(S):
+            assert [(h["yseq"], h["xpos"]) for h in got[s]] == [(h["yseq"], h["xpos"]) for h in want[s]], (enc_batch, s)
+            assert all(abs(x["score"] - y["score"]) < 1e-3 for x, y in zip(got[s], want[s])), (enc_batch, s)
+        assert sb.st[0].pcm_buffered < 400
