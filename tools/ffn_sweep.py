@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
     W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
     out = []
-    for M in (80, 160, 320, 480, 640, 800, 960, 1120, 1280, 5376):
+    for M in (640, 800, 960, 1040, 1120, 1200, 1280, 2688, 2940, 5376):
         XN, X, LN = torch.randn(M, D, device="cuda"), torch.zeros(M, D, device="cuda"), torch.zeros(M, D, device="cuda")
         for _ in range(5):
             be.ffn_ln(XN, None, M, D, F, W1p, b1, W2p, b2, X, g, b, LN)
@@ -36,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" ".join(out))
     sys.exit(0)
 
-print("rows:            " + " ".join(f"{m:7d}" for m in (80, 160, 320, 480, 640, 800, 960, 1120, 1280, 5376)))
+print("rows:            " + " ".join(f"{m:7d}" for m in (640, 800, 960, 1040, 1120, 1200, 1280, 2688, 2940, 5376)))
 for force in ["model"] + [f"{r},{c}" for r in (1, 2, 3, 4, 5) for c in (1, 2, 4)]:
     env = dict(os.environ)
     if force != "model":
