@@ -32,6 +32,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -1195,7 +1196,8 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
     if (b->stage_busy[sslot]) HIP_TRY(hipEventSynchronize(b->ev_stage[sslot]));
     b->stage_busy[sslot] = false;
   }
-  EncGroup *g = new EncGroup;
+  std::unique_ptr<EncGroup> gp(new EncGroup);   // owned here until it joins b->groups (or is merged / dropped)
+  EncGroup *g = gp.get();
   std::map<int, int> feat_new;
   std::map<int, bool> finals;
   std::vector<int> has_out;
@@ -1208,7 +1210,7 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
           int rc = launch_pending_groups(b);   // (a frontend that still has to read the old places)
           if (rc == SC_OK && b->stream_enc && hipStreamSynchronize(b->stream_enc) != hipSuccess) rc = SC_ERR_LAUNCH;
           if (rc == SC_OK) rc = compact_pcm(b, ch.s);
-          if (rc != SC_OK) { delete g; return rc; }
+          if (rc != SC_OK) return rc;
         }
       }
     snap = b->st;
@@ -1236,7 +1238,7 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
   }
   {
     const int rc = stage_copy(b, *g);
-    if (rc != SC_OK) { delete g; return rc; }
+    if (rc != SC_OK) return rc;
   }
   // eager projections: CTC rows / cross-attention K|V rows of every frame this admission emits
   for (auto &ch : chunks) {
@@ -1265,21 +1267,21 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
         open->open = false;
         if (defer) {
           const int rc = launch_group(b, open);
-          if (rc != SC_OK) { delete g; return rc; }
+          if (rc != SC_OK) return rc;
         }
         open = nullptr;
       }
     }
     if (open) {
       merge_group(b, *open, *g);
-      delete g;
+      gp.reset();
       g = open;
     } else {
       g->gen = b->gen_next++;
       g->slot = (int)(g->gen % N_ARENA);
       if (b->slot_gen[g->slot]) {   // N_ARENA groups in flight: wait for the oldest
         const int rc = wait_group(b, b->slot_gen[g->slot]);
-        if (rc != SC_OK) { delete g; return rc; }
+        if (rc != SC_OK) return rc;
       }
       b->slot_gen[g->slot] = g->gen;
       g->open = defer;
@@ -1287,7 +1289,7 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
     }
     gen = g->gen;
   } else {
-    delete g;
+    gp.reset();
     g = nullptr;
   }
   // decode schedule (beam_search.py:590-634) as per-stream queues; a block that sees frames of this admission waits

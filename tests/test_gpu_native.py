@@ -445,13 +445,13 @@ def test_fp16_kv_caches_keep_the_token_ids_of_the_fp32_reference(name, engine):
     """BASELINE configs[4] (half-precision storage), first stage: the self- and cross-attention K|V caches in fp16,
     all arithmetic / softmax / scores in fp32.  Parity definition for this mode (no fp16 run of the reference's
     native decoder exists: speechcatcher.py:205-210 disables it): token ids, xpos and process_idx of every block
-    of the six XL fixtures EQUAL the fp32 reference's, cumulative scores within 2e-2 (on sums of magnitude 1e2..1e3)."""
+    of the six XL fixtures EQUAL the fp32 reference's, cumulative scores within 5e-3 (on sums of magnitude 1e2..1e3; measured: 7e-5 on best hypotheses)."""
     from test_engine_spec import run_case
     if engine == "native":
-        run_case(name, backend="native", score_tol=2e-2, kv_dtype="float16")
+        run_case(name, backend="native", score_tol=5e-3, kv_dtype="float16")
     else:
         from speechcatcher_amd.hip_backend import HipBackend
-        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", score_tol=2e-2, kv_dtype="float16")
+        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", score_tol=5e-3, kv_dtype="float16")
 
 
 @pytest.mark.parametrize("engine", ["native", "python"])
