@@ -1285,7 +1285,7 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
       }
       b->slot_gen[g->slot] = g->gen;
       g->open = defer;
-      b->groups.push_back(g);
+      b->groups.push_back(gp.release());
     }
     gen = g->gen;
   } else {

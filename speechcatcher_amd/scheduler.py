@@ -223,7 +223,8 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
                 # ended in <eos> (A5); the default here returns the best beam of every segment
                 fa = last and (not finalize_all_last_only or idx == len(segments) - 1)
                 sch.feed(sid, seg[pos:end], is_final=last, finalize_all=fa)
-        for sid, res in sch.step().items():
+        # (C++ engine: continuous batching - a segment that is answered gets its next chunk while the others decode)
+        for sid, res in sch.pump().items():
             if isinstance(res, Exception):
                 raise res
             if not sch._queue[sid]:          # that was the final chunk of the session
