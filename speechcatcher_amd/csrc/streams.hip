@@ -1658,6 +1658,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     sb.flags = b->ring_dev;
   }
   if (const char *sp = sc_hook("SC_SCAN_SPLIT_MIN")) b->scan_split_min = atoi(sp);   // tests: 0 = never, small = always
+  if (const char *sp = sc_hook("SC_SCAN_SPLIT_STREAMS")) b->scan_split_streams = atoi(sp);   // tools: bucket limit of the T-parallel scan
   memset(b->ctrlmap_host, 0, cm);
   for (size_t i = 0; i < n; ++i) b->rm_host[0][i] = b->rm_host[1][i] = (int32_t)i;
   (void)hipMemcpy(b->ctrlmap, b->ctrlmap_host, (size_t)S * 8 * sizeof(int32_t), hipMemcpyHostToDevice);
