@@ -95,6 +95,12 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
          2 * D /*LayerNorm gamma | beta*/;
 }
 
+// key tiles per wave in flight in the attention walk of the few-streams variant (UNR = 8).  Measured in round 3 with 8
+// instead of 4 (two batches of dependent HBM round trips instead of three at T = 600): strict lock-step 2269 -> 2080
+// audio-s/s, single stream 6.8 -> 7.5-9.2 ms per hop - the walk is not bound by the number of round trips.
+#ifndef SC_LAYER_NTW
+#define SC_LAYER_NTW 4
+#endif
 template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH>
 __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       ob[2 * t + 1] = wq[64];
     }
   }
-  constexpr int NTW = (UNR >= 8) ? 4 : 2;   // tiles per wave and batch
+  constexpr int NTW = (UNR >= 8) ? SC_LAYER_NTW : 2;   // tiles per wave and batch
   constexpr int NP = SELF ? 5 : 4;
   float *pm = region;
   float *pl = pm + NP * 16;
