@@ -549,3 +549,32 @@ def test_native_pcm_ring_compaction_and_mixed_push_submit():
             assert [(h["yseq"], h["xpos"]) for h in got[s]] == [(h["yseq"], h["xpos"]) for h in want[s]], (enc_batch, s)
             assert all(abs(x["score"] - y["score"]) < 1e-3 for x, y in zip(got[s], want[s])), (enc_batch, s)
         assert sb.st[0].pcm_buffered < 400
+
+
+def test_rccl_collectives_with_a_world_of_one():
+    """The path's collectives (timing all_reduce MAX, all_gather of the final-text payload: ids + positions + length +
+    score) through RCCL on the GPU with a world of ONE rank - two RCCL ranks on one device are refused
+    (profiles/r03_rccl_two_ranks_one_device.txt), and the test boxes have one GPU.  Runs in a child process (a process
+    group per interpreter)."""
+    import sys
+    code = '''
+import os, sys, socket
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from speechcatcher_amd.distributed import gather_final_hypotheses, max_over_ranks, pack_hypotheses, shard_streams
+torch.cuda.set_device("cuda:0")
+with socket.socket() as so:
+    so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+assert list(shard_streams(5, 0, 1)) == [0, 1, 2, 3, 4]
+ids, pos, sc = [[1023, 5, 7], [1023], []], [[0, 3, 9], [0], []], [-1.25, 0.0, 0.0]
+payload = pack_hypotheses(ids, pos, sc, 16, "cuda:0")
+out = gather_final_hypotheses(payload, 4)
+assert len(out) == 1 and out[0][:3] == [(ids[i], pos[i], sc[i]) for i in range(3)] and out[0][3] == ([], [], 0.0), out
+assert max_over_ranks(2.5, "cuda:0") == 2.5
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+''' % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
