@@ -337,7 +337,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the resident-audio / no-read-back leg")
     ap.add_argument("--no-long-context", action="store_true", help="skip the T ~ 1000 / T ~ 4500 legs")
     ap.add_argument("--poll-group", type=int, default=0,
-                    help="continuous: sc_poll returns when at least this many replies are ready (0: streams / 16)")
+                    help="continuous: sc_poll returns when at least this many replies are ready (0: streams / 8)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="extra (untimed for `value`) steps with per-launch HIP-event timing of the hot kernels")
     ap.add_argument("--kv-dtype", choices=["float32", "float16"], default="float32",
@@ -351,7 +351,7 @@ def main():
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
     FFN_DTYPE = args.ffn_dtype
-    group = args.poll_group or max(1, args.streams // 16)
+    group = args.poll_group or max(1, args.streams // 8)
     S = args.streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
