@@ -313,6 +313,29 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
     return out
 
 
+_PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELb0",
+               "dec_attn_flash_kernel<cross>": "dec_attn_flash_kernelILi32ELi10ELb0",
+               "dec_attn_flash_kernel<self>": "dec_attn_flash_kernelILi32ELi10ELb1",
+               "proj_ln_proj_kernel<256,*>": "proj_ln_proj_kernelILi256",
+               "rowtile_proj_kernel<256,*>": "rowtile_proj_kernelILi256"}
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary (None if unavailable)"""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r03_bench_default_pmc_hbm_traffic.csv")
+    key = next((v for k, v in _PMC_FAMILY.items() if kernel_name.startswith(k)), None)
+    if key is None or not os.path.exists(path):
+        return None
+    tot = n = 0.0
+    with open(path) as f:
+        for row in csv.reader(f):
+            if row and row[0] != "kernel" and any(key.format(r) in row[0] for r in (1, 2, 3, 4, 5)):
+                tot += float(row[1]) * float(row[6])
+                n += float(row[1])
+    return int(tot / n) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -440,6 +463,8 @@ def main():
 
     audio_s = world * S * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
+    default_workload = (S == 128 and CHUNK == 10240 and args.beam == 10 and not args.bbd and args.mode == "continuous" and
+                        KV_DTYPE == "float32" and FFN_DTYPE == "float32")
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
              "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<self> (decoder self-attention, large buckets)",
@@ -468,9 +493,12 @@ def main():
         raw_us = ms[v] * 1e3 / nn[v]
         t_ms = max(net[v], 1e-9)
         # traffic: HBM bytes per launch need rocprofv3 --pmc passes of this command (a process cannot read the
-        # counters of its own kernels); they are committed under profiles/ with the bench sha they belong to and
-        # are NOT copied into this line - null here means "not measured by this run".
-        common = {"kernel": names[v], "traffic": None,
+        # counters of its own kernels): `traffic` is taken from the committed summary of those passes
+        # (profiles/r03_bench_default_pmc_hbm_traffic.csv, tools/prof_bench.sh: FETCH_SIZE x2 + WRITE_SIZE per launch,
+        # launch-weighted over the kernel family) when the file is there and this is the default workload, else null.
+        common = {"kernel": names[v], "traffic": pmc_traffic(names[v]) if default_workload else None,
+                  "traffic_source": "profiles/r03_bench_default_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                    "passes of this command, bytes per launch, launch-weighted over the kernel family)",
                   "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
                   "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
                   "share_of_timed_kernel_time": round(net[v] / tot_ms, 4),
