@@ -372,6 +372,95 @@ def test_c_host_program_reproduces_the_reference_fixture(tmp_path):
             assert got == sorted(tuple(y) for y in js["blocks"][nblk - 1]["yseq"])
 
 
+C_HOST_CONTINUOUS = r"""
+/* The same fixture through the continuous-batching entry points, from plain C: three streams get the SAME audio,
+ * staggered (stream k's first chunk is submitted k polls late), each with one chunk outstanding: sc_submit, sc_poll,
+ * sc_get_hyps_batch for the streams that answered, their next chunks.  One line per reply: stream, then as above. */
+#include <stdio.h>
+#include <stdlib.h>
+#include "scasr.h"
+#define NS 3
+int main(int argc, char **argv) {
+  if (argc < 6) return 2;
+  const int chunk = atoi(argv[3]), beam = atoi(argv[4]), bbd = atoi(argv[5]);
+  sc_engine *eng = NULL; sc_streams *st = NULL;
+  if (sc_engine_load(argv[1], 0, &eng) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+  sc_stream_options o = {NS, beam, 0.3f, bbd, 256, 200, 1 << 18, 32768, 1};
+  if (sc_streams_create(eng, &o, &st) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+  if (sc_streams_set_encoder_batch(st, 2) != SC_OK) return 1;
+  FILE *f = fopen(argv[2], "rb"); if (!f) return 1;
+  fseek(f, 0, SEEK_END); long n = ftell(f) / 4; fseek(f, 0, SEEK_SET);
+  float *pcm = (float *)malloc(n * 4);
+  if (fread(pcm, 4, n, f) != (size_t)n) return 1;
+  fclose(f);
+  static int32_t ids[NS * 16 * 200]; int lens[NS * 16], nh[NS]; double sc[NS * 16];
+  long pos[NS] = {0, 0, 0}; int started[NS] = {0, 0, 0}; int polls = 0;
+  while (1) {
+    int sub[NS], cnt[NS], k = 0; const float *ptr[NS]; uint8_t fin[NS];
+    for (int s = 0; s < NS; ++s) {
+      if (started[s] == 1 || pos[s] >= n || polls < s) continue;       /* one chunk outstanding; staggered start */
+      sub[k] = s; ptr[k] = pcm + pos[s]; cnt[k] = (int)(pos[s] + chunk < n ? chunk : n - pos[s]);
+      fin[k] = pos[s] + chunk >= n; pos[s] += chunk; started[s] = 1; ++k;
+    }
+    if (k && sc_submit(st, sub, ptr, cnt, fin, k) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+    if (sc_streams_outstanding(st) == 0) { if (pos[0] >= n && pos[1] >= n && pos[2] >= n) break; ++polls; continue; }
+    int done[NS], status[NS];
+    const int nd = sc_poll(st, 1, NS, done, status);
+    ++polls;
+    if (nd < 0) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
+    if (nd && sc_get_hyps_batch(st, done, nd, beam, 200, ids, NULL, lens, nh, sc, NULL, NULL) != SC_OK) return 1;
+    for (int i = 0; i < nd; ++i) {
+      if (status[i] < 0) { fprintf(stderr, "%s\n", sc_stream_last_error(st, done[i])); return 1; }
+      sc_stream_info_t info; sc_stream_info(st, done[i], &info);
+      printf("%d %d %d %d", done[i], status[i], info.enc_frames, info.processed_block);
+      for (int h = 0; h < nh[i]; ++h) { printf(" |"); for (int j = 0; j < lens[i * beam + h]; ++j) printf(" %d", ids[(i * beam + h) * 200 + j]); }
+      printf("\n");
+      started[done[i]] = 0;
+    }
+  }
+  sc_streams_destroy(st); sc_engine_destroy(eng); free(pcm);
+  return 0;
+}
+"""
+
+
+def test_c_host_program_with_continuous_batching(tmp_path):
+    """sc_submit / sc_poll / sc_get_hyps_batch from a gcc-compiled C program: three staggered streams with the fixture
+    audio; EVERY stream reproduces the reference fixture reply by reply."""
+    from speechcatcher_amd.config import TINY
+    from speechcatcher_amd.weights import PackedWeights
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    js, _ = load_case("tiny_c10240_b10_bbd0")
+    meta = js["meta"]
+    sd = synth.make_state_dict(TINY, meta["seed"])
+    mean, std = synth.stats_to_mean_std(synth.make_stats(TINY, kind=meta["stats"]))
+    PackedWeights(sd, TINY, "cpu", mean, std).save_packed(tmp_path / "tiny.scpk")
+    synth.synth_audio(meta["audio_stream"], meta["n_samples"]).astype("<f4").tofile(tmp_path / "audio.f32")
+    (tmp_path / "hostc.c").write_text(C_HOST_CONTINUOUS)
+    libdir = ROOT / "speechcatcher_amd"
+    subprocess.run([gcc, "-std=c99", "-O1", "-I", str(ROOT / "include"), str(tmp_path / "hostc.c"), "-L", str(libdir),
+                    "-lscasr", f"-Wl,-rpath,{libdir}", "-o", str(tmp_path / "hostc")], check=True)
+    res = subprocess.run([str(tmp_path / "hostc"), str(tmp_path / "tiny.scpk"), str(tmp_path / "audio.f32"),
+                          str(meta["chunk"]), str(meta["beam"]), str(int(meta["bbd"]))], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    per = {0: [], 1: [], 2: []}
+    for line in res.stdout.strip().splitlines():
+        per[int(line.split()[0])].append(line.split(" ", 1)[1])
+    for sid, lines in per.items():
+        assert len(lines) == len(js["calls"]), sid
+        nblk = 0
+        for line, call in zip(lines, js["calls"]):
+            head, *hyps = line.split(" |")
+            status, enc_frames, pblock = [int(x) for x in head.split()]
+            assert enc_frames == call["enc_buffer_len"] and pblock == call["processed_block"], sid
+            nblk += call["n_blocks"]
+            if call["n_blocks"]:
+                got = sorted(tuple(int(t) for t in h.split()) for h in hyps)
+                assert got == sorted(tuple(y) for y in js["blocks"][nblk - 1]["yseq"]), sid
+
+
 def test_cli_round_trips_a_wav(tmp_path):
     """``python -m speechcatcher_amd -m <model dir> -b 3 recording.wav``: the reference CLI's file mode (flags of
     speechcatcher.py:756-808) as a child process; the .txt / .json next to the input carry what the library gives
