@@ -72,7 +72,7 @@ def make_weights(device):
     from speechcatcher_amd.weights import PackedWeights
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    return PackedWeights(sd, XL, device, mean, std, ffn_dtype=FFN_DTYPE)
+    return PackedWeights(sd, XL, device, mean, std, ffn_dtype=FFN_DTYPE, proj_dtype=FFN_DTYPE)
 
 
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None, kv_dtype=None):
@@ -367,8 +367,8 @@ def main():
                     help="float16: self-/cross-attention K|V caches stored in fp16, arithmetic fp32 (opt-in; results "
                          "differ from the fp32 reference within the tolerance stated in tests/test_gpu_native.py)")
     ap.add_argument("--ffn-dtype", choices=["float32", "float16"], default="float32",
-                    help="float16: feed-forward weights in fp16 and fp16 MFMA inputs (fp32 accumulation) in the fused FFN "
-                         "kernels of encoder and decoder (opt-in, BASELINE configs[4]; never the headline)")
+                    help="float16: feed-forward weights (encoder and decoder) and the encoder's attention projections in fp16 "
+                         "with fp16 MFMA inputs, fp32 accumulation (opt-in, BASELINE configs[4]; never the headline)")
     args = ap.parse_args()
     global CHUNK, KV_DTYPE, FFN_DTYPE
     CHUNK = args.chunk
@@ -606,7 +606,7 @@ def main():
         "vs_baseline": None,
         "dtype": ("f32" if KV_DTYPE == "float32" and FFN_DTYPE == "float32" else
                   "f32 except: " + ", ".join(x for x in (("fp16 K|V caches" if KV_DTYPE != "float32" else ""),
-                                                         ("fp16 feed-forward weights and MFMA inputs (fp32 accumulation)"
+                                                         ("fp16 feed-forward + encoder attention-projection weights and MFMA inputs (fp32 accumulation)"
                                                           if FFN_DTYPE != "float32" else "")) if x)),
         "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {S} concurrent synthetic streams/GPU "

@@ -71,6 +71,8 @@ typedef struct sc_enc_layer {
   const float *wqkv_p, *wo_p; /* sc_pack_panel_weight of wqkv, wo (used when sc_rowtile_proj_supported(d, d)) */
   const void *w1_h, *w2_h;    /* fp16 copies of w1_p / w2_p (same fragment order) or NULL: the fused FFN then runs
                                  fp16 MFMA inputs with fp32 accumulation (sc_ffn_ln_h) */
+  const void *wqkv_h, *wo_h;  /* fp16 copies of wqkv_p / wo_p or NULL: the attention projections with fp16 MFMA inputs
+                                 (sc_rowtile_proj_h) */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -206,6 +208,10 @@ int sc_ffn_ln_supported(int D, int F);
 int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
                     float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
                     int ldc, const float *g2, const float *b2, float *LN2, void *stream);
+/* ... with fp16 weights (Wh = the fragment-packed copy with 2-byte elements) and fp16 MFMA inputs: BASELINE configs[4] */
+int sc_rowtile_proj_h(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                      float eps, const void *Wh, const float *bias, int N, const float *R, float *C,
+                      int ldc, const float *g2, const float *b2, float *LN2, void *stream);
 int sc_rowtile_proj_supported(int D, int N);
 /* The same feed-forward followed by the projection that consumes its LayerNorm - the next decoder
  * layer's Q|K|V (decoder_layer.py:85-100 of layer l+1) or the output layer

@@ -25,7 +25,7 @@ vp = C.c_void_p
 class EncLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "w1_p", "w2_p",
-                                  "wqkv_p", "wo_p", "w1_h", "w2_h")]
+                                  "wqkv_p", "wo_p", "w1_h", "w2_h", "wqkv_h", "wo_h")]
 
 
 class DecLayer(C.Structure):
@@ -92,6 +92,8 @@ _SIGS = {
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_rowtile_proj": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
                                   C.c_int, vp, vp, vp, vp]),
+    "sc_rowtile_proj_h": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
+                                    C.c_int, vp, vp, vp, vp]),
     "sc_rowtile_proj_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_workspace_bytes": (C.c_size_t, [vp]),
     "sc_ffn_ln_proj": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp,

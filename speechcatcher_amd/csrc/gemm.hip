@@ -1133,6 +1133,7 @@ struct RowProjArgs {
   float *LN2;
   float eps;
   int M, N, cpw;
+  int w_half;   // Wp holds fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation
 };
 
 template <int D>
@@ -1152,21 +1153,27 @@ __device__ __forceinline__ float4 rowtile_ln(const float4 v, bool act, const flo
   return o;
 }
 
-template <int D, int RTT, bool FULL>
+// WH: fp16 weights (the fragment order of sc_pack_panel_weight with 2-byte elements) and fp16 MFMA inputs
+// (v_mfma_f32_16x16x16_f16, as in ffn_fused_kernel<.., WH>): the (normalised) row tile is converted to fp16 once, after
+// the LayerNorm prologue; accumulation, bias, residual and the output LayerNorm stay fp32.
+template <int D, int RTT, bool FULL, bool WH = false>
 __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
   constexpr int RT = 16 * RTT, FC = 128, KI1 = D / 32;
   constexpr int LDX = D + 4, LDO = FULL ? D + 4 : FC + 4;
+  constexpr int LDXH = D + 8;           // WH: row stride of the fp16 tile (elements)
   extern __shared__ __attribute__((aligned(16))) float rowtile_smem[];
   float *Xs = rowtile_smem;             // [RT][LDX] (normalised) input rows
   float *Os = rowtile_smem + RT * LDX;  // [RT][LDO] result staging
+  _Float16 *XsH = reinterpret_cast<_Float16 *>(rowtile_smem + RT * LDX + RT * LDO);   // WH: [RT][LDXH]
+  typedef typename std::conditional<WH, h16x4, float4>::type BF;   // 4 weight elements
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int grp = blockIdx.x, m0 = blockIdx.y * RT;
   const int nch = FULL ? D / FC : p.cpw, ch0 = FULL ? 0 : grp * p.cpw;
 
-  float4 bf[KI1][2];
+  BF bf[KI1][2];
   auto load_b = [&](int chunk) {
-    const float4 *wp = reinterpret_cast<const float4 *>(p.Wp) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
+    const BF *wp = reinterpret_cast<const BF *>(p.Wp) + ((long)(chunk * 8 + wave) * KI1) * 128 + lane;
 #pragma unroll
     for (int ki = 0; ki < KI1; ++ki) {
       bf[ki][0] = wp[ki * 128];
@@ -1201,13 +1208,35 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
     }
     __syncthreads();
   }
+  if constexpr (WH) {   // fp16 copy of the (normalised) tile: the A operands of the fp16 MFMAs
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = threadIdx.x + q * 512;
+      const float4 v = *reinterpret_cast<const float4 *>(Xs + (e / (D / 4)) * LDX + 4 * (e % (D / 4)));
+      *reinterpret_cast<h16x4 *>(XsH + (e / (D / 4)) * LDXH + 4 * (e % (D / 4))) =
+          h16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    }
+    __syncthreads();
+  }
   for (int cc = 0; cc < nch; ++cc) {
     const int chunk = ch0 + cc;
     const float bias = p.bias ? p.bias[chunk * FC + wave * 16 + r] : 0.f;
     f32x4 acc[RTT];
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (WH) {
+      constexpr int NS = RTT * KI1;
+      const _Float16 *ab = XsH + r * LDXH + 8 * kk;
+      h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        h16x8 n = a;
+        if (st + 1 < NS) n = *reinterpret_cast<const h16x8 *>(ab + ((st + 1) % RTT) * 16 * LDXH + ((st + 1) / RTT) * 32);
+        acc[rt] = ffn_mma_h(acc[rt], a, bf[ki][0], bf[ki][1]);
+        a = n;
+      }
+    } else {
       constexpr int NS = RTT * KI1;
       const float *ab = Xs + r * LDX + 8 * kk;
       float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
@@ -1264,17 +1293,22 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
   }
 }
 
-template <int D, int RTT, bool FULL>
-static void launch_rowtile(const RowProjArgs &p, int ngrp, hipStream_t st) {
+template <int D, int RTT, bool FULL, bool WH>
+static void launch_rowtile_wh(const RowProjArgs &p, int ngrp, hipStream_t st) {
   constexpr int RT = 16 * RTT;
-  const size_t lds = (size_t)(RT * (D + 4) + RT * ((FULL ? D : 128) + 4)) * sizeof(float);
+  const size_t lds = (size_t)(RT * (D + 4) + RT * ((FULL ? D : 128) + 4)) * sizeof(float) + (WH ? (size_t)RT * (D + 8) * 2 : 0);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_proj_kernel<D, RTT, FULL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_proj_kernel<D, RTT, FULL, WH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  rowtile_proj_kernel<D, RTT, FULL><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+  rowtile_proj_kernel<D, RTT, FULL, WH><<<dim3(ngrp, cdiv(p.M, RT)), 512, lds, st>>>(p);
+}
+template <int D, int RTT, bool FULL>
+static void launch_rowtile(const RowProjArgs &p, int ngrp, hipStream_t st) {
+  if (p.w_half) launch_rowtile_wh<D, RTT, FULL, true>(p, ngrp, st);
+  else launch_rowtile_wh<D, RTT, FULL, false>(p, ngrp, st);
 }
 
 template <int D, bool FULL>
@@ -1291,9 +1325,9 @@ extern "C" int sc_rowtile_proj_supported(int D, int N) {
   return (D == 256 || D == 128) && N % 128 == 0 && N >= 128;
 }
 
-extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
-                               float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
-                               int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
+static int rowtile_run(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                       float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
+                       int ldc, const float *g2, const float *b2, float *LN2, void *stream, int w_half) {
   SC_CHECK_ARG(A && Wp && C, "null pointer");
   SC_CHECK_ARG(sc_rowtile_proj_supported(D, N), "unsupported dimensions");
   SC_CHECK_ARG((!ln_g) == (!ln_b) && (!LN2 || (g2 && b2)), "LayerNorm parameters missing");
@@ -1327,7 +1361,7 @@ extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const floa
       if (!full) best_cpw = c;
     }
   }
-  RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw};
+  RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw, w_half};
   ProfScope prof = sc_prof_begin(st);
   const int ngrp = full ? 1 : nch / best_cpw;
   if (D == 256) {
@@ -1338,9 +1372,23 @@ extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const floa
     else launch_rowtile_rtt<128, false>(p, best_rtt, ngrp, st);
   }
   sc_prof_end(prof, SC_PROF_ROWTILE_PROJ, 2.0 * (double)M * D * N,
-              4.0 * ((double)M * (D + N) + (double)D * N + (full ? 2.0 * M * D : 0.0)));
+              4.0 * ((double)M * (D + N) + (double)D * N / (w_half ? 2.0 : 1.0) + (full ? 2.0 * M * D : 0.0)));
   SC_CHECK_LAUNCH();
   return SC_OK;
+}
+
+extern "C" int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                               float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
+                               int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
+  return rowtile_run(A, lda, M, D, ln_g, ln_b, eps, Wp, bias, N, R, C, ldc, g2, b2, LN2, stream, 0);
+}
+// ... with fp16 weights: Wh = the fragment-packed copy with 2-byte elements; fp16 MFMA inputs (the normalised row tile is
+// rounded to fp16 when staged), fp32 accumulation, bias, residual and output LayerNorm
+extern "C" int sc_rowtile_proj_h(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                                 float eps, const void *Wh, const float *bias, int N, const float *R, float *C,
+                                 int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
+  return rowtile_run(A, lda, M, D, ln_g, ln_b, eps, reinterpret_cast<const float *>(Wh), bias, N, R, C, ldc, g2, b2, LN2,
+                     stream, 1);
 }
 
 extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128) && F % 128 == 0 && F >= 128; }

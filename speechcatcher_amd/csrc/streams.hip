@@ -1401,6 +1401,8 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
 #undef ENC
     l.w1_h = e->f(p + "w1_h", false);   // optional fp16 copies: fp16 MFMA inputs in the fused FFN
     l.w2_h = e->f(p + "w2_h", false);
+    l.wqkv_h = e->f(p + "wqkv_h", false);   // optional fp16 copies: fp16 MFMA inputs in the attention projections
+    l.wo_h = e->f(p + "wo_h", false);
   }
   e->dec.resize(cfg->dec_layers);
   e->wkv.resize(cfg->dec_layers);

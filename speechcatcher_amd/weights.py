@@ -76,12 +76,13 @@ def rowtile_proj_supported(d: int, N: int) -> bool:
 
 class PackedWeights:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
-                 mean=None, std=None, ffn_dtype: str = "float32"):
+                 mean=None, std=None, ffn_dtype: str = "float32", proj_dtype: str = "float32"):
         """``ffn_dtype="float16"``: additional fp16 copies of the fragment-packed feed-forward weights (w1_h / w2_h);
         the fused FFN kernels then run fp16 MFMA inputs with fp32 accumulation (BASELINE configs[4]; never the
-        default - the reference computes in fp32)."""
-        assert ffn_dtype in ("float32", "float16")
-        self.ffn_dtype = ffn_dtype
+        default - the reference computes in fp32).  ``proj_dtype="float16"``: the same for the attention projections
+        of the encoder layers (wqkv_h / wo_h: sc_rowtile_proj_h; the decoder's row panels stay fp32)."""
+        assert ffn_dtype in ("float32", "float16") and proj_dtype in ("float32", "float16")
+        self.ffn_dtype, self.proj_dtype = ffn_dtype, proj_dtype
         self.cfg = cfg
         self.device = torch.device(device)
         d, F2 = cfg.d_model, cfg.conv_freq2
@@ -165,6 +166,8 @@ class PackedWeights:
         for lw in self.enc:              # encoder attention projections for the row-tile kernel (sc_rowtile_proj)
             for n in ("wqkv", "wo"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if rowtile_proj_supported(d, d) else lw[n]
+                if proj_dtype == "float16" and rowtile_proj_supported(d, d):
+                    lw[n + "_h"] = lw[n + "_p"].to(torch.float16).contiguous()   # same fragment order, 2-byte elements
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]

@@ -547,7 +547,9 @@ def test_fp16_kv_caches_keep_the_token_ids_of_the_fp32_reference(name, engine):
 @pytest.mark.parametrize("name", XL_CASES)
 def test_fp16_ffn_weights_on_the_xl_fixtures(name, engine):
     """BASELINE configs[4], second stage: feed-forward weights in fp16 and fp16 MFMA inputs (fp32 accumulation) in the
-    fused FFN kernels of all 30 encoder and 14 decoder layers, next to the fp16 K|V caches.  Parity definition for
+    fused FFN kernels of all 30 encoder and 14 decoder layers, next to the fp16 K|V caches.  (The fp16 attention
+    projections of the encoder, round 3's `proj_dtype`, move the near-tied beams of two of these six fixtures: the whole
+    fp16 mode is held to the fp32 engine statistically instead - tests/test_gpu_baseline_size.py, 256 streams.)  Parity definition for
     this mode (no fp16 run of the reference's native decoder exists): the token ids / positions of the BEST hypothesis
     of every block of the six XL fixtures equal the fp32 reference's and its score is within 0.5 (sums of magnitude
     1e2..1e3; the operands of two of the three big GEMMs of every layer carry 2^-11 rounding) - the engine checks

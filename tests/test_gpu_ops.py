@@ -257,6 +257,34 @@ def test_rowtile_proj(hip, M, D):
     np.testing.assert_allclose(Lg.cpu().numpy(), refL.numpy(), atol=5e-4, rtol=5e-4)
 
 
+@pytest.mark.parametrize("M,D", [(42, 256), (2688, 256), (1000, 256), (333, 128)])
+def test_rowtile_proj_fp16_weights(hip, M, D):
+    """sc_rowtile_proj_h (v_mfma_f32_16x16x16_f16: fp16 weights, the normalised row tile rounded to fp16 when staged,
+    fp32 accumulation / bias / residual / output LayerNorm) against fp32 arithmetic on the fp16-ROUNDED operands: what
+    remains is the summation order (tolerance 2e-3 on values of magnitude 1)."""
+    from speechcatcher_amd.weights import pack_panel_weight
+    N = 3 * D
+    X, ATT = _rand(M, D, seed=91), _rand(M, D, seed=92)
+    Wqkv, bqkv = _rand(N, D, seed=93, scale=D ** -0.5), _rand(N, seed=94)
+    Wo, bo = _rand(D, D, seed=95, scale=D ** -0.5), _rand(D, seed=96)
+    g1, b1, g2, b2 = 1 + 0.1 * _rand(D, seed=97), _rand(D, seed=98), 1 + 0.1 * _rand(D, seed=99), _rand(D, seed=100)
+    r16 = lambda t: t.half().float()   # noqa: E731
+    ln = lambda t, g, b: torch.nn.functional.layer_norm(t, (D,), g, b, 1e-12)   # noqa: E731
+    Wqh, Woh = pack_panel_weight(Wqkv).half(), pack_panel_weight(Wo).half()
+    refQ = r16(ln(X, g1, b1)) @ r16(Wqkv).t() + bqkv
+    Qg = torch.full((M + 3, N), 5.0, device="cuda")
+    hip.rowtile_proj_h(X.cuda(), M, D, Wqh.cuda(), bqkv.cuda(), N, Qg, ln_g=g1.cuda(), ln_b=b1.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Qg[:M].cpu().numpy(), refQ.numpy(), atol=2e-3, rtol=2e-3)
+    assert float(Qg[M:].min()) == 5.0 and float(Qg[M:].max()) == 5.0          # rows >= M untouched
+    refX = X + (r16(ATT) @ r16(Wo).t() + bo)
+    Xg, Lg = X.cuda(), torch.full((M + 3, D), 2.0, device="cuda")
+    hip.rowtile_proj_h(ATT.cuda(), M, D, Woh.cuda(), bo.cuda(), D, Xg, R=Xg, g2=g2.cuda(), b2=b2.cuda(), LN2=Lg)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Xg.cpu().numpy(), refX.numpy(), atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(Lg[:M].cpu().numpy(), ln(refX, g2, b2).numpy(), atol=3e-3, rtol=3e-3)
+
+
 @pytest.mark.parametrize("M,D,F,N", [(10, 256, 2048, 768), (1280, 256, 2048, 768), (533, 256, 2048, 1024),
                                      (77, 128, 256, 384), (2100, 256, 2048, 768)])
 def test_ffn_ln_proj_chain(hip, M, D, F, N):
