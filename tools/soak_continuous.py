@@ -1,0 +1,90 @@
+"""Soak test of the tick engine: randomised sessions (random chunk lengths 300..24000 samples, random finals, resets,
+oversized chunks that must fail alone, random poll sizes and encoder-batch thresholds, sc_push calls mixed in) on S
+stream slots for N steps - continuous batching (sc_submit / sc_poll) against a second batch that gets the SAME calls
+through sc_push one stream at a time.  Every reply must carry the same hypotheses.  Tiny dims, beam 5.
+    gpurun -- 'python tools/soak_continuous.py [steps=400] [streams=32] [seed=0]'"""
+import os
+import sys
+
+os.environ.setdefault("SC_TEST_HOOKS", "1")
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np  # noqa: E402
+
+from speechcatcher_amd import synth  # noqa: E402
+from test_engine_spec import make_batch  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+rng = np.random.default_rng(seed)
+kw = dict(n_streams=S, max_frames=500, max_tokens=420, pcm_capacity=1 << 16, max_chunk_samples=24000, strict_reference=bool(seed % 2))
+a = make_batch("TINY", 1234, "meanstd", 5, bool(seed % 3 == 1), backend="native", **kw)      # continuous
+b = make_batch("TINY", 1234, "meanstd", 5, bool(seed % 3 == 1), backend="native", **kw)      # reference: one sc_push per call
+fed, utt, next_utt = [0] * S, list(range(S)), S
+n_calls = n_faults = n_final = longest = 0
+pending = {}
+
+
+def check(s, res_a):
+    global n_faults, longest
+    chunk, fin = pending.pop(s)
+    res_b = b.push([(s, chunk, fin)], isolate_faults=True)[s]
+    fa, fb = isinstance(res_a, Exception), isinstance(res_b, Exception)
+    assert fa == fb, (s, res_a, res_b)
+    if fa:
+        n_faults += 1
+        return True
+    assert bool(res_a) == bool(res_b), (s, res_a, res_b)
+    ha, hb = a.hypotheses(s), b.hypotheses(s)
+    assert [(h["yseq"], h["xpos"]) for h in ha] == [(h["yseq"], h["xpos"]) for h in hb], s
+    assert all(abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(y["score"])) for x, y in zip(ha, hb)), s
+    longest = max([longest] + [len(h["yseq"]) for h in ha])
+    return fin
+
+
+def recycle(s):
+    global next_utt
+    a.reset(s)
+    b.reset(s)
+    fed[s], utt[s] = 0, next_utt
+    next_utt += 1
+
+
+for step in range(steps):
+    a.set_encoder_batch(int(rng.choice([1, 2, S // 4, S])))
+    items = []
+    for s in range(S):
+        if s in pending or rng.random() < 0.4:
+            continue
+        n = int(rng.choice([300, 700, 1600, 4000, 8192, 10240, 16000, 24000, 30000]))     # 30000 > max_chunk: fails alone
+        audio = synth.synth_audio(utt[s], fed[s] + n)[fed[s]:]
+        fin = bool(rng.random() < 0.1 and fed[s] + n > 12000)
+        items.append((s, audio, fin))
+        fed[s] += n
+    if items and rng.random() < 0.25:           # a lock-step call in between (also advances the submitted streams)
+        k = int(rng.integers(1, len(items) + 1))
+        for s, c, f in items[:k]:
+            pending[s] = (c, f)
+        res = a.push(items[:k], isolate_faults=True)
+        n_calls += k
+        for s, _, _ in items[:k]:
+            if check(s, res[s]) or fed[s] > 60000:
+                recycle(s)
+                n_final += 1
+        items = items[k:]
+    if items:
+        for s, c, f in items:
+            pending[s] = (c, f)
+        a.submit(items)
+        n_calls += len(items)
+    while a.outstanding and (rng.random() < 0.7 or a.outstanding > S // 2):
+        for s, r in a.poll(int(rng.integers(1, 6))).items():
+            if check(s, r) or fed[s] > 60000:
+                recycle(s)
+                n_final += 1
+while a.outstanding:
+    for s, r in a.poll(1).items():
+        check(s, r)
+print(f"soak ok: {steps} steps, {n_calls} calls, {n_faults} isolated faults, {n_final} utterances ended, longest hypothesis {longest} tokens, "
+      f"{a.stats['dec_steps']} decode iterations (one stream at a time: {b.stats['dec_steps']})")
