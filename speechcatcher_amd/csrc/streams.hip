@@ -1377,6 +1377,7 @@ int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n,
 extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *tensors, int n_tensors, int device,
                                 sc_engine **out) {
   SC_CHECK_ARG(cfg && tensors && out && n_tensors > 0, "null");
+  SC_API_BEGIN
   sc_engine *e = new sc_engine;
   e->cfg = *cfg;
   e->device = device;
@@ -1423,6 +1424,7 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
   }
   *out = e;
   return SC_OK;
+  SC_API_END
 }
 
 // packed model file (speechcatcher_amd.weights.PackedWeights.save_packed): "SCPK1\0\0\0", int32 sizeof(sc_config),
@@ -1487,6 +1489,7 @@ extern "C" int sc_engine_config(const sc_engine *e, sc_config *out) {
 
 extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_streams **out) {
   SC_CHECK_ARG(e && o && out, "null");
+  SC_API_BEGIN
   const sc_config &c = e->cfg;
   SC_CHECK_ARG(o->n_streams > 0 && o->beam_size > 0 && o->max_frames > 0 && o->max_tokens > 1, "bad options");
   const int pre_beam = 40;
@@ -1685,6 +1688,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   for (int s = 0; s < S; ++s) init_hyp(b, s);
   *out = b;
   return SC_OK;
+  SC_API_END
 }
 
 extern "C" void sc_streams_destroy(sc_streams *b) {
