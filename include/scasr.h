@@ -73,6 +73,9 @@ typedef struct sc_enc_layer {
                                  fp16 MFMA inputs with fp32 accumulation (sc_ffn_ln_h) */
   const void *wqkv_h, *wo_h;  /* fp16 copies of wqkv_p / wo_p or NULL: the attention projections with fp16 MFMA inputs
                                  (sc_rowtile_proj_h) */
+  const void *w1_s, *w2_s;    /* fp16 hi | lo SPLIT of w1_p / w2_p (weights.py split_panel_weight; same bytes) or NULL: the
+                                 fused FFN then computes fp32-grade results with three fp16 MFMAs per product sum
+                                 (sc_ffn_ln_s); takes precedence over w1_h / w2_h */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -84,6 +87,7 @@ typedef struct sc_dec_layer {
   const float *wqkv_q;              /* sc_pack_lane_weight of wqkv (sc_ffn_ln_proj of the layer before) */
   const float *wqkv_pp, *wq_pp, *wo_pp, *wo2_pp; /* sc_pack_panel_weight of wqkv, wq, wo, wo2 (sc_dec_layer_self / _cross), or NULL */
   const void *w1_h, *w2_h;          /* fp16 copies of w1_p / w2_p or NULL (see sc_enc_layer) */
+  const void *w1_s, *w2_s;          /* fp16 hi | lo split of w1_p / w2_p or NULL (see sc_enc_layer) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -231,6 +235,19 @@ int sc_ffn_ln_h(const float *XN, const int32_t *rows, int M, int D, int F, const
                 float *ln_out, void *stream);
 int sc_ffn_ln_proj_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h, const float *b1,
                      const void *W2h, const float *b2, const float *Xin, float *Xout, const float *ln_g,
+                     const float *ln_b, float ln_eps, float *ln_out, const float *Wq, const float *bq, float *Q, int N,
+                     void *stream);
+/* ... with the fp16 hi | lo SPLIT of the fp32 weights (W1s / W2s: weights.py split_panel_weight - per lane and 32-wide
+ * k block the fp16 roundings of its 8 k values in the first slab of the fragment order, fp16((w - hi) * 2^11) in the
+ * second; the same bytes as the fp32 copies): every product sum is evaluated as
+ * sum(a_hi w_hi) + 2^-11 (sum(a_hi w_lo) + sum(a_lo w_hi)) with fp16 MFMA inputs and fp32 accumulation, the
+ * activations split the same way when staged.  Differs from the fp32 kernel by a few fp32 ulp (the dropped
+ * a_lo w_lo terms: <= 2^-22 relative), at ~1/5 of its matrix-pipe cycles.  Operands must lie within fp16's range. */
+int sc_ffn_ln_s(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1s, const float *b1,
+                const void *W2s, const float *b2, float *X, const float *ln_g, const float *ln_b, float ln_eps,
+                float *ln_out, void *stream);
+int sc_ffn_ln_proj_s(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1s, const float *b1,
+                     const void *W2s, const float *b2, const float *Xin, float *Xout, const float *ln_g,
                      const float *ln_b, float ln_eps, float *ln_out, const float *Wq, const float *bq, float *Q, int N,
                      void *stream);
 /* bytes of the split-K workspace registered for `stream` (0: none).  sc_decoder_layers /
@@ -506,6 +523,9 @@ int sc_get_hyps_batch(sc_streams *streams, const int *stream_ids, int n, int nbe
 int sc_reset(sc_streams *streams, int stream);
 int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
 int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
+/* measurement aid: encoder-layer hipGraphs captured so far (one per shape of an encoder group) and the host seconds
+ * that took */
+int sc_streams_capture_stats(const sc_streams *streams, long *n_captures, double *seconds);
 /* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
  * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
 int sc_streams_set_graphs(sc_streams *streams, int on);

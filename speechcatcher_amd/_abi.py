@@ -25,14 +25,15 @@ vp = C.c_void_p
 class EncLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "w1_p", "w2_p",
-                                  "wqkv_p", "wo_p", "w1_h", "w2_h", "wqkv_h", "wo_h")]
+                                  "wqkv_p", "wo_p", "w1_h", "w2_h", "wqkv_h", "wo_h", "w1_s", "w2_s")]
 
 
 class DecLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
-                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp", "w1_h", "w2_h")]
+                                  "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp", "w1_h", "w2_h",
+                                  "w1_s", "w2_s")]
 
 
 class Search(C.Structure):
@@ -87,6 +88,9 @@ _SIGS = {
     "sc_pack_lane_weight": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "sc_ffn_ln": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
     "sc_ffn_ln_h": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
+    "sc_ffn_ln_s": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]),
+    "sc_ffn_ln_proj_s": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp,
+                                   vp, vp, vp, C.c_int, vp]),
     "sc_ffn_ln_proj_h": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp,
                                    vp, vp, vp, C.c_int, vp]),
     "sc_ffn_ln_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -165,6 +169,7 @@ _SIGS = {
     "sc_reset": (C.c_int, [vp, C.c_int]),
     "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "sc_streams_capture_stats": (C.c_int, [vp, C.POINTER(C.c_long), c_double_p]),
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),

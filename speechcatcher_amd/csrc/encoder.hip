@@ -592,7 +592,9 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
       SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
     }
     if (ffn_fused) {
-      if (w.w1_h && w.w2_h)   // fp16 weights: fp16 MFMA inputs, fp32 accumulation
+      if (w.w1_s && w.w2_s)   // fp16 hi | lo split of the fp32 weights: fp32-grade on the fp16 matrix pipe
+        SC_TRY(sc_ffn_ln_s(xn, nullptr, M, d, F, w.w1_s, w.b1, w.w2_s, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
+      else if (w.w1_h && w.w2_h)   // fp16 weights: fp16 MFMA inputs, fp32 accumulation
         SC_TRY(sc_ffn_ln_h(xn, nullptr, M, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, nullptr, nullptr, eps, nullptr, stream));
       else
         SC_TRY(sc_ffn_ln(xn, nullptr, M, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, nullptr, nullptr, eps, nullptr, stream));

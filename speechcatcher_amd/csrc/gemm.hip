@@ -795,10 +795,11 @@ struct FfnArgs {
   const float *g, *b;
   float eps;
   int part_rows;
-  int w_half;   // W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation
+  int w_half;   // 1: W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
+                // 2: W1p / W2p hold the fp16 hi | lo SPLIT of the fp32 weights (see WF below)
 };
 
-// WH: fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
+// WF = 1 (WH): fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
 // 8 k values a lane holds per 32-wide k block feed 2 instructions instead of 8), fp32 accumulation, fp32 partial sums
 // and LayerNorms.  The row tile and the hidden activations then live in LDS as fp16 (converted once, when staged).
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
@@ -808,18 +809,36 @@ __device__ __forceinline__ f32x4 ffn_mma_h(f32x4 acc, const h16x8 &a, const h16x
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h16x4{a[4], a[5], a[6], a[7]}, b1, acc, 0, 0, 0);
   return acc;
 }
-// LDS bytes of one workgroup (host and device)
-__host__ __device__ static inline size_t ffn_lds_bytes(int D, int RT, bool pro, bool wh) {
+// WF = 2 (WS): fp32-grade arithmetic on the fp16 matrix pipe.  Every fp32 operand x is split into two fp16 numbers,
+//   hi = fp16(x),  lo = fp16((x - hi) * 2^11)        (x - hi is exact in fp32; x = hi + lo / 2^11 to ~2^-23 |x|)
+// and a product sum a.b is evaluated as  sum(a_hi b_hi) + 2^-11 (sum(a_hi b_lo) + sum(a_lo b_hi))  with three
+// v_mfma_f32_16x16x32_f16 (fp16 products are exact in the fp32 accumulators) instead of eight v_mfma_f32_16x16x4_f32:
+// 51 instead of 256 matrix-pipe cycles per 8 k values of a lane.  Only the a_lo b_lo term (<= 2^-22 |a b|) is
+// dropped: the result differs from fp32 arithmetic by a few ulp of fp32 (tests/test_gpu_ops.py), not by fp16's
+// 2^-11.  The weights are split offline (weights.py: the hi and lo halves of a lane's 8 k values take the places of
+// the two fp32 slabs of the fragment order, same bytes), the row tile and the hidden activations when they are staged
+// into LDS (hi8 | lo8 per 8 k values: the same 32 bytes per lane and row stride as the fp32 tile).  Operands must lie
+// within fp16's range (|x| < 65504: LayerNorm outputs and ReLU activations of any real model do).
+__device__ __forceinline__ void ffn_split4(const float4 &x, h16x4 &hi, h16x4 &lo) {
+  hi = h16x4{(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+  lo = h16x4{(_Float16)((x.x - (float)hi[0]) * 2048.f), (_Float16)((x.y - (float)hi[1]) * 2048.f),
+             (_Float16)((x.z - (float)hi[2]) * 2048.f), (_Float16)((x.w - (float)hi[3]) * 2048.f)};
+}
+// LDS bytes of one workgroup (host and device); wf: 0 fp32, 1 fp16, 2 split
+__host__ __device__ static inline size_t ffn_lds_bytes(int D, int RT, bool pro, int wf) {
+  const bool wh = wf == 1;
   if (!wh) return (size_t)(RT * (D + 4) + RT * (128 + 4) + (pro ? RT : 0)) * sizeof(float);
   return (size_t)RT * (D + 4) * 4 + (size_t)RT * (D + 8) * 2 + (size_t)RT * (128 + 8) * 2 + (pro ? RT * 4 : 0);
 }
 
-template <int D, int RTT, bool PRO = false, bool WH = false>
+template <int D, int RTT, bool PRO = false, int WF = 0>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
+  constexpr bool WH = WF == 1, WS = WF == 2;
   constexpr int RT = 16 * RTT, FC = 128;
   constexpr int KI1 = D / 32, KI2 = FC / 32, NT2 = D / 128;
   constexpr int LDX = D + 4, LDH = FC + 4;
   constexpr int LDXH = D + 8, LDHH = FC + 8;   // WH: row strides of the fp16 tiles (elements)
+  constexpr int LDXS = 2 * D + 8, LDHS = 2 * FC + 8;   // WS: row strides of the hi8 | lo8 tiles (fp16 elements; = the fp32 bytes)
   extern __shared__ __attribute__((aligned(16))) float ffn_smem[];
   float *Xs = ffn_smem;            // [RT][LDX]  xn tile (WH: fp32 staging of the prologue only); re-used to stage the partial result
   float *Hs = ffn_smem + RT * LDX; // [RT][LDH]  relu(h) of the current chunk (not WH)
@@ -827,7 +846,12 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
   _Float16 *HsH = XsH + RT * LDXH;                                       // WH: [RT][LDHH] relu(h)
   int *rowid = WH ? reinterpret_cast<int *>(HsH + RT * LDHH)
                   : reinterpret_cast<int *>(ffn_smem + RT * LDX + RT * LDH);   // PRO: [RT] row ids of the tile
-  typedef typename std::conditional<WH, h16x4, float4>::type BF;   // 4 weight elements
+  _Float16 *XsS = reinterpret_cast<_Float16 *>(ffn_smem);               // WS: [RT][LDXS] xn tile, IN PLACE of Xs
+  _Float16 *HsS = reinterpret_cast<_Float16 *>(ffn_smem + RT * LDX);    // WS: [RT][LDHS] relu(h), in place of Hs
+  // 4 weight elements (WS: the hi, in the second slab the lo, halves of the 8 k values of a lane)
+  typedef typename std::conditional<WS, h16x8, typename std::conditional<WH, h16x4, float4>::type>::type BF;
+  // WS: 4 consecutive columns c.. of a row -> hi4 at, lo4 8 elements behind, this offset
+  auto split_at = [](int c) { return (c >> 3) * 16 + (c & 7); };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int grp = blockIdx.x, m0 = blockIdx.y * RT;
@@ -930,7 +954,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       for (int q = 0; q < Q4; ++q) {
         const float4 o = make_float4((x[q].x - mean) * rstd * gam[q].x + bet[q].x, (x[q].y - mean) * rstd * gam[q].y + bet[q].y,
                                      (x[q].z - mean) * rstd * gam[q].z + bet[q].z, (x[q].w - mean) * rstd * gam[q].w + bet[q].w);
-        if (WH)
+        if (WS) {   // in place of the fp32 row this 16-lane group has just read
+          h16x4 hi, lo;
+          ffn_split4(o, hi, lo);
+          _Float16 *d = XsS + i * LDXS + split_at(4 * (sub + 16 * q));
+          *reinterpret_cast<h16x4 *>(d) = hi;
+          *reinterpret_cast<h16x4 *>(d + 8) = lo;
+        } else if (WH)
           *reinterpret_cast<h16x4 *>(XsH + i * LDXH + 4 * (sub + 16 * q)) =
               h16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
         else
@@ -951,7 +981,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int e = threadIdx.x + q * 512;
-      if (WH)
+      if (WS) {
+        h16x4 hi, lo;
+        ffn_split4(stage[q], hi, lo);
+        _Float16 *d = XsS + (e / (D / 4)) * LDXS + split_at(4 * (e % (D / 4)));
+        *reinterpret_cast<h16x4 *>(d) = hi;
+        *reinterpret_cast<h16x4 *>(d + 8) = lo;
+      } else if (WH)
         *reinterpret_cast<h16x4 *>(XsH + (e / (D / 4)) * LDXH + 4 * (e % (D / 4))) =
             h16x4{(_Float16)stage[q].x, (_Float16)stage[q].y, (_Float16)stage[q].z, (_Float16)stage[q].w};
       else
@@ -959,10 +995,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     }
   }
   f32x4 acc2[RTT][NT2];
+  f32x4 acc2c[WS ? RTT : 1][WS ? NT2 : 1];   // WS: the 2^11-scaled cross terms
 #pragma unroll
   for (int rt = 0; rt < RTT; ++rt)
 #pragma unroll
-    for (int t = 0; t < NT2; ++t) acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT2; ++t) {
+      acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (WS) acc2c[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   load_b1(grp * p.cpw);
   __syncthreads();
@@ -973,9 +1013,32 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     const float bias = p.b1 ? p.b1[chunk * FC + wave * 16 + r] : 0.f;
     // ---- GEMM 1: h[RT x 16] of this wave ----
     f32x4 acc1[RTT];
+    f32x4 acc1c[WS ? RTT : 1];
 #pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (WH) {
+    for (int rt = 0; rt < RTT; ++rt) {
+      acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (WS) acc1c[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (WS) {
+      constexpr int NS = RTT * KI1;
+      const _Float16 *ab = XsS + r * LDXS + 16 * kk;
+      h16x8 ah = *reinterpret_cast<const h16x8 *>(ab), al = *reinterpret_cast<const h16x8 *>(ab + 8);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        h16x8 nh = ah, nl = al;
+        if (st + 1 < NS) {
+          const _Float16 *ap = ab + ((st + 1) % RTT) * 16 * LDXS + ((st + 1) / RTT) * 64;
+          nh = *reinterpret_cast<const h16x8 *>(ap);
+          nl = *reinterpret_cast<const h16x8 *>(ap + 8);
+        }
+        acc1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bf[ki][0], acc1[rt], 0, 0, 0);
+        acc1c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bf[ki][1], acc1c[rt], 0, 0, 0);
+        acc1c[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bf[ki][0], acc1c[rt], 0, 0, 0);
+        ah = nh;
+        al = nl;
+      }
+    } else if constexpr (WH) {
       constexpr int NS = RTT * KI1;
       const _Float16 *ab = XsH + r * LDXH + 8 * kk;
       h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
@@ -1012,14 +1075,41 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     for (int rt = 0; rt < RTT; ++rt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float hv = fmaxf(acc1[rt][j] + bias, 0.f);
-        if (WH) HsH[(rt * 16 + 4 * kk + j) * LDHH + wave * 16 + r] = (_Float16)hv;
+        const float hv = fmaxf((WS ? acc1[rt][j] + acc1c[WS ? rt : 0][j] * (1.f / 2048.f) : acc1[rt][j]) + bias, 0.f);
+        if (WS) {
+          const _Float16 hi = (_Float16)hv;
+          _Float16 *d = HsS + (rt * 16 + 4 * kk + j) * LDHS + split_at(wave * 16 + r);
+          d[0] = hi;
+          d[8] = (_Float16)((hv - (float)hi) * 2048.f);
+        } else if (WH) HsH[(rt * 16 + 4 * kk + j) * LDHH + wave * 16 + r] = (_Float16)hv;
         else Hs[(rt * 16 + 4 * kk + j) * LDH + wave * 16 + r] = hv;
       }
     if (cc + 1 < p.cpw) load_b1(chunk + 1);  // next chunk's GEMM 1 weights, overlapped with GEMM 2
     __syncthreads();
     // ---- GEMM 2: partial y[RT x D/8] of this wave ----
-    if constexpr (WH) {
+    if constexpr (WS) {
+      constexpr int NS = RTT * KI2;
+      const _Float16 *ab = HsS + r * LDHS + 16 * kk;
+      h16x8 ah = *reinterpret_cast<const h16x8 *>(ab), al = *reinterpret_cast<const h16x8 *>(ab + 8);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int k = st / RTT, rt = st % RTT;
+        h16x8 nh = ah, nl = al;
+        if (st + 1 < NS) {
+          const _Float16 *ap = ab + ((st + 1) % RTT) * 16 * LDHS + ((st + 1) / RTT) * 64;
+          nh = *reinterpret_cast<const h16x8 *>(ap);
+          nl = *reinterpret_cast<const h16x8 *>(ap + 8);
+        }
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+          acc2[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b2f[k][t][0], acc2[rt][t], 0, 0, 0);
+          acc2c[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b2f[k][t][1], acc2c[rt][t], 0, 0, 0);
+          acc2c[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b2f[k][t][0], acc2c[rt][t], 0, 0, 0);
+        }
+        ah = nh;
+        al = nl;
+      }
+    } else if constexpr (WH) {
       constexpr int NS = RTT * KI2;
       const _Float16 *ab = HsH + r * LDHH + 8 * kk;
       h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
@@ -1060,7 +1150,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     for (int t = 0; t < NT2; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] = acc2[rt][t][j];
+        Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] =
+            WS ? acc2[rt][t][j] + acc2c[WS ? rt : 0][WS ? t : 0][j] * (1.f / 2048.f) : acc2[rt][t][j];
   __syncthreads();
   SC_STAMP(PRO ? 2 : 3, 2);
   float *dst = p.part + ((long)grp * p.M + m0) * D;
@@ -1077,7 +1168,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 }
 SC_PHASE_GETTER(sc_phase_debug_ffn)
 
-template <int D, int RTT, bool PRO, bool WH>
+template <int D, int RTT, bool PRO, int WH>
 static void launch_ffn_wh(const FfnArgs &p, int ngrp, hipStream_t st) {
   constexpr int RT = 16 * RTT;
   const size_t lds = ffn_lds_bytes(D, RT, PRO, WH);
@@ -1091,8 +1182,9 @@ static void launch_ffn_wh(const FfnArgs &p, int ngrp, hipStream_t st) {
 }
 template <int D, int RTT, bool PRO = false>
 static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
-  if (p.w_half) launch_ffn_wh<D, RTT, PRO, true>(p, ngrp, st);
-  else launch_ffn_wh<D, RTT, PRO, false>(p, ngrp, st);
+  if (p.w_half == 2) launch_ffn_wh<D, RTT, PRO, 2>(p, ngrp, st);
+  else if (p.w_half) launch_ffn_wh<D, RTT, PRO, 1>(p, ngrp, st);
+  else launch_ffn_wh<D, RTT, PRO, 0>(p, ngrp, st);
 }
 
 template <int D, bool PRO = false>
@@ -1391,6 +1483,10 @@ extern "C" int sc_rowtile_proj_h(const float *A, int lda, int M, int D, const fl
                      stream, 1);
 }
 
+// tallest row tile (16 * rtt rows) per weight form: the split form carries two sets of accumulators and spills
+// beyond 48 rows at D = 256 (tools/kernel_resources.py)
+static inline int ffn_rtt_max(int D, int w_form) { return (w_form == 2 && D == 256) ? 3 : 5; }
+
 extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128) && F % 128 == 0 && F >= 128; }
 
 // Wq != nullptr: the partial sums are reduced by the reduce + LayerNorm + projection row-panel
@@ -1398,7 +1494,7 @@ extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128)
 static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
                    const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
                    const float *ln_b, float ln_eps, float *ln_out, float *Xout, const float *Wq,
-                   const float *bq, float *Q, int N, void *stream, bool w_half = false) {
+                   const float *bq, float *Q, int N, void *stream, int w_form = 0) {   // w_form: FfnArgs.w_half
   SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
   SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
   SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
@@ -1424,7 +1520,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
       if (fit < 16) continue;
       const long mm = fit < (M - m_done) ? (fit / 80) * 80 : (M - m_done);
       if (mm <= 0) continue;
-      for (int rtt = 1; rtt <= 5; ++rtt) {
+      for (int rtt = 1; rtt <= ffn_rtt_max(D, w_form); ++rtt) {
         const long wgs = (long)ngrp * ((mm + 16 * rtt - 1) / (16 * rtt));
         const double rounds = (double)((wgs + 255) / 256);
         // per workgroup: fixed ~2.5 us + 4.0 us per 16 rows and chunk (measured); reduce: bytes of the partials
@@ -1446,7 +1542,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     }
     const int ngrp = nch / best_cpw;
     FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
-    p.w_half = w_half ? 1 : 0;
+    p.w_half = w_form;
     // without a row table the slab is addressed by offsetting the base pointers
     const float *xn_base = rows ? XN : XN + (long)m_done * D;
     p.XN = xn_base;
@@ -1488,7 +1584,24 @@ extern "C" int sc_ffn_ln_h(const float *XN, const int32_t *rows, int M, int D, i
                            const float *b1, const void *W2h, const float *b2, float *X, const float *ln_g,
                            const float *ln_b, float ln_eps, float *ln_out, void *stream) {
   return ffn_run(XN, rows, M, D, F, (const float *)W1h, b1, (const float *)W2h, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr,
-                 nullptr, nullptr, nullptr, 0, stream, true);
+                 nullptr, nullptr, nullptr, 0, stream, 1);
+}
+// fp16 hi | lo split of the fp32 weights (weights.py split_panel_weight): fp32-grade results from three fp16 MFMAs per
+// product sum (ffn_fused_kernel, WF = 2)
+extern "C" int sc_ffn_ln_s(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1s,
+                           const float *b1, const void *W2s, const float *b2, float *X, const float *ln_g,
+                           const float *ln_b, float ln_eps, float *ln_out, void *stream) {
+  return ffn_run(XN, rows, M, D, F, (const float *)W1s, b1, (const float *)W2s, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr,
+                 nullptr, nullptr, nullptr, 0, stream, 2);
+}
+extern "C" int sc_ffn_ln_proj_s(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1s,
+                                const float *b1, const void *W2s, const float *b2, const float *Xin, float *Xout,
+                                const float *ln_g, const float *ln_b, float ln_eps, float *ln_out, const float *Wq,
+                                const float *bq, float *Q, int N, void *stream) {
+  SC_CHECK_ARG(Xin && Xout && Xin != Xout && Wq && Q && ln_g && ln_b, "null / aliased operand");
+  SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N > 0 && N % D == 0, "projection width must be a multiple of D");
+  return ffn_run(XN, rows, M, D, F, (const float *)W1s, b1, (const float *)W2s, b2, const_cast<float *>(Xin), ln_g, ln_b,
+                 ln_eps, ln_out, Xout, Wq, bq, Q, N, stream, 2);
 }
 extern "C" int sc_ffn_ln_proj_h(const float *XN, const int32_t *rows, int M, int D, int F, const void *W1h,
                                 const float *b1, const void *W2h, const float *b2, const float *Xin, float *Xout,
@@ -1497,7 +1610,7 @@ extern "C" int sc_ffn_ln_proj_h(const float *XN, const int32_t *rows, int M, int
   SC_CHECK_ARG(Xin && Xout && Xin != Xout && Wq && Q && ln_g && ln_b, "null / aliased operand");
   SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N > 0 && N % D == 0, "projection width must be a multiple of D");
   return ffn_run(XN, rows, M, D, F, (const float *)W1h, b1, (const float *)W2h, b2, const_cast<float *>(Xin), ln_g, ln_b,
-                 ln_eps, ln_out, Xout, Wq, bq, Q, N, stream, true);
+                 ln_eps, ln_out, Xout, Wq, bq, Q, N, stream, 1);
 }
 
 extern "C" int sc_ffn_ln_proj(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
@@ -1528,6 +1641,10 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   const int M = rows ? sb.n_rows : sb.S * sb.W;
   SC_CHECK_ARG(M > 0 && M <= sb.S * sb.W && max_part >= 1, "n_rows / max_part out of range");
   const int nch = F / 128;
+  // weight form: split copies (fp32-grade on the fp16 matrix pipe) before plain fp16 copies before fp32
+  const int wf = (w.w1_s && w.w2_s) ? 2 : (w.w1_h && w.w2_h) ? 1 : 0;
+  const void *w1x = wf == 2 ? w.w1_s : wf == 1 ? w.w1_h : (const void *)w.w1_p;
+  const void *w2x = wf == 2 ? w.w2_s : wf == 1 ? w.w2_h : (const void *)w.w2_p;
   // tile height (16*rtt rows) and chunks per workgroup (cpw): fewest rounds of 256 workgroups, ties towards
   // more partial groups - the model fitted for sc_ffn_ln (tools/ffn_sweep.py)
   int best_rtt = 5, best_cpw = nch;
@@ -1535,7 +1652,7 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   for (int cpw = 1; cpw <= nch; cpw *= 2) {
     if (nch % cpw || nch / cpw > max_part) continue;
     const int ngrp = nch / cpw;
-    for (int rtt = 1; rtt <= 5; ++rtt) {
+    for (int rtt = 1; rtt <= ffn_rtt_max(D, wf); ++rtt) {
       const long wgs = (long)ngrp * ((M + 16 * rtt - 1) / (16 * rtt));
       const double rounds = (double)((wgs + 255) / 256);
       const double t = rounds * (2.5 + 4.0 * rtt * cpw) + 1.5 + 2.0 * (double)M * D * 4.0 * ngrp / 3.0e6;
@@ -1544,9 +1661,8 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   }
   SC_CHECK_ARG(best < 1e29, "max_part too small");
   const int ngrp = nch / best_cpw;
-  const bool wh = w.w1_h && w.w2_h;   // fp16 copies present: fp16 MFMA inputs
-  FfnArgs p{nullptr, rows, wh ? (const float *)w.w1_h : w.w1_p, w.b1, wh ? (const float *)w.w2_h : w.w2_p, ffn_part, M, F,
-            best_cpw, sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wh ? 1 : 0};
+  FfnArgs p{nullptr, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F,
+            best_cpw, sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);

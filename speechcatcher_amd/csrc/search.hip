@@ -385,7 +385,10 @@ static int decoder_layers_impl(const sc_search *sbp, void *stream, bool fuse_log
       const float *pw = last ? sb.out_w_q : sb.layers[li + 1].wqkv_q, *pb = last ? sb.out_b : sb.layers[li + 1].bqkv;
       float *pq = last ? sb.logits : sb.dqkv;
       const int pn = last ? sb.V : 3 * d;
-      if (wh)
+      if (w.w1_s && w.w2_s)   // fp16 hi | lo split of the fp32 weights: fp32-grade on the fp16 matrix pipe
+        SC_TRY(sc_ffn_ln_proj_s(ffn_in, rows, n, d, F, w.w1_s, w.b1, w.w2_s, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr, pw, pb,
+                                pq, pn, stream));
+      else if (wh)
         SC_TRY(sc_ffn_ln_proj_h(ffn_in, rows, n, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, xalt, ng, nb, sb.ln_eps, nullptr, pw, pb,
                                 pq, pn, stream));
       else
@@ -396,7 +399,9 @@ static int decoder_layers_impl(const sc_search *sbp, void *stream, bool fuse_log
       continue;
     }
     float *ln_next = chain ? (x == sb.dx ? sb.dxn : sb.dx) : sb.dxn;   // a buffer that is not x
-    if (ffn_fused && w.w1_h && w.w2_h) {
+    if (ffn_fused && w.w1_s && w.w2_s) {
+      SC_TRY(sc_ffn_ln_s(ffn_in, rows, n, d, F, w.w1_s, w.b1, w.w2_s, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));
+    } else if (ffn_fused && w.w1_h && w.w2_h) {
       SC_TRY(sc_ffn_ln_h(ffn_in, rows, n, d, F, w.w1_h, w.b1, w.w2_h, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));
     } else if (ffn_fused) {
       SC_TRY(sc_ffn_ln(ffn_in, rows, n, d, F, w.w1_p, w.b1, w.w2_p, w.b2, x, ng, nb, sb.ln_eps, ln_next, stream));

@@ -258,6 +258,8 @@ struct sc_streams {
   double t_bucket[17] = {0};                     // ... by compaction bucket (n_rows_step / (row_bucket*W))
   long n_bucket[17] = {0};
   bool use_graphs = true;
+  long n_enc_captures = 0;        // encoder-layer graphs captured (one per group shape) and the host time that took
+  double t_enc_capture = 0;
 
   ~sc_streams() {
     for (auto &g : dec_graphs) (void)hipGraphExecDestroy(g.second);
@@ -588,10 +590,13 @@ int enc_layers_launch(sc_streams *b, int nblk, int R, bool masked, const int32_t
   auto it = b->enc_graphs.find(key);
   if (it == b->enc_graphs.end()) {
     if (b->enc_graphs.size() >= 192) return launch();   // (one per group shape; continuous batching varies it)
+    const auto tc0 = std::chrono::steady_clock::now();
     RC_TRY(sc_graph_capture_begin(b->es));
     const int rc = launch();
     void *g = nullptr;
     const int rc2 = sc_graph_capture_end(b->es, &g);
+    b->n_enc_captures++;
+    b->t_enc_capture += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     if (rc != SC_OK) return rc;
     if (rc2 != SC_OK) return rc2;
     it = b->enc_graphs.emplace(key, (hipGraphExec_t)g).first;
@@ -1402,6 +1407,8 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
 #undef ENC
     l.w1_h = e->f(p + "w1_h", false);   // optional fp16 copies: fp16 MFMA inputs in the fused FFN
     l.w2_h = e->f(p + "w2_h", false);
+    l.w1_s = e->f(p + "w1_s", false);   // optional fp16 hi | lo split: fp32-grade fused FFN on the fp16 matrix pipe
+    l.w2_s = e->f(p + "w2_s", false);
     l.wqkv_h = e->f(p + "wqkv_h", false);   // optional fp16 copies: fp16 MFMA inputs in the attention projections
     l.wo_h = e->f(p + "wo_h", false);
   }
@@ -1416,6 +1423,7 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
     DEC(ln1_g) DEC(ln1_b) DEC(wqkv) DEC(bqkv) DEC(wo) DEC(bo) DEC(ln2_g) DEC(ln2_b) DEC(wq) DEC(bq) DEC(wo2) DEC(bo2)
     DEC(ln3_g) DEC(ln3_b) DEC(w1) DEC(b1) DEC(w2) DEC(b2) DEC(wo_p) DEC(wq_p) DEC(wo2_p) DEC(w1_p) DEC(w2_p) DEC(wqkv_q)
     DEC_OPT(wqkv_pp) DEC_OPT(wq_pp) DEC_OPT(wo_pp) DEC_OPT(wo2_pp) DEC_OPT(w1_h) DEC_OPT(w2_h)
+    DEC_OPT(w1_s) DEC_OPT(w2_s)
 #undef DEC
 #undef DEC_OPT
     e->wkv[i] = e->f(p + "wkv");
@@ -2047,6 +2055,14 @@ extern "C" int sc_streams_host_times(sc_streams *b, double *launch_s, double *wa
   *launch_s = b->t_launch;
   *wait_s = b->t_wait;
   b->t_launch = b->t_wait = 0;
+  return SC_OK;
+}
+
+// encoder-layer hipGraphs captured so far (one per shape of an encoder group) and the host seconds spent capturing
+extern "C" int sc_streams_capture_stats(const sc_streams *b, long *n_captures, double *seconds) {
+  SC_CHECK_ARG(b && n_captures && seconds, "null");
+  *n_captures = b->n_enc_captures;
+  *seconds = b->t_enc_capture;
   return SC_OK;
 }
 

@@ -109,6 +109,13 @@ class HipBackend:
         self._chk(self.lib.sc_ffn_ln_h(_p(XN), _p(rows), M, D, F, _p(W1h), _p(b1), _p(W2h), _p(b2), _p(X),
                                        _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln_h")
 
+    def ffn_ln_s(self, XN, rows, M, D, F, W1s, b1, W2s, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
+        """sc_ffn_ln with the fp16 hi | lo split of the weights (weights.split_panel_weight): fp32-grade results from
+        fp16 MFMA inputs"""
+        assert W1s.dtype == torch.float16 and W2s.dtype == torch.float16
+        self._chk(self.lib.sc_ffn_ln_s(_p(XN), _p(rows), M, D, F, _p(W1s), _p(b1), _p(W2s), _p(b2), _p(X),
+                                       _p(ln_g), _p(ln_b), eps, _p(ln_out), self._stream()), "sc_ffn_ln_s")
+
     def ffn_ln_proj(self, XN, rows, M, D, F, W1p, b1, W2p, b2, Xin, Xout, ln_g, ln_b, Wq, bq, Q, N, eps=1e-12):
         self._chk(self.lib.sc_ffn_ln_proj(_p(XN), _p(rows), M, D, F, _p(W1p), _p(b1), _p(W2p), _p(b2), _p(Xin),
                                           _p(Xout), _p(ln_g), _p(ln_b), eps, None, _p(Wq), _p(bq), _p(Q), N,

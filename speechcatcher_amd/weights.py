@@ -44,6 +44,20 @@ def unpack_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
     return Wp.reshape(N // 16, K // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5).contiguous().reshape(N, K)
 
 
+def split_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
+    """fp16 hi | lo split of a ``pack_panel_weight`` copy for the split-precision fused feed-forward (sc_ffn_ln_s,
+    csrc/gemm.hip ffn_fused_kernel WF = 2): per (tile, ki) the first 64-lane slab holds, per lane, the fp16 roundings
+    ``hi`` of its 8 k values (those of both fp32 slabs), the second slab ``fp16((w - hi) * 2**11)`` - the same bytes
+    as the fp32 copy.  w = hi + lo / 2**11 up to ~2**-23 |w|."""
+    N, K = Wp.shape
+    v = Wp.reshape(-1, 2, 64, 4)
+    v = torch.cat([v[:, 0], v[:, 1]], dim=-1)                 # [n][lane][8 k values]
+    assert float(v.abs().max()) < 65504.0, "weights beyond fp16's range cannot be split"
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo], dim=1).contiguous().reshape(N, 2 * K)
+
+
 def pack_lane_weight(W: torch.Tensor) -> torch.Tensor:
     """[N][K] Linear weight -> lane order of sc_proj_ln_proj (include/scasr.h:
     out[tile][q][lane][c] = W[tile*64 + lane][4*q + c]); a pure permutation."""
@@ -81,7 +95,7 @@ class PackedWeights:
         the fused FFN kernels then run fp16 MFMA inputs with fp32 accumulation (BASELINE configs[4]; never the
         default - the reference computes in fp32).  ``proj_dtype="float16"``: the same for the attention projections
         of the encoder layers (wqkv_h / wo_h: sc_rowtile_proj_h; the decoder's row panels stay fp32)."""
-        assert ffn_dtype in ("float32", "float16") and proj_dtype in ("float32", "float16")
+        assert ffn_dtype in ("float32", "float16", "split16") and proj_dtype in ("float32", "float16")
         self.ffn_dtype, self.proj_dtype = ffn_dtype, proj_dtype
         self.cfg = cfg
         self.device = torch.device(device)
@@ -173,6 +187,8 @@ class PackedWeights:
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]
                 if ffn_dtype == "float16" and ffn_fused_supported(d, cfg.ffn_dim):
                     lw[n + "_h"] = lw[n + "_p"].to(torch.float16).contiguous()   # same fragment order, 2-byte elements
+                if ffn_dtype == "split16" and ffn_fused_supported(d, cfg.ffn_dim):
+                    lw[n + "_s"] = split_panel_weight(lw[n + "_p"])
         self.dec_norm_g = dev(g("decoder.after_norm.weight"))
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))

@@ -200,6 +200,56 @@ def test_ffn_fused_fp16_weights(hip, M, D, F):
         assert 0.0 < diff < 3e-2, diff
 
 
+@pytest.mark.parametrize("M,D,F", [(80, 256, 2048), (1280, 256, 2048), (5376, 256, 2048), (37, 128, 512), (640, 256, 2048),
+                                   (10, 256, 2048)])
+def test_ffn_fused_split_weights(hip, M, D, F):
+    """The fused feed-forward on the fp16 matrix pipe with fp32-grade results (sc_ffn_ln_s: every operand split into
+    fp16 hi + lo / 2^11, three v_mfma_f32_16x16x32_f16 per product sum, fp32 accumulation): against float64 it must
+    be as close as the fp32 kernel is (a small multiple of its error, nowhere near fp16's 2^-11), over operand
+    magnitudes from 1e-3 to 1e2 - and the offline split of the weights must reproduce them to 2^-21 (+ 2e-11)."""
+    from speechcatcher_amd.weights import pack_panel_weight, split_panel_weight
+    XN, X0, L0 = _rand(M + 5, D, seed=61), _rand(M + 5, D, seed=62), _rand(M + 5, D, seed=63)
+    XN *= torch.logspace(-3, 2, M + 5)[:, None]            # rows of very different magnitude
+    W1, b1 = _rand(F, D, seed=64, scale=D ** -0.5), _rand(F, seed=65)
+    W2, b2 = _rand(D, F, seed=66, scale=F ** -0.5), _rand(D, seed=67)
+    W1[:, ::7] *= 1e-3                                     # columns of small weights (fp16-subnormal low parts)
+    g, be_ = 1 + 0.1 * _rand(D, seed=68), _rand(D, seed=69)
+    W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+    W1s, W2s = split_panel_weight(W1p), split_panel_weight(W2p)
+    assert W1s.dtype == torch.float16 and W1s.shape == (F, 2 * D)
+    v = W1s.reshape(-1, 2, 64, 8).float()
+    back = v[:, 0] + v[:, 1] / 2048.0                      # [n][lane][8] = the two fp32 slabs side by side
+    orig = torch.cat([W1p.reshape(-1, 2, 64, 4)[:, 0], W1p.reshape(-1, 2, 64, 4)[:, 1]], dim=-1)
+    # 22 significant bits, with an absolute floor where the low part is an fp16 subnormal (|w| < ~6e-5: 2^-25 / 2^11)
+    assert bool(((back - orig).abs() <= 2.0 ** -21 * orig.abs() + 2e-11).all())
+    for rows in (None, torch.randperm(M + 5, generator=torch.Generator().manual_seed(5))[:M].to(torch.int32)):
+        idx = torch.arange(M) if rows is None else rows.long()
+        h = torch.relu(XN[idx].double() @ W1.double().t() + b1.double())
+        y = h @ W2.double().t() + b2.double()
+        ref = X0.double().clone()
+        ref[idx] = X0[idx].double() + y
+        scale = (h.abs() @ W2.double().abs().t() + X0[idx].double().abs()).clamp_min(1e-3)   # size of the summed terms
+        out = {}
+        for form in ("f32", "split"):
+            Xg, Lg = X0.cuda(), L0.cuda()
+            if form == "f32":
+                hip.ffn_ln(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, W1p.cuda(), b1.cuda(), W2p.cuda(),
+                           b2.cuda(), Xg, g.cuda(), be_.cuda(), Lg)
+            else:
+                hip.ffn_ln_s(XN.cuda(), None if rows is None else rows.cuda(), M, D, F, W1s.cuda(), b1.cuda(), W2s.cuda(),
+                             b2.cuda(), Xg, g.cuda(), be_.cuda(), Lg)
+            torch.cuda.synchronize()
+            out[form] = (Xg.cpu(), Lg.cpu())
+        e32 = float(((out["f32"][0][idx].double() - ref[idx]).abs() / scale).max())
+        esp = float(((out["split"][0][idx].double() - ref[idx]).abs() / scale).max())
+        assert e32 < 2e-6 and esp < 2e-6, (e32, esp)       # relative to the terms of the sums: fp32 class
+        assert esp < 4.0 * e32 + 2e-7, (e32, esp)
+        untouched = torch.ones(M + 5, dtype=torch.bool)
+        untouched[idx] = False
+        assert torch.equal(out["split"][0][untouched], X0[untouched])
+        np.testing.assert_allclose(out["split"][1].numpy(), out["f32"][1].numpy(), atol=2e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("H,dk,R,nblk,masked", [(8, 32, 42, 5, True), (8, 32, 42, 130, True), (8, 32, 7, 3, False),
                                                 (8, 32, 1, 2, False), (8, 32, 2, 2, True), (8, 32, 64, 2, False),
                                                 (4, 16, 42, 3, True), (4, 64, 42, 3, True)])

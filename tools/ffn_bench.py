@@ -6,7 +6,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechcatcher_amd.hip_backend import HipBackend
-from speechcatcher_amd.weights import pack_panel_weight
+from speechcatcher_amd.weights import pack_panel_weight, split_panel_weight
 
 rows = [int(a) for a in sys.argv[1:]] or [160, 320, 560, 800, 1280, 2560, 5376]
 be = HipBackend("cuda:0")
@@ -15,6 +15,8 @@ W1, W2 = torch.randn(F, D, device="cuda") / 16, torch.randn(D, F, device="cuda")
 b1, b2 = torch.randn(F, device="cuda"), torch.randn(D, device="cuda")
 g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
 W1p, W2p = pack_panel_weight(W1), pack_panel_weight(W2)
+W1h, W2h = W1p.half(), W2p.half()
+W1s, W2s = split_panel_weight(W1p), split_panel_weight(W2p)
 for M in rows:
     XN, X, LN = torch.randn(M, D, device="cuda"), torch.zeros(M, D, device="cuda"), torch.zeros(M, D, device="cuda")
     H = torch.zeros(M, F, device="cuda")
@@ -26,7 +28,13 @@ for M in rows:
         be.gemm(XN, None, D, W1, b1, H, None, F, M, F, D, relu=True)
         be.gemm_ln(H, None, F, W2, b2, X, None, D, M, D, F, g, b, LN, residual=True)
 
-    for name, fn in (("fused ffn_ln", fused), ("gemm + gemm_ln", two)):
+    def fused_h():
+        be.ffn_ln_h(XN, None, M, D, F, W1h, b1, W2h, b2, X, g, b, LN)
+
+    def fused_s():
+        be.ffn_ln_s(XN, None, M, D, F, W1s, b1, W2s, b2, X, g, b, LN)
+
+    for name, fn in (("fused ffn_ln", fused), ("fused fp16", fused_h), ("fused split16", fused_s), ("gemm + gemm_ln", two)):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()

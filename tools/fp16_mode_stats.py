@@ -10,8 +10,10 @@ S, n, beam = 256, 7, 10
 audio = np.stack([synth.synth_audio(900 + s, CHUNK * n) for s in range(S)])
 kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
 out = {}
-for mode in ("float32", "kv16", "ffn16", "proj16", "float16"):
-    sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", ffn_dtype="float16" if mode in ("ffn16", "float16") else "float32",
+MODES = sys.argv[1:] or ["kv16", "ffn16", "proj16", "float16", "split16"]
+for mode in ["float32"] + MODES:
+    sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native",
+                    ffn_dtype="float16" if mode in ("ffn16", "float16") else "split16" if mode == "split16" else "float32",
                     proj_dtype="float16" if mode in ("proj16", "float16") else "float32",
                     kv_dtype="float16" if mode in ("kv16", "float16") else "float32", **kw)
     ids = np.arange(S, dtype=np.int32)
@@ -22,7 +24,7 @@ for mode in ("float32", "kv16", "ffn16", "proj16", "float16"):
 a = out["float32"]
 def hyp(o, s, j):
     return tuple(o["ids"][s, j, :o["lens"][s, j]].tolist())
-for mode in ("kv16", "ffn16", "proj16", "float16"):
+for mode in MODES:
     b = out[mode]
     nbest = sum(hyp(a, s, 0) != hyp(b, s, 0) for s in range(S))
     nset = sum(set(hyp(a, s, j) for j in range(beam)) != set(hyp(b, s, j) for j in range(beam)) for s in range(S))

@@ -47,8 +47,14 @@ def run(mode, g=8, eb=64):
     else:
         nxt = np.full(S, pre, np.int64)
         bench.serve(sb, a3, nxt, warm, g)
+        n0, t0c = C.c_long(), C.c_double()
+        sb.lib.sc_streams_capture_stats(sb.handle, C.byref(n0), C.byref(t0c))
         r = bench.serve(sb, a3, nxt, steps, g, before_timing=clear)
         e = r["elapsed"]
+        n1, t1c = C.c_long(), C.c_double()
+        sb.lib.sc_streams_capture_stats(sb.handle, C.byref(n1), C.byref(t1c))
+        print(f"    encoder graphs captured in the timed window (+drain): {n1.value - n0.value} in {(t1c.value - t0c.value) * 1e3:.1f} ms of host time "
+              f"({n0.value} before)")
         print(f"group {g:3d} encoder batch {eb:3d}: {S * steps * 0.64 / e:8.1f} audio-s/s  {e / steps * 1e3:6.2f} ms/step-eq  "
               f"{r['iterations_per_step']:5.2f} iterations/step  {r['polls_per_step']:.1f} polls/step  spread {r['chunks_per_stream_min_max']}\n"
               f"    bucket:iterations per step x ms  {hist(sb)}", flush=True)
