@@ -74,7 +74,7 @@ def make_weights(device, ffn_dtype=None):
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
     return PackedWeights(sd, XL, device, mean, std, ffn_dtype=ffn_dtype,
-                         proj_dtype="float16" if ffn_dtype == "float16" else "float32")
+                         proj_dtype=ffn_dtype)   # the encoder's attention projections in the same form
 
 
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None, kv_dtype=None):
@@ -576,10 +576,11 @@ def main():
         split16 = leg(args.mode, weights=w_split)
         del w_split
         split16["over_headline"] = round(split16["value"] / value, 4)
-        split16["note"] = ("NOT the headline: the same leg with `ffn_dtype=\"split16\"` - the fused feed-forward kernels of all encoder and "
-                           "decoder layers evaluate their fp32 product sums on the fp16 matrix pipe: both operands split into fp16 hi + "
-                           "lo / 2^11, three v_mfma_f32_16x16x32_f16 per sum instead of eight v_mfma_f32_16x16x4_f32, fp32 accumulation "
-                           "(sc_ffn_ln_s; 22-bit products: error against float64 within 4x the fp32 kernel's, tests/test_gpu_ops.py).  "
+        split16["note"] = ("NOT the headline: the same leg with `ffn_dtype = proj_dtype = \"split16\"` - the fused feed-forward kernels of all "
+                           "encoder and decoder layers and the encoder's attention projections evaluate their fp32 product sums on the fp16 "
+                           "matrix pipe: both operands split into fp16 hi + lo / 2^11, three v_mfma_f32_16x16x32_f16 per sum instead of "
+                           "eight v_mfma_f32_16x16x4_f32, fp32 accumulation (sc_ffn_ln_s / sc_rowtile_proj_s; 22-bit products: error "
+                           "against float64 within 4x the fp32 kernel's, tests/test_gpu_ops.py).  "
                            "Holds the fp32 parity bar unrelaxed: all hypotheses of the six XL reference fixtures on both engines "
                            "(tests/test_gpu_native.py), and on 256 streams x 7 chunks no hypothesis of any beam differs from the fp32 "
                            "run, best scores within 1.5e-5 (tools/fp16_mode_stats.py split16)")
@@ -626,8 +627,9 @@ def main():
                   "f32 except: " + ", ".join(x for x in (("fp16 K|V caches" if KV_DTYPE != "float32" else ""),
                                                          ("fp16 feed-forward + encoder attention-projection weights and MFMA inputs (fp32 accumulation)"
                                                           if FFN_DTYPE == "float16" else ""),
-                                                         ("feed-forward product sums from fp16 hi + lo splits of both fp32 operands on the fp16 "
-                                                          "matrix pipe (three MFMAs per sum, fp32 accumulation; ~2^-22 relative per product)"
+                                                         ("feed-forward and encoder attention-projection product sums from fp16 hi + lo splits of both "
+                                                          "fp32 operands on the fp16 matrix pipe (three MFMAs per sum, fp32 accumulation; ~2^-22 "
+                                                          "relative per product)"
                                                           if FFN_DTYPE == "split16" else "")) if x)),
         "data": "synthetic",
         "config": {"workload": f"de_streaming_transformer_xl dims, {S} concurrent synthetic streams/GPU "

@@ -76,6 +76,7 @@ typedef struct sc_enc_layer {
   const void *w1_s, *w2_s;    /* fp16 hi | lo SPLIT of w1_p / w2_p (weights.py split_panel_weight; same bytes) or NULL: the
                                  fused FFN then computes fp32-grade results with three fp16 MFMAs per product sum
                                  (sc_ffn_ln_s); takes precedence over w1_h / w2_h */
+  const void *wqkv_s, *wo_s;  /* the same split of wqkv_p / wo_p or NULL (sc_rowtile_proj_s); precedence over wqkv_h / wo_h */
 } sc_enc_layer;
 
 typedef struct sc_dec_layer {
@@ -215,6 +216,10 @@ int sc_rowtile_proj(const float *A, int lda, int M, int D, const float *ln_g, co
 /* ... with fp16 weights (Wh = the fragment-packed copy with 2-byte elements) and fp16 MFMA inputs: BASELINE configs[4] */
 int sc_rowtile_proj_h(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
                       float eps, const void *Wh, const float *bias, int N, const float *R, float *C,
+                      int ldc, const float *g2, const float *b2, float *LN2, void *stream);
+/* ... with the fp16 hi | lo split of the fp32 weights (see sc_ffn_ln_s): fp32-grade results from fp16 MFMA inputs */
+int sc_rowtile_proj_s(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                      float eps, const void *Ws, const float *bias, int N, const float *R, float *C,
                       int ldc, const float *g2, const float *b2, float *LN2, void *stream);
 int sc_rowtile_proj_supported(int D, int N);
 /* The same feed-forward followed by the projection that consumes its LayerNorm - the next decoder

@@ -25,7 +25,8 @@ vp = C.c_void_p
 class EncLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo",
                                   "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "w1_p", "w2_p",
-                                  "wqkv_p", "wo_p", "w1_h", "w2_h", "wqkv_h", "wo_h", "w1_s", "w2_s")]
+                                  "wqkv_p", "wo_p", "w1_h", "w2_h", "wqkv_h", "wo_h", "w1_s", "w2_s",
+                                  "wqkv_s", "wo_s")]
 
 
 class DecLayer(C.Structure):
@@ -97,6 +98,8 @@ _SIGS = {
     "sc_rowtile_proj": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
                                   C.c_int, vp, vp, vp, vp]),
     "sc_rowtile_proj_h": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
+                                    C.c_int, vp, vp, vp, vp]),
+    "sc_rowtile_proj_s": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, vp, vp,
                                     C.c_int, vp, vp, vp, vp]),
     "sc_rowtile_proj_supported": (C.c_int, [C.c_int, C.c_int]),
     "sc_workspace_bytes": (C.c_size_t, [vp]),

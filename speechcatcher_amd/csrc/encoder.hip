@@ -570,7 +570,11 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
     const sc_enc_layer &w = L[li];
     const bool rowtile = rowtile_ok && w.wqkv_p && w.wo_p;
     const bool proj_h = rowtile && w.wqkv_h && w.wo_h;   // fp16 attention projections (fp16 MFMA inputs, fp32 sums)
-    if (proj_h) {
+    const bool proj_s = rowtile && w.wqkv_s && w.wo_s;   // fp16 hi | lo split: fp32-grade on the fp16 matrix pipe
+    if (proj_s) {
+      SC_TRY(sc_rowtile_proj_s(x, d, M, d, w.ln1_g, w.ln1_b, eps, w.wqkv_s, w.bqkv, 3 * d, nullptr, qkv, 3 * d,
+                               nullptr, nullptr, nullptr, stream));
+    } else if (proj_h) {
       SC_TRY(sc_rowtile_proj_h(x, d, M, d, w.ln1_g, w.ln1_b, eps, w.wqkv_h, w.bqkv, 3 * d, nullptr, qkv, 3 * d,
                                nullptr, nullptr, nullptr, stream));
     } else if (rowtile) {  // norm1 + q|k|v Linear in one launch
@@ -581,7 +585,10 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
       SC_TRY(sc_gemm(xn, nullptr, d, w.wqkv, w.bqkv, qkv, nullptr, 3 * d, M, 3 * d, d, 0, 0, stream));
     }
     SC_TRY(sc_enc_attention(qkv, att, nblk, R, H, d, masked, stream));
-    if (proj_h) {
+    if (proj_s) {
+      SC_TRY(sc_rowtile_proj_s(att, d, M, d, nullptr, nullptr, eps, w.wo_s, w.bo, d, x, x, d, w.ln2_g, w.ln2_b, xn,
+                               stream));
+    } else if (proj_h) {
       SC_TRY(sc_rowtile_proj_h(att, d, M, d, nullptr, nullptr, eps, w.wo_h, w.bo, d, x, x, d, w.ln2_g, w.ln2_b, xn,
                                stream));
     } else if (rowtile) {  // output Linear + residual + norm2 in one launch

@@ -1225,7 +1225,8 @@ struct RowProjArgs {
   float *LN2;
   float eps;
   int M, N, cpw;
-  int w_half;   // Wp holds fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation
+  int w_half;   // 1: Wp holds fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
+                // 2: Wp holds the fp16 hi | lo split of the fp32 weights (ffn_fused_kernel, WF = 2)
 };
 
 template <int D>
@@ -1248,16 +1249,22 @@ __device__ __forceinline__ float4 rowtile_ln(const float4 v, bool act, const flo
 // WH: fp16 weights (the fragment order of sc_pack_panel_weight with 2-byte elements) and fp16 MFMA inputs
 // (v_mfma_f32_16x16x16_f16, as in ffn_fused_kernel<.., WH>): the (normalised) row tile is converted to fp16 once, after
 // the LayerNorm prologue; accumulation, bias, residual and the output LayerNorm stay fp32.
-template <int D, int RTT, bool FULL, bool WH = false>
+// WF = 2 (WS): the fp16 hi | lo split of both operands, three v_mfma_f32_16x16x32_f16 per product sum - fp32-grade
+// results on the fp16 matrix pipe, see ffn_fused_kernel.  The row tile is split IN PLACE (hi8 | lo8 per 8 k values:
+// the bytes of the fp32 row) by the wave that normalises the row.
+template <int D, int RTT, bool FULL, int WF = 0>
 __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
+  constexpr bool WH = WF == 1, WS = WF == 2;
   constexpr int RT = 16 * RTT, FC = 128, KI1 = D / 32;
+  constexpr int LDXS = 2 * D + 8;       // WS: row stride of the hi8 | lo8 tile (fp16 elements)
   constexpr int LDX = D + 4, LDO = FULL ? D + 4 : FC + 4;
   constexpr int LDXH = D + 8;           // WH: row stride of the fp16 tile (elements)
   extern __shared__ __attribute__((aligned(16))) float rowtile_smem[];
   float *Xs = rowtile_smem;             // [RT][LDX] (normalised) input rows
   float *Os = rowtile_smem + RT * LDX;  // [RT][LDO] result staging
   _Float16 *XsH = reinterpret_cast<_Float16 *>(rowtile_smem + RT * LDX + RT * LDO);   // WH: [RT][LDXH]
-  typedef typename std::conditional<WH, h16x4, float4>::type BF;   // 4 weight elements
+  _Float16 *XsS = reinterpret_cast<_Float16 *>(rowtile_smem);                          // WS: [RT][LDXS], in place of Xs
+  typedef typename std::conditional<WS, h16x8, typename std::conditional<WH, h16x4, float4>::type>::type BF;   // 4 weight elements
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int grp = blockIdx.x, m0 = blockIdx.y * RT;
@@ -1290,13 +1297,21 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
     }
   }
   __syncthreads();
-  if (p.ln_g) {  // wave w normalises rows w, w+8, ... in place
+  if (p.ln_g || WS) {  // wave w normalises (WS: and splits) rows w, w+8, ... in place
     const bool act = lane < D / 4;
     for (int i = wave; i < RT; i += 8) {
       float4 *row = reinterpret_cast<float4 *>(Xs + i * LDX);
       const float4 v = act ? row[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 o = rowtile_ln<D>(v, act, p.ln_g, p.ln_b, p.eps, lane);
-      if (act) row[lane] = o;
+      const float4 o = p.ln_g ? rowtile_ln<D>(v, act, p.ln_g, p.ln_b, p.eps, lane) : v;
+      if (WS) {   // every lane of the wave has read its piece of the row
+        h16x4 hi, lo;
+        ffn_split4(o, hi, lo);
+        _Float16 *d = XsS + i * LDXS + ((4 * lane) >> 3) * 16 + ((4 * lane) & 7);
+        if (act) {
+          *reinterpret_cast<h16x4 *>(d) = hi;
+          *reinterpret_cast<h16x4 *>(d + 8) = lo;
+        }
+      } else if (act) row[lane] = o;
     }
     __syncthreads();
   }
@@ -1314,9 +1329,32 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
     const int chunk = ch0 + cc;
     const float bias = p.bias ? p.bias[chunk * FC + wave * 16 + r] : 0.f;
     f32x4 acc[RTT];
+    f32x4 accc[WS ? RTT : 1];   // WS: the 2^11-scaled cross terms
 #pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (WH) {
+    for (int rt = 0; rt < RTT; ++rt) {
+      acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (WS) accc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (WS) {
+      constexpr int NS = RTT * KI1;
+      const _Float16 *ab = XsS + r * LDXS + 16 * kk;
+      h16x8 ah = *reinterpret_cast<const h16x8 *>(ab), al = *reinterpret_cast<const h16x8 *>(ab + 8);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int ki = st / RTT, rt = st % RTT;
+        h16x8 nh = ah, nl = al;
+        if (st + 1 < NS) {
+          const _Float16 *ap = ab + ((st + 1) % RTT) * 16 * LDXS + ((st + 1) / RTT) * 64;
+          nh = *reinterpret_cast<const h16x8 *>(ap);
+          nl = *reinterpret_cast<const h16x8 *>(ap + 8);
+        }
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bf[ki][0], acc[rt], 0, 0, 0);
+        accc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bf[ki][1], accc[rt], 0, 0, 0);
+        accc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bf[ki][0], accc[rt], 0, 0, 0);
+        ah = nh;
+        al = nl;
+      }
+    } else if constexpr (WH) {
       constexpr int NS = RTT * KI1;
       const _Float16 *ab = XsH + r * LDXH + 8 * kk;
       h16x8 a = *reinterpret_cast<const h16x8 *>(ab);
@@ -1352,7 +1390,8 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Os[(rt * 16 + 4 * kk + j) * LDO + ocol] = acc[rt][j] + bias;
+      for (int j = 0; j < 4; ++j)
+        Os[(rt * 16 + 4 * kk + j) * LDO + ocol] = (WS ? acc[rt][j] + accc[WS ? rt : 0][j] * (1.f / 2048.f) : acc[rt][j]) + bias;
     if (!FULL) {
       __syncthreads();
       for (int e = threadIdx.x; e < RT * (FC / 4); e += 512) {
@@ -1385,10 +1424,10 @@ __global__ __launch_bounds__(512) void rowtile_proj_kernel(RowProjArgs p) {
   }
 }
 
-template <int D, int RTT, bool FULL, bool WH>
+template <int D, int RTT, bool FULL, int WH>
 static void launch_rowtile_wh(const RowProjArgs &p, int ngrp, hipStream_t st) {
   constexpr int RT = 16 * RTT;
-  const size_t lds = (size_t)(RT * (D + 4) + RT * ((FULL ? D : 128) + 4)) * sizeof(float) + (WH ? (size_t)RT * (D + 8) * 2 : 0);
+  const size_t lds = (size_t)(RT * (D + 4) + RT * ((FULL ? D : 128) + 4)) * sizeof(float) + (WH == 1 ? (size_t)RT * (D + 8) * 2 : 0);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rowtile_proj_kernel<D, RTT, FULL, WH>),
@@ -1399,8 +1438,9 @@ static void launch_rowtile_wh(const RowProjArgs &p, int ngrp, hipStream_t st) {
 }
 template <int D, int RTT, bool FULL>
 static void launch_rowtile(const RowProjArgs &p, int ngrp, hipStream_t st) {
-  if (p.w_half) launch_rowtile_wh<D, RTT, FULL, true>(p, ngrp, st);
-  else launch_rowtile_wh<D, RTT, FULL, false>(p, ngrp, st);
+  if (p.w_half == 2) launch_rowtile_wh<D, RTT, FULL, 2>(p, ngrp, st);
+  else if (p.w_half) launch_rowtile_wh<D, RTT, FULL, 1>(p, ngrp, st);
+  else launch_rowtile_wh<D, RTT, FULL, 0>(p, ngrp, st);
 }
 
 template <int D, bool FULL>
@@ -1464,7 +1504,7 @@ static int rowtile_run(const float *A, int lda, int M, int D, const float *ln_g,
     else launch_rowtile_rtt<128, false>(p, best_rtt, ngrp, st);
   }
   sc_prof_end(prof, SC_PROF_ROWTILE_PROJ, 2.0 * (double)M * D * N,
-              4.0 * ((double)M * (D + N) + (double)D * N / (w_half ? 2.0 : 1.0) + (full ? 2.0 * M * D : 0.0)));
+              4.0 * ((double)M * (D + N) + (double)D * N / (w_half == 1 ? 2.0 : 1.0) + (full ? 2.0 * M * D : 0.0)));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -1481,6 +1521,15 @@ extern "C" int sc_rowtile_proj_h(const float *A, int lda, int M, int D, const fl
                                  int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
   return rowtile_run(A, lda, M, D, ln_g, ln_b, eps, reinterpret_cast<const float *>(Wh), bias, N, R, C, ldc, g2, b2, LN2,
                      stream, 1);
+}
+
+// ... with the fp16 hi | lo split of the fp32 weights (weights.py split_panel_weight): fp32-grade results from three fp16
+// MFMAs per product sum (rowtile_proj_kernel, WF = 2)
+extern "C" int sc_rowtile_proj_s(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
+                                 float eps, const void *Ws, const float *bias, int N, const float *R, float *C,
+                                 int ldc, const float *g2, const float *b2, float *LN2, void *stream) {
+  return rowtile_run(A, lda, M, D, ln_g, ln_b, eps, reinterpret_cast<const float *>(Ws), bias, N, R, C, ldc, g2, b2, LN2,
+                     stream, 2);
 }
 
 // tallest row tile (16 * rtt rows) per weight form: the split form carries two sets of accumulators and spills

@@ -1411,6 +1411,8 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
     l.w2_s = e->f(p + "w2_s", false);
     l.wqkv_h = e->f(p + "wqkv_h", false);   // optional fp16 copies: fp16 MFMA inputs in the attention projections
     l.wo_h = e->f(p + "wo_h", false);
+    l.wqkv_s = e->f(p + "wqkv_s", false);   // optional fp16 hi | lo split of the attention projections
+    l.wo_s = e->f(p + "wo_s", false);
   }
   e->dec.resize(cfg->dec_layers);
   e->wkv.resize(cfg->dec_layers);

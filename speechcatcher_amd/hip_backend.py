@@ -103,6 +103,12 @@ class HipBackend:
         self._chk(self.lib.sc_rowtile_proj_h(_p(A), A.shape[-1], M, D, _p(ln_g), _p(ln_b), eps, _p(Wh), _p(bias), N, _p(R), _p(C),
                                              C.shape[-1], _p(g2), _p(b2), _p(LN2), self._stream()), "sc_rowtile_proj_h")
 
+    def rowtile_proj_s(self, A, M, D, Ws, bias, N, C, ln_g=None, ln_b=None, R=None, g2=None, b2=None, LN2=None, eps=1e-12):
+        """sc_rowtile_proj with the fp16 hi | lo split of the weights (weights.split_panel_weight): fp32-grade results"""
+        assert Ws.dtype == torch.float16
+        self._chk(self.lib.sc_rowtile_proj_s(_p(A), A.shape[-1], M, D, _p(ln_g), _p(ln_b), eps, _p(Ws), _p(bias), N, _p(R), _p(C),
+                                             C.shape[-1], _p(g2), _p(b2), _p(LN2), self._stream()), "sc_rowtile_proj_s")
+
     def ffn_ln_h(self, XN, rows, M, D, F, W1h, b1, W2h, b2, X, ln_g, ln_b, ln_out, eps=1e-12):
         """sc_ffn_ln with fp16 weights (the packed fragments as torch.float16): fp16 MFMA inputs, fp32 accumulation"""
         assert W1h.dtype == torch.float16 and W2h.dtype == torch.float16

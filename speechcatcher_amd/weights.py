@@ -94,8 +94,12 @@ class PackedWeights:
         """``ffn_dtype="float16"``: additional fp16 copies of the fragment-packed feed-forward weights (w1_h / w2_h);
         the fused FFN kernels then run fp16 MFMA inputs with fp32 accumulation (BASELINE configs[4]; never the
         default - the reference computes in fp32).  ``proj_dtype="float16"``: the same for the attention projections
-        of the encoder layers (wqkv_h / wo_h: sc_rowtile_proj_h; the decoder's row panels stay fp32)."""
-        assert ffn_dtype in ("float32", "float16", "split16") and proj_dtype in ("float32", "float16")
+        of the encoder layers (wqkv_h / wo_h: sc_rowtile_proj_h; the decoder's row panels stay fp32).
+        ``"split16"`` (either): fp16 hi | lo splits of the fp32 weights instead (``split_panel_weight``: w1_s / w2_s,
+        wqkv_s / wo_s) - the kernels split the activations the same way and evaluate every product sum with three fp16
+        MFMAs: fp32-grade results (all reference fixtures at the fp32 tolerance) at a fraction of the f32 matrix-pipe
+        time.  Opt-in as well: the default computes on the f32 MFMA path."""
+        assert ffn_dtype in ("float32", "float16", "split16") and proj_dtype in ("float32", "float16", "split16")
         self.ffn_dtype, self.proj_dtype = ffn_dtype, proj_dtype
         self.cfg = cfg
         self.device = torch.device(device)
@@ -182,6 +186,8 @@ class PackedWeights:
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if rowtile_proj_supported(d, d) else lw[n]
                 if proj_dtype == "float16" and rowtile_proj_supported(d, d):
                     lw[n + "_h"] = lw[n + "_p"].to(torch.float16).contiguous()   # same fragment order, 2-byte elements
+                if proj_dtype == "split16" and rowtile_proj_supported(d, d):
+                    lw[n + "_s"] = split_panel_weight(lw[n + "_p"])
         for lw in self.enc + self.dec:   # ... and for the fused feed-forward kernel
             for n in ("w1", "w2"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if ffn_fused_supported(d, cfg.ffn_dim) else lw[n]

@@ -566,17 +566,17 @@ def test_fp16_ffn_weights_on_the_xl_fixtures(name, engine):
 @pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("name", XL_CASES)
 def test_split16_ffn_on_the_xl_fixtures(name, engine):
-    """`ffn_dtype="split16"`: the fused feed-forward kernels of all encoder and decoder layers evaluate their fp32
-    product sums on the fp16 matrix pipe from fp16 hi + lo splits of BOTH operands (sc_ffn_ln_s; 22-bit products,
-    fp32 accumulation).  Held to the fp32 engine's own bar, unrelaxed: every hypothesis of every block of the six XL
+    """`ffn_dtype = proj_dtype = "split16"`: the fused feed-forward kernels of all encoder and decoder layers and the
+    attention projections of the encoder layers evaluate their fp32 product sums on the fp16 matrix pipe from fp16
+    hi + lo splits of BOTH operands (sc_ffn_ln_s, sc_rowtile_proj_s; 22-bit products, fp32 accumulation).  Held to the fp32 engine's own bar, unrelaxed: every hypothesis of every block of the six XL
     fixtures of the reference - ids, positions, order - and the scores within the fp32 tolerance (2e-3 on sums of
     1e2..1e3; the unit test bounds the kernel itself: tests/test_gpu_ops.py test_ffn_fused_split_weights)."""
     from test_engine_spec import run_case
     if engine == "native":
-        run_case(name, backend="native", ffn_dtype="split16")
+        run_case(name, backend="native", ffn_dtype="split16", proj_dtype="split16")
     else:
         from speechcatcher_amd.hip_backend import HipBackend
-        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", ffn_dtype="split16")
+        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", ffn_dtype="split16", proj_dtype="split16")
 
 
 @pytest.mark.parametrize("engine", ["native", "python"])

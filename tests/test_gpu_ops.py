@@ -335,6 +335,46 @@ def test_rowtile_proj_fp16_weights(hip, M, D):
     np.testing.assert_allclose(Lg[:M].cpu().numpy(), ln(refX, g2, b2).numpy(), atol=3e-3, rtol=3e-3)
 
 
+@pytest.mark.parametrize("M,D", [(10, 256), (210, 256), (2100, 256), (8400, 256), (77, 128)])
+def test_rowtile_proj_split_weights(hip, M, D):
+    """sc_rowtile_proj_s (fp16 hi | lo split of weights and row tile, three v_mfma_f32_16x16x32_f16 per product sum):
+    against float64 as close as the fp32 kernel is - both forms of the kernel (q|k|v behind norm1; output Linear +
+    residual + norm2), rows of very different magnitude."""
+    from speechcatcher_amd.weights import pack_panel_weight, split_panel_weight
+    N = 3 * D
+    X, ATT = _rand(M, D, seed=91), _rand(M, D, seed=92)
+    ATT *= torch.logspace(-3, 2, M)[:, None]
+    Wqkv, bqkv = _rand(N, D, seed=93, scale=D ** -0.5), _rand(N, seed=94)
+    Wo, bo = _rand(D, D, seed=95, scale=D ** -0.5), _rand(D, seed=96)
+    g1, b1, g2, b2 = 1 + 0.1 * _rand(D, seed=97), _rand(D, seed=98), 1 + 0.1 * _rand(D, seed=99), _rand(D, seed=100)
+    ln64 = lambda t, g, b: torch.nn.functional.layer_norm(t.double(), (D,), g.double(), b.double(), 1e-12)   # noqa: E731
+    Wqp, Wop = pack_panel_weight(Wqkv), pack_panel_weight(Wo)
+    Wqs, Wos = split_panel_weight(Wqp), split_panel_weight(Wop)
+    xn = ln64(X, g1, b1)
+    refQ = xn @ Wqkv.double().t() + bqkv.double()
+    scaleQ = xn.abs() @ Wqkv.double().abs().t() + bqkv.double().abs()
+    refX = X.double() + ATT.double() @ Wo.double().t() + bo.double()
+    scaleX = ATT.double().abs() @ Wo.double().abs().t() + X.double().abs() + bo.double().abs()   # size of the summed terms
+    err = {}
+    for form in ("f32", "split"):
+        Qg = torch.full((M + 3, N), 5.0, device="cuda")
+        Xg, Lg = X.cuda(), torch.full((M + 3, D), 2.0, device="cuda")
+        if form == "f32":
+            hip.rowtile_proj(X.cuda(), M, D, Wqp.cuda(), bqkv.cuda(), N, Qg, ln_g=g1.cuda(), ln_b=b1.cuda())
+            hip.rowtile_proj(ATT.cuda(), M, D, Wop.cuda(), bo.cuda(), D, Xg, R=Xg, g2=g2.cuda(), b2=b2.cuda(), LN2=Lg)
+        else:
+            hip.rowtile_proj_s(X.cuda(), M, D, Wqs.cuda(), bqkv.cuda(), N, Qg, ln_g=g1.cuda(), ln_b=b1.cuda())
+            hip.rowtile_proj_s(ATT.cuda(), M, D, Wos.cuda(), bo.cuda(), D, Xg, R=Xg, g2=g2.cuda(), b2=b2.cuda(), LN2=Lg)
+        torch.cuda.synchronize()
+        assert float(Qg[M:].min()) == 5.0 and float(Qg[M:].max()) == 5.0 and float(Lg[M:].min()) == 2.0   # rows >= M untouched
+        err[form] = (float(((Qg[:M].cpu().double() - refQ).abs() / scaleQ).max()),
+                     float(((Xg.cpu().double() - refX).abs() / scaleX).max()))
+        np.testing.assert_allclose(Lg[:M].cpu().numpy(), ln64(refX, g2, b2).float().numpy(), atol=2e-5, rtol=2e-5)
+    for k in (0, 1):
+        assert err["f32"][k] < 2e-6 and err["split"][k] < 2e-6, err
+        assert err["split"][k] < 4.0 * err["f32"][k] + 2e-7, err
+
+
 @pytest.mark.parametrize("M,D,F,N", [(10, 256, 2048, 768), (1280, 256, 2048, 768), (533, 256, 2048, 1024),
                                      (77, 128, 256, 384), (2100, 256, 2048, 768)])
 def test_ffn_ln_proj_chain(hip, M, D, F, N):

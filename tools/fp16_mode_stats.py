@@ -14,7 +14,7 @@ MODES = sys.argv[1:] or ["kv16", "ffn16", "proj16", "float16", "split16"]
 for mode in ["float32"] + MODES:
     sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native",
                     ffn_dtype="float16" if mode in ("ffn16", "float16") else "split16" if mode == "split16" else "float32",
-                    proj_dtype="float16" if mode in ("proj16", "float16") else "float32",
+                    proj_dtype="float16" if mode in ("proj16", "float16") else "split16" if mode == "split16" else "float32",
                     kv_dtype="float16" if mode in ("kv16", "float16") else "float32", **kw)
     ids = np.arange(S, dtype=np.int32)
     for k in range(n):
