@@ -795,7 +795,7 @@ struct FfnArgs {
   const float *g, *b;
   float eps;
   int part_rows;
-  int w_half;   // 1: W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
+  int w_form;   // 0: fp32 weights; 1: W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
                 // 2: W1p / W2p hold the fp16 hi | lo SPLIT of the fp32 weights (see WF below)
 };
 
@@ -1182,8 +1182,8 @@ static void launch_ffn_wh(const FfnArgs &p, int ngrp, hipStream_t st) {
 }
 template <int D, int RTT, bool PRO = false>
 static void launch_ffn(const FfnArgs &p, int ngrp, hipStream_t st) {
-  if (p.w_half == 2) launch_ffn_wh<D, RTT, PRO, 2>(p, ngrp, st);
-  else if (p.w_half) launch_ffn_wh<D, RTT, PRO, 1>(p, ngrp, st);
+  if (p.w_form == 2) launch_ffn_wh<D, RTT, PRO, 2>(p, ngrp, st);
+  else if (p.w_form) launch_ffn_wh<D, RTT, PRO, 1>(p, ngrp, st);
   else launch_ffn_wh<D, RTT, PRO, 0>(p, ngrp, st);
 }
 
@@ -1225,7 +1225,7 @@ struct RowProjArgs {
   float *LN2;
   float eps;
   int M, N, cpw;
-  int w_half;   // 1: Wp holds fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
+  int w_form;   // 0: fp32 weights; 1: Wp holds fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
                 // 2: Wp holds the fp16 hi | lo split of the fp32 weights (ffn_fused_kernel, WF = 2)
 };
 
@@ -1438,8 +1438,8 @@ static void launch_rowtile_wh(const RowProjArgs &p, int ngrp, hipStream_t st) {
 }
 template <int D, int RTT, bool FULL>
 static void launch_rowtile(const RowProjArgs &p, int ngrp, hipStream_t st) {
-  if (p.w_half == 2) launch_rowtile_wh<D, RTT, FULL, 2>(p, ngrp, st);
-  else if (p.w_half) launch_rowtile_wh<D, RTT, FULL, 1>(p, ngrp, st);
+  if (p.w_form == 2) launch_rowtile_wh<D, RTT, FULL, 2>(p, ngrp, st);
+  else if (p.w_form) launch_rowtile_wh<D, RTT, FULL, 1>(p, ngrp, st);
   else launch_rowtile_wh<D, RTT, FULL, 0>(p, ngrp, st);
 }
 
@@ -1459,7 +1459,7 @@ extern "C" int sc_rowtile_proj_supported(int D, int N) {
 
 static int rowtile_run(const float *A, int lda, int M, int D, const float *ln_g, const float *ln_b,
                        float eps, const float *Wp, const float *bias, int N, const float *R, float *C,
-                       int ldc, const float *g2, const float *b2, float *LN2, void *stream, int w_half) {
+                       int ldc, const float *g2, const float *b2, float *LN2, void *stream, int w_form) {
   SC_CHECK_ARG(A && Wp && C, "null pointer");
   SC_CHECK_ARG(sc_rowtile_proj_supported(D, N), "unsupported dimensions");
   SC_CHECK_ARG((!ln_g) == (!ln_b) && (!LN2 || (g2 && b2)), "LayerNorm parameters missing");
@@ -1493,7 +1493,7 @@ static int rowtile_run(const float *A, int lda, int M, int D, const float *ln_g,
       if (!full) best_cpw = c;
     }
   }
-  RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw, w_half};
+  RowProjArgs p{A, lda, ln_g, ln_b, Wp, bias, R, C, ldc, g2, b2, LN2, eps, M, N, best_cpw, w_form};
   ProfScope prof = sc_prof_begin(st);
   const int ngrp = full ? 1 : nch / best_cpw;
   if (D == 256) {
@@ -1504,7 +1504,7 @@ static int rowtile_run(const float *A, int lda, int M, int D, const float *ln_g,
     else launch_rowtile_rtt<128, false>(p, best_rtt, ngrp, st);
   }
   sc_prof_end(prof, SC_PROF_ROWTILE_PROJ, 2.0 * (double)M * D * N,
-              4.0 * ((double)M * (D + N) + (double)D * N / (w_half == 1 ? 2.0 : 1.0) + (full ? 2.0 * M * D : 0.0)));
+              4.0 * ((double)M * (D + N) + (double)D * N / (w_form == 1 ? 2.0 : 1.0) + (full ? 2.0 * M * D : 0.0)));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -1543,7 +1543,7 @@ extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128)
 static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
                    const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
                    const float *ln_b, float ln_eps, float *ln_out, float *Xout, const float *Wq,
-                   const float *bq, float *Q, int N, void *stream, int w_form = 0) {   // w_form: FfnArgs.w_half
+                   const float *bq, float *Q, int N, void *stream, int w_form = 0) {   // FfnArgs.w_form
   SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
   SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
   SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
@@ -1591,7 +1591,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     }
     const int ngrp = nch / best_cpw;
     FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
-    p.w_half = w_form;
+    p.w_form = w_form;
     // without a row table the slab is addressed by offsetting the base pointers
     const float *xn_base = rows ? XN : XN + (long)m_done * D;
     p.XN = xn_base;

@@ -613,6 +613,44 @@ def test_m_like_dimensions_head_dim_64(engine):
         assert len(sb.hypotheses(0)[0]["yseq"]) > 5
 
 
+@pytest.mark.parametrize("form", ["split16", "float16"])
+def test_packed_model_file_carries_the_optional_weight_forms(tmp_path, form):
+    """A packed model file saved from weights with split-precision (w1_s / w2_s / wqkv_s / wo_s) or fp16 (.._h)
+    copies: an engine loaded from the file (sc_engine_load, no Python weights behind it) gives exactly the results of the
+    engine built on the in-memory tensors - and those differ from the fp32 engine's scores, i.e. the copies are used."""
+    from speechcatcher_amd.config import ModelConfig, SearchConfig
+    from speechcatcher_amd.native import NativeEngine, NativeStreamBatch
+    from speechcatcher_amd.weights import PackedWeights
+    cfg = ModelConfig(d_model=256, enc_heads=4, enc_layers=2, dec_heads=4, dec_layers=2)
+    sd = synth.make_state_dict(cfg, 4321)
+    mean, std = synth.stats_to_mean_std(synth.make_stats(cfg, kind="meanstd"))
+    audio = synth.synth_audio(55, 16000 * 4)
+    kw = dict(max_frames=200, max_tokens=300, pcm_capacity=1 << 18)
+
+    def run(sb):
+        for pos in range(0, len(audio), 10240):
+            end = min(pos + 10240, len(audio))
+            sb.push([(0, audio[pos:end], end >= len(audio))])
+        h = sb.hypotheses(0)
+        sb.close()
+        return h
+
+    w = PackedWeights(sd, cfg, "cuda:0", mean, std, ffn_dtype=form, proj_dtype=form)
+    assert any(k.endswith("_s" if form == "split16" else "_h") for k in w.enc[0]) and any(
+        k.endswith("_s" if form == "split16" else "_h") for k in w.dec[0])
+    mem = run(NativeStreamBatch(w, 1, SearchConfig(beam_size=5, use_bbd=False), **kw))
+    w.save_packed(tmp_path / "m.scpk")
+    eng = NativeEngine(packed_path=str(tmp_path / "m.scpk"))
+    filed = run(NativeStreamBatch(None, 1, SearchConfig(beam_size=5, use_bbd=False), engine=eng, **kw))
+    assert len(mem) == len(filed) > 0 and len(mem[0]["yseq"]) > 3
+    for a, b in zip(mem, filed):
+        assert a["yseq"] == b["yseq"] and a["xpos"] == b["xpos"] and a["score"] == b["score"]
+    ref = run(NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std), 1, SearchConfig(beam_size=5, use_bbd=False), **kw))
+    assert ref[0]["yseq"] == mem[0]["yseq"]
+    d = abs(ref[0]["score"] - mem[0]["score"])
+    assert 0.0 < d < (2e-3 if form == "split16" else 0.05), d   # not the fp32 kernels - and as close as the form promises
+
+
 def test_native_pcm_ring_compaction_and_mixed_push_submit():
     """A PCM ring that holds only ~3 chunks (the carry-over is moved to the front again and again, also while encoder
     groups of other streams are pending), every admission issued as its own encoder group (no merging) and then
