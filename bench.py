@@ -156,14 +156,15 @@ def strict_window(sb, audio, k0, steps, dist=None, before_timing=None):
     return elapsed, (n_dec_steps(sb) - steps0) / float(sb.S) / max(steps, 1), last
 
 
-def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None):
+def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None, depth=1):
     """CONTINUOUS batching, closed loop: every stream is served on its own - sc_submit its chunk, sc_poll until replies
     are ready, read the best hypothesis of the streams that answered (sc_get_hyps_batch), submit THEIR next chunks
     (stream i continues at chunk nxt[i] of a3 [S][chunks][CHUNK]).  boundary: host PCM in (pinned staging, one H2D
     per admission) and hypotheses out per reply; False: chunks already resident in the device PCM ring, no read-back.
     The clock stops when S x steps replies have been delivered - `steps` chunk steps' worth of audio; a stream whose
     blocks need fewer decode steps gets further than one that needs more (a3 must hold spare chunks).  What is in
-    flight then is drained untimed."""
+    flight then is drained untimed.  depth > 1 (sc_streams_set_queue_depth): every stream keeps `depth` chunks with the
+    engine - its next chunk is submitted while the previous one is still decoding (a host that has the audio already)."""
     S = sb.S
     end = a3.shape[1]
     k_start = nxt.copy()
@@ -184,7 +185,8 @@ def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=Non
             nxt[streams] += 1
 
     t0 = time.perf_counter()
-    submit(np.arange(S, dtype=np.int32))
+    for _ in range(depth):
+        submit(np.arange(S, dtype=np.int32))
     n_polls, n_replies, target, res = 0, 0, S * steps, None
     while sb.outstanding:
         done, st = sb.poll_ids(min(group, sb.outstanding))
@@ -271,9 +273,12 @@ def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
                                                 "12-15 steps in its 10 s budget: +-10 %"}}
 
 
-def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True, kv_dtype=None):
+def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True, kv_dtype=None,
+            depth=1):
     """one fresh batch: pre-roll (lock-step, resident audio, untimed), warm-up in the timed mode, then the timed leg"""
     sb = build_native(w, streams, beam, bbd, total, kv_dtype=kv_dtype)
+    if depth > 1:
+        sb.set_queue_depth(depth)
     roll(sb, audio, preroll)
     k0 = preroll + warmup
     a3 = audio.reshape(streams, -1, CHUNK)
@@ -286,8 +291,8 @@ def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, t
         if not boundary:
             preload_audio(sb, audio, a3.shape[1])
         if warmup > 0:
-            serve(sb, a3, nxt, warmup, group, boundary=boundary)
-        out = serve(sb, a3, nxt, steps, group, dist, boundary=boundary)
+            serve(sb, a3, nxt, warmup, group, boundary=boundary, depth=depth)
+        out = serve(sb, a3, nxt, steps, group, dist, boundary=boundary, depth=depth)
         out["next_chunk"] = nxt
     out["value"] = streams * steps * CHUNK / 16000.0 / out["elapsed"]
     return sb, out
@@ -356,6 +361,9 @@ def main():
     ap.add_argument("--bbd", type=int, default=0, help="block boundary detection (reference CLI default: on)")
     ap.add_argument("--chunk", type=int, default=10240,
                     help="samples per chunk step (10240 = 640 ms = one encoder hop; also 8192 = CLI default, 25600 = block size)")
+    ap.add_argument("--queue-depth", type=int, default=1,
+                    help="continuous mode: chunks a stream keeps with the engine (sc_streams_set_queue_depth); 1 = call -> reply -> "
+                         "next call (the headline), 2+ = the next chunk is submitted while the previous one decodes (file / backlog hosts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the leg of the mode that is not the headline")
@@ -408,7 +416,7 @@ def main():
     audio = make_audio(S, total_steps, stream_offset=rank * S)
     a3 = audio.reshape(S, -1, CHUNK)
     sb, head = measure(w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, args.mode,
-                       total_steps, dist)
+                       total_steps, dist, depth=args.queue_depth)
     lib = sb.lib
     elapsed, dec_steps_per_hop = head["elapsed"], head["dec_steps_per_hop"]
     state = state_of(sb)
@@ -434,7 +442,7 @@ def main():
                 lib.sc_prof_enable(0)
                 rows_at_target.append(sb.take_xattn_rows_by_kernel())
 
-            serve(sb, a3, head["next_chunk"], args.roofline_steps, group, at_target=stop_timing)
+            serve(sb, a3, head["next_chunk"], args.roofline_steps, group, at_target=stop_timing, depth=args.queue_depth)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
@@ -468,7 +476,7 @@ def main():
     audio_s = world * S * args.steps * CHUNK / 16000.0
     value = audio_s / elapsed
     default_workload = (S == 128 and CHUNK == 10240 and args.beam == 10 and not args.bbd and args.mode == "continuous" and
-                        KV_DTYPE == "float32" and FFN_DTYPE == "float32")
+                        KV_DTYPE == "float32" and FFN_DTYPE == "float32" and args.queue_depth == 1)
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
              "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<self> (decoder self-attention, large buckets)",
@@ -536,9 +544,9 @@ def main():
     sb.close()
     del sb
 
-    def leg(mode, boundary=True, kv_dtype=None, weights=None):
-        sbx, r = measure(weights or w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, mode, total_steps,
-                         boundary=boundary, kv_dtype=kv_dtype)
+    def leg(mode, boundary=True, kv_dtype=None, weights=None, bbd=None, depth=1):
+        sbx, r = measure(weights or w, audio, S, args.beam, bool(args.bbd) if bbd is None else bbd, args.preroll, args.warmup, args.steps, group, mode, total_steps,
+                         boundary=boundary, kv_dtype=kv_dtype, depth=depth)
         sbx.close()
         o = {"value": round(r["value"], 2), "unit": "audio_s/s", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
              "decode_steps_per_hop": round(r["dec_steps_per_hop"], 2)}
@@ -569,6 +577,27 @@ def main():
         kv16["note"] = ("NOT the headline: the same leg with the self- / cross-attention K|V caches STORED in fp16 (arithmetic, softmax and "
                         "all scores fp32; opt-in `kv_dtype`): tools/fp16_mode_stats.py - 256 streams x 7 chunks, no hypothesis of any "
                         "stream changes, best scores within 7e-5 of the fp32 run")
+
+    bbd_on = None
+    if not args.no_other_mode and world == 1 and not args.bbd:
+        bbd_on = leg(args.mode, bbd=True)
+        bbd_on["over_headline"] = round(bbd_on["value"] / value, 4)
+        bbd_on["note"] = ("the other search regime of BASELINE.md section 3: the same leg WITH block-boundary detection (the reference CLI's "
+                          "default).  On random weights it ends most blocks after ~1.3 decode steps (real speech: 3-5), so this is an "
+                          "upper bound for a real checkpoint as the headline (detection off, ~9 steps per block) is a lower bound")
+
+    queued = None
+    if not args.no_other_mode and world == 1 and args.mode == "continuous" and args.queue_depth == 1:
+        queued = leg("continuous", depth=2)
+        queued["over_headline"] = round(queued["value"] / value, 4)
+        queued["note"] = ("NOT the headline: the same leg with TWO chunks per stream at the engine (sc_streams_set_queue_depth(2)): a host "
+                          "that has the audio already - a file (the reference CLI's chunk loop, speechcatcher.py:574-592), a backlog - "
+                          "submits a stream's next chunk while the previous one is still decoding, so its frontend + encoder run beside "
+                          "the decoding and the stream does not idle between its reply and its next call.  Per chunk the replies are "
+                          "those of the one-at-a-time protocol (tests/test_gpu_native.py test_native_queued_chunks_*).  Live streams "
+                          "deliver a chunk per 640 ms and never have a second one ready: for them tools/realtime_sim.py is the measure.  "
+                          "At 128 streams the decode iterations are work-bound, so fewer but fuller iterations buy ~1 %; the gain is at "
+                          "fewer streams (32 streams: +12 %, one stream: +6 %; DESIGN section 4)")
 
     split16 = None
     if not args.no_other_mode and world == 1 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
@@ -614,8 +643,10 @@ def main():
             cpu = {"error": repr(e)}
 
     semantics = ("continuous batching: every stream is called, answers and is called again on its own (sc_submit / sc_poll) - a "
-                 "reply is delivered when ITS decode blocks are done, exactly one chunk per stream outstanding (the reference's "
-                 "concurrency model: one independent call loop per stream, speechcatcher_server.py:331-397); per call the "
+                 "reply is delivered when ITS decode blocks are done, " + ("exactly one chunk per stream outstanding (the reference's "
+                 "concurrency model: one independent call loop per stream, speechcatcher_server.py:331-397)" if args.queue_depth == 1 else
+                 f"{args.queue_depth} chunks per stream at the engine (the next chunk is submitted while the previous one decodes: a "
+                 "host that has the audio already)") + "; per call the "
                  "results are those of the strict lock-step run" if args.mode == "continuous" else
                  "strict lock-step: one batched call per chunk step, every block completes inside its call")
     out = {
@@ -635,7 +666,7 @@ def main():
         "config": {"workload": f"de_streaming_transformer_xl dims, {S} concurrent synthetic streams/GPU "
                                f"(batched encoder + batched beam), beam {args.beam}, chunk {CHUNK} samples, bbd {args.bbd}",
                    "streams_per_gpu": S, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
-                   "mode": args.mode, "semantics": semantics,
+                   "mode": args.mode, "queue_depth": args.queue_depth, "semantics": semantics,
                    "step": (f"one step = one {CHUNK}-sample chunk of EVERY stream = {S} calls / replies; the clock stops when "
                             f"{S} x steps replies have been delivered" if args.mode == "continuous" else
                             f"one step = one batched call with a {CHUNK}-sample chunk of every stream"),
@@ -651,7 +682,7 @@ def main():
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
-        "kv_cache_fp16": kv16, "ffn_split16": split16, "long_context": long_ctx,
+        "kv_cache_fp16": kv16, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "long_context": long_ctx,
     }
     if args.mode == "continuous":
         out["continuous"] = {k: head[k] for k in ("iterations_per_step", "polls_per_step", "chunks_per_stream_min_max")}

@@ -513,6 +513,16 @@ int sc_streams_outstanding(const sc_streams *streams);
  * half of the streams) or as soon as a queued decode block needs its frames.  1: every admission is issued at once.
  * Results do not depend on it. */
 int sc_streams_set_encoder_batch(sc_streams *streams, int min_streams);
+/* Chunks a stream may have outstanding at a time (1..8; default 1 = the reference's call -> reply -> next call,
+ * speechcatcher_server.py:359-397).  depth > 1: sc_submit accepts the next chunk(s) of a stream while an earlier one
+ * is still being decoded, for hosts that already have the audio (a file: the reference CLI's chunk loop,
+ * speechcatcher.py:574-592; a backlog): the frontend + encoder of chunk k+1 run beside the decoding of chunk k and the
+ * stream does not idle between its reply and its next call.  Per stream the chunks are processed and reported in
+ * order, at most one per sc_poll call, each with the results of the one-at-a-time protocol; the hypotheses of a
+ * reported chunk are a copy taken when it completed, returned by sc_get_hyps / sc_get_hyps_batch until the NEXT
+ * sc_poll call.  Nothing can be queued behind a final or a failed chunk; a failure fails the chunks queued behind
+ * it as well.  Only while nothing is outstanding. */
+int sc_streams_set_queue_depth(sc_streams *streams, int depth);
 /* message of the stream's last failure (status < 0 from sc_push / sc_poll); "" if it never failed */
 const char *sc_stream_last_error(const sc_streams *streams, int stream);
 /* live hypotheses, best first (BeamState.hypotheses: yseq, xpos, score, scores{decoder, ctc}; hypothesis.py).

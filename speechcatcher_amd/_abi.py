@@ -168,6 +168,7 @@ _SIGS = {
     "sc_poll": (C.c_int, [vp, C.c_int, C.c_int, c_int_p, c_int_p]),
     "sc_streams_outstanding": (C.c_int, [vp]),
     "sc_streams_set_encoder_batch": (C.c_int, [vp, C.c_int]),
+    "sc_streams_set_queue_depth": (C.c_int, [vp, C.c_int]),
     "sc_stream_last_error": (C.c_char_p, [vp, C.c_int]),
     "sc_reset": (C.c_int, [vp, C.c_int]),
     "sc_stream_info": (C.c_int, [vp, C.c_int, C.POINTER(StreamInfo)]),

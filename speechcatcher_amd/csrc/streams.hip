@@ -117,20 +117,34 @@ struct St {
 
 // a decode block of the schedule (beam_search.py:590-634): the T frames [0, T) it presents to the scorers, whether
 // it is the final block, and the encoder group whose frames it sees (0: only frames that were there before)
-struct Blk { int T; bool fin; long gen; };
+// ... and the chunk (Job::seq of its stream) that queued it
+struct Blk { int T; bool fin; long gen; long job; };
 
 // the block a stream is inside (the loop state of _decode_one_block, beam_search.py:655-838)
 struct Run {
   bool inblk = false, live = false, took = false, pvalid = false, has = false, hasp = false, fin = false;
   int cur = 0, L = 1, nhyp = 1, nhp = 1, pidx = 0, T = 0, Tc = 0, out = 0;
   long nsteps = 0;
+  long job = 0;   // Job::seq of the chunk the block belongs to
 };
 
-// a stream's outstanding chunk (sc_push / sc_submit): open until it has been reported
+// a stream's outstanding chunk (sc_push / sc_submit): open until it has been reported.  With a queue depth > 1
+// (sc_streams_set_queue_depth) further chunks of the stream wait behind it (sc_streams::ahead), in order.
 struct Job {
   bool open = false;
   int has_out = 0;   // 1: the call produced output, 0: the reference's early `return []`
   int fault = 0;     // SC_ERR_*: the chunk failed, the stream is reset when it is reported
+  long seq = 0;      // per-stream sequence number of the chunk (tags its decode blocks)
+  bool fin = false;  // is_final chunk: nothing may be queued behind it
+  bool dropped = false;   // failed only because an EARLIER chunk of the stream failed (the reset has happened by then)
+};
+
+// hypotheses of a stream's last complete chunk, copied aside when later chunks of the stream may go on decoding
+// (queue depth > 1): what sc_get_hyps_batch returns for the stream until the next sc_poll call
+struct Snap {
+  bool valid = false, reported = false;
+  long seq = 0;
+  int L = 1, nhyp = 0;
 };
 
 template <typename T>
@@ -236,7 +250,14 @@ struct sc_streams {
   std::vector<St> st;
   std::vector<Run> run;
   std::vector<std::deque<Blk>> bq;
-  std::vector<Job> job;
+  std::vector<Job> job;                    // the OLDEST outstanding chunk of a stream (reported next)
+  std::vector<std::deque<Job>> ahead;      // chunks queued behind it (queue_depth > 1)
+  std::vector<long> job_seq;               // sequence number of the stream's latest chunk
+  int queue_depth = 1;                     // outstanding chunks a stream may have (sc_streams_set_queue_depth)
+  std::vector<Snap> snap;
+  int32_t *snap_yseq = nullptr, *snap_xpos = nullptr;   // [S*W][LCAP]
+  double *snap_score = nullptr;                         // [S*W][3]
+  hipEvent_t ev_snap = nullptr;
   std::vector<std::string> fault_msg;
   std::vector<long> enc_gen;       // group of the stream's latest encoder stage
   std::deque<EncGroup *> groups;   // planned or in flight, oldest first
@@ -275,6 +296,7 @@ struct sc_streams {
       if (ev_group[i]) (void)hipEventDestroy(ev_group[i]);
     for (int i = 0; i < N_STAGE; ++i)
       if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]);
+    if (ev_snap) (void)hipEventDestroy(ev_snap);
     for (EncGroup *g : groups) delete g;
     for (void *p : owned) (void)hipFree(p);
     for (void *p : owned_host) (void)hipHostFree(p);
@@ -344,21 +366,43 @@ __global__ __launch_bounds__(256) void scatter_f32_kernel(const float *__restric
 // live hypotheses of the listed streams -> one packed buffer (sc_get_hyps_batch).  jobs[j] = {hypothesis row
 // ((side*S + s)*W + h), L, destination offset (int32 units), 0}: ids at [off, off+L), positions at [off+L, off+2L),
 // then the three float64 totals (score, decoder, ctc) at the next 8-byte boundary.
-__global__ __launch_bounds__(128) void pack_hyps_kernel(sc_search sb, const int32_t *__restrict__ jobs, int32_t *__restrict__ out) {
+// jobs[j][3] = 1: the row is a row (s*W + h) of the snapshot copies (snap_*) instead of the live state.
+__global__ __launch_bounds__(128) void pack_hyps_kernel(sc_search sb, const int32_t *__restrict__ jobs, int32_t *__restrict__ out,
+                                                        const int32_t *__restrict__ snap_yseq, const int32_t *__restrict__ snap_xpos,
+                                                        const double *__restrict__ snap_score) {
   const int32_t *j = jobs + (size_t)blockIdx.x * 4;
   const size_t row = (size_t)j[0];
   const int L = j[1];
+  const bool snap = j[3] != 0;
   int32_t *o = out + (size_t)j[2];
-  const int32_t *ys = sb.yseq + row * sb.LCAP, *xp = sb.xpos + row * sb.LCAP;
+  const int32_t *ys = (snap ? snap_yseq : sb.yseq) + row * sb.LCAP, *xp = (snap ? snap_xpos : sb.xpos) + row * sb.LCAP;
   for (int i = threadIdx.x; i < L; i += 128) {
     o[i] = ys[i];
     o[L + i] = xp[i];
   }
   if (threadIdx.x == 0) {
     double *sc = (double *)(o + ((2 * L + 1) & ~1));
-    sc[0] = sb.score[row];
-    sc[1] = sb.sc_dec[row];
-    sc[2] = sb.sc_ctc[row];
+    sc[0] = snap ? snap_score[row * 3] : sb.score[row];
+    sc[1] = snap ? snap_score[row * 3 + 1] : sb.sc_dec[row];
+    sc[2] = snap ? snap_score[row * 3 + 2] : sb.sc_ctc[row];
+  }
+}
+
+// live hypotheses of up to 32 streams -> the snapshot copies (grid: entry x hypothesis slot)
+struct SnapArgs { int n; int s[32], cur[32], L[32], nhyp[32]; };
+__global__ __launch_bounds__(128) void snapshot_hyps_kernel(sc_search sb, SnapArgs a, int32_t *__restrict__ snap_yseq,
+                                                            int32_t *__restrict__ snap_xpos, double *__restrict__ snap_score) {
+  const int e = blockIdx.x, h = blockIdx.y;
+  if (h >= a.nhyp[e]) return;
+  const size_t src = ((size_t)a.cur[e] * sb.S + a.s[e]) * sb.W + h, dst = (size_t)a.s[e] * sb.W + h;
+  for (int i = threadIdx.x; i < a.L[e]; i += 128) {
+    snap_yseq[dst * sb.LCAP + i] = sb.yseq[src * sb.LCAP + i];
+    snap_xpos[dst * sb.LCAP + i] = sb.xpos[src * sb.LCAP + i];
+  }
+  if (threadIdx.x == 0) {
+    snap_score[dst * 3] = sb.score[src];
+    snap_score[dst * 3 + 1] = sb.sc_dec[src];
+    snap_score[dst * 3 + 2] = sb.sc_ctc[src];
   }
 }
 
@@ -379,6 +423,7 @@ void reset_stream(sc_streams *b, int s) {
   b->st[s] = ns;
   b->run[s] = Run();
   b->bq[s].clear();
+  b->snap[s] = Snap();
   init_hyp(b, s);
 }
 
@@ -916,11 +961,69 @@ void finish_block(sc_streams *b, int s) {
   r.inblk = false;
 }
 
+// the block the stream is inside cannot go on: the chunk that owns it fails, and with it the chunks queued behind it
+// (blocks run in order: every earlier chunk of the stream has been decoded by then)
 void fault_stream(sc_streams *b, int s, int code, const std::string &msg) {
-  b->job[s].fault = code;
+  const long seq = b->run[s].inblk ? b->run[s].job : b->job[s].seq;
+  bool hit = false;
+  auto mark = [&](Job &j) {
+    if (!j.open) return;
+    if (j.seq == seq) { j.fault = code; hit = true; }
+    else if (hit && !j.fault) { j.fault = code; j.dropped = true; }
+  };
+  mark(b->job[s]);
+  for (Job &j : b->ahead[s]) mark(j);
   b->fault_msg[s] = msg;
   b->run[s] = Run();
   b->bq[s].clear();
+}
+
+inline bool chunk_decoded(const sc_streams *b, int s);
+
+// a block of a LATER chunk of the stream starts only when the hypotheses of the chunk before it have been copied
+// aside (snapshot_completed; queue depth > 1) - until then the stream is held back
+inline bool may_start(const sc_streams *b, int s) {
+  const Job &j = b->job[s];
+  const long q = b->bq[s].front().job;
+  if (!j.open || q <= j.seq) return true;
+  return q == j.seq + 1 && b->snap[s].valid && b->snap[s].seq == j.seq;
+}
+
+// queue depth > 1: the hypotheses of every stream whose oldest chunk has just been decoded -> the snapshot copies, on
+// the batch's stream, i.e. before any later step changes them.  One snapshot per stream: a chunk that completes while
+// the previous one's snapshot has not been handed out yet (sc_poll) waits, and holds the stream's later blocks back.
+int snapshot_completed(sc_streams *b) {
+  if (b->queue_depth <= 1) return SC_OK;
+  SnapArgs a;
+  a.n = 0;
+  bool any = false;
+  auto flush = [&]() -> int {
+    if (!a.n) return SC_OK;
+    snapshot_hyps_kernel<<<dim3(a.n, b->W), 128, 0, b->stream>>>(b->sb, a, b->snap_yseq, b->snap_xpos, b->snap_score);
+    SC_CHECK_LAUNCH();
+    a.n = 0;
+    return SC_OK;
+  };
+  for (int s = 0; s < b->S; ++s) {
+    const Job &j = b->job[s];
+    Snap &sn = b->snap[s];
+    if (!j.open || j.fault || sn.valid || !chunk_decoded(b, s)) continue;
+    const St &x = b->st[s];
+    sn.valid = true;
+    sn.reported = false;
+    sn.seq = j.seq;
+    sn.L = x.L;
+    sn.nhyp = x.started ? x.nhyp : 0;
+    if (sn.nhyp > 0) {
+      a.s[a.n] = s; a.cur[a.n] = x.cur; a.L[a.n] = x.L; a.nhyp[a.n] = x.nhyp;
+      a.n++;
+      any = true;
+      if (a.n == 32) RC_TRY(flush());
+    }
+  }
+  RC_TRY(flush());
+  if (any) HIP_TRY(hipEventRecord(b->ev_snap, b->stream));
+  return SC_OK;
 }
 
 // idle streams whose next block is ready start it: extend_scorers' search-side half (beam_search.py:403-464) -
@@ -930,7 +1033,7 @@ int start_blocks(sc_streams *b) {
   const long gen_ok = std::max(b->gen_done, b->gen_ordered);
   std::vector<int> starts;
   for (int s = 0; s < S; ++s)
-    if (!b->run[s].inblk && !b->bq[s].empty() && b->bq[s].front().gen <= gen_ok) starts.push_back(s);
+    if (!b->run[s].inblk && !b->bq[s].empty() && b->bq[s].front().gen <= gen_ok && may_start(b, s)) starts.push_back(s);
   if (starts.empty()) return SC_OK;
   if (!b->decode_prepared) {
     b->decode_prepared = true;
@@ -947,7 +1050,7 @@ int start_blocks(sc_streams *b) {
     Run &r = b->run[s];
     r = Run();
     r.inblk = r.live = true;
-    r.T = k.T; r.fin = k.fin;
+    r.T = k.T; r.fin = k.fin; r.job = k.job;
     r.cur = x.cur; r.L = x.L; r.nhyp = x.nhyp; r.has = x.has_ctc; r.pidx = x.process_idx; r.pvalid = x.prev_valid;
     const int told = x.T_ctc;
     r.Tc = std::max(k.T, told);   // the CTC table never shrinks (stale table after reset())
@@ -982,6 +1085,7 @@ int tick_issue(sc_streams *b, bool *progress) {
   *progress = false;
   if (b->inflight) RC_TRY(tick_collect(b));
   RC_TRY(retire_groups(b));
+  RC_TRY(snapshot_completed(b));
   RC_TRY(start_blocks(b));
   {
     // a queued block that sees frames of a group which has not even been issued (sc_submit defers and merges the
@@ -1116,11 +1220,19 @@ int engine_tick(sc_streams *b, bool *progress) {
   return tick_collect(b);
 }
 
-// a stream's outstanding chunk is complete: all of its blocks are decoded and its encoder stage has finished
-inline bool chunk_decoded(const sc_streams *b, int s) { return !b->run[s].inblk && b->bq[s].empty(); }
+// a stream's OLDEST outstanding chunk is decoded: the stream is not inside one of its blocks and none is queued
+// (blocks of chunks queued behind it carry a larger Job::seq)
+inline bool chunk_decoded(const sc_streams *b, int s) {
+  const long q = b->job[s].seq;
+  return !(b->run[s].inblk && b->run[s].job <= q) && (b->bq[s].empty() || b->bq[s].front().job > q);
+}
+// ... and can be reported: with a queue depth > 1 its hypotheses must have been copied aside first
 inline bool chunk_complete(const sc_streams *b, int s) {
   const Job &j = b->job[s];
-  return j.open && (j.fault != 0 || chunk_decoded(b, s));
+  if (!j.open) return false;
+  if (j.fault != 0) return true;
+  if (!chunk_decoded(b, s)) return false;
+  return b->queue_depth <= 1 || (b->snap[s].valid && b->snap[s].seq == j.seq);
 }
 
 // ---- admission ------------------------------------------------------------------------------------------------------
@@ -1239,10 +1351,20 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
           chunks.erase(chunks.begin() + k);
           break;
         }
-      b->job[f.stream] = Job();
-      b->job[f.stream].open = true;
-      b->n_open++;
-      fault_stream(b, f.stream, f.code, f.msg);
+      {
+        Job fj;
+        fj.open = true;
+        fj.fault = f.code;
+        fj.seq = ++b->job_seq[f.stream];
+        b->fault_msg[f.stream] = f.msg;
+        if (b->job[f.stream].open) b->ahead[f.stream].push_back(fj);   // the earlier chunks of the stream go on
+        else {
+          b->job[f.stream] = fj;
+          b->run[f.stream] = Run();
+          b->bq[f.stream].clear();
+        }
+        b->n_open++;
+      }
       if (chunks.empty()) { *g = EncGroup(); break; }
     }
   }
@@ -1302,6 +1424,8 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
     gp.reset();
     g = nullptr;
   }
+  std::map<int, long> seq_of;   // the chunks of this admission: their per-stream sequence numbers
+  for (auto &ch : chunks) seq_of[ch.s] = ++b->job_seq[ch.s];
   // decode schedule (beam_search.py:590-634) as per-stream queues; a block that sees frames of this admission waits
   // for the group that carries it
   for (auto &kv : feat_new) {
@@ -1314,18 +1438,21 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
     while (t_avail > 0) {
       const int cur_end = c.block_size - c.look_ahead + c.hop_size * pb;
       if (!(cur_end < t_avail)) break;
-      q.push_back({cur_end, false, cur_end > t_old ? gen : st_gen(b, s)});
+      q.push_back({cur_end, false, cur_end > t_old ? gen : st_gen(b, s), seq_of.at(s)});
       ++pb;
     }
-    if (finals.at(s) && t_avail > 0) q.push_back({t_avail, true, t_avail > t_old ? gen : st_gen(b, s)});
+    if (finals.at(s) && t_avail > 0) q.push_back({t_avail, true, t_avail > t_old ? gen : st_gen(b, s), seq_of.at(s)});
   }
   if (gen)
     for (int s : g->streams) b->enc_gen[s] = gen;
   for (size_t k = 0; k < chunks.size(); ++k) {
-    Job &j = b->job[chunks[k].s];
-    j = Job();
+    Job j;
     j.open = true;
     j.has_out = has_out[k];
+    j.seq = seq_of.at(chunks[k].s);
+    j.fin = chunks[k].fin;
+    if (b->job[chunks[k].s].open) b->ahead[chunks[k].s].push_back(j);   // behind the stream's outstanding chunk(s)
+    else b->job[chunks[k].s] = j;
     b->n_open++;
     if (has_out_by_pos) (*has_out_by_pos)[chunks[k].pos] = has_out[k];
   }
@@ -1356,7 +1483,8 @@ int poison(sc_streams *b, int rc) {
     return SC_ERR_ARG;                                                       \
   }
 
-int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n, const char *what) {
+// depth: outstanding chunks a stream may have INCLUDING the new one (sc_push, sc_push_features: 1)
+int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n, const char *what, int depth = 1) {
   std::vector<char> seen(b->S, 0);
   for (int i = 0; i < n; ++i) {
     if (stream_ids[i] < 0 || stream_ids[i] >= b->S || counts[i] < 0) {
@@ -1368,9 +1496,22 @@ int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n,
       return SC_ERR_ARG;
     }
     seen[stream_ids[i]] = 1;
-    if (b->job[stream_ids[i]].open) {
-      sc_set_error("%s: stream %d still has a chunk outstanding (sc_poll reports it)", what, stream_ids[i]);
+    const int s = stream_ids[i];
+    const int out = (b->job[s].open ? 1 : 0) + (int)b->ahead[s].size();
+    if (out >= depth) {
+      sc_set_error(depth > 1 ? "%s: stream %d already has %d chunks outstanding (the queue depth; sc_poll reports them)"
+                             : "%s: stream %d still has a chunk outstanding (sc_poll reports it)", what, s, out);
       return SC_ERR_ARG;
+    }
+    if (out > 0) {   // queueing behind an outstanding chunk
+      const Job &last = b->ahead[s].empty() ? b->job[s] : b->ahead[s].back();
+      bool failed = b->job[s].fault != 0;
+      for (const Job &j : b->ahead[s]) failed = failed || j.fault != 0;
+      if (last.fin || failed) {
+        sc_set_error("%s: stream %d: nothing can be queued behind %s (sc_poll reports it first)", what, s,
+                     failed ? "a failed chunk" : "a final chunk");
+        return SC_ERR_ARG;
+      }
     }
   }
   return SC_OK;
@@ -1693,6 +1834,9 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->run.assign(S, Run());
   b->bq.assign(S, std::deque<Blk>());
   b->job.assign(S, Job());
+  b->ahead.assign(S, std::deque<Job>());
+  b->job_seq.assign(S, 0);
+  b->snap.assign(S, Snap());
   b->fault_msg.assign(S, std::string());
   b->enc_gen.assign(S, 0);
   for (int s = 0; s < S; ++s) init_hyp(b, s);
@@ -1730,8 +1874,13 @@ namespace {
 int report_chunk(sc_streams *b, int s) {
   Job &j = b->job[s];
   const int status = j.fault ? j.fault : j.has_out;
-  if (j.fault) reset_stream(b, s);   // (fault_msg[s] keeps the message: sc_stream_last_error)
-  j = Job();
+  if (j.fault && !j.dropped) reset_stream(b, s);   // (fault_msg[s] keeps the message: sc_stream_last_error)
+  if (b->snap[s].valid && b->snap[s].seq == j.seq) b->snap[s].reported = true;   // handed out: free at the next sc_poll
+  if (b->ahead[s].empty()) j = Job();
+  else {   // the next chunk of the stream is now its oldest
+    j = b->ahead[s].front();
+    b->ahead[s].pop_front();
+  }
   b->n_open--;
   return status;
 }
@@ -1827,7 +1976,7 @@ extern "C" int sc_submit(sc_streams *b, const int *stream_ids, const float *cons
     return SC_ERR_LAUNCH;
   }
   HIP_TRY(hipSetDevice(b->eng->device));
-  RC_TRY(check_chunks(b, stream_ids, n_samples, n, "sc_submit"));
+  RC_TRY(check_chunks(b, stream_ids, n_samples, n, "sc_submit", b->queue_depth));
   if (n == 0) return SC_OK;
   std::vector<Chunk> chunks;
   for (int i = 0; i < n; ++i) chunks.push_back({stream_ids[i], pcm ? pcm[i] : nullptr, n_samples[i], is_final[i] != 0, i});
@@ -1850,10 +1999,13 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
   }
   HIP_TRY(hipSetDevice(b->eng->device));
   min_done = std::min(std::min(min_done, max_done), b->n_open);
+  for (Snap &sn : b->snap)   // the hypotheses handed out by the previous call have been read: their copies are free
+    if (sn.valid && sn.reported) sn.valid = false;
   int stalled = 0;
   while (true) {
     int rc = tick_collect(b);   // the step enqueued by the previous call (or iteration)
     if (rc == SC_OK) rc = retire_groups(b);
+    if (rc == SC_OK) rc = snapshot_completed(b);
     if (rc != SC_OK) return poison(b, rc);
     int n_complete = 0;
     for (int s = 0; s < b->S; ++s) n_complete += chunk_complete(b, s) ? 1 : 0;
@@ -1869,6 +2021,7 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
     }
     if (enough) break;
     if (b->inflight || progress) stalled = 0;
+    else if (n_complete > 0 && b->queue_depth > 1) break;   // the rest waits for these replies to be handed out (one snapshot per stream)
     else if (++stalled > 1) {   // (once: blocks that were closed without a step change the count above)
       sc_set_error("sc_poll: schedule stalled (internal error)");
       return poison(b, SC_ERR_LAUNCH);
@@ -1887,6 +2040,30 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
 }
 
 extern "C" int sc_streams_outstanding(const sc_streams *b) { return b ? b->n_open : 0; }
+
+// Chunks a stream may have outstanding at a time (default 1: the reference's call -> reply -> next call).  depth > 1:
+// sc_submit accepts the NEXT chunk(s) of a stream while an earlier one is still being decoded - a host that has the
+// audio already (a file, a backlog) lets the frontend + encoder of chunk k+1 run beside the decoding of chunk k, so
+// that the stream does not idle between its reply and its next call.  Chunks of a stream are processed and reported
+// in order, one per sc_poll call; per chunk the results are those of the one-at-a-time protocol.  The hypotheses of a
+// reported chunk are a copy taken when it completed: sc_get_hyps / sc_get_hyps_batch return them until the NEXT
+// sc_poll call.  Nothing can be queued behind a final or a failed chunk; a failure fails the chunks queued behind it.
+extern "C" int sc_streams_set_queue_depth(sc_streams *b, int depth) {
+  SC_CHECK_ARG(b && depth >= 1 && depth <= 8, "bad arguments");
+  SC_API_BEGIN
+  SC_CHECK_ARG(b->n_open == 0, "chunks are outstanding");
+  HIP_TRY(hipSetDevice(b->eng->device));
+  if (depth > 1 && !b->snap_yseq) {
+    RC_TRY(b->alloc(&b->snap_yseq, (size_t)b->S * b->W * b->LCAP));
+    RC_TRY(b->alloc(&b->snap_xpos, (size_t)b->S * b->W * b->LCAP));
+    RC_TRY(b->alloc(&b->snap_score, (size_t)b->S * b->W * 3));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_snap, hipEventDisableTiming));
+  }
+  for (Snap &sn : b->snap) sn = Snap();
+  b->queue_depth = depth;
+  return SC_OK;
+  SC_API_END
+}
 
 // sc_submit policy: the frontend + encoder stages of successive admissions are merged and issued as ONE group when it
 // holds min_streams streams (default: half of the streams), or as soon as a queued decode block needs its frames.
@@ -1927,9 +2104,22 @@ extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, in
   HIP_TRY(hipSetDevice(b->eng->device));
   std::vector<int32_t> jobs;
   size_t off = 0;
+  bool from_snapshot = false;
   for (int i = 0; i < n; ++i) {
     const int s = stream_ids[i];
     SC_CHECK_ARG(s >= 0 && s < b->S, "stream out of range");
+    const Snap &sn = b->snap[s];
+    if (sn.valid) {   // queue depth > 1: the copy taken when the stream's last reported chunk completed
+      const int nh = std::min(nbest, sn.nhyp);
+      n_hyps[i] = nh;
+      SC_CHECK_ARG(nh == 0 || (!ids && !xpos) || max_len >= sn.L, "max_len is smaller than the hypotheses");
+      for (int h = 0; h < nh; ++h) {
+        jobs.insert(jobs.end(), {(int32_t)((size_t)s * b->W + h), sn.L, (int32_t)off, 1});
+        off += (size_t)((2 * sn.L + 1) & ~1) + 6;
+      }
+      from_snapshot = true;
+      continue;
+    }
     SC_CHECK_ARG(!b->run[s].inblk && b->bq[s].empty(), "stream is inside a decode block (its chunk has not been reported yet)");
     const St &st = b->st[s];
     const int nh = st.started ? std::min(nbest, st.nhyp) : 0;
@@ -1947,7 +2137,8 @@ extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, in
   // on the read-back stream: a decode step of OTHER streams may be in flight on the batch's stream (sc_poll); the
   // listed streams' last steps have been collected (host-synchronised) by then
   HIP_TRY(hipMemcpyAsync(b->pjobs_dev, b->pjobs_host, jobs.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream_rb));
-  pack_hyps_kernel<<<m, 128, 0, b->stream_rb>>>(b->sb, b->pjobs_dev, b->pack_dev);
+  if (from_snapshot) HIP_TRY(hipStreamWaitEvent(b->stream_rb, b->ev_snap, 0));   // the copies are written on the batch's stream
+  pack_hyps_kernel<<<m, 128, 0, b->stream_rb>>>(b->sb, b->pjobs_dev, b->pack_dev, b->snap_yseq, b->snap_xpos, b->snap_score);
   HIP_TRY(hipMemcpyAsync(b->pack_host, b->pack_dev, off * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream_rb));
   HIP_TRY(hipStreamSynchronize(b->stream_rb));
   int k = 0;

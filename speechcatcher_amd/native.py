@@ -255,6 +255,14 @@ class NativeStreamBatch:
         many streams (or as soon as a decode block needs its frames); results do not depend on it"""
         _abi.check(self.lib.sc_streams_set_encoder_batch(self.handle, int(min_streams)), "sc_streams_set_encoder_batch")
 
+    def set_queue_depth(self, depth: int):
+        """chunks a stream may have outstanding (default 1: call -> reply -> next call).  depth > 1: ``submit`` accepts the
+        next chunk(s) of a stream while an earlier one is still decoding (file / backlog hosts: the encoder of chunk k+1
+        runs beside the decoding of chunk k); chunks are reported in order, one per ``poll`` and stream, with the same
+        results, and the hypotheses of a reported chunk stay readable until the next ``poll``"""
+        _abi.check(self.lib.sc_streams_set_queue_depth(self.handle, int(depth)), "sc_streams_set_queue_depth")
+        self.queue_depth = int(depth)
+
     @property
     def outstanding(self) -> int:
         return int(self.lib.sc_streams_outstanding(self.handle))

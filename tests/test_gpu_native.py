@@ -265,6 +265,146 @@ def test_native_random_sessions_equal_the_python_engine(seed, bbd, continuous, s
     assert longest > 30 and resets >= 5, (longest, resets)   # the sessions did decode and did end
 
 
+@pytest.mark.parametrize("seed,bbd,depth", [(0, False, 2), (1, True, 3), (2, False, 4), (3, True, 2)])
+def test_native_queued_chunks_equal_one_at_a_time(seed, bbd, depth):
+    """sc_streams_set_queue_depth > 1: a host that has the audio already hands a stream's next chunk(s) to the engine
+    while an earlier one is still being decoded.  12 streams of random utterances (random chunk lengths, final chunks,
+    resets, new utterances on the same slot), submitted ahead up to the depth in random subsets and polled in random
+    portions: EVERY reply - has-output flag and all hypotheses, read between the polls while the stream's next chunk is
+    already decoding - equals the reply of the one-call-at-a-time protocol (sc_push) for that chunk."""
+    from speechcatcher_amd.engine import EngineError
+    from test_engine_spec import make_batch
+    S, beam = 12, 5
+    kw = dict(n_streams=S, max_frames=400, max_tokens=400, pcm_capacity=1 << 17, strict_reference=False)
+    ref = make_batch("TINY", 1234, "meanstd", beam, bbd, backend="native", **kw)
+    que = make_batch("TINY", 1234, "meanstd", beam, bbd, backend="native", **kw)
+    que.set_queue_depth(depth)
+    rng = np.random.default_rng(100 + seed)
+    # per stream: utterances = lists of (samples, is_final)
+    plan, expect = [], []
+    for s in range(S):
+        chunks = []
+        for u in range(int(rng.integers(1, 4))):
+            n_chunks = int(rng.integers(2, 9))
+            lens = [int(rng.choice([700, 1600, 4000, 8192, 10240, 16000])) for _ in range(n_chunks)]
+            audio = synth.synth_audio(1000 * seed + 10 * s + u, sum(lens))
+            pos = 0
+            for k, n in enumerate(lens):
+                chunks.append((audio[pos:pos + n], k == n_chunks - 1))
+                pos += n
+        plan.append(chunks)
+        rec = []
+        for pcm, fin in chunks:                       # the one-at-a-time protocol on this stream
+            out = ref.push([(s, pcm, fin)])
+            rec.append((bool(out[s]), ref.hypotheses(s)))
+            if fin:
+                ref.reset(s)
+        expect.append(rec)
+    sub = [0] * S      # chunks submitted
+    rep = [0] * S      # chunks reported
+    wait_reset = [False] * S
+    n_ahead, longest = 0, 0
+    while any(rep[s] < len(plan[s]) for s in range(S)):
+        for _ in range(depth):                         # one chunk per stream and call: up to `depth` calls
+            items = []
+            for s in range(S):
+                if sub[s] - rep[s] < depth and sub[s] < len(plan[s]) and not wait_reset[s] and rng.random() < 0.8:
+                    pcm, fin = plan[s][sub[s]]
+                    items.append((s, pcm, fin))
+                    n_ahead += sub[s] > rep[s]
+                    sub[s] += 1
+                    wait_reset[s] = fin                # nothing behind a final chunk: wait for its reply, then reset
+            if items:
+                que.submit(items)
+        if not que.outstanding:
+            continue
+        got = que.poll(int(rng.integers(1, 4)))
+        assert got
+        for s, has in got.items():
+            exp_has, exp_hyps = expect[s][rep[s]]
+            assert not isinstance(has, Exception), (s, has)
+            assert bool(has) == exp_has, (s, rep[s])
+            hy = que.hypotheses(s)
+            assert [(h["yseq"], h["xpos"]) for h in hy] == [(h["yseq"], h["xpos"]) for h in exp_hyps], (s, rep[s])
+            for x, y in zip(hy, exp_hyps):
+                assert abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(y["score"])), (s, rep[s])
+            longest = max([longest] + [len(h["yseq"]) for h in hy])
+            fin = plan[s][rep[s]][1]
+            rep[s] += 1
+            if fin:
+                assert sub[s] == rep[s]
+                que.reset(s)
+                wait_reset[s] = False
+    assert n_ahead > 20 and longest > 20, (n_ahead, longest)      # chunks WERE queued behind outstanding ones
+    # the rules: no more than `depth` outstanding, nothing behind a final chunk
+    que.submit([(0, synth.synth_audio(7, 8192), False)])
+    for _ in range(depth - 1):
+        que.submit([(0, synth.synth_audio(7, 8192), True if _ == depth - 2 else False)])
+    with pytest.raises(EngineError, match="outstanding"):
+        que.submit([(0, synth.synth_audio(7, 8192), False)])
+    while que.outstanding:
+        que.poll(1)
+    que.reset(0)
+    que.submit([(0, synth.synth_audio(7, 8192), True)])
+    with pytest.raises(EngineError, match="final chunk"):
+        que.submit([(0, synth.synth_audio(7, 8192), False)])
+    while que.outstanding:
+        que.poll(1)
+
+
+def test_native_queued_chunks_and_failures():
+    """queue depth 3 and failures: (a) a chunk that cannot be admitted (longer than max_chunk_samples) fails alone when
+    it is reported, in order, after the good chunk before it; nothing can be queued behind it; (b) a chunk that fails
+    while decoding (max_tokens exceeded) takes the chunks queued behind it with it.  Other streams are not affected and
+    the failed streams work again after their reset."""
+    from speechcatcher_amd.engine import EngineError
+    from test_engine_spec import make_batch
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", n_streams=3, max_frames=400, max_tokens=48,
+                    pcm_capacity=1 << 18, strict_reference=False, max_chunk_samples=20000)
+    one = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", n_streams=1, max_frames=400, max_tokens=48,
+                     pcm_capacity=1 << 18, strict_reference=False, max_chunk_samples=20000)
+    sb.set_queue_depth(3)
+    a = synth.synth_audio(11, 10240 * 12)
+    # (a) stream 0: good, too long, (refused)
+    sb.submit([(0, a[:10240], False)])
+    sb.submit([(0, a[10240:10240 + 30000], False)])
+    with pytest.raises(EngineError, match="failed chunk"):
+        sb.submit([(0, a[:8192], False)])
+    # (b) stream 1: chunks until its hypotheses outgrow max_tokens, three in the queue at a time; stream 2: healthy
+    sb.submit([(2, a[:10240], False)])
+    got, k1, failed_at = {0: [], 1: [], 2: []}, 0, None
+    while failed_at is None or sb.outstanding:
+        while failed_at is None and k1 < 12 and (k1 - len(got[1])) < 3:
+            try:
+                sb.submit([(1, a[k1 * 10240:(k1 + 1) * 10240], False)])
+            except EngineError:
+                break                                   # (behind a chunk that has failed by now)
+            k1 += 1
+        for s, r in sb.poll(1).items():
+            got[s].append(r)
+            if s == 1 and isinstance(r, Exception) and failed_at is None:
+                failed_at = len(got[1]) - 1
+    assert got[0][0] is True and isinstance(got[0][1], EngineError) and "max_chunk_samples" in str(got[0][1])
+    assert got[2] == [True]
+    assert failed_at is not None and failed_at >= 2 and "max_tokens" in str(got[1][failed_at])
+    assert all(r is True or r is False for r in got[1][:failed_at])
+    assert all(isinstance(r, Exception) for r in got[1][failed_at:]) and len(got[1]) == k1   # the queued ones went with it
+    # the one-at-a-time protocol fails at the same chunk
+    for k in range(failed_at + 1):
+        r = one.push([(0, a[k * 10240:(k + 1) * 10240], False)], isolate_faults=True)[0]
+        assert isinstance(r, Exception) == (k == failed_at), k
+    # all three streams go on (0 and 1 were reset by their failures)
+    for s in range(3):
+        sb.submit([(s, a[:10240], False)])
+    while sb.outstanding:
+        for s, r in sb.poll(3).items():
+            assert r is True, (s, r)
+    one.reset(0)
+    one.push([(0, a[:10240], False)])
+    assert [h["yseq"] for h in sb.hypotheses(0)] == [h["yseq"] for h in one.hypotheses(0)]
+    assert [h["yseq"] for h in sb.hypotheses(1)] == [h["yseq"] for h in one.hypotheses(0)]
+
+
 def test_native_xl_batch_equals_python_engine():
     """XL dims, 12 streams: the C++ engine and the Python engine (same kernels) end with identical hypotheses."""
     from speechcatcher_amd.hip_backend import HipBackend
