@@ -1505,11 +1505,8 @@ int check_chunks(sc_streams *b, const int *stream_ids, const int *counts, int n,
     }
     if (out > 0) {   // queueing behind an outstanding chunk
       const Job &last = b->ahead[s].empty() ? b->job[s] : b->ahead[s].back();
-      bool failed = b->job[s].fault != 0;
-      for (const Job &j : b->ahead[s]) failed = failed || j.fault != 0;
-      if (last.fin || failed) {
-        sc_set_error("%s: stream %d: nothing can be queued behind %s (sc_poll reports it first)", what, s,
-                     failed ? "a failed chunk" : "a final chunk");
+      if (last.fin && !last.fault) {
+        sc_set_error("%s: stream %d: nothing can be queued behind a final chunk (sc_poll reports it first)", what, s);
         return SC_ERR_ARG;
       }
     }
@@ -1979,7 +1976,24 @@ extern "C" int sc_submit(sc_streams *b, const int *stream_ids, const float *cons
   RC_TRY(check_chunks(b, stream_ids, n_samples, n, "sc_submit", b->queue_depth));
   if (n == 0) return SC_OK;
   std::vector<Chunk> chunks;
-  for (int i = 0; i < n; ++i) chunks.push_back({stream_ids[i], pcm ? pcm[i] : nullptr, n_samples[i], is_final[i] != 0, i});
+  for (int i = 0; i < n; ++i) {
+    const int s = stream_ids[i];
+    int failed = b->job[s].open ? b->job[s].fault : 0;
+    for (const Job &j : b->ahead[s])
+      if (j.fault) failed = j.fault;
+    if (failed) {   // queued behind a chunk that has failed (the host cannot know yet): it fails with it, reported in order
+      Job j;
+      j.open = true;
+      j.fault = failed;
+      j.dropped = true;
+      j.seq = ++b->job_seq[s];
+      b->ahead[s].push_back(j);
+      b->n_open++;
+      continue;
+    }
+    chunks.push_back({s, pcm ? pcm[i] : nullptr, n_samples[i], is_final[i] != 0, i});
+  }
+  if (chunks.empty()) return SC_OK;
   const int rc = admit(b, chunks, false, /*launch_now=*/true, nullptr);
   return rc == SC_OK ? SC_OK : poison(b, rc);
   SC_API_END
@@ -2047,7 +2061,7 @@ extern "C" int sc_streams_outstanding(const sc_streams *b) { return b ? b->n_ope
 // that the stream does not idle between its reply and its next call.  Chunks of a stream are processed and reported
 // in order, one per sc_poll call; per chunk the results are those of the one-at-a-time protocol.  The hypotheses of a
 // reported chunk are a copy taken when it completed: sc_get_hyps / sc_get_hyps_batch return them until the NEXT
-// sc_poll call.  Nothing can be queued behind a final or a failed chunk; a failure fails the chunks queued behind it.
+// sc_poll call.  Nothing can be queued behind a final chunk; a failure fails the chunks queued behind it.
 extern "C" int sc_streams_set_queue_depth(sc_streams *b, int depth) {
   SC_CHECK_ARG(b && depth >= 1 && depth <= 8, "bad arguments");
   SC_API_BEGIN

@@ -292,7 +292,8 @@ class NativeStreamBatch:
         nb = self.W if nbest is None else int(nbest)
         sid = np.ascontiguousarray(streams, dtype=np.int32)
         n = len(sid)
-        lmax = max([1] + [self.st[int(s)].L for s in sid]) if n <= 4 else self.LCAP
+        # (queue depth > 1: the copies taken at completion may be longer than the stream's live hypotheses)
+        lmax = max([1] + [self.st[int(s)].L for s in sid]) if n <= 4 and getattr(self, "queue_depth", 1) <= 1 else self.LCAP
         ids = np.zeros((n, nb, lmax), np.int32)
         xp = np.zeros((n, nb, lmax), np.int32)
         lens = np.zeros((n, nb), np.int32)

@@ -31,8 +31,13 @@ class ServerBusy(RuntimeError):
 
 class StreamScheduler:
     def __init__(self, batch: StreamBatch, token_list: Optional[List[str]] = None,
-                 result_format: str = "native", reset_after_final: bool = True, reset_on_open: bool = True):
-        """``reset_after_final`` / ``reset_on_open`` (default True): a finalised utterance and a newly opened
+                 result_format: str = "native", reset_after_final: bool = True, reset_on_open: bool = True,
+                 queue_depth: int = 1):
+        """``queue_depth`` > 1 (C++ engine, ``pump``): up to that many queued chunks of a session are handed to the engine
+        at a time (sc_streams_set_queue_depth) - for sessions whose audio is already there (files): the encoder stage of
+        the next chunk runs beside the decoding of the current one.  Replies and their order per session do not change.
+
+        ``reset_after_final`` / ``reset_on_open`` (default True): a finalised utterance and a newly opened
         session start from a reset stream - what the reference CLI does (speechcatcher.py:618-619).  The
         reference SERVER does neither (speechcatcher_server.py:270,364-397: no reset after is_final=True, models
         go back to the pool as they are); ``ServerLoop(strict_reference=True)`` switches both off to reproduce
@@ -44,8 +49,13 @@ class StreamScheduler:
         self._free: Deque[int] = deque(range(batch.S))
         self._slot_of: Dict[int, int] = {}
         self._queue: Dict[int, Deque[Tuple[np.ndarray, bool, bool]]] = {}
-        self._in_flight: Dict[int, Tuple[int, bool, bool]] = {}     # continuous batching: session -> (slot, final, finalize_all)
+        # continuous batching: session -> its chunks at the engine, oldest first: (slot, final, finalize_all)
+        self._in_flight: Dict[int, Deque[Tuple[int, bool, bool]]] = {}
         self._stash: Dict[int, list] = {}                           # replies that became ready inside close()
+        self.queue_depth = 1
+        if queue_depth > 1 and hasattr(batch, "set_queue_depth"):
+            batch.set_queue_depth(queue_depth)
+            self.queue_depth = queue_depth
         self._next_sid = 0
 
     # ---- session lifecycle -------------------------------------------------
@@ -62,8 +72,8 @@ class StreamScheduler:
         return sid
 
     def close(self, sid: int):
-        while sid in self._in_flight:        # its chunk must be reported before the slot can be reset;
-            for k, v in self.pump(1, _collect=False).items():   # replies of OTHER sessions wait for their pump()
+        while sid in self._in_flight:        # its chunks must be reported before the slot can be reset;
+            for k, v in self.pump(1, _collect=False, _feed=False).items():   # replies of OTHER sessions wait for their pump()
                 if k != sid:
                     self._stash[k] = v
         slot = self._slot_of.pop(sid)
@@ -85,9 +95,14 @@ class StreamScheduler:
         return sum(1 for sid, q in self._queue.items() if q or sid in self._in_flight or sid in self._stash)
 
     def _take_queued(self, skip=()):
+        """the next queued chunk of every session that may hand one over: none at the engine (``skip`` = the sessions
+        that have), or - queue depth > 1 - fewer than the depth and no final chunk among them"""
         items, meta = [], {}
         for sid, q in self._queue.items():
-            if q and sid not in skip:
+            fl = skip.get(sid) if isinstance(skip, dict) else (True if sid in skip else None)
+            if fl is not None and (self.queue_depth <= 1 or len(fl) >= self.queue_depth or fl[-1][1]):
+                continue
+            if q:
                 pcm, fin, fa = q.popleft()
                 slot = self._slot_of[sid]
                 items.append((slot, pcm, fin))
@@ -139,7 +154,7 @@ class StreamScheduler:
         return self._results(has, meta)
 
     # ---- continuous batching ------------------------------------------------------
-    def pump(self, min_done: int = 1, _collect: bool = True) -> Dict[int, list]:
+    def pump(self, min_done: int = 1, _collect: bool = True, _feed: bool = True) -> Dict[int, list]:
         """Continuous batching (C++ engine: sc_submit / sc_poll).  Hands the engine the next queued chunk of every
         session that has none in flight - ONE admission group - and then lets it decode until at least ``min_done``
         replies are ready.  A session's reply is delivered when ITS decode blocks are done: sessions that finish
@@ -149,19 +164,26 @@ class StreamScheduler:
         speechcatcher_server.py:359-397).  Returns {session: results} of the replies that became ready."""
         if not hasattr(self.batch, "submit"):
             return self.step()                      # the Python engine has no resumable decode loop any more
-        items, meta = self._take_queued(skip=self._in_flight)
-        if items:
+        for _ in range(self.queue_depth if _feed else 0):     # one chunk per session and submit call
+            items, meta = self._take_queued(skip=self._in_flight)
+            if not items:
+                break
             self.batch.submit(items)
             for sid, m in meta.items():
-                self._in_flight[sid] = m
+                self._in_flight.setdefault(sid, deque()).append(m)
         out: Dict[int, list] = {}
         if _collect and self._stash:
             out, self._stash = self._stash, {}
         if not self._in_flight or len(out) >= min_done:
             return out
         has = self.batch.poll(max(1, min(min_done - len(out), len(self._in_flight))), isolate_faults=True)
-        sid_of = {m[0]: sid for sid, m in self._in_flight.items()}
-        done = {sid_of[slot]: self._in_flight.pop(sid_of[slot]) for slot in has}
+        sid_of = {fl[0][0]: sid for sid, fl in self._in_flight.items()}
+        done = {}
+        for slot in has:                       # one reply per session and poll: that of its OLDEST chunk at the engine
+            sid = sid_of[slot]
+            done[sid] = self._in_flight[sid].popleft()
+            if not self._in_flight[sid]:
+                del self._in_flight[sid]
         out.update(self._results(has, done))
         return out
 
@@ -205,7 +227,9 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
     is_final=finalize_all=True.  Token timestamps follow the reference's
     convention: encoder-frame position / 24.0 s + segment start
     (speechcatcher.py:48,509-536)."""
-    sch = StreamScheduler(batch, token_list, result_format="espnet")
+    # (C++ engine: two chunks of a segment at the engine - the audio is all there, the encoder stage of the next chunk runs
+    # beside the decoding of the current one)
+    sch = StreamScheduler(batch, token_list, result_format="espnet", queue_depth=2)
     out: List[Optional[dict]] = [None] * len(segments)
     todo = list(enumerate(segments))
     sid_to_seg: Dict[int, int] = {}
@@ -227,7 +251,7 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
         for sid, res in sch.pump().items():
             if isinstance(res, Exception):
                 raise res
-            if not sch._queue[sid]:          # that was the final chunk of the session
+            if not sch._queue[sid] and sid not in sch._in_flight:    # that was the final chunk of the session
                 idx = sid_to_seg.pop(sid)
                 start_s = segments[idx][0] / 16000.0
                 if res:
