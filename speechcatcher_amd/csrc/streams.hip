@@ -1905,6 +1905,7 @@ int push_impl(sc_streams *b, const int *stream_ids, const float *const *host, co
   }
   HIP_TRY(hipSetDevice(b->eng->device));
   RC_TRY(check_chunks(b, stream_ids, counts, n, what));
+  for (int i = 0; i < n; ++i) b->snap[stream_ids[i]] = Snap();   // (queue depth > 1) a new call supersedes the copy of the last reply
   std::vector<Chunk> chunks;
   std::vector<int> streams, has_out(n, 0);
   for (int i = 0; i < n; ++i) {

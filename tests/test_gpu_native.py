@@ -352,6 +352,42 @@ def test_native_queued_chunks_equal_one_at_a_time(seed, bbd, depth):
         que.poll(1)
 
 
+def test_native_queue_depth_with_lock_step_calls_and_late_reads():
+    """queue depth 2 on a batch that is ALSO driven with sc_push, and hypotheses read late: a push supersedes the copy
+    of the stream's last polled reply (its hypotheses are the live ones again), and a polled reply stays readable while
+    the stream's next chunk - already queued - is decoding."""
+    from test_engine_spec import make_batch
+    kw = dict(n_streams=2, max_frames=400, max_tokens=400, pcm_capacity=1 << 17, strict_reference=False)
+    one = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", **kw)
+    two = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", **kw)
+    two.set_queue_depth(2)
+    a = synth.synth_audio(31, 10240 * 8)
+    ck = [a[k * 10240:(k + 1) * 10240] for k in range(8)]
+    exp = []
+    for k in range(8):
+        one.push([(0, ck[k], False)])
+        exp.append([(h["yseq"], h["xpos"]) for h in one.hypotheses(0)])
+    ids = lambda sb: [(h["yseq"], h["xpos"]) for h in sb.hypotheses(0)]   # noqa: E731
+    two.push([(0, ck[0], False)])
+    assert ids(two) == exp[0]
+    two.submit([(0, ck[1], False)])
+    two.submit([(0, ck[2], False)])                   # queued behind chunk 1
+    assert list(two.poll(1)) == [0] and ids(two) == exp[1]      # chunk 2 may be decoding by now
+    assert list(two.poll(1)) == [0] and ids(two) == exp[2]
+    two.push([(0, ck[3], False)])                     # lock-step again: live hypotheses, not the copy of chunk 2's reply
+    assert ids(two) == exp[3]
+    two.push([(0, ck[4], False)])
+    assert ids(two) == exp[4]
+    two.submit([(0, ck[5], False)])
+    two.submit([(0, ck[6], False)])
+    two.submit([(1, ck[0], False)])
+    got = {}
+    while two.outstanding:
+        for s in two.poll(1):
+            got.setdefault(s, []).append([(h["yseq"], h["xpos"]) for h in two.hypotheses(s)])
+    assert got[0] == [exp[5], exp[6]] and got[1] == [exp[0]]
+
+
 def test_native_queued_chunks_and_failures():
     """queue depth 3 and failures: (a) a chunk that cannot be admitted (longer than max_chunk_samples) is reported as
     failed in its turn, after the good chunk before it, and so is the chunk queued behind it; (b) a chunk that fails
