@@ -521,8 +521,9 @@ int sc_streams_set_encoder_batch(sc_streams *streams, int min_streams);
  * order, at most one per sc_poll call, each with the results of the one-at-a-time protocol; the hypotheses of a
  * reported chunk are a copy taken when it completed, returned by sc_get_hyps / sc_get_hyps_batch until the NEXT
  * sc_poll call.  Nothing can be queued behind a final chunk; a chunk that fails (at admission or while decoding)
- * fails the chunks queued behind it as well - each is reported in its turn, the stream is reset once.  The depth can
- * only be changed while nothing is outstanding. */
+ * fails the chunks queued behind it as well - each is reported in its turn (also those submitted before the last of
+ * them has been reported), the stream is reset once, when the chunk that failed is reported.  The depth can only be
+ * changed while nothing is outstanding.  sc_push on such a handle works as always (it needs the stream idle). */
 int sc_streams_set_queue_depth(sc_streams *streams, int depth);
 /* message of the stream's last failure (status < 0 from sc_push / sc_poll); "" if it never failed */
 const char *sc_stream_last_error(const sc_streams *streams, int stream);
