@@ -42,6 +42,9 @@ extern "C" {
 #define SC_GEMM_RESIDUAL 2
 #define SC_GEMM_LN_AT_CROWS 8 /* sc_gemm_ln: ln_out rows follow c_rows instead of 0..M-1 */
 #define SC_GEMM_NAIVE 4 /* force the scalar reference kernel (debugging) */
+#define SC_GEMM_SPLIT16 16 /* tiled kernels only: fp16 hi | lo split of both operands when the tiles are staged, three fp16
+                              MFMAs per product sum, fp32 accumulation - fp32-grade results at a fraction of the f32
+                              matrix-pipe time (see sc_ffn_ln_s); the small-M kernels ignore it */
 
 /* beam_prune stop flags (one int32 per stream) */
 #define SC_F_ANY_EOS 1

@@ -17,6 +17,15 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// fp16 hi | lo split of four fp32 values: hi = fp16(x), lo = fp16((x - hi) * 2^11) - see ffn_fused_kernel (WF = 2)
+__device__ __forceinline__ void ffn_split4(const float4 &x, h16x4 &hi, h16x4 &lo) {
+  hi = h16x4{(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+  lo = h16x4{(_Float16)((x.x - (float)hi[0]) * 2048.f), (_Float16)((x.y - (float)hi[1]) * 2048.f),
+             (_Float16)((x.z - (float)hi[2]) * 2048.f), (_Float16)((x.w - (float)hi[3]) * 2048.f)};
+}
 
 struct GemmArgs {
   const float *A;
@@ -40,16 +49,23 @@ __device__ __forceinline__ long gemm_kofs(const GemmArgs &g, int k0) {
   return k0;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32>
+// SPLIT (flag SC_GEMM_SPLIT16): the same product sums on the fp16 matrix pipe - both tiles are split into fp16 hi | lo
+// when they are staged into LDS (k-contiguous rows instead of the transposed fp32 tiles), three
+// v_mfma_f32_32x32x16_f16 per 16 k values instead of eight v_mfma_f32_32x32x2_f32 (see ffn_fused_kernel, WF = 2).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK = 32, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
   constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
   constexpr int KQ = BK / 4;            // float4 per K row of a tile
   constexpr int RP = 256 / KQ;          // tile rows loaded per pass of the 256 threads
   constexpr int AI = BM / RP, BI = BN / RP;
+  constexpr int LDH = BK + 8;           // SPLIT: row stride (fp16 elements) of the k-contiguous hi / lo tiles
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-  __shared__ float As[BK * LDA_S];
-  __shared__ float Bs[BK * LDB_S];
+  static_assert(!SPLIT || BK == 32, "the split form stages 32-wide K tiles");
+  constexpr size_t SM_BYTES = SPLIT ? (size_t)(BM + BN) * LDH * 2 * sizeof(_Float16) : (size_t)BK * (LDA_S + LDB_S) * sizeof(float);
+  __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[SM_BYTES];
+  float *As = reinterpret_cast<float *>(gemm_smem), *Bs = As + BK * LDA_S;
+  _Float16 *AsH = reinterpret_cast<_Float16 *>(gemm_smem), *AsL = AsH + BM * LDH, *BsH = AsL + BM * LDH, *BsL = BsH + BN * LDH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -94,12 +110,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 
   f32x16 acc[TM][TN];
+  f32x16 accc[SPLIT ? TM : 1][SPLIT ? TN : 1];   // SPLIT: the 2^11-scaled cross terms
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if (SPLIT) accc[i][j][r] = 0.f;
+      }
 
   float4 ra[AI], rb[BI];
 
@@ -114,21 +134,38 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
   }
 
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      float *p = As + (kq * 4) * LDA_S + lr + RP * i;
-      p[0] = ra[i].x * amask[i];
-      p[LDA_S] = ra[i].y * amask[i];
-      p[2 * LDA_S] = ra[i].z * amask[i];
-      p[3 * LDA_S] = ra[i].w * amask[i];
-    }
+      for (int i = 0; i < AI; ++i) {
+        h16x4 hi, lo;
+        ffn_split4(make_float4(ra[i].x * amask[i], ra[i].y * amask[i], ra[i].z * amask[i], ra[i].w * amask[i]), hi, lo);
+        *reinterpret_cast<h16x4 *>(AsH + (lr + RP * i) * LDH + kq * 4) = hi;
+        *reinterpret_cast<h16x4 *>(AsL + (lr + RP * i) * LDH + kq * 4) = lo;
+      }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      float *p = Bs + (kq * 4) * LDB_S + lr + RP * i;
-      p[0] = rb[i].x;
-      p[LDB_S] = rb[i].y;
-      p[2 * LDB_S] = rb[i].z;
-      p[3 * LDB_S] = rb[i].w;
+      for (int i = 0; i < BI; ++i) {
+        h16x4 hi, lo;
+        ffn_split4(rb[i], hi, lo);
+        *reinterpret_cast<h16x4 *>(BsH + (lr + RP * i) * LDH + kq * 4) = hi;
+        *reinterpret_cast<h16x4 *>(BsL + (lr + RP * i) * LDH + kq * 4) = lo;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        float *p = As + (kq * 4) * LDA_S + lr + RP * i;
+        p[0] = ra[i].x * amask[i];
+        p[LDA_S] = ra[i].y * amask[i];
+        p[2 * LDA_S] = ra[i].z * amask[i];
+        p[3 * LDA_S] = ra[i].w * amask[i];
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        float *p = Bs + (kq * 4) * LDB_S + lr + RP * i;
+        p[0] = rb[i].x;
+        p[LDB_S] = rb[i].y;
+        p[2 * LDB_S] = rb[i].z;
+        p[3 * LDB_S] = rb[i].w;
+      }
     }
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch the next K tile into registers
@@ -140,22 +177,58 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       for (int i = 0; i < BI; ++i)
         rb[i] = *reinterpret_cast<const float4 *>(g.W + wbase[i] + (k0 + BK) + kq * 4);
     }
-    const float *ap = As + (lane >> 5) * LDA_S + wm * (TM * 32) + (lane & 31);
-    const float *bp = Bs + (lane >> 5) * LDB_S + wn * (TN * 32) + (lane & 31);
+    if constexpr (SPLIT) {   // lane l: row l % 32 of a 32-row tile, the 8 k values 8 * (l / 32) .. of a 16-wide k step
+      const int ro = (lane & 31) * LDH + (lane >> 5) * 8;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+      for (int ks = 0; ks < BK; ks += 16) {
+        h16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = ap[kk * LDA_S + i * 32];
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = *reinterpret_cast<const h16x8 *>(AsH + (wm * (TM * 32) + i * 32) * LDH + ro + ks);
+          al[i] = *reinterpret_cast<const h16x8 *>(AsL + (wm * (TM * 32) + i * 32) * LDH + ro + ks);
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bp[kk * LDB_S + j * 32];
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const h16x8 *>(BsH + (wn * (TN * 32) + j * 32) * LDH + ro + ks);
+          bl[j] = *reinterpret_cast<const h16x8 *>(BsL + (wn * (TN * 32) + j * 32) * LDH + ro + ks);
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+      const float *ap = As + (lane >> 5) * LDA_S + wm * (TM * 32) + (lane & 31);
+      const float *bp = Bs + (lane >> 5) * LDB_S + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = ap[kk * LDA_S + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bp[kk * LDB_S + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
+    if constexpr (SPLIT) {
+      if (k0 + BK >= kend) {   // last K tile: fold the cross terms in
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r] * (1.f / 2048.f);
+      }
+    }
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31,
@@ -669,7 +742,12 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
     if (M <= 32) gemm_skinny_kernel<1><<<dim3(cdiv(N, 32), ksplit, 1), 256, 0, st>>>(g);
     else gemm_skinny_kernel<2><<<dim3(cdiv(N, 32), ksplit, cdiv(M, 64)), 256, 0, st>>>(g);
   } else if (variant == 2) {
-    gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), ksplit), 256, 0, st>>>(g);
+    if (g.flags & SC_GEMM_SPLIT16)
+      gemm_mfma_kernel<128, 128, 2, 2, 32, true><<<dim3(cdiv(N, 128), cdiv(M, 128), ksplit), 256, 0, st>>>(g);
+    else
+      gemm_mfma_kernel<128, 128, 2, 2><<<dim3(cdiv(N, 128), cdiv(M, 128), ksplit), 256, 0, st>>>(g);
+  } else if (g.flags & SC_GEMM_SPLIT16) {
+    gemm_mfma_kernel<64, 64, 2, 2, 32, true><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
   } else {
     if (g_bk64 && g.kslice % 64 == 0 && K % 64 == 0 && (g.conv_f1 == 0 || g.lda % 64 == 0))
       gemm_mfma_kernel<64, 64, 2, 2, 64><<<dim3(cdiv(N, 64), cdiv(M, 64), ksplit), 256, 0, st>>>(g);
@@ -802,8 +880,6 @@ struct FfnArgs {
 // WF = 1 (WH): fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
 // 8 k values a lane holds per 32-wide k block feed 2 instructions instead of 8), fp32 accumulation, fp32 partial sums
 // and LayerNorms.  The row tile and the hidden activations then live in LDS as fp16 (converted once, when staged).
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 ffn_mma_h(f32x4 acc, const h16x8 &a, const h16x4 &b0, const h16x4 &b1) {
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h16x4{a[0], a[1], a[2], a[3]}, b0, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h16x4{a[4], a[5], a[6], a[7]}, b1, acc, 0, 0, 0);
@@ -819,11 +895,7 @@ __device__ __forceinline__ f32x4 ffn_mma_h(f32x4 acc, const h16x8 &a, const h16x
 // the two fp32 slabs of the fragment order, same bytes), the row tile and the hidden activations when they are staged
 // into LDS (hi8 | lo8 per 8 k values: the same 32 bytes per lane and row stride as the fp32 tile).  Operands must lie
 // within fp16's range (|x| < 65504: LayerNorm outputs and ReLU activations of any real model do).
-__device__ __forceinline__ void ffn_split4(const float4 &x, h16x4 &hi, h16x4 &lo) {
-  hi = h16x4{(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
-  lo = h16x4{(_Float16)((x.x - (float)hi[0]) * 2048.f), (_Float16)((x.y - (float)hi[1]) * 2048.f),
-             (_Float16)((x.z - (float)hi[2]) * 2048.f), (_Float16)((x.w - (float)hi[3]) * 2048.f)};
-}
+// (ffn_split4: top of the file)
 // LDS bytes of one workgroup (host and device); wf: 0 fp32, 1 fp16, 2 split
 __host__ __device__ static inline size_t ffn_lds_bytes(int D, int RT, bool pro, int wf) {
   const bool wh = wf == 1;

@@ -214,6 +214,8 @@ struct sc_streams {
   int graph_key() const { return n_rows_step * 2 + (step_split_min() > 0 ? 1 : 0); }
   int enc_start_thr = 0;         // sc_push: launch the planned encoder group when at most this many streams are still decoding
   int enc_batch_min = 0;         // sc_submit: launch the open encoder group when it holds this many streams (sc_streams_set_encoder_batch)
+  int gemm_flags = 0;            // SC_GEMM_SPLIT16 when the engine carries split-precision weight copies: the tiled GEMMs of the
+                                 // encoder stage (conv2, subsampling Linear, CTC / cross-K|V projections) in the same form
   void *ws = nullptr, *ws_enc = nullptr;
   std::vector<void *> owned, owned_host;
   // device buffers
@@ -678,10 +680,10 @@ int encode_launch(sc_streams *b, EncPlan &P) {
   RC_TRY(sc_conv1(b->featbuf, c.n_mels, cj, P.n_conv, P.max_t1, e->f("conv1_w"), e->f("conv1_b"), d, b->c1, b->es));
   RC_TRY(b->itensor(P.a_rows, &ar));
   RC_TRY(sc_gemm(b->c1, ar, d, e->f("conv2_w"), e->f("conv2_b"), b->c2, nullptr, d, (int)P.a_rows.size(), d, 9 * d,
-                 SC_GEMM_RELU, F1, b->es));
+                 SC_GEMM_RELU | b->gemm_flags, F1, b->es));
   RC_TRY(b->itensor(P.lin_dst, &ld));
   RC_TRY(sc_gemm(b->c2, nullptr, F2 * d, e->f("sub_out_w"), e->f("sub_out_b"), b->subbuf, ld, d, (int)P.lin_dst.size(), d,
-                 F2 * d, 0, 0, b->es));
+                 F2 * d, b->gemm_flags, 0, b->es));
   if (!P.feat_src.empty()) {
     const int32_t *a, *z;
     RC_TRY(b->itensor(P.feat_src, &a));
@@ -829,7 +831,7 @@ int project_rows(sc_streams *b, EncGroup &g) {
   if (!g.ctc_rows.empty()) {
     RC_TRY(b->itensor(g.ctc_rows, &ar));
     RC_TRY(sc_gemm(b->enc, ar, d, e->f("ctc_w"), e->f("ctc_b"), const_cast<float *>(b->sb.ctcx), ar, V, (int)g.ctc_rows.size(),
-                   V, d, 0, 0, b->es));
+                   V, d, b->gemm_flags, 0, b->es));
   }
   if (!g.kv_dst.empty()) {
     if (!g.same_rows || !ar) RC_TRY(b->itensor(g.kv_src, &ar));
@@ -839,14 +841,14 @@ int project_rows(sc_streams *b, EncGroup &g) {
     if (!b->sb.kv_half) {
       for (int li = 0; li < Ld; ++li)
         RC_TRY(sc_gemm(b->enc, ar, d, e->wkv[li], e->bkv[li], const_cast<float *>(b->sb.ckv) + (size_t)li * b->TCAP * 2 * d,
-                       kvt, 2 * d, m, 2 * d, d, 0, 0, b->es));
+                       kvt, 2 * d, m, 2 * d, d, b->gemm_flags, 0, b->es));
     } else {
       // fp16 cache: project into the fp32 staging buffer (dense rows), then convert + scatter all layers at once
       for (int r0 = 0; r0 < m; r0 += b->kv_stage_rows) {
         const int mm = std::min(b->kv_stage_rows, m - r0);
         for (int li = 0; li < Ld; ++li)
           RC_TRY(sc_gemm(b->enc, ar + r0, d, e->wkv[li], e->bkv[li], b->kv_stage + (size_t)li * mm * 2 * d, nullptr, 2 * d,
-                         mm, 2 * d, d, 0, 0, b->es));
+                         mm, 2 * d, d, b->gemm_flags, 0, b->es));
         RC_TRY(sc_kv_rows_to_half(b->kv_stage, kvt + r0, mm, Ld, b->TCAP, 2 * d, const_cast<float *>(b->sb.ckv), b->es));
       }
     }
@@ -1824,6 +1826,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->rowmap_key.resize(S);
   for (int s = 0; s < S; ++s) b->rowmap_key[s] = s;
   b->enc_batch_min = std::max(1, S / 2);
+  b->gemm_flags = (!b->eng->enc.empty() && b->eng->enc[0].w1_s) ? SC_GEMM_SPLIT16 : 0;
   b->row_bucket = std::max(1, S / 32);   // 32 compaction buckets (graphs): 16 -> 32 measured +1 % at 128 streams, 64 nothing more
   if (const char *rb = sc_hook("SC_ROW_BUCKETS")) b->row_bucket = std::max(1, S / std::max(1, atoi(rb)));   // tools: sweep
   b->n_rows_step = S * W;

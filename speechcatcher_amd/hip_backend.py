@@ -76,8 +76,8 @@ class HipBackend:
                                     _p(w.conv1_b), cfg.d_model, _p(c1), self._stream()), "sc_conv1")
 
     def gemm(self, A, a_rows, lda, W, bias, Cm, c_rows, ldc, M, N, K, relu=False, conv_f1=0,
-             residual=False, naive=False):
-        flags = (1 if relu else 0) | (2 if residual else 0) | (4 if naive else 0)
+             residual=False, naive=False, split16=False):
+        flags = (1 if relu else 0) | (2 if residual else 0) | (4 if naive else 0) | (16 if split16 else 0)
         self._chk(self.lib.sc_gemm(_p(A), _p(a_rows), lda, _p(W), _p(bias), _p(Cm), _p(c_rows), ldc,
                                    M, N, K, flags, conv_f1, self._stream()), "sc_gemm")
 

@@ -82,6 +82,60 @@ def test_gemm_row_tables_and_implicit_conv(hip):
     np.testing.assert_allclose(out.cpu()[c_rows.long()].numpy(), y.numpy(), atol=2e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(300, 320, 256, "plain"), (2100, 256, 4864, "plain"), (1100, 1024, 256, "relu"),
+                                        (4000, 512, 256, "residual"), (129, 130, 96, "plain"), (700, 64, 2304, "relu")])
+def test_gemm_split16(hip, M, N, K, mode):
+    """SC_GEMM_SPLIT16: the tiled GEMM with both operands split into fp16 hi + lo / 2^11 when the tiles are staged
+    (three v_mfma_f32_32x32x16_f16 per 16 k values, fp32 accumulation): against float64 as close as the f32-MFMA kernel
+    (a small multiple of its error), rows of very different magnitude, with a gather / scatter row table, split-K shapes
+    included (K = 4864: the subsampling Linear)."""
+    A, W, b = _rand(M + 9, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3)
+    A *= torch.logspace(-3, 2, M + 9)[:, None]
+    C0 = _rand(M + 9, N, seed=4)
+    a_rows = torch.randperm(M + 9, generator=torch.Generator().manual_seed(3))[:M].to(torch.int32)
+    c_rows = torch.randperm(M + 9, generator=torch.Generator().manual_seed(4))[:M].to(torch.int32)
+    y = A[a_rows.long()].double() @ W.double().t() + b.double()
+    scale = A[a_rows.long()].double().abs() @ W.double().abs().t() + b.double().abs()
+    if mode == "relu":
+        y = torch.relu(y)
+    ref = C0.double().clone()
+    ref[c_rows.long()] = (C0[c_rows.long()].double() if mode == "residual" else 0.0) + y
+    if mode == "residual":
+        scale = scale + C0[c_rows.long()].double().abs()
+    err = {}
+    for form in ("f32", "split"):
+        Cg = C0.cuda()
+        hip.gemm(A.cuda(), a_rows.cuda(), K, W.cuda(), b.cuda(), Cg, c_rows.cuda(), N, M, N, K, relu=(mode == "relu"),
+                 residual=(mode == "residual"), split16=(form == "split"))
+        torch.cuda.synchronize()
+        out = Cg.cpu()
+        untouched = torch.ones(M + 9, dtype=torch.bool)
+        untouched[c_rows.long()] = False
+        assert torch.equal(out[untouched], C0[untouched])
+        err[form] = float(((out[c_rows.long()].double() - ref[c_rows.long()]).abs() / scale).max())
+    assert err["f32"] < 2e-6 and err["split"] < 2e-6, err
+    assert err["split"] < 4.0 * err["f32"] + 2e-7, err
+
+
+def test_gemm_split16_implicit_conv(hip):
+    """... and the second Conv2d of the subsampling as an implicit GEMM (row gather + tap offsets) in the split form,
+    against torch's conv2d."""
+    d, F1, F2, T1 = 256, 39, 19, 33
+    T2 = (T1 - 3) // 2 + 1
+    c1 = torch.relu(_rand(T1 * F1 + 5, d, seed=8))
+    tt, ff = np.meshgrid(np.arange(T2), np.arange(F2), indexing="ij")
+    a_rows = torch.from_numpy(((2 * tt) * F1 + 2 * ff).reshape(-1).astype(np.int32))
+    M = a_rows.numel()
+    W, b = _rand(d, 9 * d, seed=9, scale=0.02), _rand(d, seed=10)
+    out = torch.zeros(M, d, device="cuda")
+    hip.gemm(c1.cuda(), a_rows.cuda(), d, W.cuda(), b.cuda(), out, None, d, M, d, 9 * d, relu=True, conv_f1=F1, split16=True)
+    torch.cuda.synchronize()
+    x = c1[:T1 * F1].view(T1, F1, d).permute(2, 0, 1).unsqueeze(0).double()
+    wconv = W.view(d, 3, 3, d).permute(0, 3, 1, 2).contiguous().double()
+    y = torch.relu(torch.nn.functional.conv2d(x, wconv, b.double(), stride=2))[0].permute(1, 2, 0).reshape(M, d)
+    np.testing.assert_allclose(out.cpu().numpy(), y.float().numpy(), atol=2e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(10, 256, 256), (10, 256, 2048), (42, 64, 64), (1280, 256, 256), (1280, 256, 2048), (300, 256, 512)])
 def test_gemm_ln_fused(hip, M, N, K):
     """GEMM + residual + LayerNorm fused into the split-K reduce epilogue."""
