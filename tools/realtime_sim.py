@@ -4,7 +4,7 @@ operational meaning of BASELINE.json's "concurrent real-time streams".  A chunk 
 the stream's previous reply has been delivered (one call outstanding per stream, like the reference's session loop,
 speechcatcher_server.py:359-397); its latency is reply time - arrival time.  XL dims, beam 10, host PCM in, best
 hypothesis read back per reply.
-    gpurun -- 'python tools/realtime_sim.py [streams=1024] [seconds=30] [bbd=0] [kv_dtype=float32]'"""
+    gpurun -- 'python tools/realtime_sim.py [streams=1024] [seconds=30] [bbd=0] [kv_dtype=float32] [ffn_dtype=float32]'"""
 import json
 import sys
 import time
@@ -18,6 +18,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 bbd = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 kv = sys.argv[4] if len(sys.argv) > 4 else "float32"
+bench.FFN_DTYPE = sys.argv[5] if len(sys.argv) > 5 else "float32"     # "split16": DESIGN section 4a
 HOP = bench.CHUNK / 16000.0
 n_chunks = int(seconds / HOP)
 w = bench.make_weights("cuda:0")
@@ -61,7 +62,7 @@ wall = time.perf_counter() - t0
 lat, when = np.array(lat), np.array(when)
 steady = lat[when > 2.0] * 1e3
 T = [st.T_enc for st in sb.st]
-out = {"streams": S, "seconds_of_audio_per_stream": round(n_chunks * HOP, 2), "wall_s": round(wall, 2), "bbd": int(bbd), "kv_dtype": kv,
+out = {"streams": S, "seconds_of_audio_per_stream": round(n_chunks * HOP, 2), "wall_s": round(wall, 2), "bbd": int(bbd), "kv_dtype": kv, "ffn_dtype": bench.FFN_DTYPE,
        "replies": int(len(lat)), "engine_busy_fraction": round(poll_s / wall, 3),
        "latency_ms_after_the_first_2s": {"p50": round(float(np.percentile(steady, 50)), 2), "p90": round(float(np.percentile(steady, 90)), 2),
                                          "p99": round(float(np.percentile(steady, 99)), 2), "max": round(float(steady.max()), 2)},
