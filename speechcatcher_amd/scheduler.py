@@ -219,7 +219,8 @@ def _select_hyps(a: dict, i: int, is_final: bool, finalize_all: bool) -> List[di
 
 def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tuple[int, int]],
                        chunk_length: int = 8192, token_list: Optional[List[str]] = None,
-                       frames_per_second: float = 24.0, finalize_all_last_only: bool = False) -> List[dict]:
+                       frames_per_second: float = 24.0, finalize_all_last_only: bool = False,
+                       queue_depth: int = 1) -> List[dict]:
     """Decode the (start, end) sample ranges of one recording as PARALLEL streams
     of one batch instead of the reference's process pool over segments
     (speechcatcher/speechcatcher.py:474-497, chunk loop :574-592; SURVEY 8(f)
@@ -227,9 +228,10 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
     is_final=finalize_all=True.  Token timestamps follow the reference's
     convention: encoder-frame position / 24.0 s + segment start
     (speechcatcher.py:48,509-536)."""
-    # (C++ engine: two chunks of a segment at the engine - the audio is all there, the encoder stage of the next chunk runs
-    # beside the decoding of the current one)
-    sch = StreamScheduler(batch, token_list, result_format="espnet", queue_depth=2)
+    # queue_depth > 1 (C++ engine): that many chunks of a segment at the engine - the audio is all there.  Measured: worth
+    # +6..12 % when the search is decode-heavy (no block-boundary detection, <= 32 segments), nothing to -8 % with
+    # detection on (the CLI's default), hence off by default (DESIGN section 4)
+    sch = StreamScheduler(batch, token_list, result_format="espnet", queue_depth=queue_depth)
     out: List[Optional[dict]] = [None] * len(segments)
     todo = list(enumerate(segments))
     sid_to_seg: Dict[int, int] = {}

@@ -1,6 +1,7 @@
 """Continuous batching (sc_submit / sc_poll) at 128 streams: throughput against the number of replies sc_poll waits for
 (= the size of the next admission group), with the decode iterations by compaction bucket.
-    gpurun -- 'python tools/served_sweep.py 4 8 16 32 e1 e64'      (eN: encoder batch of N streams)"""
+    gpurun -- 'python tools/served_sweep.py 4 8 16 32 e1 e64 [bbd] [d2]'      (eN: encoder batch of N streams; bbd: block-
+boundary detection on; dN: N chunks per stream at the engine)"""
 import ctypes as C
 import sys
 
@@ -9,8 +10,10 @@ import numpy as np  # noqa: E402
 
 import bench  # noqa: E402
 
-groups = [int(a) for a in sys.argv[1:] if not a.startswith("e")] or [8, 16, 32]
-encb = [int(a[1:]) for a in sys.argv[1:] if a.startswith("e")] or [64]
+BBD = "bbd" in sys.argv[1:]
+DEPTH = max([1] + [int(a[1:]) for a in sys.argv[1:] if a.startswith("d") and a[1:].isdigit()])
+groups = [int(a) for a in sys.argv[1:] if a.isdigit()] or [8, 16, 32]
+encb = [int(a[1:]) for a in sys.argv[1:] if a.startswith("e") and a[1:].isdigit()] or [64]
 S, pre, warm, steps = 128, 21, 5, 20
 w = bench.make_weights("cuda:0")
 total = pre + warm + steps + bench.SERVED_SPARE + 2
@@ -36,8 +39,10 @@ a3 = audio.reshape(S, -1, bench.CHUNK)
 
 
 def run(mode, g=8, eb=64):
-    sb = bench.build_native(w, S, 10, False, total)
+    sb = bench.build_native(w, S, 10, BBD, total)
     sb.set_encoder_batch(eb)
+    if DEPTH > 1:
+        sb.set_queue_depth(DEPTH)
     bench.roll(sb, audio, pre)
     if mode == "strict":
         bench.run_host(sb, bench.step_blocks(audio, pre, pre + warm), np.arange(S, dtype=np.int32))
@@ -46,10 +51,10 @@ def run(mode, g=8, eb=64):
               f"    bucket:iterations per step x ms  {hist(sb)}", flush=True)
     else:
         nxt = np.full(S, pre, np.int64)
-        bench.serve(sb, a3, nxt, warm, g)
+        bench.serve(sb, a3, nxt, warm, g, depth=DEPTH)
         n0, t0c = C.c_long(), C.c_double()
         sb.lib.sc_streams_capture_stats(sb.handle, C.byref(n0), C.byref(t0c))
-        r = bench.serve(sb, a3, nxt, steps, g, before_timing=clear)
+        r = bench.serve(sb, a3, nxt, steps, g, before_timing=clear, depth=DEPTH)
         e = r["elapsed"]
         n1, t1c = C.c_long(), C.c_double()
         sb.lib.sc_streams_capture_stats(sb.handle, C.byref(n1), C.byref(t1c))
