@@ -200,8 +200,11 @@ struct sc_streams {
   hipStream_t stream = nullptr;
   // Encoder side on its OWN HIP stream: frontend + encoder of a chunk do not feed the decode blocks whose frames
   // were already there before the chunk (the block schedule runs one hop behind the encoder), so both
-  // proceed concurrently - the encoder's MFMA-bound grids fill the CUs that the latency-bound decode iterations
-  // leave idle.  `es` is the stream the current phase launches into.
+  // are in flight together: the encoder's kernels run in the gaps of the decode chain (between a step's last kernel
+  // and the next step's first - the host reads the stop flags there) and behind its thin iterations.  Kernel traces
+  // (tools/rocpd_busy.py) show the kernels of the two streams ALTERNATING, not sharing CUs: 1.5 % of the wall time
+  // has both running - every kernel of the path fills the registers or the LDS of the CUs it occupies.
+  // `es` is the stream the current phase launches into.
   hipStream_t stream_enc = nullptr, es = nullptr;
   hipEvent_t ev_iter[2] = {nullptr, nullptr};   // end of decode iteration k (k & 1)
   int32_t *ring_dev = nullptr;                  // device view of flags_host [S]: the prune kernel stores the stop flags there
