@@ -137,6 +137,7 @@ struct Job {
   long seq = 0;      // per-stream sequence number of the chunk (tags its decode blocks)
   bool fin = false;  // is_final chunk: nothing may be queued behind it
   bool dropped = false;   // failed only because an EARLIER chunk of the stream failed (the reset has happened by then)
+  bool started = false;   // St::started right after THIS chunk's admission (a later admission may set it before this one is reported)
 };
 
 // hypotheses of a stream's last complete chunk, copied aside when later chunks of the stream may go on decoding
@@ -1018,7 +1019,7 @@ int snapshot_completed(sc_streams *b) {
     sn.reported = false;
     sn.seq = j.seq;
     sn.L = x.L;
-    sn.nhyp = x.started ? x.nhyp : 0;
+    sn.nhyp = j.started ? x.nhyp : 0;
     if (sn.nhyp > 0) {
       a.s[a.n] = s; a.cur[a.n] = x.cur; a.L[a.n] = x.L; a.nhyp[a.n] = x.nhyp;
       a.n++;
@@ -1456,6 +1457,7 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
     j.has_out = has_out[k];
     j.seq = seq_of.at(chunks[k].s);
     j.fin = chunks[k].fin;
+    j.started = b->st[chunks[k].s].started;
     if (b->job[chunks[k].s].open) b->ahead[chunks[k].s].push_back(j);   // behind the stream's outstanding chunk(s)
     else b->job[chunks[k].s] = j;
     b->n_open++;
