@@ -83,7 +83,8 @@ def test_xl_128_streams_native_equals_python_engine_solo_runs_and_continuous_bat
 
 
 def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
-    """Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward + encoder attention-projection weights / MFMA
+    """(also: the split-precision form `split16` on the same 256 streams - identical beams, see the end.)
+    Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward + encoder attention-projection weights / MFMA
     inputs and fp16 K|V caches
     (hipGraph replay on, token positions read back) against the fp32 engine on the same audio: the best hypothesis
     keeps its token ids AND positions for at least 98 % of the streams, the whole beam for 96 % (fp16 rounding of the
@@ -93,8 +94,9 @@ def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     audio = np.stack([synth.synth_audio(900 + s, CHUNK * n) for s in range(S)])
     kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
     out = {}
-    for mode in ("float32", "float16"):
-        sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", ffn_dtype=mode, proj_dtype=mode, kv_dtype=mode, **kw)
+    for mode in ("float32", "float16", "split16"):
+        sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", ffn_dtype=mode, proj_dtype=mode,
+                        kv_dtype="float32" if mode == "split16" else mode, **kw)
         _feed(sb, audio, n)
         out[mode] = sb.hypotheses_arrays(list(range(S)))
         sb.close()
@@ -113,6 +115,14 @@ def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     assert len(best_differs) <= S // 50 and len(beam_differs) <= S // 25, (best_differs, beam_differs)
     same = [s for s in range(S) if s not in best_differs]
     assert np.abs(a["score"][same, 0] - b["score"][same, 0]).max() < 0.5
+    # the split-precision form (fp32 operands as fp16 hi + lo pairs) is held to the fp32 engine itself:
+    # EVERY hypothesis of EVERY beam - ids, positions, order - and the scores to fp32 rounding level
+    c = out["split16"]
+    assert (c["n_hyps"] == beam).all()
+    for s in range(S):
+        for j in range(beam):
+            assert hyp(a, s, j) == hyp(c, s, j), (s, j)
+    assert np.abs(a["score"] - c["score"]).max() < 2e-4
 
 
 def test_l_like_dims_128_streams_equal_solo_oracle_runs():
