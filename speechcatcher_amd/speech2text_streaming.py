@@ -238,7 +238,9 @@ class Speech2TextStreaming:
         ``dtype="float16"`` (the reference keeps fp32 weights under autocast for this constructor argument,
         speech2text_streaming.py:57,64-70): fp16 feed-forward weights with fp16 MFMA inputs and fp16 K|V caches, every
         sum / softmax / LayerNorm / score in fp32 (BASELINE configs[4]; `load_model(fp16=True)` stays fp32 with the
-        reference's warning)."""
+        reference's warning).  ``dtype="split16"`` (no counterpart in the reference): fp32 results - every hypothesis of
+        the reference fixtures at the fp32 tolerance - with the feed-forward, encoder-projection and tiled-GEMM product
+        sums evaluated on the fp16 matrix pipe from fp16 hi + lo splits of both operands."""
         self.model_dir = Path(model_dir)
         self.beam_size = beam_size
         self.ctc_weight = ctc_weight
@@ -246,7 +248,7 @@ class Speech2TextStreaming:
         if not str(self.device).startswith("cuda"):
             raise _abi.ScasrError(
                 "speechcatcher_amd has no CPU path; pass device='cuda' (use the reference package for CPU)")
-        if dtype not in ("float32", "float16"):
+        if dtype not in ("float32", "float16", "split16"):
             logger.warning("dtype %s requested; using float32", dtype)
             dtype = "float32"
         self.dtype = torch.float32     # activations, scores and results
@@ -261,8 +263,7 @@ class Speech2TextStreaming:
             self.mean, self.std = load_stats(self.model_dir)
             self.token_list = load_token_list(self.model_dir)
         self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std,
-                                     ffn_dtype="float16" if half else "float32",
-                                     proj_dtype="float16" if half else "float32")
+                                     ffn_dtype=dtype, proj_dtype=dtype)
         self.model = self.weights
         # the decoder itself: the C++ engine behind the stream-level C ABI (csrc/streams.hip); raises without
         # the built library or without a GPU - there is no fallback
