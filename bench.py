@@ -320,7 +320,7 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
     return out
 
 
-_PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELb0",
+_PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",   # <256, RTT, PRO = false, WF = 0 (fp32 weights)>
                "dec_attn_flash_kernel<cross>": "dec_attn_flash_kernelILi32ELi10ELb0",
                "dec_attn_flash_kernel<self>": "dec_attn_flash_kernelILi32ELi10ELb1",
                "proj_ln_proj_kernel<256,*>": "proj_ln_proj_kernelILi256",
