@@ -41,6 +41,17 @@ def main():
     for q in qs[:4]:
         print(f"queue {q}: busy {100.0 * busy[q] / wall:5.1f} %  ({sum(1 for r in rows if r[2] == q)} kernels)")
     print(f"any queue busy: {100.0 * allb / wall:5.1f} %   two queues at once: {100.0 * (sum(busy.values()) - allb) / wall:5.1f} % (sum of queue busy - union)")
+    # idle gaps (no kernel of any queue running) by length
+    iv = sorted((r[0], r[1]) for r in rows)
+    gaps, ce = [], iv[0][1]
+    for st, en in iv[1:]:
+        if st > ce:
+            gaps.append(st - ce)
+        ce = max(ce, en)
+    classes = [(0, 5e3), (5e3, 20e3), (20e3, 50e3), (50e3, 100e3), (100e3, 300e3), (300e3, 1e12)]
+    print("idle gaps: " + ", ".join(
+        f"{lo / 1e3:.0f}-{'inf' if hi > 1e11 else f'{hi / 1e3:.0f}'} us: {sum(1 for g in gaps if lo <= g < hi)} = "
+        f"{100.0 * sum(g for g in gaps if lo <= g < hi) / wall:.1f} %" for lo, hi in classes))
 
 
 if __name__ == "__main__":
