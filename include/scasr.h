@@ -143,6 +143,10 @@ typedef struct sc_search {
 } sc_search;
 
 const char *sc_last_error(void);
+/* ABI revision of this header: bumped whenever a struct layout or a signature changes incompatibly.  sc_version()
+ * returns the revision the LIBRARY was built with; a host compares the two before it passes any struct
+ * (speechcatcher_amd/_abi.py does at load time, the C hosts in tests/ at start-up). */
+#define SC_ABI_VERSION 4
 int sc_version(void);
 
 /* hipGraph capture / replay of any sequence of the launches below on a

@@ -188,6 +188,10 @@ _SIGS = {
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 
+# revision of include/scasr.h these ctypes mirrors were written against (SC_ABI_VERSION): a library built from another
+# revision would be handed mis-laid-out structs
+ABI_VERSION = 4
+
 _lib = None
 
 
@@ -226,6 +230,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.sc_version()
+    if got != ABI_VERSION:
+        raise ScasrError(f"{LIB_PATH} was built from ABI revision {got} of include/scasr.h, this binding is revision "
+                         f"{ABI_VERSION}: rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
     _lib = lib
     return lib
 

@@ -14,7 +14,7 @@ void sc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *sc_last_error(void) { return g_err; }
-extern "C" int sc_version(void) { return 1; }
+extern "C" int sc_version(void) { return SC_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------
 // hipGraph capture / replay of a launch sequence (the ~190 launches of one

@@ -261,6 +261,8 @@ struct sc_streams {
   std::vector<long> job_seq;               // sequence number of the stream's latest chunk
   int queue_depth = 1;                     // outstanding chunks a stream may have (sc_streams_set_queue_depth)
   std::vector<Snap> snap;
+  std::vector<long> done_at;               // sc_poll: order in which the streams' oldest chunks became complete (0: not yet)
+  long done_counter = 0;
   int32_t *snap_yseq = nullptr, *snap_xpos = nullptr;   // [S*W][LCAP]
   double *snap_score = nullptr;                         // [S*W][3]
   hipEvent_t ev_snap = nullptr;
@@ -1371,7 +1373,13 @@ int admit(sc_streams *b, std::vector<Chunk> chunks, bool features, bool defer, s
         }
         b->n_open++;
       }
-      if (chunks.empty()) { *g = EncGroup(); break; }
+      if (chunks.empty()) {   // every chunk of the call failed: nothing of the last (aborted) plan may survive
+        *g = EncGroup();
+        feat_new.clear();
+        finals.clear();
+        has_out.clear();
+        break;
+      }
     }
   }
   {
@@ -1842,6 +1850,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->ahead.assign(S, std::deque<Job>());
   b->job_seq.assign(S, 0);
   b->snap.assign(S, Snap());
+  b->done_at.assign(S, 0);
   b->fault_msg.assign(S, std::string());
   b->enc_gen.assign(S, 0);
   for (int s = 0; s < S; ++s) init_hyp(b, s);
@@ -1881,6 +1890,7 @@ int report_chunk(sc_streams *b, int s) {
   const int status = j.fault ? j.fault : j.has_out;
   if (j.fault && !j.dropped) reset_stream(b, s);   // (fault_msg[s] keeps the message: sc_stream_last_error)
   if (b->snap[s].valid && b->snap[s].seq == j.seq) b->snap[s].reported = true;   // handed out: free at the next sc_poll
+  b->done_at[s] = 0;
   if (b->ahead[s].empty()) j = Job();
   else {   // the next chunk of the stream is now its oldest
     j = b->ahead[s].front();
@@ -2031,7 +2041,11 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
     if (rc == SC_OK) rc = snapshot_completed(b);
     if (rc != SC_OK) return poison(b, rc);
     int n_complete = 0;
-    for (int s = 0; s < b->S; ++s) n_complete += chunk_complete(b, s) ? 1 : 0;
+    for (int s = 0; s < b->S; ++s)
+      if (chunk_complete(b, s)) {
+        ++n_complete;
+        if (!b->done_at[s]) b->done_at[s] = ++b->done_counter;   // (streams that complete in one tick: by index)
+      }
     const bool enough = n_complete >= min_done || b->n_open == 0;
     // the next step is enqueued BEFORE the replies go back to the caller: the device decodes the streams that are still
     // inside their blocks while the host reads the finished streams' hypotheses and admits their next chunks
@@ -2050,14 +2064,18 @@ extern "C" int sc_poll(sc_streams *b, int min_done, int max_done, int *done_ids,
       return poison(b, SC_ERR_LAUNCH);
     }
   }
+  // oldest completion first: with a small max_done no stream waits behind lower-numbered ones that completed later
+  std::vector<std::pair<long, int>> ready;
+  for (int s = 0; s < b->S; ++s)
+    if (chunk_complete(b, s)) ready.push_back({b->done_at[s] ? b->done_at[s] : ++b->done_counter, s});
+  std::sort(ready.begin(), ready.end());
   int n = 0;
-  for (int s = 0; s < b->S && n < max_done; ++s)
-    if (chunk_complete(b, s)) {
-      done_ids[n] = s;
-      const int st = report_chunk(b, s);
-      if (status) status[n] = st;
-      ++n;
-    }
+  for (size_t i = 0; i < ready.size() && n < max_done; ++i, ++n) {
+    const int s = ready[i].second;
+    done_ids[n] = s;
+    const int st = report_chunk(b, s);
+    if (status) status[n] = st;
+  }
   return n;
   SC_API_END
 }
@@ -2128,9 +2146,14 @@ extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, in
   std::vector<int32_t> jobs;
   size_t off = 0;
   bool from_snapshot = false;
+  // the job tables hold one entry per hypothesis row of the batch (S*W): every stream at most once
+  SC_CHECK_ARG(n <= b->S, "more streams listed than the batch has");
+  std::vector<char> listed(b->S, 0);
   for (int i = 0; i < n; ++i) {
     const int s = stream_ids[i];
     SC_CHECK_ARG(s >= 0 && s < b->S, "stream out of range");
+    SC_CHECK_ARG(!listed[s], "a stream is listed twice");
+    listed[s] = 1;
     const Snap &sn = b->snap[s];
     if (sn.valid) {   // queue depth > 1: the copy taken when the stream's last reported chunk completed
       const int nh = std::min(nbest, sn.nhyp);
@@ -2155,7 +2178,7 @@ extern "C" int sc_get_hyps_batch(sc_streams *b, const int *stream_ids, int n, in
   }
   const int m = (int)jobs.size() / 4;
   if (m == 0) return SC_OK;
-  SC_CHECK_ARG(off <= b->pack_cap, "hypotheses exceed the read-back buffer");
+  SC_CHECK_ARG(off <= b->pack_cap && (size_t)m <= (size_t)b->S * b->W, "hypotheses exceed the read-back buffer");
   memcpy(b->pjobs_host, jobs.data(), jobs.size() * sizeof(int32_t));
   // on the read-back stream: a decode step of OTHER streams may be in flight on the batch's stream (sc_poll); the
   // listed streams' last steps have been collected (host-synchronised) by then

@@ -51,7 +51,10 @@ class StreamScheduler:
         self._queue: Dict[int, Deque[Tuple[np.ndarray, bool, bool]]] = {}
         # continuous batching: session -> its chunks at the engine, oldest first: (slot, final, finalize_all)
         self._in_flight: Dict[int, Deque[Tuple[int, bool, bool]]] = {}
-        self._stash: Dict[int, list] = {}                           # replies that became ready inside close()
+        # replies that are ready but have not gone out yet, per session and oldest first: pump() hands out at most ONE
+        # reply per session and call (its return value is {session: reply}); a second one of the same session (queue
+        # depth > 1, or one collected inside close() of another session) waits here for the next call
+        self._stash: Dict[int, Deque[list]] = {}
         self.queue_depth = 1
         if queue_depth > 1 and hasattr(batch, "set_queue_depth"):
             batch.set_queue_depth(queue_depth)
@@ -75,7 +78,8 @@ class StreamScheduler:
         while sid in self._in_flight:        # its chunks must be reported before the slot can be reset;
             for k, v in self.pump(1, _collect=False, _feed=False).items():   # replies of OTHER sessions wait for their pump()
                 if k != sid:
-                    self._stash[k] = v
+                    self._stash.setdefault(k, deque()).append(v)
+        self._stash.pop(sid, None)
         slot = self._slot_of.pop(sid)
         self._queue.pop(sid)
         if self.reset_on_open:
@@ -171,20 +175,27 @@ class StreamScheduler:
             self.batch.submit(items)
             for sid, m in meta.items():
                 self._in_flight.setdefault(sid, deque()).append(m)
+        n_ready = len(self._stash) if _collect else 0           # sessions with a reply waiting from an earlier call
+        new: Dict[int, list] = {}
+        if self._in_flight and n_ready < min_done:
+            has = self.batch.poll(max(1, min(min_done - n_ready, len(self._in_flight))), isolate_faults=True)
+            sid_of = {fl[0][0]: sid for sid, fl in self._in_flight.items()}
+            done = {}
+            for slot in has:                       # one reply per session and poll: that of its OLDEST chunk at the engine
+                sid = sid_of[slot]
+                done[sid] = self._in_flight[sid].popleft()
+                if not self._in_flight[sid]:
+                    del self._in_flight[sid]
+            new = self._results(has, done)
+        if not _collect:
+            return new                             # close(): the caller parks them
+        for sid, res in new.items():               # behind what the session already has waiting: replies stay in order
+            self._stash.setdefault(sid, deque()).append(res)
         out: Dict[int, list] = {}
-        if _collect and self._stash:
-            out, self._stash = self._stash, {}
-        if not self._in_flight or len(out) >= min_done:
-            return out
-        has = self.batch.poll(max(1, min(min_done - len(out), len(self._in_flight))), isolate_faults=True)
-        sid_of = {fl[0][0]: sid for sid, fl in self._in_flight.items()}
-        done = {}
-        for slot in has:                       # one reply per session and poll: that of its OLDEST chunk at the engine
-            sid = sid_of[slot]
-            done[sid] = self._in_flight[sid].popleft()
-            if not self._in_flight[sid]:
-                del self._in_flight[sid]
-        out.update(self._results(has, done))
+        for sid in list(self._stash):
+            out[sid] = self._stash[sid].popleft()
+            if not self._stash[sid]:
+                del self._stash[sid]
         return out
 
     @property
@@ -195,7 +206,7 @@ class StreamScheduler:
         """Run steps until every queue is empty; returns the LAST result of each session."""
         last: Dict[int, list] = {}
         while self.pending():
-            for sid, res in (self.pump() if self._in_flight else self.step()).items():
+            for sid, res in (self.pump() if (self._in_flight or self._stash) else self.step()).items():
                 if isinstance(res, Exception):
                     raise res
                 last[sid] = res
@@ -253,7 +264,7 @@ def recognize_segments(batch: StreamBatch, speech: np.ndarray, segments: List[Tu
         for sid, res in sch.pump().items():
             if isinstance(res, Exception):
                 raise res
-            if not sch._queue[sid] and sid not in sch._in_flight:    # that was the final chunk of the session
+            if not sch._queue[sid] and sid not in sch._in_flight and sid not in sch._stash:    # the final chunk's reply
                 idx = sid_to_seg.pop(sid)
                 start_s = segments[idx][0] / 16000.0
                 if res:

@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in scasr.h but not exported"
     assert set(declared) == set(_abi.EXPORTED_SYMBOLS)
-    assert lib.sc_version() >= 1
+    assert lib.sc_version() == _abi.ABI_VERSION   # = SC_ABI_VERSION of include/scasr.h
+    hdr = (ROOT / 'include' / 'scasr.h').read_text()
+    assert int(re.search(r'#define SC_ABI_VERSION (\d+)', hdr).group(1)) == _abi.ABI_VERSION
 
 
 def test_argument_errors_do_not_need_a_gpu():

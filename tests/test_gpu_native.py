@@ -88,6 +88,46 @@ def test_native_capacity_faults_are_isolated():
         sb.push([(0, a[:40000], False)])
 
 
+def test_native_final_chunk_that_faults_on_a_running_stream():
+    """the LAST remaining chunk of a call faults inside the encoder planning on a stream that already has
+    encoder frames (T_enc > 0) - a final chunk beyond max_frames, and a final chunk of < 7 feature frames without a reset
+    after the previous final (strict server mode).  The call must report SC_ERR_CAPACITY / SC_ERR_INPUT for that stream
+    (not an out_of_range from the block schedule), reset it, and accept the next push (sc_push-only hosts such as
+    Speech2TextStreaming were wedged: 'still has a chunk outstanding')."""
+    from speechcatcher_amd.engine import EngineError
+    from test_engine_spec import make_batch
+    a = synth.synth_audio(0, 120000)
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, backend="native", max_frames=48, max_tokens=160,
+                    pcm_capacity=1 << 18)
+    for pos in range(0, 30720, 10240):
+        sb.push([(0, a[pos:pos + 10240], False)])
+    assert sb.st[0].T_enc > 0
+    with pytest.raises(EngineError, match="capacity"):       # 26 s more: beyond 48 encoder frames
+        sb.push([(0, a[30720:30720 + 32768], True)])
+    assert sb.st[0].T_enc == 0                                # the stream has been reset ...
+    ref = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, backend="native", max_frames=48, max_tokens=160,
+                     pcm_capacity=1 << 18)
+    for b in (sb, ref):                                       # ... and serves the next utterance like a fresh one
+        b.push([(0, a[:10240], False)])
+        b.push([(0, a[10240:20480], True)])
+    assert [h["yseq"] for h in sb.hypotheses(0)] == [h["yseq"] for h in ref.hypotheses(0)]
+    # the same call through the isolating interface: the exception object is the stream's result
+    out = sb.push([(0, a[:10240], False)], isolate_faults=True)
+    out = sb.push([(0, a[10240:10240 + 10240], False)], isolate_faults=True)
+    out = sb.push([(0, a[20480:20480 + 32768], True)], isolate_faults=True)
+    assert isinstance(out[0], EngineError)
+    assert sb.push([(0, a[:10240], False)], isolate_faults=True)[0] is True
+    # a too-short final chunk right after a final chunk, no reset in between (the reference server never resets)
+    sb2 = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=1, backend="native", max_frames=128, max_tokens=160,
+                     pcm_capacity=1 << 18)
+    sb2.push([(0, a[:10240], False)])
+    sb2.push([(0, a[10240:20480], True)])
+    assert sb2.st[0].T_enc > 0
+    with pytest.raises(RuntimeError):
+        sb2.push([(0, a[:700], True)])
+    sb2.push([(0, a[:10240], False)])                         # not wedged
+
+
 def test_native_batch_of_distinct_streams_equals_one_by_one():
     """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
     head-parallel and six-launch layer forms by bucket size) = every stream alone = the same streams served by
@@ -485,6 +525,7 @@ int main(int argc, char **argv) {
   if (argc < 6) return 2;
   const int chunk = atoi(argv[3]), beam = atoi(argv[4]), bbd = atoi(argv[5]);
   sc_engine *eng = NULL; sc_streams *st = NULL;
+  if (sc_version() != SC_ABI_VERSION) { fprintf(stderr, "libscasr ABI %d, header %d\n", sc_version(), SC_ABI_VERSION); return 3; }
   if (sc_engine_load(argv[1], 0, &eng) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
   sc_stream_options o = {1, beam, 0.3f, bbd, 256, 200, 1 << 18, 32768, 1};
   if (sc_streams_create(eng, &o, &st) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
@@ -557,6 +598,7 @@ int main(int argc, char **argv) {
   if (argc < 6) return 2;
   const int chunk = atoi(argv[3]), beam = atoi(argv[4]), bbd = atoi(argv[5]);
   sc_engine *eng = NULL; sc_streams *st = NULL;
+  if (sc_version() != SC_ABI_VERSION) { fprintf(stderr, "libscasr ABI %d, header %d\n", sc_version(), SC_ABI_VERSION); return 3; }
   if (sc_engine_load(argv[1], 0, &eng) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }
   sc_stream_options o = {NS, beam, 0.3f, bbd, 256, 200, 1 << 18, 32768, 1};
   if (sc_streams_create(eng, &o, &st) != SC_OK) { fprintf(stderr, "%s\n", sc_last_error()); return 1; }

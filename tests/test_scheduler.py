@@ -99,3 +99,63 @@ def run_segments_serial_strict(backend=None, device="cpu"):
 
 def test_recognize_segments_serial_strict_equals_reference_cli_semantics():
     run_segments_serial_strict()
+
+
+class _FakeContinuousBatch:
+    """submit / poll stand-in for NativeStreamBatch: every submitted chunk is 'decoded' at once, poll reports the
+    oldest outstanding chunk of every slot (one per slot and call, like sc_poll)."""
+
+    def __init__(self, n):
+        from collections import deque
+        self.S = n
+        self.out = {s: deque() for s in range(n)}
+        self.n_poll = 0
+
+    def reset(self, slot):
+        pass
+
+    def set_queue_depth(self, d):
+        self.depth = d
+
+    def submit(self, items):
+        for slot, pcm, fin in items:
+            self.out[slot].append(float(pcm[0]))
+
+    def poll(self, min_done, isolate_faults=True):
+        self.n_poll += 1
+        has = {}
+        for s, q in self.out.items():
+            if q:                     # every complete chunk is reported (min_done is a lower bound)
+                q.popleft()
+                has[s] = False        # "the reference's early return []": no hypotheses to read back
+        return has
+
+
+def test_close_parks_other_sessions_replies_and_drain_terminates():
+    """a reply of another session that becomes ready inside close() must be handed out by the next
+    pump() / drain() - drain() used to spin on it - and a second reply of the same session must not overwrite it."""
+    import numpy as np
+    one = np.ones(4, dtype=np.float32)
+
+    def scenario():
+        fb = _FakeContinuousBatch(2)
+        sch = StreamScheduler(fb, queue_depth=2)
+        a, b = sch.open(), sch.open()
+        sch.feed(b, one * 1)
+        sch.feed(b, one * 2)
+        sch.feed(a, one * 9)
+        sch.pump(0, _collect=False, _feed=True)      # everything to the engine, no reply collected
+        assert set(sch._in_flight) == {a, b} and len(sch._in_flight[b]) == 2
+        sch.close(a)                                 # polls until a's chunk is reported: b's first reply comes with it
+        assert len(sch._stash[b]) == 1 and len(sch._in_flight[b]) == 1 and sch.pending() == 1
+        return fb, sch, b
+
+    fb, sch, b = scenario()
+    n0 = fb.n_poll
+    assert sch.pump() == {b: []} and fb.n_poll == n0       # the parked reply, without another poll
+    assert sch.pending() == 1
+    assert sch.pump() == {b: []} and fb.n_poll == n0 + 1   # the second reply of b: not overwritten, not lost
+    assert sch.pending() == 0 and not sch._stash and not sch._in_flight
+
+    fb, sch, b = scenario()
+    assert sch.drain() == {b: []} and sch.pending() == 0   # (the old drain() never returned here)
