@@ -23,6 +23,7 @@ noise.
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
+    python bench.py --gpus 8 ...        (no launcher: bench.py starts the 8 rank processes itself, rank i on GPU i)
 
 Prints ONE JSON line (rank 0).  value = whole-job audio-seconds processed per wall-clock second = number of
 concurrent real-time streams the job sustains.  Extra keys: `served` (continuous batching through sc_submit / sc_poll:
@@ -143,7 +144,8 @@ def strict_window(sb, audio, k0, steps, dist=None, before_timing=None):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    steps0 = n_dec_steps(sb)
+    steps0, iters0, enc0 = n_dec_steps(sb), sb.stats["dec_steps"], sb.stats["enc_calls"]
+    sb.take_attn_counters()
     if before_timing:
         before_timing(sb)
     torch.cuda.synchronize()
@@ -153,7 +155,9 @@ def strict_window(sb, audio, k0, steps, dist=None, before_timing=None):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    return elapsed, (n_dec_steps(sb) - steps0) / float(sb.S) / max(steps, 1), last
+    extra = {"attn": sb.take_attn_counters(), "encoder_groups": sb.stats["enc_calls"] - enc0,
+             "iterations": sb.stats["dec_steps"] - iters0}
+    return elapsed, (n_dec_steps(sb) - steps0) / float(sb.S) / max(steps, 1), last, extra
 
 
 def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None, depth=1):
@@ -171,7 +175,8 @@ def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=Non
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    steps0, iters0 = n_dec_steps(sb), sb.stats["dec_steps"]
+    steps0, iters0, enc0 = n_dec_steps(sb), sb.stats["dec_steps"], sb.stats["enc_calls"]
+    sb.take_attn_counters()
     if before_timing:
         before_timing(sb)
 
@@ -199,10 +204,13 @@ def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=Non
             if res is None:
                 torch.cuda.synchronize()
                 elapsed = time.perf_counter() - t0
+                attn_cnt = sb.take_attn_counters()
                 if at_target:
-                    at_target()
+                    at_target(attn_cnt)
                 adv = nxt - k_start
                 res = {"elapsed": elapsed, "dec_steps_per_hop": (n_dec_steps(sb) - steps0) / float(n_replies),
+                       "attn": attn_cnt, "encoder_groups": sb.stats["enc_calls"] - enc0,
+                       "iterations": sb.stats["dec_steps"] - iters0,
                        "iterations_per_step": (sb.stats["dec_steps"] - iters0) / float(steps), "polls_per_step": n_polls / float(steps),
                        "chunks_per_stream_min_max": [int(adv.min()), int(adv.max())]}
             continue          # (drain what is in flight, untimed)
@@ -227,50 +235,104 @@ def state_of(sb):
 # single-process setting measured for the reference), and N independent single-thread
 # processes - the reference's own concurrency model (one process / model copy per worker or client:
 # speechcatcher.py:482,787, speechcatcher_server.py:331-357).
-def cpu_baseline_worker(args):
-    threads, budget_s, beam, bbd, warm_calls, max_steps, stream_id = args
-    import torch as th
-    th.set_num_threads(threads)
-    from oracle.ref_port import RefPortModel, RefPortStreaming
+class _StatePickler(__import__("pickle").Pickler):
+    """an oracle stream WITHOUT its model: the model object, its weight dict and its PE table go out as tags"""
+
+    def __init__(self, f, model):
+        super().__init__(f, protocol=4)
+        self._tags = {id(model): "model", id(model.sd): "sd", id(model.pe): "pe"}
+
+    def persistent_id(self, obj):
+        return self._tags.get(id(obj))
+
+
+class _StateUnpickler(__import__("pickle").Unpickler):
+    def __init__(self, f, model):
+        super().__init__(f)
+        self._objs = {"model": model, "sd": model.sd, "pe": model.pe}
+
+    def persistent_load(self, tag):
+        return self._objs[tag]
+
+
+def _oracle_model():
+    from oracle.ref_port import RefPortModel
     from speechcatcher_amd.mel import melscale_fbanks_slaney
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    model = RefPortModel(sd, XL, melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000), mean, std)
+    return RefPortModel(sd, XL, melscale_fbanks_slaney(257, 0.0, 8000.0, 80, 16000), mean, std)
+
+
+def cpu_fast_forward_worker(args):
+    """untimed: stream 0 through the chunks IN FRONT of the GPU's timed window, state -> file"""
+    threads, beam, bbd, k0, path = args
+    import torch as th
+    th.set_num_threads(threads)
+    from oracle.ref_port import RefPortStreaming
+    model = _oracle_model()
     s = RefPortStreaming(model, beam_size=beam, ctc_weight=0.3, use_bbd=bbd)
-    audio = synth.synth_audio(stream_id, CHUNK * (warm_calls + max_steps))
-    for i in range(warm_calls):
+    audio = synth.synth_audio(0, CHUNK * k0)
+    t0 = time.perf_counter()
+    for i in range(k0):
         s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
+    with open(path, "wb") as f:
+        _StatePickler(f, model).dump(s)
+    T = 0 if s.encoder_buffer is None else int(s.encoder_buffer.shape[1])
+    return time.perf_counter() - t0, T, max(len(h.yseq) for h in s.running_hyps)
+
+
+def cpu_baseline_worker(args):
+    threads, budget_s, k0, max_steps, path = args
+    import torch as th
+    th.set_num_threads(threads)
+    model = _oracle_model()
+    with open(path, "rb") as f:
+        s = _StateUnpickler(f, model).load()
+    audio = synth.synth_audio(0, CHUNK * (k0 + max_steps))
     t0 = time.perf_counter()
     n = 0
     while n < max_steps and time.perf_counter() - t0 < budget_s:
-        i = warm_calls + n
+        i = k0 + n
         s(audio[i * CHUNK:(i + 1) * CHUNK], is_final=False)
         n += 1
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(budget_s=10.0, beam=10, bbd=False, warm_calls=4, max_steps=40):
+def cpu_baseline(k0, budget_s=10.0, beam=10, bbd=False, max_steps=20):
+    """The oracle on the SAME window as the GPU's timed region: chunks k0.. of stream 0 (T and the hypothesis lengths
+    are what they are there - attention and the CTC scan walk the whole prefix).  The prefix is fast-forwarded once,
+    untimed, and the state handed to every timed process."""
     import multiprocessing as mp
+    import tempfile
     ncpu = os.cpu_count() or 1
     hop_s = CHUNK / 16000.0
     legs = []
     ctx = mp.get_context("spawn")       # fresh interpreters: never fork a process that has initialised the GPU
-    for threads, procs in ((8, 1), (1, 1), (1, min(16, ncpu))):
-        threads = min(threads, ncpu)
-        with ctx.Pool(procs) as pool:
-            res = pool.map(cpu_baseline_worker, [(threads, budget_s, beam, bbd, warm_calls, max_steps, k) for k in range(procs)])
-        rate = sum(n * hop_s / dt for n, dt in res)
-        legs.append({"processes": procs, "threads_per_process": threads, "audio_s_per_s": round(rate, 4),
-                     "steps": [n for n, _ in res][:4], "wall_s": round(max(dt for _, dt in res), 1)})
+    fd, path = tempfile.mkstemp(suffix=".oracle_state")
+    os.close(fd)
+    try:
+        with ctx.Pool(1) as pool:
+            ff_s, T0, L0 = pool.map(cpu_fast_forward_worker, [(min(8, ncpu), beam, bbd, k0, path)])[0]
+        for threads, procs in ((8, 1), (1, 1), (1, min(16, ncpu))):
+            threads = min(threads, ncpu)
+            with ctx.Pool(procs) as pool:
+                res = pool.map(cpu_baseline_worker, [(threads, budget_s, k0, max_steps, path) for _ in range(procs)])
+            rate = sum(n * hop_s / dt for n, dt in res)
+            legs.append({"processes": procs, "threads_per_process": threads, "audio_s_per_s": round(rate, 4),
+                         "steps": [n for n, _ in res][:4], "wall_s": round(max(dt for _, dt in res), 1)})
+    finally:
+        os.unlink(path)
     best = legs[0]
     return {"value": best["audio_s_per_s"], "unit": "audio_s/s", "cores": best["threads_per_process"], "kind": "port",
-            "sample": f"1 stream, chunk steps {warm_calls}.. of stream 0 ({best['steps'][0]} steps, {best['wall_s']} s wall), "
+            "sample": f"1 stream, chunk steps {k0}.. of stream 0 - the GPU's timed window (T = {T0} encoder frames, "
+                      f"{L0} tokens per hypothesis at its start; the {k0} chunks in front of it fast-forwarded untimed in "
+                      f"{ff_s:.0f} s) - {best['steps'][0]} steps, {best['wall_s']} s wall, "
                       f"beam {beam}, bbd {int(bbd)}, XL dims, torch-CPU oracle (oracle/ref_port.py), 8 intra-op threads",
             "host_cores": ncpu, "torch": torch.__version__, "legs": legs,
             "streams_per_node_on_cpu": {"value": legs[2]["audio_s_per_s"], "processes": legs[2]["processes"],
                                         "note": "N independent single-thread processes (the reference's concurrency "
-                                                "model), aggregate audio-seconds per second; each process completes only "
-                                                "12-15 steps in its 10 s budget: +-10 %"}}
+                                                "model) on the same window, aggregate audio-seconds per second; each "
+                                                "process completes only a few steps in its 10 s budget: +-10 %"}}
 
 
 def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True, kv_dtype=None,
@@ -284,8 +346,8 @@ def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, t
     a3 = audio.reshape(streams, -1, CHUNK)
     if mode == "strict":
         run_host(sb, step_blocks(audio, preroll, k0), np.arange(streams, dtype=np.int32))
-        e, dsh, _ = strict_window(sb, audio, k0, steps, dist)
-        out = {"elapsed": e, "dec_steps_per_hop": dsh}
+        e, dsh, _, extra = strict_window(sb, audio, k0, steps, dist)
+        out = dict(extra, elapsed=e, dec_steps_per_hop=dsh)
     else:
         nxt = np.full(streams, preroll, np.int64)
         if not boundary:
@@ -343,6 +405,45 @@ def pmc_traffic(kernel_name):
     return int(tot / n) if n else None
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N rank processes
+    here - fresh children of a parent that never touches a GPU (torch.cuda.device_count() does not initialise one),
+    rank i bound to GPU i and to its own slice of the host cores (the reference's process pool over segments,
+    speechcatcher/speechcatcher.py:474-497, is one process per worker too).  Rank 0 prints the JSON line; the exit code
+    is the worst child's.  A rank that dies takes the others down instead of leaving them in a barrier."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n and os.environ.get("SC_BENCH_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // n)
+    procs = []
+    for r in range(n):
+        mine = cpus[r * per:(r + 1) * per] or cpus
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SC_BENCH_CPUS=",".join(map(str, mine)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or (code if code > 0 else 1)
+                for q in live:          # the exact children started above
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +483,12 @@ def main():
                          "split16: the feed-forward kernels evaluate their fp32 product sums on the fp16 matrix pipe from "
                          "fp16 hi + lo splits of both operands (three MFMAs per sum, fp32-grade results: sc_ffn_ln_s)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if os.environ.get("SC_BENCH_CPUS"):      # a rank started by launch_ranks: its own slice of the host cores
+        mine = [int(c) for c in os.environ["SC_BENCH_CPUS"].split(",")]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(8, len(mine))))
     global CHUNK, KV_DTYPE, FFN_DTYPE
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
@@ -409,6 +516,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_device = device if (dist is None or dist.get_backend() == "nccl") else "cpu"
+    per_rank_elapsed = None
 
     k0 = args.preroll + args.warmup
     total_steps = k0 + args.steps + args.roofline_steps + SERVED_SPARE
@@ -429,7 +537,7 @@ def main():
     ev_over_ms, xattn_bytes = 0.0, {}
     if args.roofline_steps > 0:
         sb.set_graphs(False)
-        sb.take_xattn_rows()
+        sb.take_attn_counters()
         lib.sc_prof_enable(1)
         if args.mode == "strict":
             run_host(sb, step_blocks(audio, k0 + args.steps, k0 + args.steps + args.roofline_steps), np.arange(S, dtype=np.int32))
@@ -438,25 +546,32 @@ def main():
             # compaction buckets that the steady state never sees)
             rows_at_target = []
 
-            def stop_timing():
+            def stop_timing(counters):
                 lib.sc_prof_enable(0)
-                rows_at_target.append(sb.take_xattn_rows_by_kernel())
+                rows_at_target.append(counters)
 
             serve(sb, a3, head["next_chunk"], args.roofline_steps, group, at_target=stop_timing, depth=args.queue_depth)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
         sb.set_graphs(True)
-        rows = sb.take_xattn_rows_by_kernel()
+        rows = sb.take_attn_counters()
         if args.mode != "strict":
             rows = rows_at_target[0]
         ev_over_ms = float(lib.sc_prof_event_overhead_ms(sb.hip_stream))
-        # cross-attention: K|V rows of every active stream are read once per layer and step
+        # algorithmic K|V bytes: the cross-attention reads the T encoder rows of every active stream once per layer and
+        # step; the self-attention the DISTINCT (position, slot) rows its hypotheses descend from (device counter) -
+        # a row = K|V of all heads = 2d elements
         esz = 2 if KV_DTYPE == "float16" else 4
-        xattn_bytes = {7: float(rows[0]) * 2 * XL.d_model * esz, 11: float(rows[1]) * 2 * XL.d_model * esz}
+        rowb = 2 * XL.d_model * esz
+        xattn_bytes = {7: float(rows["cross_rows"][0]) * rowb, 11: float(rows["cross_rows"][1]) * rowb,
+                       6: float(rows["self_distinct_rows"][0]) * rowb, 10: float(rows["self_distinct_rows"][1]) * rowb}
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
+        each = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(each, t)
+        per_rank_elapsed = [float(x.item()) for x in each]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the path's single collective: gather of the final text (token ids + positions + length + score)
@@ -540,7 +655,42 @@ def main():
              "achieved_tflops_whole_step": round(gflop_step / ms_step, 2),
              "frac_of_f32_mfma_peak": round(gflop_step / ms_step / PEAK_F32_MFMA_TFLOPS, 4),
              "note": f"{args.streams} x (3.83 + 0.437 x decode steps per hop) GFLOP per chunk step (SURVEY 8(d)) / ms_per_step; "
-                     "attention and the CTC scan over the prefix are not in this FLOP count"}
+                     "attention and the CTC scan over the prefix are not in this FLOP count (see with_attention / hbm)"}
+    if head.get("attn"):
+        c = XL
+        d, F, V, Ld, Le, W = c.d_model, c.ffn_dim, c.vocab_size, c.dec_layers, c.enc_layers, args.beam
+        at = head["attn"]
+        cross_rows, self_pos, self_rows = sum(at["cross_rows"]), sum(at["self_positions"]), sum(at["self_distinct_rows"])
+        # decoder attention: q.k and p.v of every hypothesis over its L tokens / the T frames: 4 d flop per key, layer, hypothesis
+        gflop_attn = 4.0 * d * W * (cross_rows + self_pos) / 1e9 / args.steps
+        esz = 2 if KV_DTYPE == "float16" else 4
+        K = 40
+        sum_T = cross_rows / float(Ld)                   # sum over decode iterations and active streams of T
+        hbm = {"decoder_weights_per_iteration": head["iterations"] * 4.0 * (Ld * (6 * d * d + 2 * d * F) + V * d),
+               "encoder_side_weights_per_group": head["encoder_groups"] * 4.0 * (Le * (4 * d * d + 2 * d * F) + 9 * d * d
+                                                                                  + c.conv_freq2 * d * d + V * d + Ld * 2 * d * d),
+               "cross_attention_kv": cross_rows * 2.0 * d * esz,
+               "self_attention_kv_distinct_rows": self_rows * 2.0 * d * esz,
+               # prefix scan per (iteration, stream, frame): W*K table elements read, r of the W hypotheses read, r of the
+               # W*K candidates written (ctc_rnew), the W selected ones copied (read + write)
+               "ctc_table_and_state": sum_T * 4.0 * (W * K + 2 * W + 2 * W * K + 4 * W)}
+        tot = sum(hbm.values())
+        whole["with_attention"] = {"algorithmic_gflop_per_step": round(gflop_step + gflop_attn, 1),
+                                   "attention_gflop_per_step": round(gflop_attn, 1),
+                                   "achieved_tflops": round((gflop_step + gflop_attn) / ms_step, 2),
+                                   "frac_of_f32_mfma_peak": round((gflop_step + gflop_attn) / ms_step / PEAK_F32_MFMA_TFLOPS, 4)}
+        whole["hbm"] = {"algorithmic_gb_per_step": {k: round(v / 1e9 / args.steps, 3) for k, v in hbm.items()},
+                        "total_gb_per_step": round(tot / 1e9 / args.steps, 3),
+                        "achieved_gbs": round(tot / 1e9 / elapsed, 1), "peak_gbs": PEAK_HBM_GBS,
+                        "frac_of_hbm_peak": round(tot / 1e9 / elapsed / PEAK_HBM_GBS, 4),
+                        "decode_iterations": int(head["iterations"]), "encoder_groups": int(head["encoder_groups"]),
+                        "self_attention_distinct_rows_per_position": round(self_rows / max(self_pos, 1), 3),
+                        "note": "algorithmic HBM bytes of the timed window / its wall time: weights once per decode iteration "
+                                "(one graph replay = one pass over the decoder) and once per encoder group, K|V rows the "
+                                "attention has to read (cross: T rows per active stream, layer and step; self: the distinct "
+                                "rows, device counter), CTC table + forward variables of the prefix scan; activations "
+                                "(< 3 %) left out.  The weights mostly stay in the 256 MB Infinity Cache between iterations: "
+                                "this is an upper bound of the HBM traffic the algorithm needs, not a PMC reading"}
     sb.close()
     del sb
 
@@ -638,7 +788,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
-            cpu = cpu_baseline(beam=args.beam, bbd=bool(args.bbd))
+            cpu = cpu_baseline(k0, beam=args.beam, bbd=bool(args.bbd))
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
 
@@ -679,6 +829,9 @@ def main():
                              "C++ (sc_push + sc_get_hyps_batch, csrc/streams.hip)",
                    "parallelism": f"streams sharded x{world}, no collective in the hot loop"},
         "chunk_steps_per_s": round(world * S * args.steps / elapsed, 2),
+        "per_rank": (None if per_rank_elapsed is None else
+                     [{"rank": r, "gpu": r, "audio_s_per_s": round(S * args.steps * CHUNK / 16000.0 / e, 2),
+                       "ms_per_step": round(e / args.steps * 1e3, 3)} for r, e in enumerate(per_rank_elapsed)]),
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,

@@ -140,6 +140,10 @@ typedef struct sc_search {
    * arithmetic, softmax and everything else stay fp32.  Written through sc_kv_rows_to_half (cross) and by the
    * self-attention kernels (self); read by the single-pass attention kernels. */
   int32_t kv_half;
+  /* measurement aid (bench.py: algorithmic bytes of the self-attention): when not NULL, every self-attention launch
+   * adds the DISTINCT (position, slot) K|V rows it walked for a stream (plus its new rows) to stat_rows[0]
+   * (sc_dec_self_attn) / stat_rows[1] (sc_dec_layer_self) - one atomic per (stream, layer), by head 0 */
+  unsigned long long *stat_rows;
 } sc_search;
 
 const char *sc_last_error(void);
@@ -296,6 +300,9 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_KINDS 12
 /* decoder layers run as head-parallel launches (sc_dec_layer_*) for compaction buckets up to this many rows */
 #define SC_FUSED_MAX_ROWS 960
+/* ... with one head per workgroup; from SC_HPW_MIN_ROWS rows on with FOUR heads per workgroup (1024 threads: the
+ * prologue reduce + LayerNorm once per four heads, H/4 partial products per row) - the form of the large buckets */
+#define SC_HPW_MIN_ROWS 640
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
@@ -561,6 +568,11 @@ int sc_streams_bucket_times(sc_streams *streams, double *seconds, long *iteratio
 long sc_streams_take_xattn_rows(sc_streams *streams);
 /* ... split by the kernel that read them: rows[0] dec_attn_flash (large buckets), rows[1] sc_dec_layer_cross */
 int sc_streams_take_xattn_rows_by_kernel(sc_streams *streams, long *rows);
+/* all attention counters since the last call (returned and cleared), each summed over decode iterations, active streams
+ * and decoder layers, [0] stand-alone attention kernels / [1] head-parallel layer kernels:
+ *   out[0..1] encoder K|V rows the cross-attention read, out[2..3] token positions the self-attention covered (L per
+ *   hypothesis: the algorithmic length), out[4..5] DISTINCT self-attention K|V rows read (device counter) */
+int sc_streams_take_attn_counters(sc_streams *streams, long *out /*HOST [6]*/);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);
 float *sc_streams_pcm(sc_streams *streams, long *capacity);

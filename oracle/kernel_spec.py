@@ -440,14 +440,27 @@ class SpecBackend:
             if act and nh > 0:
                 yield s, cur, T, L, nh
 
+    # heads per workgroup of the HIP kernels (csrc/decoder_layer.hip: HPW): the partial products of `dec_hpw`
+    # consecutive heads are summed before they are stored, a row carries H / dec_hpw of them
+    dec_hpw = 1
+
     def _head_partials(self, ctx, wo, H, nh):
-        """ph[w, h, :] = ctx[w, h*dk:(h+1)*dk] . wo[:, h*dk:(h+1)*dk]^T; rows >= nh are zero"""
+        """ph[w, g, :] = sum over the heads h of group g (in head order) of ctx[w, h*dk:(h+1)*dk] . wo[:, h*dk:(h+1)*dk]^T;
+        rows >= nh are zero"""
         Wn, d = ctx.shape
         dk = d // H
-        ph = torch.zeros(Wn, H, d)
+        hpw = self.dec_hpw
+        ph = torch.zeros(Wn, H // hpw, d)
         for h in range(H):
-            ph[:nh, h] = ctx[:nh, h * dk:(h + 1) * dk] @ wo[:, h * dk:(h + 1) * dk].t()
+            part = ctx[:nh, h * dk:(h + 1) * dk] @ wo[:, h * dk:(h + 1) * dk].t()
+            ph[:nh, h // hpw] = part if h % hpw == 0 else ph[:nh, h // hpw] + part
         return ph
+
+    def _ph_view(self, buf, H):
+        """the partial-product buffer [S*W][H][d] as the kernels lay it out with H / dec_hpw partials per row"""
+        n, _, d = buf.shape
+        nph = H // self.dec_hpw
+        return buf.view(-1)[:n * nph * d].view(n, nph, d)
 
     def dec_layer_self(self, sb, li, xin, xout, npart):
         """sc_dec_layer_self: x (embedding for layer 0, else residual + feed-forward partial sums + b2 of the
@@ -474,7 +487,7 @@ class SpecBackend:
         self.dec_self_attn(sb, li)     # dqkv -> K|V rows appended to skv, context of rows < nh in datt
         for s, cur, T, L, nh in self._active_rows(sb):
             rows = slice(s * W, (s + 1) * W)
-            sb.ph1[rows] = self._head_partials(sb.datt[rows], lw["wo"], H, nh)
+            self._ph_view(sb.ph1, H)[rows] = self._head_partials(sb.datt[rows], lw["wo"], H, nh)
 
     def dec_layer_cross(self, sb, li, xin, xout):
         """sc_dec_layer_cross: x = xin + bo + sum_h ph1 -> xout; norm2, q, cross-attention
@@ -484,9 +497,10 @@ class SpecBackend:
         lw = w.dec[li]
         for s, cur, T, L, nh in self._active_rows(sb):
             rows = slice(s * W, (s + 1) * W)
-            y = sb.ph1[rows, 0].clone()
-            for h in range(1, H):
-                y = y + sb.ph1[rows, h]
+            ph1 = self._ph_view(sb.ph1, H)
+            y = ph1[rows, 0].clone()
+            for h in range(1, ph1.shape[1]):
+                y = y + ph1[rows, h]
             x = xin[rows] + (y + lw["bo"])
             xout[rows] = x
             xn = torch.nn.functional.layer_norm(x, (d,), lw["ln2_g"], lw["ln2_b"], cfg.ln_eps)
@@ -494,7 +508,7 @@ class SpecBackend:
         self.dec_cross_attn(sb, li)
         for s, cur, T, L, nh in self._active_rows(sb):
             rows = slice(s * W, (s + 1) * W)
-            sb.ph2[rows] = self._head_partials(sb.datt[rows], lw["wo2"], H, nh)
+            self._ph_view(sb.ph2, H)[rows] = self._head_partials(sb.datt[rows], lw["wo2"], H, nh)
 
     def dec_layer_ffn(self, sb, li, xin, xout):
         """sc_dec_layer_ffn over the compacted rows: x = xin + bo2 + sum_h ph2 -> xout; feed-forward of norm3(x)
@@ -503,9 +517,10 @@ class SpecBackend:
         d, H = cfg.d_model, cfg.dec_heads
         lw = w.dec[li]
         r = sb.rowmap[:int(sb.n_rows_step)].to(torch.long)
-        y = sb.ph2[r, 0].clone()
-        for h in range(1, H):
-            y = y + sb.ph2[r, h]
+        ph2 = self._ph_view(sb.ph2, H)
+        y = ph2[r, 0].clone()
+        for h in range(1, ph2.shape[1]):
+            y = y + ph2[r, h]
         x = xin[r] + (y + lw["bo2"])
         xout[r] = x
         xn = torch.nn.functional.layer_norm(x, (d,), lw["ln3_g"], lw["ln3_b"], cfg.ln_eps)

@@ -48,7 +48,7 @@ class Search(C.Structure):
                              "cand_score", "cand_tok", "cand_ctc", "sel", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
-           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32)]
+           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32), ("stat_rows", vp)]
     )
 
 
@@ -179,6 +179,7 @@ _SIGS = {
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
     "sc_streams_take_xattn_rows_by_kernel": (C.c_int, [vp, vp]),
+    "sc_streams_take_attn_counters": (C.c_int, [vp, vp]),
     "sc_streams_hip_stream": (vp, [vp]),
     "sc_streams_pcm": (vp, [vp, C.POINTER(C.c_long)]),
     "sc_streams_write_pcm": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_long]),

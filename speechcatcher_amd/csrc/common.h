@@ -44,6 +44,10 @@ void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 // search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel)
 int sc_decode_step_form(const sc_search *sb);
 
+// decoder_layer.hip: heads per workgroup of the head-parallel layer kernels for the bucket sb.n_rows (1, 2 or 4): the
+// consumer of their partial products (the next layer kernel, sc_dec_layer_ffn) reduces sb.H / hpw of them per row
+int sc_dec_layer_hpw(const sc_search &sb);
+
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,

@@ -19,11 +19,21 @@
 // rows and an output projection needs all heads, which used to force a launch boundary after every attention.
 // Here every (stream, head) workgroup REDUCES THE PRODUCER'S PARTIAL SUMS ITSELF (W <= 16 rows x d: 10 KB per
 // partial, L2-resident - blockIdx.x is the stream, so the H workgroups of a stream share an XCD and its L2)
-// and recomputes the cheap row-local LayerNorm redundantly, while the expensive parts - weight streaming,
+// and recomputes the cheap row-local LayerNorm redundantly (HPW heads per workgroup, see below: H / HPW times), while
+// the expensive parts - weight streaming,
 // K/V streaming, MFMA work - are split across heads without redundancy: Wqkv / Wq by output columns of the
 // head, Wo / Wo2 by the head's K slice (their partial products are summed by the next kernel's prologue in
 // fixed head order: deterministic).  No cross-workgroup hand-off inside a launch (an agent-scope release /
 // acquire costs an L2 write-back + invalidate on this part); the kernel boundary is the only barrier.
+//
+// HPW (heads per workgroup, round 4).  With one head per workgroup every one of the H workgroups of a stream re-reads
+// ALL partial sums of its stream's rows (8 x redundant at XL dims): cheap while few streams are active, but at a full
+// bucket (1280 rows) it is ~80 MB per layer through the fabric and costs more than the three launches the form saves
+// (result (k)).  HPW = 4 puts four heads into one 1024-thread workgroup (four head groups of four
+// waves, each running exactly the single-head code on its own LDS region): the prologue - reduce + LayerNorm - is
+// done ONCE per four heads and shared through LDS, the four heads' shares of the output projection are summed in LDS
+// before they are stored, so the next kernel reduces H / HPW = 2 partial products per row instead of 8.  256 workgroups
+// of 16 waves fill the 256 CUs of a full 128-stream bucket exactly like the 1024 workgroups of 4 waves did.
 #include "common.h"
 #include "attn.h"
 
@@ -90,9 +100,13 @@ __host__ __device__ static inline int dl_region_floats(int D, int DK, int W, boo
   r = r > outp ? r : outp;
   return r > attn ? r : attn;
 }
-__host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self) {
-  return dl_region_floats(D, DK, W, self) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/ +
-         2 * D /*LayerNorm gamma | beta*/;
+// ... of one head group: region, qs, kvn, ctx
+__host__ __device__ static inline int dl_group_floats(int D, int DK, int W, int WM, bool self) {
+  return dl_region_floats(D, DK, W, self) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
+}
+// HPW head groups + LayerNorm gamma | beta + (HPW > 1) the LayerNorm tile shared by the head groups
+__host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
+  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + (hpw > 1 ? 16 * (D + 4) : 0);
 }
 
 // key tiles per wave in flight in the attention walk of the few-streams variant (UNR = 8).  Measured in round 3 with 8
@@ -101,8 +115,9 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #ifndef SC_LAYER_NTW
 #define SC_LAYER_NTW 4
 #endif
-template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH>
-__global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
+template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1>
+__global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
+  constexpr int NTH = 256 * HPW;   // threads: HPW head groups of 4 waves
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
   constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
   constexpr int NTQ = DK / 16, NT = (SELF ? 3 : 1) * NTQ, LDP = NT * 16 + 4;
@@ -114,18 +129,21 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // so the H workgroups of a stream - and the same stream's workgroups of the next launch - share one XCD's L2)
   if ((int)blockIdx.x >= (sb.rowmap ? sb.n_rows / sb.W : sb.S)) return;
   const int s = sb.rowmap ? sb.rowmap[blockIdx.x * sb.W] / sb.W : blockIdx.x;
-  const int head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = tid >> 8, gt = tid & 255, wave = gt >> 6;   // head group, thread and wave inside it
+  const int head = blockIdx.y * HPW + g;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
   const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
-  const int W = sb.W, LCAP = sb.LCAP, H = sb.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float *region = smem;
-  float *qs = smem + dl_region_floats(D, DK, W, SELF);  // [16][DK] queries / sqrt(dk), rows >= W zero
+  const int W = sb.W, LCAP = sb.LCAP, NPH = sb.H / HPW;
+  const int GS = dl_group_floats(D, DK, W, WM, SELF);        // LDS floats of one head group
+  float *region = smem + g * GS;
+  float *qs = region + dl_region_floats(D, DK, W, SELF);     // [16][DK] queries / sqrt(dk), rows >= W zero
   float *kvn = qs + 16 * DK;                                 // SELF: [WM][2*DK] k|v of the new token
   float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
-  float *gb = ctx + WM * DK;                                 // [2][D] LayerNorm gamma | beta
+  float *gb = smem + HPW * GS;                               // [2][D] LayerNorm gamma | beta (shared)
+  float *Xsh = HPW > 1 ? gb + 2 * D : region;                // [16][D+4] LayerNorm tile: shared by the head groups
 
   // ------------------------------------------------------------------ L2 warm-up of this head's weight slices
   // One dword per 128-B line of the projection fragments and of the output-projection fragments, issued before
@@ -138,14 +156,15 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // PF (few streams active: registers are plentiful): the projection's B fragments are fetched into registers
   // right here instead, so that the MFMAs behind the LayerNorm wait for nothing.
   constexpr bool PF = UNR >= 8;
+  static_assert(!(PF && HPW > 1), "the few-streams variant runs one head per workgroup");
   float4 pfb[PF ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
   int slp[(PF && SELF) ? WM : 1];
   if (PF && SELF) {
     const int *anc0 = ANC(cur, s);
-    const bool live0 = tid < PCH && tid < L - 1;
+    const bool live0 = gt < PCH && gt < L - 1;
 #pragma unroll
-    for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? tid : 0) * W + min(h, nh - 1)];
+    for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? gt : 0) * W + min(h, nh - 1)];
   }
   float touch = 0.f, kvtouch = 0.f;
   // (loads return in issue order: the fragments are requested right BEHIND the first batch of partial sums, which
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       if (FIRST) prefetch_w();
     } else {
       constexpr int NW = (SELF ? 3 : 1);
-      const int ofs = tid * 32;   // floats: 128 B per thread, 32 KB per workgroup and instruction
+      const int ofs = gt * 32;   // floats: 128 B per thread, 32 KB per head group and instruction
 #pragma unroll
       for (int wh = 0; wh < NW; ++wh) {
         const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     }
     // output projection: D/16 tiles, k-block (head*DK)/32, 2 KB each
     constexpr int TPW = D / 16 * 16;   // lines: 16 per tile
-    if (tid < TPW) touch += p.wop[((long)((tid >> 4) * KI + (head * DK) / 32) * 2) * 256 + (tid & 15) * 32];
+    if (gt < TPW) touch += p.wop[((long)((gt >> 4) * KI + (head * DK) / 32) * 2) * 256 + (gt & 15) * 32];
   }
 
   // ------------------------------------------------------------------ prologue: x rows, LayerNorm -> Xn
@@ -181,14 +200,14 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // them with ALL loads of a batch in flight at once (one memory round trip per ZB partial sums); the row-wise
   // LayerNorm then runs on the LDS tile.
   {
-    float *Xn = region;  // [16][LDX], rows >= W zero
-    constexpr int C4 = D / 4, QT = 16 * C4 / 256;           // float4 pieces per row; pieces per thread (16 rows)
-    constexpr int QN = (WM * C4 + 255) / 256;               // ... of the rows that can be live (W <= WM)
+    float *Xn = Xsh;  // [16][LDX], rows >= W zero
+    constexpr int C4 = D / 4, QT = (16 * C4 + NTH - 1) / NTH;   // float4 pieces per row; pieces per thread (16 rows)
+    constexpr int QN = (WM * C4 + NTH - 1) / NTH;               // ... of the rows that can be live (W <= WM)
     constexpr int ZB = (UNR >= 8) ? 8 : 4;          // partial sums per batch (register budget of the variant)
     float4 xv[QN];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+      const int e = tid + NTH * q, i = e / C4, c4 = e % C4;
       xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < W) {
         if (FIRST) {
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
         float4 pv[QN][ZB];
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
-          const int e = tid + 256 * q, i = min(e / C4, W - 1), c4 = e % C4;
+          const int e = tid + NTH * q, i = min(e / C4, W - 1), c4 = e % C4;
           const long row = (long)s * W + i;
 #pragma unroll
           for (int z = 0; z < ZB; ++z)
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       }
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+        const int e = tid + NTH * q, i = e / C4, c4 = e % C4;
         if (i < W) {
           const long row = (long)s * W + i;
           const float4 xi = *reinterpret_cast<const float4 *>(p.xin + row * D + 4 * c4);
@@ -253,17 +272,19 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     }
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
-      const int e = tid + 256 * q, i = e / C4, c4 = e % C4;
+      const int e = tid + NTH * q, i = e / C4, c4 = e % C4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                   // rows >= W: zeros
       if (q < QN) v = xv[q];
-      *reinterpret_cast<float4 *>(Xn + i * LDX + 4 * c4) = v;
-      if (head == 0 && i < W) *reinterpret_cast<float4 *>(p.xout + ((long)s * W + i) * D + 4 * c4) = v;
+      if (16 * C4 % NTH == 0 || e < 16 * C4) {
+        *reinterpret_cast<float4 *>(Xn + i * LDX + 4 * c4) = v;
+        if (blockIdx.y == 0 && i < W) *reinterpret_cast<float4 *>(p.xout + ((long)s * W + i) * D + 4 * c4) = v;
+      }
     }
     if (tid < D / 2) *reinterpret_cast<float4 *>(gb + 4 * tid) = gbv;
     if (touch == 123456.789f) Xn[0] = touch;   // never true: keeps the warm-up loads (they have returned by now:
     __syncthreads();                           // loads return in order and the partial sums were waited for)
     SC_STAMP(SELF ? 0 : 1, 1);
-    {   // LayerNorm in place: 16 lanes per row, all 16 rows of the tile at once (DPP reductions)
+    if (HPW == 1 || tid < 256) {   // LayerNorm in place: 16 lanes per row, all 16 rows of the tile at once (DPP reductions)
       constexpr int Q4 = D / 64;
       const int i = tid >> 4, sub = tid & 15;
       float4 x[Q4];
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
   // straight from the fragment-packed weights (1 KB contiguous per wave load)
   {
-    const float *Xn = region;
+    const float *Xn = Xsh;
     const int r = lane & 15, kk = lane >> 4;
     f32x4 acc[NT];
 #pragma unroll
@@ -353,8 +374,8 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
-    for (int e = WM * DK + tid; e < 16 * DK; e += 256) qs[e] = 0.f;   // hypothesis rows the MFMA tiles pad with
-    for (int e = tid; e < WM * NT * 16; e += 256) {
+    for (int e = WM * DK + gt; e < 16 * DK; e += 256) qs[e] = 0.f;   // hypothesis rows the MFMA tiles pad with
+    for (int e = gt; e < WM * NT * 16; e += 256) {
       const int w = e / (NT * 16), n = e % (NT * 16);
       const int which = n / DK, c = n % DK;
       float v = 0.f;
@@ -409,9 +430,9 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
     // entry = local position | slot << 8 | hypothesis bit set << 12
     auto build = [&](int *rw, int c0) -> int {
-      for (int e = tid; e < PCH * W; e += 256) rw[e] = 0;
-      const int pp = c0 + tid;
-      const bool live = tid < PCH && pp < Lc;
+      for (int e = gt; e < PCH * W; e += 256) rw[e] = 0;
+      const int pp = c0 + gt;
+      const bool live = gt < PCH && pp < Lc;
       int sl[WM];
 #pragma unroll
       for (int h = 0; h < WM; ++h) sl[h] = (PF && c0 == 0) ? slp[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
@@ -435,16 +456,18 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
         for (int h = 0; h < WM; ++h) {
           if (h < nh) {
             const int rank = __popc(mask & ((1u << sl[h]) - 1u));
-            atomicOr(&rw[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
+            atomicOr(&rw[base + rank], gt | (sl[h] << 8) | (1 << (12 + h)));
           }
         }
       }
       __syncthreads();  // list complete; wtot may be rewritten
       return U;
     };
+    int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
       const int U = build(rows, c0);
+      urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
         hm = (unsigned)e >> 12;
@@ -452,9 +475,10 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       });
       if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
     }
+    if (sb.stat_rows && head == 0 && gt == 0) atomicAdd(&sb.stat_rows[1], (unsigned long long)urows);
     // the new token: hypothesis h attends to its own row (slot h at position L-1, still in LDS) only
-    if (tid < 16) {
-      const int h = tid;
+    if (gt < 16) {
+      const int h = gt;
       float sdot = -INFINITY;
       if (h < nh) {
         sdot = 0.f;
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
   SC_STAMP(SELF ? 0 : 1, 5);
   mattn_store_partial<DK>(st, pm, pl, pO, wave, lane);
   __syncthreads();
-  for (int e = tid; e < WM * DK; e += 256) {
+  for (int e = gt; e < WM * DK; e += 256) {
     const int h = e / DK, c = e % DK;
     ctx[e] = h < nh ? mattn_final<DK, NP>(pm, pl, pO, h, c) : 0.f;  // rows >= nh: zero context (their partial products stay finite)
   }
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
     float *As = region;              // [16][LDA]
     float *Os = region + 16 * LDA;   // [16][LDO]
     const int kb = (head * DK) / 32, koff = (head * DK) % 32;
-    for (int e = tid; e < 16 * 32; e += 256) {
+    for (int e = gt; e < 16 * 32; e += 256) {
       const int w = e / 32, c = e % 32;
       As[w * LDA + c] = (w < WM && c >= koff && c < koff + DK) ? ctx[w * DK + c - koff] : 0.f;
     }
@@ -523,10 +547,16 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
       for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = oacc[t][j];
     __syncthreads();
     SC_STAMP(SELF ? 0 : 1, 7);
-    for (int e = tid; e < W * (D / 4); e += 256) {
+    // (HPW > 1: the head groups' shares are summed here, in head order - one partial product per workgroup)
+    for (int e = tid; e < W * (D / 4); e += NTH) {
       const int w = e / (D / 4), c4 = e % (D / 4);
-      *reinterpret_cast<float4 *>(p.ph + (((long)s * W + w) * H + head) * D + 4 * c4) =
-          *reinterpret_cast<const float4 *>(Os + w * LDO + 4 * c4);
+      float4 o = *reinterpret_cast<const float4 *>(smem + 16 * LDA + w * LDO + 4 * c4);
+#pragma unroll
+      for (int gg = 1; gg < HPW; ++gg) {
+        const float4 t = *reinterpret_cast<const float4 *>(smem + gg * GS + 16 * LDA + w * LDO + 4 * c4);
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      *reinterpret_cast<float4 *>(p.ph + (((long)s * W + w) * NPH + blockIdx.y) * D + 4 * c4) = o;
     }
   }
   if (kvtouch == 123456.789f) p.ph[0] = kvtouch;   // never true: keeps the K|V warm-up loads
@@ -535,25 +565,59 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer
 SC_PHASE_GETTER(sc_phase_debug_layer)
 
 // ---------------------------------------------------------------------------------------------------------------
+// Heads per workgroup for this launch's compaction bucket (see the top of the file).  One head per workgroup while few
+// streams are active (latency-bound chains: more, smaller workgroups spread the weight and K/V streaming over more
+// CUs); four from SC_HPW_MIN_ROWS hypothesis rows on, where the redundant prologue reads are what costs.
+// SC_DEC_HPW = 1 | 2 | 4 forces one form at any size (tests, sweeps).
+int sc_dec_layer_hpw(const sc_search &sb) {
+  const int dk = sb.d / sb.H;
+  const bool can = sb.d == 256 && dk == 32 && sb.W > 5 && sb.W <= 10;   // the instantiated HPW > 1 variants
+  int hpw = 1;
+  if (can && (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= SC_HPW_MIN_ROWS) hpw = 4;
+  if (const char *e = sc_hook("SC_DEC_HPW")) {
+    const int v = atoi(e);
+    if (v == 1 || (can && (v == 2 || v == 4))) hpw = v;
+  }
+  while (hpw > 1 && sb.H % hpw) hpw >>= 1;
+  return hpw;
+}
+
+template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW>
+static void launch_dec_layer_variant(const DecLayerArgs &p, int ns, hipStream_t st) {
+  const sc_search &sb = p.sb;
+  // one or two streams: pad grid.x to 8 so that all H workgroups of a stream land on ONE XCD (linear id x + 8*y) and
+  // share its L2 - single stream 5.41 -> 5.25 ms per hop; with more streams the padding concentrates the work on
+  // fewer XCDs and costs 1 % at 128 streams, so larger buckets keep their natural spread
+  const dim3 grid(ns <= 2 ? 8 : ns, sb.H / HPW);
+  const size_t lds = (size_t)dl_lds_floats(D, DK, sb.W, WM, SELF, HPW) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW><<<grid, 256 * HPW, lds, st>>>(p);
+}
+
 template <int D, int DK, bool SELF, bool FIRST, bool KVH>
 static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   const sc_search &sb = p.sb;
   const int ns = sb.rowmap ? sb.n_rows / sb.W : sb.S;   // streams of the compaction bucket only
-  // one or two streams: pad grid.x to 8 so that all H workgroups of a stream land on ONE XCD (linear id x + 8*y) and
-  // share its L2 - single stream 5.41 -> 5.25 ms per hop; with more streams the padding concentrates the work on
-  // fewer XCDs and costs 1 % at 128 streams, so larger buckets keep their natural spread
-  const dim3 grid(ns <= 2 ? 8 : ns, sb.H);
   // compaction bucket of this launch (scasr.h: rowmap / n_rows): at most half of the streams active
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
-  auto lds = [&](int wm) { return (size_t)dl_lds_floats(D, DK, sb.W, wm, SELF) * sizeof(float); };
+  const int hpw = sc_dec_layer_hpw(sb);
+  if constexpr (D == 256 && DK == 32) {
+    if (hpw == 4) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 4>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
+    if (hpw == 2) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 2>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
+  }
   if (sb.W <= 5) {
-    dec_layer_attn_kernel<D, DK, 5, SELF, 4, FIRST, KVH><<<grid, 256, lds(5), st>>>(p);
+    launch_dec_layer_variant<D, DK, 5, SELF, 4, FIRST, KVH, 1>(p, ns, st);
   } else if (sb.W <= 10) {
-    if (deep) dec_layer_attn_kernel<D, DK, 10, SELF, 8, FIRST, KVH><<<grid, 256, lds(10), st>>>(p);
-    else dec_layer_attn_kernel<D, DK, 10, SELF, 2, FIRST, KVH><<<grid, 256, lds(10), st>>>(p);
+    if (deep) launch_dec_layer_variant<D, DK, 10, SELF, 8, FIRST, KVH, 1>(p, ns, st);
+    else launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 1>(p, ns, st);
   } else {
-    dec_layer_attn_kernel<D, DK, 16, SELF, 2, FIRST, KVH><<<grid, 256, lds(16), st>>>(p);
+    launch_dec_layer_variant<D, DK, 16, SELF, 2, FIRST, KVH, 1>(p, ns, st);
   }
   SC_CHECK_LAUNCH();
   return SC_OK;
@@ -609,7 +673,8 @@ extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *
   SC_CHECK_ARG(sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F), "unsupported dimensions");
   const sc_dec_layer &w = sb.layers[layer];
   SC_CHECK_ARG(w.wq_pp && w.wo2_pp, "panel-packed Wq / Wo2 missing");
-  DecLayerArgs p{sb, layer, xin, xout, sb.ph1, sb.H, (long)sb.d, (long)sb.H * sb.d, w.bo, w.ln2_g, w.ln2_b,
+  const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_self (same bucket, same form)
+  DecLayerArgs p{sb, layer, xin, xout, sb.ph1, nph, (long)sb.d, (long)nph * sb.d, w.bo, w.ln2_g, w.ln2_b,
                  w.wq_pp, w.bq, w.wo2_pp, sb.ph2};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);

@@ -1670,9 +1670,10 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     ProfScope prof = sc_prof_begin(st);
     if (D == 256) launch_ffn_rtt<256>(p, best_rtt, ngrp, st);
     else launch_ffn_rtt<128>(p, best_rtt, ngrp, st);
-    // algorithmic: 4*D*F flop per row; xn read, W1 + W2 read once, partials written
+    // algorithmic: 4*D*F flop per row; W1 + W2 once, x in, x out.  The split sums this decomposition
+    // writes (ngrp x slab x D) and the reduce kernel re-reads are traffic, not algorithmic bytes
     sc_prof_end(prof, SC_PROF_FFN_FUSED, 4.0 * (double)slab * D * F,
-                4.0 * ((double)slab * D + 2.0 * (double)D * F + (double)ngrp * slab * D));
+                4.0 * (2.0 * (double)slab * D + 2.0 * (double)D * F));
     SC_CHECK_LAUNCH();
     GemmArgs g{nullptr, nullptr, D, nullptr, b2, rows ? X : X + (long)m_done * D, rows ? rows + m_done : nullptr, D,
                (int)slab, D, F, SC_GEMM_RESIDUAL | (rows ? SC_GEMM_LN_AT_CROWS : 0), 0, g_ws, 0};
@@ -1782,15 +1783,17 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   }
   SC_CHECK_ARG(best < 1e29, "max_part too small");
   const int ngrp = nch / best_cpw;
+  const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_cross (decoder_layer.hip)
   FfnArgs p{nullptr, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F,
-            best_cpw, sb.ph2, sb.H, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf};
+            best_cpw, sb.ph2, nph, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);
   else launch_ffn_rtt<128, true>(p, best_rtt, ngrp, st);
   // algorithmic: 4*D*F flop per row; x + H head partials read, W1 + W2 read once, x and the partials written
-  sc_prof_end(prof, SC_PROF_FFN_PRO, 4.0 * (double)M * D * F,
-              4.0 * ((double)M * D * (2 + sb.H) + 2.0 * (double)D * F + (double)ngrp * M * D));
+  // algorithmic: 4*D*F flop per row; weights once + x in + x out - the head partials read and the
+  // split sums written are TRAFFIC of this decomposition, not algorithmic bytes
+  sc_prof_end(prof, SC_PROF_FFN_PRO, 4.0 * (double)M * D * F, 4.0 * (2.0 * (double)M * D + 2.0 * (double)D * F));
   SC_CHECK_LAUNCH();
   *n_part = ngrp;
   return SC_OK;

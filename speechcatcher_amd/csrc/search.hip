@@ -220,9 +220,11 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
       return U;
     };
     if (nchunk == 0) __syncthreads();   // qs
+    int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
       const int U = build(rows, c0);
+      urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, d, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
         hm = (unsigned)e >> 12;
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
       });
       if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
     }
+    if (sb.stat_rows && head == 0 && tid == 0) atomicAdd(&sb.stat_rows[0], (unsigned long long)urows);
     // the new token: hypothesis h attends to its own row (slot h at position L-1) only
     if (tid < 16) {
       const int h = tid;
@@ -1186,7 +1189,8 @@ static bool dec_fused_ok(const sc_search &sb) {
     return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;
   int max_rows = SC_FUSED_MAX_ROWS;
   if (const char *e = sc_hook("SC_FUSED_MAX")) max_rows = atoi(e);   // tools: threshold sweep
-  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > max_rows) return false;
+  // (round 4) beyond that limit the form needs the four-heads-per-workgroup variant (decoder_layer.hip: HPW)
+  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > max_rows && sc_dec_layer_hpw(sb) < 2) return false;
   return sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.ph2 && sb.ffn_part &&
          sb.max_ffn_part >= 1 && sb.out_w_q && sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp &&
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;

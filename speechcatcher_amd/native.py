@@ -351,6 +351,14 @@ class NativeStreamBatch:
     def take_xattn_rows(self) -> int:
         return int(self.lib.sc_streams_take_xattn_rows(self.handle))
 
+    def take_attn_counters(self):
+        """{cross_rows, self_positions, self_distinct_rows}: [stand-alone kernels, layer kernels], summed over decode
+        iterations, active streams and decoder layers since the last call"""
+        r = (C.c_long * 6)()
+        _abi.check(self.lib.sc_streams_take_attn_counters(self.handle, r), "sc_streams_take_attn_counters")
+        return {"cross_rows": [int(r[0]), int(r[1])], "self_positions": [int(r[2]), int(r[3])],
+                "self_distinct_rows": [int(r[4]), int(r[5])]}
+
     def take_xattn_rows_by_kernel(self):
         """(rows read by the dec_attn_flash launches, rows read by the sc_dec_layer_cross launches)"""
         r = (C.c_long * 2)()

@@ -40,3 +40,35 @@ def run_oracle_stream(model, audio, chunk, beam, bbd, finalize_all=True, **kw):
         calls.append({"results": res, "n_blocks": len(s.trace) - nb0})
         pos = end
     return s, feats, encs, calls
+
+
+def _oracle_calls_worker(args):
+    """one stream through the oracle, call by call (a fresh interpreter of a spawn pool): the live hypotheses after
+    every call as plain lists"""
+    cfg_name, seed, stats, stream_seed, n_samples, chunk, beam, bbd, threads = args
+    torch.set_num_threads(threads)
+    from oracle.ref_port import RefPortStreaming
+    ora = RefPortStreaming(oracle_model(cfg_name, seed, stats), beam_size=beam, use_bbd=bbd)
+    audio = synth.synth_audio(stream_seed, n_samples)
+    calls = []
+    for pos in range(0, n_samples, chunk):
+        ora(audio[pos:pos + chunk], is_final=False)
+        ref = ora.running_hyps or []
+        calls.append({"yseq": [list(h.yseq) for h in ref], "xpos": [list(h.xpos) for h in ref],
+                      "score": [float(h.score) for h in ref],
+                      "score_dec": [float(h.scores.get("decoder", 0.0)) for h in ref],
+                      "score_ctc": [float(h.scores.get("ctc", 0.0)) for h in ref],
+                      "process_idx": int(ora.process_idx),
+                      "T": 0 if ora.encoder_buffer is None else int(ora.encoder_buffer.shape[1])})
+    return calls
+
+
+def oracle_calls_parallel(cfg_name, stream_seeds, n_samples, chunk, beam, bbd, threads=8):
+    """The oracle run SOLO on several streams at once (one spawned process per stream, `threads` intra-op threads each):
+    {stream seed: [per-call snapshot]}.  Non-final calls only (the bench regime)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")      # never fork a process that holds a GPU context
+    with ctx.Pool(len(stream_seeds)) as pool:
+        res = pool.map(_oracle_calls_worker, [(cfg_name, 1234, "meanstd", sd, n_samples, chunk, beam, bbd, threads)
+                                              for sd in stream_seeds])
+    return dict(zip(stream_seeds, res))

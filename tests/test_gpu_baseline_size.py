@@ -74,12 +74,122 @@ def test_xl_128_streams_native_equals_python_engine_solo_runs_and_continuous_bat
         _same(solo.hypotheses(0), got[s], 1e-3, f"solo run of stream {s}")
         solo.close()
     nat.close()
+    # three streams against the oracle run solo on the same audio (hypothesis sets equal, best exact, scores 1e-3)
+    from helpers import oracle_calls_parallel
+    seeds = {s: 500 + (s if s < 120 else s - 120) for s in (5, 70, 123)}
+    ora = oracle_calls_parallel("XL", list(seeds.values()), CHUNK * n, CHUNK, beam, False)
+    for s, sd in seeds.items():
+        ref = ora[sd][-1]
+        assert sorted(tuple(h["yseq"]) for h in got[s]) == sorted(tuple(y) for y in ref["yseq"]), s
+        by = {tuple(y): (x, sc) for y, x, sc in zip(ref["yseq"], ref["xpos"], ref["score"])}
+        for h in got[s]:
+            assert h["xpos"] == by[tuple(h["yseq"])][0] and abs(h["score"] - by[tuple(h["yseq"])][1]) <= 1e-3, s
+        assert got[s][0]["yseq"] == ref["yseq"][0], s
     # the Python engine over the same kernels
     pye = make_batch("XL", 1234, "meanstd", beam, False, backend=HipBackend("cuda:0"), device="cuda:0", **kw)
     for k in range(n):
         pye.push([(s, audio[s, k * CHUNK:(k + 1) * CHUNK], False) for s in range(S)])
     for s in range(S):
         _same(pye.hypotheses(s), got[s], 1e-3, f"python engine, stream {s}")
+
+
+def _serve_continuous(sb, a3, poll, track=()):
+    """bench.py's serving loop: sc_submit one chunk per stream, sc_poll(poll), every answered stream gets its next chunk.
+    Returns {tracked stream: [(hypotheses, process_idx, T) after each of its replies]}."""
+    S, n = a3.shape[0], a3.shape[1]
+    nxt = np.zeros(S, np.int64)
+    seen = {s: [] for s in track}
+    sb.submit_block(np.arange(S, dtype=np.int32), np.ascontiguousarray(a3[:, 0]))
+    nxt += 1
+    while sb.outstanding:
+        done, st = sb.poll_ids(min(poll, sb.outstanding))
+        assert (st >= 0).all()
+        for s in done:
+            if int(s) in seen:
+                seen[int(s)].append((sb.hypotheses(int(s)), sb.st[int(s)].process_idx, sb.st[int(s)].T_enc))
+        again = done[nxt[done] < n]
+        if len(again):
+            sb.submit_block(again, a3[again, nxt[again]])
+            nxt[again] += 1
+    return seen
+
+
+def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
+    """The regime and the mode bench.py times: XL dims, 128 streams, beam 10, no block-boundary
+    detection, CONTINUOUS batching (sc_submit / sc_poll(16)) on the C++ engine, 60 chunks per stream so that the streams
+    reach T >= 700 encoder frames and >= 330 tokens with full compaction buckets (large-bucket kernels, multi-chunk K/V
+    walks).  Three streams are compared CALL BY CALL with the oracle run solo on the same audio: token ids / positions /
+    process_idx exact after every reply, cumulative scores within 1e-3 (north star), drift per decode step <= 1e-4; all
+    128 streams well formed.  The same run in the split-precision form and with fp16 K|V storage against the f32 engine."""
+    import json
+    import os
+    from helpers import oracle_calls_parallel
+    from test_engine_spec import check_hyps
+    S, n, beam, poll = 128, 60, 10, 16
+    tracked = (3, 64, 125)
+    audio = np.stack([synth.synth_audio(4000 + s, CHUNK * n) for s in range(S)])
+    a3 = audio.reshape(S, n, CHUNK)
+    kw = dict(n_streams=S, max_frames=16 * n + 80, max_tokens=640, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+    sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", **kw)
+    seen = _serve_continuous(sb, a3, poll, tracked)
+    sec, it = (C.c_double * 17)(), (C.c_long * 17)()
+    sb.lib.sc_streams_bucket_times(sb.handle, sec, it)
+    assert sum(it[12:]) > 0.5 * sum(it), list(it)                    # most decode iterations ran with >= 3/4 of the streams
+    base = sb.hypotheses_arrays(list(range(S)))
+    T = [sb.st[s].T_enc for s in range(S)]
+    assert min(T) >= 700 and base["lens"][:, 0].min() >= 330, (min(T), int(base["lens"][:, 0].min()))
+    assert (base["n_hyps"] == beam).all()
+    for s in range(S):                                                # well formed: sos first, positions non-decreasing
+        L = base["lens"][s, 0]
+        assert base["ids"][s, 0, 0] == 1023 and (np.diff(base["xpos"][s, 0, :L]) >= 0).all() and base["xpos"][s, 0, L - 1] < T[s]
+    sb.close()
+    ora = oracle_calls_parallel("XL", [4000 + s for s in tracked], CHUNK * n, CHUNK, beam, False)
+    report = {}
+    for s in tracked:
+        calls = ora[4000 + s]
+        assert len(seen[s]) == len(calls) == n
+        worst, worst_step, prev_diff, prev_pidx, compared = 0.0, 0.0, 0.0, 0, 0
+        for k, ((hyps, pidx, t_enc), ref) in enumerate(zip(seen[s], calls)):
+            assert t_enc == ref["T"], (s, k)
+            if not ref["yseq"] or pidx == prev_pidx:
+                continue
+            check_hyps(hyps, pidx, ref, 1e-3)
+            by = {tuple(y): sc for y, sc in zip(ref["yseq"], ref["score"])}
+            diff = max(abs(h["score"] - by[tuple(h["yseq"])]) for h in hyps)
+            worst = max(worst, diff)
+            worst_step = max(worst_step, abs(diff - prev_diff) / max(pidx - prev_pidx, 1))
+            prev_diff, prev_pidx, compared = diff, pidx, compared + 1
+        assert compared >= n - 6 and worst_step <= 1e-4, (s, compared, worst_step)
+        report[s] = {"calls_compared": compared, "max_abs_total_score_diff": worst, "max_drift_per_decode_step": worst_step,
+                     "T_end": seen[s][-1][2], "tokens_end": len(seen[s][-1][0][0]["yseq"])}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "r04_xl_continuous_128_parity.json"), "w") as f:
+        json.dump({"streams": S, "chunks": n, "poll": poll, "T_min_max": [min(T), max(T)],
+                   "tokens_min_max": [int(base["lens"][:, 0].min()), int(base["lens"][:, 0].max())],
+                   "bucket_iterations": list(it), "tracked": report}, f)
+
+    def hyp(o, s, j):
+        n_ = o["lens"][s, j]
+        return tuple(o["ids"][s, j, :n_].tolist()), tuple(o["xpos"][s, j, :n_].tolist())
+
+    # the opt-in forms against the f32 engine, same audio, same serving loop: the best hypothesis of (nearly) every stream
+    moved = {}
+    for name, extra in (("split16", dict(ffn_dtype="split16", proj_dtype="split16")), ("kv_fp16", dict(kv_dtype="float16"))):
+        alt = make_batch("XL", 1234, "meanstd", beam, False, backend="native", **dict(kw, **extra))
+        _serve_continuous(alt, a3, poll)
+        o = alt.hypotheses_arrays(list(range(S)))
+        alt.close()
+        diff = [s for s in range(S) if hyp(o, s, 0) != hyp(base, s, 0)]
+        same = [s for s in range(S) if s not in diff]
+        moved[name] = {"best_hypothesis_moved": diff, "max_score_diff_of_the_others": float(np.abs(o["score"][same, 0] - base["score"][same, 0]).max())}
+        print(f"{name}: best hypothesis moved on {len(diff)} of {S} streams {diff}; scores of the others within "
+              f"{moved[name]['max_score_diff_of_the_others']:.2e}")
+        # 60 chunks x ~9 steps of a random-weight model without boundary detection: a near-tie decided the other way
+        # moves a stream onto another path for good (DESIGN section 2); bar: <= 3 % of the streams, scores of the rest 1e-3
+        assert len(diff) <= max(1, S * 3 // 100), (name, diff)
+        assert moved[name]["max_score_diff_of_the_others"] <= (1e-3 if name == "split16" else 2e-2), (name, moved[name])
+    with open(os.path.join("gpurun_out", "r04_xl_continuous_128_forms.json"), "w") as f:
+        json.dump(moved, f)
 
 
 def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
@@ -175,7 +285,7 @@ def test_feature_input_on_the_native_engine_matches_oracle(cfg_name):
         got, ref = sb.hypotheses(2 * i), oras[i].running_hyps
         assert [h["yseq"] for h in got] == [list(h.yseq) for h in ref], i
         assert [h["xpos"] for h in got] == [list(h.xpos) for h in ref], i
-        np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=5e-3 if cfg_name == "XL" else 2e-3)
+        np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=1e-3, rtol=0)
     assert sb.hypotheses(1) == [] or len(sb.hypotheses(1)[0]["yseq"]) == 1
     # a feature matrix that does not fit fails that stream only
     from speechcatcher_amd.engine import EngineError

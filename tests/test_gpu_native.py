@@ -30,7 +30,7 @@ def test_native_engine_matches_reference_tiny(name):
 @pytest.mark.parametrize("name", XL_CASES)
 def test_native_engine_matches_reference_xl(name):
     from test_engine_spec import run_case
-    run_case(name, backend="native", score_tol=5e-3)
+    run_case(name, backend="native", score_tol=1e-3)
 
 
 @pytest.mark.parametrize("name", ["tiny_c10240_b10_bbd0", "tiny_c8192_b10_bbd1", "xl_c10240_b10_bbd0"])
@@ -39,7 +39,7 @@ def test_native_engine_with_the_t_parallel_ctc_scan(name, monkeypatch):
     the first one takes the 16-segment kernel"""
     from test_engine_spec import run_case
     monkeypatch.setenv("SC_SCAN_SPLIT_MIN", "32")
-    run_case(name, backend="native", score_tol=5e-3)
+    run_case(name, backend="native", score_tol=1e-3)
 
 
 def test_native_short_utterances_and_the_reference_exception():
@@ -61,9 +61,9 @@ def test_native_short_utterances_and_the_reference_exception():
 
 def test_native_reset_quirk_and_calls_after_final():
     from test_engine_spec import run_after_final, run_reset_quirk
-    run_reset_quirk(backend="native", score_tol=5e-3)
+    run_reset_quirk(backend="native", score_tol=1e-3)
     for bbd in (0, 1):
-        run_after_final(bbd, backend="native", score_tol=5e-3)
+        run_after_final(bbd, backend="native", score_tol=1e-3)
 
 
 def test_native_capacity_faults_are_isolated():

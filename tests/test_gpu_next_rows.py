@@ -20,13 +20,13 @@ def hip():
 
 def test_hip_reset_keeps_stale_ctc_table_like_the_reference(hip):
     from test_engine_spec import run_reset_quirk
-    run_reset_quirk(backend=hip, device="cuda:0", score_tol=5e-3)
+    run_reset_quirk(backend=hip, device="cuda:0", score_tol=1e-3)
 
 
 @pytest.mark.parametrize("bbd", [0, 1])
 def test_hip_calls_after_final_without_reset(hip, bbd):
     from test_engine_spec import run_after_final
-    run_after_final(bbd, backend=hip, device="cuda:0", score_tol=5e-3)
+    run_after_final(bbd, backend=hip, device="cuda:0", score_tol=1e-3)
 
 
 def test_hip_scheduler_sessions_with_different_chunking_match_reference(hip):

@@ -566,16 +566,22 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
 
-@pytest.mark.parametrize("layers", ["head_parallel", "six_launch"])
+@pytest.mark.parametrize("layers", ["head_parallel", "head_parallel_hpw4", "head_parallel_hpw2", "six_launch"])
 def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
-    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; both forms of the
-    decoder layers (3 launches per layer: small buckets; 6 launches: large ones)."""
+    """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; the forms of the decoder layers:
+    3 launches per layer with one head per workgroup (small buckets), with four / two heads per workgroup (large
+    buckets: 1024- / 512-thread workgroups, H/4 partial products per row) and the 6 launches of round 1."""
     from lockstep import LockstepBackend
     monkeypatch.setenv("SC_DEC_FUSED", "0" if layers == "six_launch" else "1")
+    hpw = int(layers[-1]) if "hpw" in layers else 1
+    monkeypatch.setenv("SC_DEC_HPW", str(hpw))
+    monkeypatch.setattr(LockstepBackend, "dec_hpw", hpw)
+    if hpw > 1:
+        monkeypatch.setenv("SC_ATTN_DEEP", "0")      # (the few-streams variant runs one head per workgroup)
     monkeypatch.setattr(LockstepBackend, "fused_layers", layers != "six_launch")
     ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=5, atol=5e-4, rtol=5e-4)
     _dump(ls, "lockstep_xl_" + layers)
-    assert ("dec_layer_self" in ls.calls) == (layers == "head_parallel")
+    assert ("dec_layer_self" in ls.calls) == (layers != "six_launch")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
