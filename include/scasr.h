@@ -103,13 +103,19 @@ typedef struct sc_search {
   int32_t *flags;      /* [S] */
   const float *ctcx;   /* [S][TCAP][V]  CTC posterior table (quirk A1 rows) */
   const float *ckv;    /* [S][n_layers][TCAP][2d] cross-attention K|V */
-  float *skv;          /* [S][n_layers][LCAP][W][2d] self-attention K|V, append-only */
+  float *skv;          /* [S][n_layers][kv_rows][2d] self-attention K|V rows of a stream: a POOL (round 4) - a row holds
+                          the K|V of one (position, hypothesis) token; sc_kv_alloc hands every live hypothesis the row
+                          of its newest token at the start of a decode step (rows no live hypothesis descends from
+                          are free again), `anc` is the index.  Hypotheses of a beam share almost all of their
+                          history (1.2 distinct rows per position at beam 10), so kv_rows ~ 1.5 x LCAP instead of the
+                          W x LCAP of one slot per (position, hypothesis) */
   int32_t *yseq, *xpos; /* [2][S][W][LCAP] */
-  int32_t *anc;         /* [2][S][LCAP][W] slot of the ancestor's K/V row per position */
+  int32_t *anc;         /* [2][S][LCAP][W] pool row (of skv) of the K|V row hypothesis h attends to at position p */
   double *score, *sc_dec, *sc_ctc; /* [2][S][W] */
   float *ctc_r;    /* [2][S][TCAP][2][W] forward variables r^n, r^b per hypothesis */
   float *ctc_s;    /* [2][S][W] prefix score log_psi of the chosen token */
-  float *ctc_rnew; /* [S][TCAP][2][W*K] r of every (hypothesis, candidate) */
+  float *ctc_rnew; /* [S][ceil(TCAP/16)][2][W*K] r of every (hypothesis, candidate) at the CHECKPOINT frames t % 16 == 15
+                      (row j = frame 16 j + 15): sc_ctc_gather_state rebuilds the winners' r[t] at every frame from them */
   float *dx, *dxn, *dqkv, *datt, *dq, *dffh, *logits, *logp; /* [S*W][...] */
   int32_t *pre_ids;       /* [S*W][K] */
   float *psi, *psi_eos;   /* [S*W][K], [S*W] */
@@ -144,6 +150,9 @@ typedef struct sc_search {
    * adds the DISTINCT (position, slot) K|V rows it walked for a stream (plus its new rows) to stat_rows[0]
    * (sc_dec_self_attn) / stat_rows[1] (sc_dec_layer_self) - one atomic per (stream, layer), by head 0 */
   unsigned long long *stat_rows;
+  int32_t kv_rows;   /* rows of the self-attention K|V pool per (stream, layer), <= 65536 */
+  int32_t *kvflags;  /* [S] written by sc_kv_alloc: 1 = the stream's pool is exhausted (its step computes garbage: the
+                        host fails the stream with SC_ERR_CAPACITY), 0 = fine */
 } sc_search;
 
 const char *sc_last_error(void);
@@ -366,6 +375,13 @@ int sc_encoder_layers(const sc_enc_layer *layers /*HOST*/, int n_layers, float *
 
 /* CTCPrefixScoreTH.extend_state (ctc_prefix_score_full.py:349-368) */
 int sc_ctc_extend_state(const sc_search *sb /*HOST*/, void *stream);
+/* Self-attention K|V pool, first launch of a decode step: every live hypothesis h of an active stream gets the pool
+ * row for its newest token (position L-1) - anc[cur][s][L-1][h] - out of the rows that no live hypothesis descends
+ * from (mark over the ancestor table, lowest free rows first).  The reference keeps a per-hypothesis output cache
+ * instead and deep-copies it when hypotheses fork (transformer_decoder.py:210-249, hypothesis.py: states); the pool +
+ * ancestor table is the same information without the copies.  Idempotent: a step that is re-run after a rollback
+ * (beam_search.py:827-836) allocates again from the state it is given. */
+int sc_kv_alloc(const sc_search *sb, void *stream);
 /* embed*sqrt(d)+PE of the newest token (transformer_decoder.py:231) */
 int sc_dec_embed(const sc_search *sb, void *stream);
 /* kv_half: cross-attention K|V rows of all layers from an fp32 staging buffer [n_layers][m][d2] (the output of
@@ -477,6 +493,8 @@ typedef struct sc_stream_options {
   int32_t max_chunk_samples; /* longest single call (0: 32768) */
   int32_t strict_reference;  /* reset() leaves the stale CTC table / PE counter like the reference (scorers.py:342-350) */
   int32_t kv_half;           /* K|V caches in fp16 (fp32 arithmetic): BASELINE configs[4]'s storage mode; 0 = fp32 */
+  int32_t kv_pool_rows;      /* rows of the self-attention K|V pool per stream and layer (capacity; 0: 1.5 x max_tokens + 4 x beam,
+                                at most max_tokens x beam = one row per (position, hypothesis)) */
 } sc_stream_options;
 
 typedef struct sc_stream_info_t {

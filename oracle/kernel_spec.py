@@ -257,26 +257,41 @@ class SpecBackend:
             tok = sb.yseq[cur, s, :nh, L - 1].to(torch.long)
             sb.dx[s * sb.W:s * sb.W + nh] = w.embed[tok] * sq + w.pe[L - 1]
 
+    def kv_alloc(self, sb):
+        """sc_kv_alloc: pool rows for the K|V of the newest token (position L-1) of every live hypothesis - the lowest
+        rows of the stream's pool that no live hypothesis descends from (ancestor table, positions < L-1), in
+        hypothesis order; kvflags[s] = 1 when the pool is exhausted (rows clamp to the last one)."""
+        ctrl = sb.ctrl.cpu().numpy()
+        NR = int(sb.kv_rows)
+        for s in range(sb.S):
+            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
+            if not act or nh <= 0:
+                continue
+            used = set(sb.anc[cur, s, :L - 1, :nh].reshape(-1).tolist()) if L > 1 else set()
+            free = [r for r in range(NR) if r not in used][:nh]
+            sb.kvflags[s] = 1 if len(free) < nh else 0
+            free += [NR - 1] * (nh - len(free))
+            sb.anc[cur, s, L - 1, :nh] = torch.tensor(free, dtype=torch.int32)
+
     def dec_self_attn(self, sb, li):
-        """decoder_layer.py:85-101 with a true K/V cache: the new K/V row is
-        appended at position L-1 of slot h; older rows are found through the
-        ancestor table.  (A14: identical to re-projecting the output cache.)"""
+        """decoder_layer.py:85-101 with a true K/V cache: the new K/V row goes
+        into the pool row kv_alloc gave the hypothesis (anc[L-1][h]); older rows
+        are found through the ancestor table.  (A14: identical to re-projecting
+        the output cache.)"""
         cfg = sb.cfg
         d, H, W = cfg.d_model, cfg.dec_heads, sb.W
         dk = d // H
         ctrl = sb.ctrl.cpu().numpy()
-        skv = sb.skv.view(sb.S, cfg.dec_layers, sb.LCAP, W, 2 * d)
+        skv = sb.skv.view(sb.S, cfg.dec_layers, int(sb.kv_rows), 2 * d)
         for s in range(sb.S):
             act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
             if not act:
                 continue
             rows = slice(s * W, s * W + nh)
             qkv = sb.dqkv[rows]
-            skv[s, li, L - 1, :nh] = qkv[:, d:]
-            anc = sb.anc[cur, s, :L, :nh].to(torch.long).clone()   # (L, nh)
-            anc[L - 1] = torch.arange(nh)
-            pos = torch.arange(L).unsqueeze(1).expand(L, nh)
-            kv = skv[s, li][pos, anc]                               # (L, nh, 2d)
+            anc = sb.anc[cur, s, :L, :nh].to(torch.long)           # (L, nh) pool rows
+            skv[s, li, anc[L - 1]] = qkv[:, d:].to(skv.dtype)
+            kv = skv[s, li][anc].to(torch.float32)                  # (L, nh, 2d)
             k = kv[..., :d].permute(1, 0, 2).reshape(nh, L, H, dk).transpose(1, 2)
             v = kv[..., d:].permute(1, 0, 2).reshape(nh, L, H, dk).transpose(1, 2)
             q = qkv[:, :d].reshape(nh, 1, H, dk).transpose(1, 2)
@@ -565,7 +580,8 @@ class SpecBackend:
         K pre-beam candidates of every live hypothesis.  Outputs
         psi[(s,h),k] = log_psi of candidate k (blank candidate -> logzero,
         eos candidate -> r_sum[T-1]), psi_eos[(s,h)] = r_sum[T-1],
-        ctc_rnew[s,t,:,h*K+k] = r."""
+        ctc_rnew[s,j,:,h*K+k] = r at the checkpoint frame 16 j + 15 (what the kernels store; the
+        full-resolution r of the step stays in sb._rnew_full for ctc_gather_state)."""
         cfg = sb.cfg
         V, W, K = cfg.vocab_size, sb.W, sb.K
         ctrl = sb.ctrl.cpu().numpy()
@@ -605,7 +621,13 @@ class SpecBackend:
             psi = torch.where(ids == cfg.blank_id, torch.full_like(psi, LOGZERO), psi)
             sb.psi[s * W:s * W + nh] = psi
             sb.psi_eos[s * W:s * W + nh] = eos_val
-            sb.ctc_rnew[s, :T, :, :nh * K] = r.reshape(T, 2, nh * K)
+            rf = r.reshape(T, 2, nh * K)
+            if getattr(sb, "_rnew_full", None) is None:
+                sb._rnew_full = {}
+            sb._rnew_full[s] = rf
+            nck = T // 16
+            if nck:
+                sb.ctc_rnew[s, :nck, :, :nh * K] = rf[15:16 * nck:16]
 
     def fuse_topw(self, sb):
         """beam_search.py:113-185 fusion + :723 per-hypothesis top-W.
@@ -662,9 +684,7 @@ class SpecBackend:
                 sb.score[o, s, i] = tot
                 sb.sc_dec[o, s, i] = float(sb.sc_dec[cur, s, h]) + float(sb.logp[s * W + h, tok])
                 sb.sc_ctc[o, s, i] = float(sb.sc_ctc[cur, s, h]) + float(sb.cand_ctc[s * W + h, j])
-                if L - 1 > 0:
-                    sb.anc[o, s, :L - 1, i] = sb.anc[cur, s, :L - 1, h]
-                sb.anc[o, s, L - 1, i] = h
+                sb.anc[o, s, :L, i] = sb.anc[cur, s, :L, h]   # pool rows of the parent's history incl. its newest token
                 ids = sb.pre_ids[s * W + h].tolist()
                 k = ids.index(tok) if tok in ids else -1
                 if tok == cfg.blank_id:
@@ -702,7 +722,7 @@ class SpecBackend:
             nout = min(W, nh * W)
             for i in range(nout):
                 h, k = int(sb.sel[s, i, 0]), int(sb.sel[s, i, 1])
-                sb.ctc_r[o, s, :T, :, i] = sb.ctc_rnew[s, :T, :, h * K + k]
+                sb.ctc_r[o, s, :T, :, i] = sb._rnew_full[s][:T, :, h * K + k]
 
     def decode_step(self, sb):
         """One beam-search step for every active stream
@@ -710,6 +730,7 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
+        self.kv_alloc(sb)
         if getattr(sb, "ph1", None) is not None and self.fused_layers:
             # head-parallel layer kernels, 3 ops per layer (sc_decode_step takes this path for the same models)
             xa, xb, npart = sb.dx, sb.dxn, 0

@@ -48,7 +48,8 @@ class Search(C.Structure):
                              "cand_score", "cand_tok", "cand_ctc", "sel", "embed", "pe",
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
-           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32), ("stat_rows", vp)]
+           ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32), ("stat_rows", vp),
+           ("kv_rows", C.c_int32), ("kvflags", vp)]
     )
 
 
@@ -67,7 +68,8 @@ class NamedTensor(C.Structure):
 class StreamOptions(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("beam_size", C.c_int32), ("ctc_weight", C.c_float), ("use_bbd", C.c_int32),
                 ("max_frames", C.c_int32), ("max_tokens", C.c_int32), ("pcm_capacity", C.c_int32),
-                ("max_chunk_samples", C.c_int32), ("strict_reference", C.c_int32), ("kv_half", C.c_int32)]
+                ("max_chunk_samples", C.c_int32), ("strict_reference", C.c_int32), ("kv_half", C.c_int32),
+                ("kv_pool_rows", C.c_int32)]
 
 
 class StreamInfo(C.Structure):
@@ -134,6 +136,7 @@ _SIGS = {
     "sc_relpos_attention_masked": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "sc_ctc_extend_state": (C.c_int, [vp, vp]),
     "sc_dec_embed": (C.c_int, [vp, vp]),
+    "sc_kv_alloc": (C.c_int, [vp, vp]),
     "sc_kv_rows_to_half": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "sc_dec_self_attn": (C.c_int, [vp, C.c_int, vp]),
     "sc_dec_cross_attn": (C.c_int, [vp, C.c_int, vp]),

@@ -200,3 +200,59 @@ __device__ __forceinline__ float mattn_final(const float *pm, const float *pl, c
 }
 // LDS floats of the partial states
 __host__ __device__ static inline int mattn_partial_floats(int DK, int np) { return np * 16 * (DK + 3); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row list of the decoder self-attention for the positions [c0, c0 + 128) of one stream: the DISTINCT K|V pool rows the
+// live hypotheses attend to there (ancestor table anc[p][h] = pool row; hypotheses of a beam share almost all of
+// their history), each with the bit set of hypotheses that use it:   entry = pool row | hypothesis bit set << 16.
+// Called by the 256 threads of a head group (gt = thread, wave = its wave in the group); thread p handles position
+// c0 + p: duplicates among its <= WM rows are found by comparison in registers, a wave scan + the wave totals give
+// every position its place in the list.  rw [128 * W] and wtot [8] are LDS of the group; contains __syncthreads()
+// (all threads of the workgroup must call it the same number of times).  Returns the number of entries.
+template <int WM>
+__device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *anc, int c0, int Lc, int W, int nh,
+                                                int gt, int lane, int wave, const int *preloaded = nullptr) {
+  constexpr int PCH = 128;
+  for (int e = gt; e < PCH * W; e += 256) rw[e] = 0;
+  const int pp = c0 + gt;
+  const bool live = gt < PCH && pp < Lc;
+  int r[WM];
+#pragma unroll
+  for (int h = 0; h < WM; ++h) r[h] = preloaded ? preloaded[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
+  unsigned first = 0;   // hypotheses that are the first to name their row
+#pragma unroll
+  for (int h = 0; h < WM; ++h) {
+    if (h < nh) {
+      bool f = true;
+#pragma unroll
+      for (int h2 = 0; h2 < h; ++h2) f = f && r[h2] != r[h];
+      if (f) first |= 1u << h;
+    }
+  }
+  const int cnt = live ? __popc(first) : 0;
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();   // also orders the zero fill before the ORs
+  const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
+  const int U = wtot[0] + wtot[1];
+  if (live) {
+#pragma unroll
+    for (int h = 0; h < WM; ++h) {
+      if (h < nh) {
+        int rep = h;   // the first hypothesis with the same row
+#pragma unroll
+        for (int h2 = WM - 1; h2 >= 0; --h2)
+          if (h2 < h && r[h2] == r[h]) rep = h2;
+        const int rank = __popc(first & ((1u << rep) - 1u));
+        atomicOr(&rw[base + rank], (r[h] & 0xFFFF) | (1 << (16 + h)));
+      }
+    }
+  }
+  __syncthreads();   // list complete; wtot may be rewritten
+  return U;
+}

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
   const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
-  const int W = sb.W, LCAP = sb.LCAP, NPH = sb.H / HPW;
+  const int W = sb.W, NPH = sb.H / HPW;
   const int GS = dl_group_floats(D, DK, W, WM, SELF);        // LDS floats of one head group
   float *region = smem + g * GS;
   float *qs = region + dl_region_floats(D, DK, W, SELF);     // [16][DK] queries / sqrt(dk), rows >= W zero
@@ -370,7 +370,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   }
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 3);
-  const long skv0 = ((long)s * sb.n_layers + p.li) * LCAP * W * 2 * D + head * DK;   // element offset (fp32 or fp16 cache)
+  const long skv0 = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;   // element offset (fp32 or fp16 pool)
+  const int *ancn = ANC(cur, s) + (long)(L - 1) * W;   // pool rows of the new tokens (sc_kv_alloc)
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         qs[w * DK + c] = v / scale;
       } else if (SELF) {
         kvn[w * 2 * DK + (which - 1) * DK + c] = v;
-        // append this token's K|V row at (position L-1, slot w); later steps read it from the cache
-        if (w < nh) kv_store1<KVH>(sb.skv, skv0 + ((long)(L - 1) * W + w) * 2 * D + (which - 1) * D + c, v);
+        // append this token's K|V row into its pool row; later steps read it from the cache
+        if (w < nh) kv_store1<KVH>(sb.skv, skv0 + (long)ancn[w] * 2 * D + (which - 1) * D + c, v);
       }
     }
   }
@@ -427,51 +428,16 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     const int *anc = ANC(cur, s);
     const int Lc = L - 1;  // cached positions; the new token's row is the fifth partial state
     const int nchunk = cdiv(Lc, PCH);
-    // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
-    // entry = local position | slot << 8 | hypothesis bit set << 12
-    auto build = [&](int *rw, int c0) -> int {
-      for (int e = gt; e < PCH * W; e += 256) rw[e] = 0;
-      const int pp = c0 + gt;
-      const bool live = gt < PCH && pp < Lc;
-      int sl[WM];
-#pragma unroll
-      for (int h = 0; h < WM; ++h) sl[h] = (PF && c0 == 0) ? slp[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
-      unsigned mask = 0;
-#pragma unroll
-      for (int h = 0; h < WM; ++h)
-        if (h < nh) mask |= 1u << sl[h];
-      const int cnt = live ? __popc(mask) : 0;
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      if (lane == 63) wtot[wave] = incl;
-      __syncthreads();  // also orders the zero fill before the ORs
-      const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
-      const int U = wtot[0] + wtot[1];
-      if (live) {
-#pragma unroll
-        for (int h = 0; h < WM; ++h) {
-          if (h < nh) {
-            const int rank = __popc(mask & ((1u << sl[h]) - 1u));
-            atomicOr(&rw[base + rank], gt | (sl[h] << 8) | (1 << (12 + h)));
-          }
-        }
-      }
-      __syncthreads();  // list complete; wtot may be rewritten
-      return U;
-    };
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
-      const int U = build(rows, c0);
+      const int U = mattn_build_rows<WM>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave,
+                                         (PF && SELF && c0 == 0) ? slp : nullptr);   // (attn.h)
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
-        hm = (unsigned)e >> 12;
-        ke = skv0 + ((long)(c0 + (e & 255)) * W + ((e >> 8) & 15)) * 2 * D;
+        hm = (unsigned)e >> 16;
+        ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
       });
       if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
     }
@@ -568,7 +534,8 @@ SC_PHASE_GETTER(sc_phase_debug_layer)
 // Heads per workgroup for this launch's compaction bucket (see the top of the file).  One head per workgroup while few
 // streams are active (latency-bound chains: more, smaller workgroups spread the weight and K/V streaming over more
 // CUs); four from SC_HPW_MIN_ROWS hypothesis rows on, where the redundant prologue reads are what costs.
-// SC_DEC_HPW = 1 | 2 | 4 forces one form at any size (tests, sweeps).
+// SC_DEC_HPW = 1 | 4 forces one form at any size (tests, sweeps).  (Two heads per workgroup, 512 threads, was measured
+// between the two: 3005 against 2890 / 3068 audio-s/s for one / four at every bucket size - not instantiated.)
 int sc_dec_layer_hpw(const sc_search &sb) {
   const int dk = sb.d / sb.H;
   const bool can = sb.d == 256 && dk == 32 && sb.W > 5 && sb.W <= 10;   // the instantiated HPW > 1 variants
@@ -576,7 +543,7 @@ int sc_dec_layer_hpw(const sc_search &sb) {
   if (can && (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= SC_HPW_MIN_ROWS) hpw = 4;
   if (const char *e = sc_hook("SC_DEC_HPW")) {
     const int v = atoi(e);
-    if (v == 1 || (can && (v == 2 || v == 4))) hpw = v;
+    if (v == 1 || (can && v == 4)) hpw = v;
   }
   while (hpw > 1 && sb.H % hpw) hpw >>= 1;
   return hpw;
@@ -609,7 +576,6 @@ static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   const int hpw = sc_dec_layer_hpw(sb);
   if constexpr (D == 256 && DK == 32) {
     if (hpw == 4) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 4>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
-    if (hpw == 2) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 2>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
   }
   if (sb.W <= 5) {
     launch_dec_layer_variant<D, DK, 5, SELF, 4, FIRST, KVH, 1>(p, ns, st);

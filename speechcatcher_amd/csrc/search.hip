@@ -95,6 +95,66 @@ extern "C" int sc_kv_rows_to_half(const float *stage, const int32_t *rows, int m
 }
 
 // ---------------------------------------------------------------------------
+// Self-attention K|V pool: rows for the newest tokens of the live hypotheses (scasr.h: sc_kv_alloc).  One workgroup
+// per stream: mark the rows the live hypotheses descend from (ancestor table, positions < L-1) in an LDS bit map,
+// then wave 0 hands the lowest unmarked rows to hypotheses 0 .. nh-1 in order.  No allocator state survives the
+// launch - the ancestor table of the live side IS the state - so rollbacks and re-runs need no undo.
+#define SC_KV_MAX_ROWS 65536
+__global__ __launch_bounds__(256) void kv_alloc_kernel(sc_search sb) {
+  __shared__ unsigned bm[SC_KV_MAX_ROWS / 32];
+  const int s = sb.rowmap ? sb.rowmap[blockIdx.x * sb.W] / sb.W : blockIdx.x;
+  if (!CTRL(s, SC_C_ACTIVE)) return;
+  const int nh = CTRL(s, SC_C_NHYP);
+  if (nh <= 0) return;
+  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), W = sb.W, NR = sb.kv_rows;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nwords = (NR + 31) / 32;
+  int *anc = ANC(cur, s);
+  for (int w = tid; w < nwords; w += 256) bm[w] = 0u;
+  __syncthreads();
+  const int n = (L - 1) * nh;
+  for (int e = tid; e < n; e += 256) {
+    const int p = e / nh, h = e % nh;
+    const int r = anc[(long)p * W + h];
+    atomicOr(&bm[(r >> 5) & (SC_KV_MAX_ROWS / 32 - 1)], 1u << (r & 31));
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  int *out = anc + (long)(L - 1) * W;
+  int got = 0;
+  for (int w0 = 0; w0 < nwords && got < nh; w0 += 64) {
+    const int w = w0 + lane;
+    unsigned fr = w < nwords ? ~bm[w] : 0u;
+    if (w == nwords - 1 && (NR & 31)) fr &= (1u << (NR & 31)) - 1u;
+    const int c = __popc(fr);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int k = got + incl - c;   // index of this lane's first free row among all free rows
+    while (fr && k < nh) {
+      const int b = __ffs(fr) - 1;
+      fr &= fr - 1u;
+      out[k++] = w * 32 + b;
+    }
+    got += __shfl(incl, 63, 64);
+  }
+  if (got < nh && lane >= got && lane < nh) out[lane] = NR - 1;   // exhausted: in-bounds garbage, the host fails the stream
+  if (lane == 0 && sb.kvflags) sb.kvflags[s] = got < nh ? 1 : 0;
+}
+
+extern "C" int sc_kv_alloc(const sc_search *sbp, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->anc, "null");
+  SC_CHECK_ARG(sbp->kv_rows >= sbp->W && sbp->kv_rows <= SC_KV_MAX_ROWS, "kv_rows out of range (beam .. 65536)");
+  const int ns = sbp->rowmap ? sbp->n_rows / sbp->W : sbp->S;   // streams of the compaction bucket only
+  kv_alloc_kernel<<<ns, 256, 0, (hipStream_t)stream>>>(*sbp);
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
 __global__ void dec_embed_kernel(sc_search sb, float sq) {
   const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
   if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
@@ -144,7 +204,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
   const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
-  const int W = sb.W, d = sb.d, LCAP = sb.LCAP;
+  const int W = sb.W, d = sb.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // LDS: partial states pm / pl [NP][16], pO [NP*16][DK+1]; rows[PCH*W]; wtot[8]; qs [16][DK]
   float *pm = smem;
@@ -158,14 +218,15 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
   const float *qbase = SELF ? sb.dqkv + (long)s * W * 3 * d + head * DK : sb.dq + (long)s * W * d + head * DK;
   const int qld = SELF ? 3 * d : d;
   // element offsets of this (stream, layer, head) in the K|V caches (fp32, or fp16 when KVH: same offsets)
-  const long skv0 = ((long)s * sb.n_layers + li) * LCAP * W * 2 * d + head * DK;
+  const long skv0 = ((long)s * sb.n_layers + li) * sb.kv_rows * 2 * d + head * DK;
   const long ckv0 = ((long)s * sb.n_layers + li) * sb.TCAP * 2 * d + head * DK;
   if (SELF) {
-    // append this token's K|V rows at (position L-1, slot h); this launch reads
-    // them from dqkv, later steps from the cache
+    // append this token's K|V rows into the pool rows sc_kv_alloc gave the hypotheses (anc[L-1][h]); this launch
+    // reads them from dqkv, later steps from the cache
+    const int *ancn = ANC(cur, s) + (long)(L - 1) * W;
     for (int e = tid; e < nh * DK; e += 256) {
       const int h = e / DK, c = e % DK;
-      const long dst = skv0 + ((long)(L - 1) * W + h) * 2 * d;
+      const long dst = skv0 + (long)ancn[h] * 2 * d;
       kv_store1<KVH>(sb.skv, dst + c, qbase[(long)h * 3 * d + d + c]);
       kv_store1<KVH>(sb.skv, dst + d + c, qbase[(long)h * 3 * d + 2 * d + c]);
     }
@@ -183,57 +244,21 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
     const int *anc = ANC(cur, s);
     const int Lc = L - 1;   // cached positions; the new token's row (still in dqkv) is the fifth partial state
     const int nchunk = cdiv(Lc, PCH);
-    // distinct (position, slot) rows of positions [c0, c0+PCH) -> list rw, count returned:
-    // entry = local position | slot << 8 | hypothesis bit set << 12
-    auto build = [&](int *rw, int c0) -> int {
-      for (int e = tid; e < PCH * W; e += 256) rw[e] = 0;
-      const int p = c0 + tid;
-      const bool live = tid < PCH && p < Lc;
-      int sl[WM];
-#pragma unroll
-      for (int h = 0; h < WM; ++h) sl[h] = anc[(long)(live ? p : 0) * W + min(h, nh - 1)];
-      unsigned mask = 0;
-#pragma unroll
-      for (int h = 0; h < WM; ++h)
-        if (h < nh) mask |= 1u << sl[h];
-      const int cnt = live ? __popc(mask) : 0;
-      int incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      if (lane == 63) wtot[wave] = incl;
-      __syncthreads();   // also orders the zero fill (and qs) before the ORs
-      const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
-      const int U = wtot[0] + wtot[1];
-      if (live) {
-#pragma unroll
-        for (int h = 0; h < WM; ++h) {
-          if (h < nh) {
-            const int rank = __popc(mask & ((1u << sl[h]) - 1u));
-            atomicOr(&rw[base + rank], tid | (sl[h] << 8) | (1 << (12 + h)));
-          }
-        }
-      }
-      __syncthreads();   // list complete; wtot may be rewritten
-      return U;
-    };
     if (nchunk == 0) __syncthreads();   // qs
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
-      const int U = build(rows, c0);
+      const int U = mattn_build_rows<WM>(rows, wtot, anc, c0, Lc, W, nh, tid, lane, wave);   // (attn.h)
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, d, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
-        hm = (unsigned)e >> 12;
-        ke = skv0 + ((long)(c0 + (e & 255)) * W + ((e >> 8) & 15)) * 2 * d;
+        hm = (unsigned)e >> 16;
+        ke = skv0 + (long)(e & 0xFFFF) * 2 * d;
       });
       if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
     }
     if (sb.stat_rows && head == 0 && tid == 0) atomicAdd(&sb.stat_rows[0], (unsigned long long)urows);
-    // the new token: hypothesis h attends to its own row (slot h at position L-1) only
+    // the new token: hypothesis h attends to its own row (position L-1, still in dqkv) only
     if (tid < 16) {
       const int h = tid;
       float sdot = -INFINITY;
@@ -621,6 +646,22 @@ struct CtcChunkT {
   float4 xc[4], xb[4];
   float pn[16], pb[16];
 };
+// Forward variables of the candidates are kept at CHECKPOINT frames only (t % 16 == 15): ctc_rnew [S][tck][2][W*K],
+// tck = ceil(TCAP / 16).  The W x K candidates of a stream used to write r[t] for EVERY frame (3.2 KB per frame at beam
+// 10: 47 MB per launch at 128 streams, 1.9 GB per step at T = 4500) although only the W winners' histories survive the
+// step; ctc_gather_state_kernel now rebuilds the winners' full-resolution r[t] from the checkpoints - the same
+// recurrence (ctc_frame below, bit for bit) over 16 frames per thread, all segments in parallel.
+#define SC_CTC_CK 16
+__host__ __device__ static inline int ctc_tck(int TCAP) { return (TCAP + SC_CTC_CK - 1) / SC_CTC_CK; }
+// one frame of Watanabe Alg. 2 for one (hypothesis, candidate): (r_n, r_b) at t-1 -> t; pn / pb = r of the PREFIX at t-1
+__device__ __forceinline__ void ctc_frame(float &r_n, float &r_b, float pn, float pb, bool same, float xc, float xb, float &phi) {
+  const float rs = lse2(pn, pb);
+  phi = same ? pb : rs;          // select, not a branch: lanes of a wave differ in `same`
+  const float nr_n = lse2(r_n, phi) + xc;
+  const float nr_b = lse2(r_n, r_b) + xb;
+  r_n = nr_n;
+  r_b = nr_b;
+}
 // a stream's scan is split over T (ctc_prefix_scan_tpar_kernel) when it has at least split_min frames to walk
 __device__ __forceinline__ bool ctc_scan_is_split(int T, int L, int split_min) {
   const int out_len = L - 1;
@@ -647,19 +688,21 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
   const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
   const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
   const float *__restrict__ rp = CTCR(cur, s);
-  float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
+  float *rn = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * (W * K);   // checkpoints: r[16 j + 15] at row j
   const int WK = W * K;
   const int out_len = L - 1;
   int start = out_len > 1 ? out_len : 1;
   if (start > T) start = T;
-  for (int t = 0; t < start - 1; ++t) {   // rows before start-1 are never read again; keep them at logzero
-    rn[((long)t * 2) * WK + e] = SC_LOGZERO;
-    rn[((long)t * 2 + 1) * WK + e] = SC_LOGZERO;
+  for (int j = 0; SC_CTC_CK * j + SC_CTC_CK - 1 < start - 1; ++j) {   // frames before start-1: logzero
+    rn[((long)j * 2) * WK + e] = SC_LOGZERO;
+    rn[((long)j * 2 + 1) * WK + e] = SC_LOGZERO;
   }
   float r_n = (out_len == 0) ? xcol[0] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
   float r_b = SC_LOGZERO;
-  rn[((long)(start - 1) * 2) * WK + e] = r_n;
-  rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b;
+  if (((start - 1) & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {
+    rn[((long)((start - 1) / SC_CTC_CK) * 2) * WK + e] = r_n;
+    rn[((long)((start - 1) / SC_CTC_CK) * 2 + 1) * WK + e] = r_b;
+  }
   float cum = 0.f;   // running blank log-prob sum of the initial (state None) hypothesis: sum_{tau < start} x[tau, blank]
   if (!has)
     for (int t = 0; t < start; ++t) cum += xblk[t];
@@ -689,14 +732,12 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
     const float xb = (i & 3) == 0 ? b4.x : (i & 3) == 1 ? b4.y : (i & 3) == 2 ? b4.z : b4.w;
     const float pn = has ? q.pn[i] : SC_LOGZERO;
     const float pb = has ? q.pb[i] : cum;     // r_prev[t-1]
-    const float rs = lse2(pn, pb);
-    const float phi = same ? pb : rs;          // select, not a branch: lanes of a wave differ in `same`
-    const float nr_n = lse2(r_n, phi) + xc;
-    const float nr_b = lse2(r_n, r_b) + xb;
-    r_n = nr_n;
-    r_b = nr_b;
-    rn[((long)t * 2) * WK + e] = r_n;
-    rn[((long)t * 2 + 1) * WK + e] = r_b;
+    float phi;
+    ctc_frame(r_n, r_b, pn, pb, same, xc, xb, phi);
+    if ((i & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {   // (chunks are 16-frame aligned: i == 15 <=> t % 16 == 15; compile-time per unrolled frame)
+      rn[((long)(t / SC_CTC_CK) * 2) * WK + e] = r_n;
+      rn[((long)(t / SC_CTC_CK) * 2 + 1) * WK + e] = r_b;
+    }
     const float v = phi + xc;       // branch-free running log-sum-exp
     const float m = sc_max_raw(pm, v);
     ps = ps * sc_exp_neg(pm - m) + sc_exp_neg(v - m);
@@ -776,21 +817,21 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
   const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
   const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
   const float *__restrict__ rp = CTCR(cur, s);
-  float *rn = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
+  float *rn = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * (W * K);   // checkpoints: r[16 j + 15] at row j
   const int WK = W * K;
   const int out_len = L - 1;
   int start = out_len > 1 ? out_len : 1;
   if (start > T) start = T;
   if (valid)
-    for (int t = p; t < start - 1; t += CTC_NSEG) {   // rows before start-1 are never read again; keep them at logzero
-      rn[((long)t * 2) * WK + e] = SC_LOGZERO;
-      rn[((long)t * 2 + 1) * WK + e] = SC_LOGZERO;
+    for (int j = p; SC_CTC_CK * j + SC_CTC_CK - 1 < start - 1; j += CTC_NSEG) {   // frames before start-1: logzero
+      rn[((long)j * 2) * WK + e] = SC_LOGZERO;
+      rn[((long)j * 2 + 1) * WK + e] = SC_LOGZERO;
     }
   const float r_n0 = (out_len == 0) ? xcol[0] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
   const float r_b0 = SC_LOGZERO;
-  if (valid && p == 0) {
-    rn[((long)(start - 1) * 2) * WK + e] = r_n0;
-    rn[((long)(start - 1) * 2 + 1) * WK + e] = r_b0;
+  if (valid && p == 0 && ((start - 1) & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {
+    rn[((long)((start - 1) / SC_CTC_CK) * 2) * WK + e] = r_n0;
+    rn[((long)((start - 1) / SC_CTC_CK) * 2 + 1) * WK + e] = r_b0;
   }
   // segments: boundaries at multiples of 16 frames (the loads are 16-frame chunks)
   const int base = start & ~15;
@@ -920,14 +961,11 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
       const float xc = comp(q.xc[i >> 2], i), xb = comp(q.xb[i >> 2], i);
       const float pn = has ? q.pn[i] : SC_LOGZERO;
       const float pb = has ? q.pb[i] : cu;
-      const float phi = same ? pb : lse2(pn, pb);
-      const float nr_n = lse2(r_n, phi) + xc;
-      const float nr_b = lse2(r_n, r_b) + xb;
-      r_n = nr_n;
-      r_b = nr_b;
-      if (valid) {
-        rn[((long)t * 2) * WK + e] = r_n;
-        rn[((long)t * 2 + 1) * WK + e] = r_b;
+      float phi;
+      ctc_frame(r_n, r_b, pn, pb, same, xc, xb, phi);
+      if (valid && (t & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {
+        rn[((long)(t / SC_CTC_CK) * 2) * WK + e] = r_n;
+        rn[((long)(t / SC_CTC_CK) * 2 + 1) * WK + e] = r_b;
       }
       if (!has) cu += xb;
     });
@@ -1120,13 +1158,13 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
       const int e = e0 + 256 * u;
       if (e >= ntot) break;
       const int i = e / (L + 1), p = e % (L + 1);
-      const int h = win_h[i], tok = win_tok[i];
+      const int tok = win_tok[i];
       int *ydst = YSEQ(o, s, i), *xdst = XPOS(o, s, i);
       if (p < L) {
         ydst[p] = yv[u];
         xdst[p] = xv[u];
         if (p >= 1 && yv[u] == tok && tok != sb.sos && tok != sb.eos) rep = true;
-        adst[(long)p * W + i] = (p < L - 1) ? av[u] : h;
+        adst[(long)p * W + i] = av[u];   // pool rows of the parent's history, incl. its newest token's row (position L-1)
       } else {
         ydst[L] = tok;
         xdst[L] = T - 1;
@@ -1150,28 +1188,74 @@ extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void ctc_gather_state_kernel(sc_search sb) {
+// CTCPrefixScorer.select_state (scorers.py:382-431) for the W winners of the step - and the rebuild of their forward
+// variables from the checkpoints the scan left (see SC_CTC_CK above): thread = (winner i, 16-frame segment j) walks its
+// segment with the scan's own recurrence from the checkpoint in front of it (or from the scan's initial state in the
+// segment that holds frame start-1) and writes r[t] of all its frames into the other side of ctc_r.
+__global__ __launch_bounds__(256) void ctc_gather_state_kernel(sc_search sb) {
   const int s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
-  const int W = sb.W, K = sb.K, T = SC_CTC_T(s), nh = CTRL(s, SC_C_NHYP);
+  const int W = sb.W, K = sb.K, V = sb.V, T = SC_CTC_T(s), nh = CTRL(s, SC_C_NHYP), L = CTRL(s, SC_C_L);
   const int nout = nh * W < W ? nh * W : W;
-  const int o = 1 - CTRL(s, SC_C_CUR);
+  const int cur = CTRL(s, SC_C_CUR), o = 1 - cur;
+  const bool has = CTRL(s, SC_C_HAS);
+  const int nseg = cdiv(T, SC_CTC_CK);
+  const int WK = W * K, tct = sb.tct;
   float *dst = CTCR(o, s);
-  const float *src = sb.ctc_rnew + (long)s * sb.TCAP * 2 * (W * K);
-  const long total = (long)T * 2 * nout;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long)gridDim.x * blockDim.x) {
-    const int i = idx % nout;
-    const long t2 = idx / nout;  // t*2 + {n,b}
-    const int hsel = sb.sel[((long)s * W + i) * 2], ksel = sb.sel[((long)s * W + i) * 2 + 1];
-    dst[t2 * W + i] = src[t2 * (W * K) + hsel * K + ksel];
+  const float *__restrict__ rp = CTCR(cur, s);
+  const float *ck = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * WK;
+  const int out_len = L - 1;
+  int start = out_len > 1 ? out_len : 1;
+  if (start > T) start = T;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nout * nseg; idx += gridDim.x * blockDim.x) {
+    const int i = idx % nout, j = idx / nout;
+    const int h = sb.sel[((long)s * W + i) * 2], k = sb.sel[((long)s * W + i) * 2 + 1];
+    const int e = h * K + k;
+    const int c = sb.pre_ids[((long)s * W + h) * K + k];
+    const bool same = c == YSEQ(cur, s, h)[L - 1];
+    const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
+    const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
+    const int t0 = j * SC_CTC_CK, t1 = min(t0 + SC_CTC_CK, T);
+    float r_n, r_b;
+    int begin;
+    if (t0 <= start - 1) {   // the segment that holds frame start-1 (or lies in front of it)
+      r_n = (out_len == 0) ? xcol[0] : SC_LOGZERO;
+      r_b = SC_LOGZERO;
+      for (int t = t0; t < min(start - 1, t1); ++t) {
+        dst[((long)t * 2) * W + i] = SC_LOGZERO;
+        dst[((long)t * 2 + 1) * W + i] = SC_LOGZERO;
+      }
+      if (start - 1 < t1) {
+        dst[((long)(start - 1) * 2) * W + i] = r_n;
+        dst[((long)(start - 1) * 2 + 1) * W + i] = r_b;
+      }
+      begin = start;
+    } else {
+      r_n = ck[((long)(j - 1) * 2) * WK + e];
+      r_b = ck[((long)(j - 1) * 2 + 1) * WK + e];
+      begin = t0;
+    }
+    float cum = 0.f;   // !has: running blank log-prob sum of the initial (state None) hypothesis, in the scan's order
+    if (!has)
+      for (int t = 0; t < begin && t < t1; ++t) cum += xblk[t];
+    for (int t = begin; t < t1; ++t) {
+      const float pn = has ? rp[((long)(t - 1) * 2) * W + h] : SC_LOGZERO;
+      const float pb = has ? rp[((long)(t - 1) * 2 + 1) * W + h] : cum;
+      float phi;
+      const float xb = xblk[t];
+      ctc_frame(r_n, r_b, pn, pb, same, xcol[t], xb, phi);
+      dst[((long)t * 2) * W + i] = r_n;
+      dst[((long)t * 2 + 1) * W + i] = r_b;
+      if (!has) cum += xb;
+    }
   }
 }
 
 extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
-  int gx = cdiv(sbp->TCAP * 2 * sbp->W, 256);
-  if (gx > 64) gx = 64;
+  SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4, "the state rebuild needs the column-major table copy (sc_search.ctcxT)");
+  int gx = cdiv(ctc_tck(sbp->TCAP) * sbp->W, 256);
+  if (gx > 16) gx = 16;
   ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp);
   SC_CHECK_LAUNCH();
   return SC_OK;
@@ -1207,6 +1291,7 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
+  SC_TRY(sc_kv_alloc(sbp, stream));   // pool rows for the K|V of this step's tokens
   if (dec_fused_ok(sb)) {
     // 3 launches per layer; x ping-pongs dx <-> dxn
     float *xa = sb.dx, *xb = sb.dxn;

@@ -1195,6 +1195,11 @@ int tick_collect(sc_streams *b) {
   // ---- the accept / stop rules of the step loop (:759-821)
   for (int s : b->tick_active) {
     Run &r = b->run[s];
+    if (b->flags_host[S + s]) {   // sc_kv_alloc found no free row: the step computed garbage for this stream
+      b->flags_host[S + s] = 0;
+      fault_stream(b, s, SC_ERR_CAPACITY, "self-attention K|V pool exhausted (kv_pool_rows / max_tokens)");
+      continue;
+    }
     const int f = b->flags_host[s];
     const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
     r.out += 1;
@@ -1742,14 +1747,27 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   }
   sb.tct = (b->TCAP + 3) / 4 * 4;
   A(sb.ctcxT, (size_t)S * V * sb.tct);
-  A(sb.skv, (size_t)S * c.dec_layers * b->LCAP * W * 2 * d / kvdiv + 4);
+  // self-attention K|V: a pool of rows per stream and layer (scasr.h: sc_kv_alloc) - a beam's hypotheses share almost all
+  // of their history, so 1.5 rows per token position (+ the W rows a step appends, with slack) instead of W
+  {
+    const long full = (long)b->LCAP * W;
+    long rows = o->kv_pool_rows > 0 ? o->kv_pool_rows : (long)b->LCAP + b->LCAP / 2 + 4 * W;
+    rows = std::max<long>(std::min(rows, full), 2 * W);
+    if (rows > 65536) {
+      sc_set_error("sc_streams_create: the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)");
+      delete b;
+      return SC_ERR_ARG;
+    }
+    sb.kv_rows = (int32_t)rows;
+  }
+  A(sb.skv, (size_t)S * c.dec_layers * sb.kv_rows * 2 * d / kvdiv + 4);
   A(sb.yseq, (size_t)2 * n * b->LCAP);
   A(sb.xpos, (size_t)2 * n * b->LCAP);
   A(sb.anc, (size_t)2 * S * b->LCAP * W);
   A(sb.score, 2 * n); A(sb.sc_dec, 2 * n); A(sb.sc_ctc, 2 * n);
   A(sb.ctc_r, (size_t)2 * S * b->TCAP * 2 * W);
   A(sb.ctc_s, 2 * n);
-  A(sb.ctc_rnew, (size_t)S * b->TCAP * 2 * W * K);
+  A(sb.ctc_rnew, (size_t)S * ((b->TCAP + 15) / 16) * 2 * W * K);   // checkpoints every 16 frames (search.hip: SC_CTC_CK)
   A(sb.dx, n * d); A(sb.dxn, n * d); A(sb.dqkv, n * 3 * d); A(sb.datt, n * d); A(sb.dq, n * d); A(sb.dffh, n * F);
   A(sb.logits, n * V); A(sb.logp, n * V);
   A(sb.pre_ids, n * K); A(sb.psi, n * K); A(sb.psi_eos, n);
@@ -1836,6 +1854,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
     }
     b->ring_dev = (int32_t *)dv;
     sb.flags = b->ring_dev;
+    sb.kvflags = b->ring_dev + S;   // second half of the host-mapped flag array: "K|V pool exhausted" per stream
   }
   if (const char *sp = sc_hook("SC_SCAN_SPLIT_MIN")) b->scan_split_min = atoi(sp);   // tests: 0 = never, small = always
   if (const char *sp = sc_hook("SC_SCAN_SPLIT_STREAMS")) b->scan_split_streams = atoi(sp);   // tools: bucket limit of the T-parallel scan

@@ -117,7 +117,8 @@ class StreamBatch:
     def __init__(self, weights: PackedWeights, backend, n_streams: int,
                  search: SearchConfig = SearchConfig(), max_frames: int = 1600,
                  max_tokens: int = 640, pcm_capacity: int = 1 << 20,
-                 max_chunk_samples: int = 32768, strict_reference: bool = True, kv_dtype: str = "float32"):
+                 max_chunk_samples: int = 32768, strict_reference: bool = True, kv_dtype: str = "float32",
+                 kv_pool_rows: int = 0):
         self.w = weights
         self.cfg = cfg = weights.cfg
         self.be = backend
@@ -173,7 +174,13 @@ class StreamBatch:
         if kvt != f32 and not hasattr(backend, "kv_rows_to_half"):
             raise EngineError("half-precision K|V caches need the HIP backend")
         self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d, dtype=kvt)
-        self.skv = z(S * cfg.dec_layers * self.LCAP * W, 2 * d, dtype=kvt)
+        # self-attention K|V: a pool of rows per stream and layer (include/scasr.h: sc_kv_alloc); `anc` holds pool rows
+        self.kv_rows = max(2 * W, min(self.LCAP * W, kv_pool_rows if kv_pool_rows > 0 else self.LCAP + self.LCAP // 2 + 4 * W))
+        if self.kv_rows > 65536:
+            raise EngineError("the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)")
+        self.skv = z(S * cfg.dec_layers * self.kv_rows, 2 * d, dtype=kvt)
+        self._flags2 = z(2 * S, dtype=i32)          # stop flags of the prune kernel | "K|V pool exhausted" of sc_kv_alloc
+        self.kvflags = self._flags2[S:]
         self.kv_stage_rows = max(256, S * 24)
         self.kv_stage = z(cfg.dec_layers * self.kv_stage_rows, 2 * d) if kvt != f32 else None
         self.yseq = z(2, S, W, self.LCAP, dtype=i32)
@@ -184,7 +191,7 @@ class StreamBatch:
         self.sc_ctc = z(2, S, W, dtype=f64)
         self.ctc_r = z(2, S, self.TCAP, 2, W)
         self.ctc_s = z(2, S, W)
-        self.ctc_rnew = z(S, self.TCAP, 2, W * K)
+        self.ctc_rnew = z(S, (self.TCAP + 15) // 16, 2, W * K)     # checkpoints: r of the candidates at frames t % 16 == 15
         # ctrl rows and the compaction row map share one buffer: one upload per step
         self._ctrlmap = z(S * 8 + S * W, dtype=i32)
         self.ctrl = self._ctrlmap[: S * 8].view(S, 8)
@@ -193,7 +200,7 @@ class StreamBatch:
         self.n_rows_step = S * W
         self._decode_prepared = False
         self._isolate, self._faults = False, {}
-        self.flags = z(S, dtype=i32)
+        self.flags = self._flags2[:S]
         # pinned host mirrors: the per-step ctrl upload / flag read-back are the
         # only host<->device traffic of the decode loop
         pin = dev.type == "cuda"
@@ -206,7 +213,7 @@ class StreamBatch:
         self._rowmap_key = None
         self._rowmap_identity = np.arange(S * W, dtype=np.int32)
         self.row_bucket = max(1, S // 16)        # compaction granularity in streams
-        self._flags_host = torch.zeros(S, dtype=i32, pin_memory=pin)
+        self._flags_host = torch.zeros(2 * S, dtype=i32, pin_memory=pin)
         self._ctrl_host0 = torch.zeros(S, 8, dtype=i32, pin_memory=pin)   # block-start upload (own buffer:
         self._ctrl_np0 = self._ctrl_host0.numpy()                         # it may still be in flight when step 1 is built)
         self._ctrl_np = self._ctrl_host.numpy()
@@ -287,10 +294,10 @@ class StreamBatch:
 
     def _read_flags(self) -> np.ndarray:
         if self.stream is not None:
-            self._flags_host.copy_(self.flags, non_blocking=True)
+            self._flags_host.copy_(self._flags2, non_blocking=True)
             self.stream.synchronize()
         else:
-            self._flags_host.copy_(self.flags)
+            self._flags_host.copy_(self._flags2)
         return self._flags_np
 
     def _itensor(self, arr) -> torch.Tensor:
@@ -994,6 +1001,16 @@ class StreamBatch:
             t_st = time.perf_counter()
             f = self._read_flags()[ids]
             self._tick("decode_wait_flags", t_st)
+            full = act & (self._flags_np[self.S:][ids] != 0)    # sc_kv_alloc found no free K|V pool row: garbage step
+            if full.any():
+                err = EngineError(f"self-attention K|V pool exhausted (kv_pool_rows={self.kv_rows}, max_tokens={self.LCAP})")
+                if not self._isolate:
+                    raise err
+                for i in np.nonzero(full)[0]:   # isolate: the stream leaves the loop here and is reset by push()
+                    self._faults[int(ids[i])] = err
+                live &= ~full
+                act = act & ~full
+                f = np.where(full, 0, f)
             f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
             out_idx += act
             nsteps += act

@@ -245,6 +245,7 @@ class HipBackend:
         s.rowmap, s.n_rows = sb.rowmap.data_ptr(), sb.S * sb.W
         s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
         s.kv_half = 1 if sb.ckv.dtype == torch.float16 else 0
+        s.kv_rows, s.kvflags = int(sb.kv_rows), sb.kvflags.data_ptr()
         if getattr(sb, "ctcxT", None) is not None:  # column-major CTC table copy
             s.ctcxT, s.tct = sb.ctcxT.data_ptr(), sb.ctcxT.shape[-1]
         if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)
@@ -263,6 +264,9 @@ class HipBackend:
 
     def dec_embed(self, sb):
         self._sb_call("sc_dec_embed", sb)
+
+    def kv_alloc(self, sb):
+        self._sb_call("sc_kv_alloc", sb)
 
     def dec_self_attn(self, sb, li):
         self._sb_call("sc_dec_self_attn", sb, li)

@@ -95,10 +95,13 @@ class NativeStreamBatch:
 
     def __init__(self, weights, n_streams: int, search: SearchConfig = SearchConfig(), max_frames: int = 1600,
                  max_tokens: int = 640, pcm_capacity: int = 1 << 20, max_chunk_samples: int = 32768,
-                 strict_reference: bool = True, engine: Optional[NativeEngine] = None, kv_dtype: str = "float32"):
+                 strict_reference: bool = True, engine: Optional[NativeEngine] = None, kv_dtype: str = "float32",
+                 kv_pool_rows: int = 0):
         """``kv_dtype``: "float32" (the reference's arithmetic) or "float16" - the self- and cross-attention K|V
         caches in fp16 (half the HBM stream of the attention kernels and half the cache memory; arithmetic,
-        softmax and all scores stay fp32): the storage mode of BASELINE configs[4], opt-in, never the parity mode."""
+        softmax and all scores stay fp32): the storage mode of BASELINE configs[4], opt-in, never the parity mode.
+        ``kv_pool_rows``: rows of the self-attention K|V pool per stream and layer (0: 1.5 x max_tokens + 4 x beam; a stream
+        that needs more fails with a capacity error)."""
         if not torch.cuda.is_available():
             raise _abi.ScasrError("NativeStreamBatch needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.engine = engine or NativeEngine(weights, device=weights.device)
@@ -111,7 +114,7 @@ class NativeStreamBatch:
             raise EngineError("the native engine implements the reference's constants: pre-beam 40, max_length 500")
         o = _abi.StreamOptions(n_streams, search.beam_size, search.ctc_weight, int(search.use_bbd), max_frames,
                                max_tokens, pcm_capacity, max_chunk_samples, int(strict_reference),
-                               {"float32": 0, "float16": 1}[kv_dtype])
+                               {"float32": 0, "float16": 1}[kv_dtype], int(kv_pool_rows))
         self.kv_dtype = kv_dtype
         h = C.c_void_p()
         try:

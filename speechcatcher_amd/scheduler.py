@@ -203,10 +203,12 @@ class StreamScheduler:
         return len(self._in_flight)
 
     def drain(self) -> Dict[int, list]:
-        """Run steps until every queue is empty; returns the LAST result of each session."""
+        """Run steps until every queue is empty; returns the LAST result of each session.  On the C++ engine through the
+        continuous path (``pump``: sc_submit / sc_poll) - per session the same calls and replies as ``step``."""
         last: Dict[int, list] = {}
+        cont = hasattr(self.batch, "submit")
         while self.pending():
-            for sid, res in (self.pump() if (self._in_flight or self._stash) else self.step()).items():
+            for sid, res in (self.pump() if (cont or self._in_flight or self._stash) else self.step()).items():
                 if isinstance(res, Exception):
                     raise res
                 last[sid] = res

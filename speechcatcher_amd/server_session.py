@@ -104,10 +104,11 @@ class ServerLoop:
 
     def __init__(self, scheduler: StreamScheduler, vosk_output_format: bool = False,
                  finalize_update_iters: int = 6, max_partial_iters: int = 42, strict_reference: bool = False,
-                 continuous: bool = False, min_replies: int = 1):
+                 continuous: Optional[bool] = None, min_replies: int = 1):
         """``strict_reference``: no stream reset after a finalised utterance nor between clients, exactly like
         ``recognize_ws`` / ``process_audio_chunk`` (speechcatcher_server.py:270,359-397); the default resets.
-        ``continuous``: a step hands the engine the chunks of the sessions that are ready and returns as soon as
+        ``continuous`` (default: on whenever the batch has the C++ engine's submit / poll - round 4; False forces one
+        batched lock-step call per step): a step hands the engine the chunks of the sessions that are ready and returns as soon as
         ``min_replies`` replies are (``StreamScheduler.pump``): every client is answered when ITS chunk is decoded
         and may send the next one at once, instead of all clients waiting for the slowest stream of a batch -
         the reference's per-client handler loop (:359-397), same calls and replies per session."""
@@ -115,6 +116,8 @@ class ServerLoop:
         if strict_reference:
             scheduler.reset_after_final = scheduler.reset_on_open = False
         self.sch = scheduler
+        if continuous is None:
+            continuous = hasattr(scheduler.batch, "submit")
         self.continuous, self.min_replies = continuous, min_replies
         self.vosk = vosk_output_format
         self.fui, self.mpi = finalize_update_iters, max_partial_iters

@@ -141,7 +141,16 @@ def test_oracle_is_only_used_as_the_checker():
     for path in sorted((ROOT / "speechcatcher_amd").rglob("*.py")):
         assert oracle_imports(path) == [], f"{path.relative_to(ROOT)} imports the oracle"
     # (the worker function of the cpu_baseline leg: it runs in spawned processes, so it is a top-level function)
-    assert set(oracle_imports(ROOT / "bench.py")) == {"cpu_baseline_worker"}
+    # (_oracle_model builds the oracle's model for them; cpu_fast_forward_worker brings the stream to the timed window)
+    assert set(oracle_imports(ROOT / "bench.py")) == {"_oracle_model", "cpu_fast_forward_worker"}
+    # ... and they are reachable from the cpu_baseline leg only
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    refs = {node.name: {n.id for n in ast.walk(node) if isinstance(n, ast.Name)}
+            for node in tree.body if isinstance(node, (ast.FunctionDef, ast.ClassDef))}
+    users = lambda name: {f for f, names in refs.items() if name in names and f != name}   # noqa: E731
+    assert users("_oracle_model") == {"cpu_fast_forward_worker", "cpu_baseline_worker"}
+    assert users("cpu_fast_forward_worker") == users("cpu_baseline_worker") == {"cpu_baseline"}
+    assert users("cpu_baseline") == {"main"}
     assert set(oracle_imports(ROOT / "__graft_entry__.py")) == {"smoke"}
     # the product's only compute backend is the HIP library: no torch arithmetic fallback in the engine
     engine_src = (ROOT / "speechcatcher_amd" / "engine.py").read_text()

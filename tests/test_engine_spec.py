@@ -11,7 +11,7 @@ import pytest
 from conftest import GOLDEN, load_case
 from speechcatcher_amd import synth
 from speechcatcher_amd.config import TINY, XL, SearchConfig
-from speechcatcher_amd.engine import StreamBatch
+from speechcatcher_amd.engine import EngineError, StreamBatch
 from speechcatcher_amd.weights import PackedWeights
 
 from speechcatcher_amd.config import L_LIKE, M_DEFAULTS  # noqa: E402
@@ -244,3 +244,48 @@ def run_after_final(bbd, backend=None, device="cpu", score_tol=1e-3):
 @pytest.mark.parametrize("bbd", [0, 1])
 def test_engine_calls_after_final_without_reset(bbd):
     run_after_final(bbd)
+
+
+def run_kv_pool_exhaustion(backend=None, device="cpu"):
+    """The self-attention K|V pool (include/scasr.h: sc_kv_alloc): rows are handed out per step and reclaimed when no
+    live hypothesis descends from them.  A pool of one row per (position, hypothesis) can never run out; the default
+    (1.5 rows per position) serves the fixture utterance with the same results; a pool that is too small fails the
+    stream with a capacity error - alone, when faults are isolated."""
+    js, _ = load_case("tiny_c10240_b10_bbd0")
+    meta = js["meta"]
+    audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
+    kw = dict(max_frames=256, max_tokens=160, pcm_capacity=1 << 18)
+    if backend is not None:
+        kw.update(backend=backend)
+        if not isinstance(backend, str):
+            kw.update(device=device)
+
+    def run(sb, streams=(0,)):
+        out = None
+        for pos in range(0, len(audio), meta["chunk"]):
+            end = min(pos + meta["chunk"], len(audio))
+            out = sb.push([(s, audio[pos:end], end >= len(audio)) for s in streams], isolate_faults=len(streams) > 1)
+        return out
+
+    full = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], kv_pool_rows=160 * 10, **kw)
+    run(full)
+    dflt = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], **kw)
+    run(dflt)
+    assert [h["yseq"] for h in dflt.hypotheses(0)] == [h["yseq"] for h in full.hypotheses(0)]
+    check_against_blocks(dflt, 0, js["blocks"][-1])
+    small = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], kv_pool_rows=24, **kw)
+    with pytest.raises(EngineError, match="pool"):
+        run(small)
+    # two streams, the pool is per stream: both fail in isolation (each is reset), the call itself succeeds
+    two = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], n_streams=2, kv_pool_rows=24, **kw)
+    failed = set()
+    for pos in range(0, len(audio), meta["chunk"]):
+        end = min(pos + meta["chunk"], len(audio))
+        out = two.push([(s, audio[pos:end], end >= len(audio)) for s in (0, 1) if s not in failed], isolate_faults=True)
+        failed |= {s for s, r in out.items() if isinstance(r, EngineError)}
+    assert failed == {0, 1}
+    assert two.st[0].T_enc == 0 and two.st[1].T_enc == 0       # both have been reset
+
+
+def test_kv_pool_exhaustion_is_a_capacity_fault():
+    run_kv_pool_exhaustion()

@@ -128,6 +128,18 @@ def test_native_final_chunk_that_faults_on_a_running_stream():
     sb2.push([(0, a[:10240], False)])                         # not wedged
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
+def test_kv_pool_exhaustion_on_the_gpu(engine):
+    """self-attention K|V pool (sc_kv_alloc) on both engines: default pool = full pool = fixture; too small a pool is a
+    per-stream capacity fault"""
+    from test_engine_spec import run_kv_pool_exhaustion
+    if engine == "native":
+        run_kv_pool_exhaustion(backend="native")
+    else:
+        from speechcatcher_amd.hip_backend import HipBackend
+        run_kv_pool_exhaustion(backend=HipBackend("cuda:0"), device="cuda:0")
+
+
 def test_native_batch_of_distinct_streams_equals_one_by_one():
     """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
     head-parallel and six-launch layer forms by bucket size) = every stream alone = the same streams served by

@@ -547,7 +547,7 @@ def _dump(ls, name):
 ALL_OPS = {"logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
            "dec_self_attn", "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw",
            "beam_prune", "ctc_gather_state", "ctc_extend_state", "dec_embed", "copy_rows",
-           "log_softmax_rows"}
+           "log_softmax_rows", "kv_alloc"}
 
 
 def test_every_kernel_lockstep_tiny(hip):
@@ -566,7 +566,7 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
 
-@pytest.mark.parametrize("layers", ["head_parallel", "head_parallel_hpw4", "head_parallel_hpw2", "six_launch"])
+@pytest.mark.parametrize("layers", ["head_parallel", "head_parallel_hpw4", "six_launch"])
 def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
     """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; the forms of the decoder layers:
     3 launches per layer with one head per workgroup (small buckets), with four / two heads per workgroup (large
@@ -703,8 +703,9 @@ def test_ctc_prefix_scan_long_table(hip, T, L, has, split):
     tol = 2e-4 + 2e-6 * T      # T dependent log-add-exps in fp32 on values of magnitude 1e1..1e4
     assert float((psi_c[fin] - psi_g[fin]).abs().max()) <= tol * max(1.0, float(psi_c[fin].abs().max()) * 1e-2)
     np.testing.assert_allclose(sg.psi_eos.cpu().numpy(), sc.psi_eos.numpy(), rtol=1e-5, atol=1e-3)
-    rc = sc.ctc_rnew.view(2, sc.TCAP, 2, W * K)[:, :T]
-    rg = sg.ctc_rnew.cpu().view(2, sc.TCAP, 2, W * K)[:, :T]
+    nck = T // 16                                   # checkpoints: r at the frames t % 16 == 15
+    rc = sc.ctc_rnew.view(2, -1, 2, W * K)[:, :nck]
+    rg = sg.ctc_rnew.cpu().view(2, -1, 2, W * K)[:, :nck]
     live = rc > -1e9
     assert torch.equal(live, rg > -1e9)
     assert float(((rc - rg).abs() / rc.abs().clamp(min=1.0))[live].max()) <= 1e-4
