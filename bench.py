@@ -383,6 +383,9 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
 
 
 _PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",   # <256, RTT, PRO = false, WF = 0 (fp32 weights)>
+               "ffn_fused_kernel<256,*,PRO>": "ffn_fused_kernelILi256ELi{}ELb1ELi0",
+               "dec_layer_attn_kernel<self>": "dec_layer_attn_kernelILi256ELi32ELi10ELb1",
+               "dec_layer_attn_kernel<cross>": "dec_layer_attn_kernelILi256ELi32ELi10ELb0",
                "dec_attn_flash_kernel<cross>": "dec_attn_flash_kernelILi32ELi10ELb0",
                "dec_attn_flash_kernel<self>": "dec_attn_flash_kernelILi32ELi10ELb1",
                "proj_ln_proj_kernel<256,*>": "proj_ln_proj_kernelILi256",
@@ -392,7 +395,7 @@ _PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary (None if unavailable)"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r03_bench_default_pmc_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", "r04_bench_default_pmc_hbm_traffic.csv")
     key = next((v for k, v in _PMC_FAMILY.items() if kernel_name.startswith(k)), None)
     if key is None or not os.path.exists(path):
         return None
@@ -534,7 +537,7 @@ def main():
     NK = 12   # scasr.h: SC_PROF_KINDS
     ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
-    ev_over_ms, xattn_bytes = 0.0, {}
+    ev_over_ms, xattn_bytes, xattn_flops = 0.0, {}, {}
     if args.roofline_steps > 0:
         sb.set_graphs(False)
         sb.take_attn_counters()
@@ -566,6 +569,10 @@ def main():
         rowb = 2 * XL.d_model * esz
         xattn_bytes = {7: float(rows["cross_rows"][0]) * rowb, 11: float(rows["cross_rows"][1]) * rowb,
                        6: float(rows["self_distinct_rows"][0]) * rowb, 10: float(rows["self_distinct_rows"][1]) * rowb}
+        # ... and the attention's own flops: q.k + p.v = 4 d per (hypothesis, key, layer) - keys = the T frames / the L tokens
+        fa = 4.0 * XL.d_model * args.beam
+        xattn_flops = {7: fa * rows["cross_rows"][0], 11: fa * rows["cross_rows"][1],
+                       6: fa * rows["self_positions"][0], 10: fa * rows["self_positions"][1]}
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
@@ -594,58 +601,62 @@ def main():
                         KV_DTYPE == "float32" and FFN_DTYPE == "float32" and args.queue_depth == 1)
     # dominant kernel of the path = the kernel kind with the largest summed launch time in the roofline leg
     names = ["gemm_naive_kernel", "gemm_skinny_kernel", "gemm_mfma_kernel<128,128>", "gemm_mfma_kernel<64,64>",
-             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<self> (decoder self-attention, large buckets)",
-             "dec_attn_flash_kernel<cross> (decoder cross-attention, large buckets)", "rowtile_proj_kernel<256,*>",
-             "ffn_fused_kernel<256,*,PRO> (decoder layer FFN with reduce + norm3 prologue, small buckets)",
-             "dec_layer_attn_kernel<self> (head-parallel layer: reduce + norm1 + Q|K|V + self-attention + out-projection, small buckets)",
-             "dec_layer_attn_kernel<cross> (head-parallel layer: reduce + norm2 + q + cross-attention + out-projection, small buckets)"]
+             "proj_ln_proj_kernel<256,*>", "ffn_fused_kernel<256,*>", "dec_attn_flash_kernel<self> (stand-alone decoder self-attention: six-launch layers)",
+             "dec_attn_flash_kernel<cross> (stand-alone decoder cross-attention: six-launch layers)", "rowtile_proj_kernel<256,*>",
+             "ffn_fused_kernel<256,*,PRO> (decoder layer FFN: reduce of the head partials + norm3 prologue)",
+             "dec_layer_attn_kernel<self> (decoder layer: reduce + norm1 + Q|K|V + self-attention + out-projection; 1 or 4 heads per workgroup)",
+             "dec_layer_attn_kernel<cross> (decoder layer: reduce + norm2 + q + cross-attention + out-projection; 1 or 4 heads per workgroup)"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
-    per_kernel = []
+    # every kind against BOTH roofs: algorithmic flops (incl. the attention's q.k / p.v) at the f32 matrix peak, algorithmic
+    # bytes (operands once + the K|V rows the attention must read) at the HBM peak; the bound is the one that takes longer
+    per_kernel, bound_of = [], {}
     for i in range(NK):
         if nn[i] == 0:
             continue
+        t_s = max(net[i], 1e-9) * 1e-3
+        flops_i = fl[i] + xattn_flops.get(i, 0.0)
+        bytes_i = by[i] + xattn_bytes.get(i, 0.0)
+        tf, gbs = flops_i / t_s / 1e12, bytes_i / t_s / 1e9
+        f_mfma, f_hbm = tf / PEAK_F32_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
+        bound_of[i] = ("mfma", tf, f_mfma, flops_i, bytes_i) if f_mfma >= f_hbm else ("hbm", gbs, f_hbm, flops_i, bytes_i)
         ent = {"kernel": names[i], "launches": int(nn[i]), "avg_launch_us": round(net[i] * 1e3 / nn[i], 2),
-               "share_of_timed_kernel_time": round(net[i] / tot_ms, 4)}
-        if fl[i] > 0:
-            ent["tflops"] = round(fl[i] / (max(net[i], 1e-9) * 1e-3) / 1e12, 3)
-            ent["frac_of_f32_mfma_peak"] = round(ent["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+               "share_of_timed_kernel_time": round(net[i] / tot_ms, 4), "bound": bound_of[i][0],
+               "frac_of_bound": round(bound_of[i][2], 4)}
+        if flops_i > 0:
+            ent["tflops"] = round(tf, 3)
+            ent["frac_of_f32_mfma_peak"] = round(f_mfma, 4)
+        if bytes_i > 0:
+            ent["hbm_gbs_algorithmic"] = round(gbs, 1)
+            ent["frac_of_hbm_peak"] = round(f_hbm, 4)
         if xattn_bytes.get(i, 0) > 0:
-            ent["hbm_gbs_algorithmic"] = round(xattn_bytes[i] / (max(net[i], 1e-9) * 1e-3) / 1e9, 1)
-            ent["frac_of_hbm_peak"] = round(ent["hbm_gbs_algorithmic"] / PEAK_HBM_GBS, 4)
+            ent["kv_bytes_per_launch_avg"] = int(xattn_bytes[i] / nn[i])
         per_kernel.append(ent)
     roof = None
     if any(nn[i] > 0 for i in range(NK)):
         v = max(range(NK), key=lambda i: net[i])
         raw_us = ms[v] * 1e3 / nn[v]
         t_ms = max(net[v], 1e-9)
+        kind, ach, frac, flops_v, bytes_v = bound_of[v]
         # traffic: HBM bytes per launch need rocprofv3 --pmc passes of this command (a process cannot read the
         # counters of its own kernels): `traffic` is taken from the committed summary of those passes
-        # (profiles/r03_bench_default_pmc_hbm_traffic.csv, tools/prof_bench.sh: FETCH_SIZE x2 + WRITE_SIZE per launch,
+        # (profiles/r04_bench_default_pmc_hbm_traffic.csv, tools/prof_bench.sh: FETCH_SIZE x2 + WRITE_SIZE per launch,
         # launch-weighted over the kernel family) when the file is there and this is the default workload, else null.
-        common = {"kernel": names[v], "traffic": pmc_traffic(names[v]) if default_workload else None,
-                  "traffic_source": "profiles/r03_bench_default_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                    "passes of this command, bytes per launch, launch-weighted over the kernel family)",
-                  "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
-                  "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
-                  "share_of_timed_kernel_time": round(net[v] / tot_ms, 4),
-                  "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
-                                   "hipGraph replay off, HIP events around every launch",
-                  "per_kernel": per_kernel}
-        if fl[v] > 0:
-            ach = fl[v] / (t_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "flops_per_launch_avg": round(fl[v] / nn[v] / 1e6, 1),
-                    "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 4)",
-                    "algorithmic_bytes_per_launch_avg": int(by[v] / nn[v])}
-        else:
-            bytes_v = xattn_bytes.get(v, 0.0)
-            ach = bytes_v / (t_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4),
-                    "algorithmic_bytes_per_launch_avg": int(bytes_v / nn[v])}
-        roof.update(common)
+        roof = {"bound": kind, "achieved": round(ach, 3 if kind == "mfma" else 1),
+                "peak": PEAK_F32_MFMA_TFLOPS if kind == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if kind == "mfma" else "GB/s",
+                "frac": round(frac, 4),
+                "flops_per_launch_avg": round(flops_v / nn[v] / 1e6, 1),
+                "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 4)",
+                "algorithmic_bytes_per_launch_avg": int(bytes_v / nn[v]),
+                "kernel": names[v], "traffic": pmc_traffic(names[v]) if default_workload else None,
+                "traffic_source": "profiles/r04_bench_default_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes of this command, bytes per launch, launch-weighted over the kernel family)",
+                "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
+                "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
+                "share_of_timed_kernel_time": round(net[v] / tot_ms, 4),
+                "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
+                                 "hipGraph replay off, HIP events around every launch",
+                "per_kernel": per_kernel}
 
     # whole chunk step against the matrix-core peak: algorithmic FLOPs of SURVEY 8(d) / wall time
     gflop_step = args.streams * (GFLOP_ENCODER_SIDE_PER_HOP * CHUNK / 10240.0 + GFLOP_PER_DECODE_STEP * args.beam / 10.0
@@ -672,8 +683,9 @@ def main():
                "cross_attention_kv": cross_rows * 2.0 * d * esz,
                "self_attention_kv_distinct_rows": self_rows * 2.0 * d * esz,
                # prefix scan per (iteration, stream, frame): W*K table elements read, r of the W hypotheses read, r of the
-               # W*K candidates written (ctc_rnew), the W selected ones copied (read + write)
-               "ctc_table_and_state": sum_T * 4.0 * (W * K + 2 * W + 2 * W * K + 4 * W)}
+               # W*K candidates written at every 16th frame (checkpoints); rebuild of the W winners: their table column
+               # + r of the prefix (2 W) read, checkpoints read, r written (2 W)
+               "ctc_table_and_state": sum_T * 4.0 * (W * K + 2 * W + 2 * W * K / 16.0 + 7 * W)}
         tot = sum(hbm.values())
         whole["with_attention"] = {"algorithmic_gflop_per_step": round(gflop_step + gflop_attn, 1),
                                    "attention_gflop_per_step": round(gflop_attn, 1),

@@ -123,10 +123,14 @@ __device__ __forceinline__ float lse2(float a, float b) {
 // in the shipped library).  Workgroup (0,0), thread 0 stores the 100 MHz shader real-time counter at phase
 // boundaries into a per-source-file table that sc_phase_debug_<file>() copies out.
 #ifdef SC_PHASE_DBG
+#ifndef SC_PHASE_MIN_GRID
+#define SC_PHASE_MIN_GRID 0   // -DSC_PHASE_MIN_GRID=200: only launches of at least that many workgroups leave stamps (full buckets)
+#endif
 static __device__ long long sc_phase_stamps[4][32];
 #define SC_STAMP(k, i)                                                                        \
   do {                                                                                        \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sc_phase_stamps[k][i] = (long long)__builtin_amdgcn_s_memtime(); \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (int)(gridDim.x * gridDim.y) >= SC_PHASE_MIN_GRID) \
+      sc_phase_stamps[k][i] = (long long)__builtin_amdgcn_s_memtime();                       \
   } while (0)
 #define SC_PHASE_GETTER(name)                                                                 \
   extern "C" int name(long long *out) {                                                       \

@@ -157,7 +157,12 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // right here instead, so that the MFMAs behind the LayerNorm wait for nothing.
   constexpr bool PF = UNR >= 8;
   static_assert(!(PF && HPW > 1), "the few-streams variant runs one head per workgroup");
-  float4 pfb[PF ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
+  // EARLY (HPW > 1, full buckets; phase stamps r04: 6.7 of the self kernel's 40 us went into a projection with 1.3 us of
+  // MFMA work - its first B fragments were requested behind the LayerNorm's barrier): k-block 0 of the projection is
+  // requested as soon as the x rows are in LDS and travels during the LayerNorm; the output projection's fragments
+  // travel during the merge of the attention's partial states.
+  constexpr bool EARLY = HPW > 1;
+  float4 pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
   int slp[(PF && SELF) ? WM : 1];
   if (PF && SELF) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     float *Xn = Xsh;  // [16][LDX], rows >= W zero
     constexpr int C4 = D / 4, QT = (16 * C4 + NTH - 1) / NTH;   // float4 pieces per row; pieces per thread (16 rows)
     constexpr int QN = (WM * C4 + NTH - 1) / NTH;               // ... of the rows that can be live (W <= WM)
-    constexpr int ZB = (UNR >= 8) ? 8 : 4;          // partial sums per batch (register budget of the variant)
+    constexpr int ZB = (UNR >= 8 || HPW > 1) ? 8 : 4;   // partial sums per batch (register budget of the variant; HPW > 1: one piece per thread)
     float4 xv[QN];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         if (blockIdx.y == 0 && i < W) *reinterpret_cast<float4 *>(p.xout + ((long)s * W + i) * D + 4 * c4) = v;
       }
     }
+    if (EARLY) prefetch_w();
     if (tid < D / 2) *reinterpret_cast<float4 *>(gb + 4 * tid) = gbv;
     if (touch == 123456.789f) Xn[0] = touch;   // never true: keeps the warm-up loads (they have returned by now:
     __syncthreads();                           // loads return in order and the partial sums were waited for)
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       }
     };
     float4 b0[NT], b1[NT];
-    if (PF) {
+    if (PF || EARLY) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         b0[t] = pfb[t * 2];
@@ -404,15 +410,16 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // take tiles round-robin and leave one partial state each (+ one for the new token's own row, SELF)
   // PF: the output projection's B fragments travel while the attention runs
   constexpr int TWO = D / 16 / 4;
-  float4 ob[PF ? TWO * 2 : 1];
-  if (PF) {
+  float4 ob[(PF || EARLY) ? TWO * 2 : 1];
+  auto prefetch_o = [&]() {
 #pragma unroll
     for (int t = 0; t < TWO; ++t) {
       const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32) * 128 + lane;
       ob[2 * t] = wq[0];
       ob[2 * t + 1] = wq[64];
     }
-  }
+  };
+  if (PF) prefetch_o();
   constexpr int NTW = (UNR >= 8) ? SC_LAYER_NTW : 2;   // tiles per wave and batch
   constexpr int NP = SELF ? 5 : 4;
   float *pm = region;
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   }
   SC_STAMP(SELF ? 0 : 1, 5);
   mattn_store_partial<DK>(st, pm, pl, pO, wave, lane);
+  if (EARLY) prefetch_o();   // (the walk's registers are free now)
   __syncthreads();
   for (int e = gt; e < WM * DK; e += 256) {
     const int h = e / DK, c = e % DK;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     float4 b0[TW], b1[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
-      if (PF) {
+      if (PF || EARLY) {
         b0[t] = ob[2 * t];
         b1[t] = ob[2 * t + 1];
       } else {
@@ -540,7 +548,9 @@ int sc_dec_layer_hpw(const sc_search &sb) {
   const int dk = sb.d / sb.H;
   const bool can = sb.d == 256 && dk == 32 && sb.W > 5 && sb.W <= 10;   // the instantiated HPW > 1 variants
   int hpw = 1;
-  if (can && (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= SC_HPW_MIN_ROWS) hpw = 4;
+  int min_rows = SC_HPW_MIN_ROWS;
+  if (const char *e = sc_hook("SC_HPW_MIN")) min_rows = atoi(e);   // tools: threshold sweep
+  if (can && (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= min_rows) hpw = 4;
   if (const char *e = sc_hook("SC_DEC_HPW")) {
     const int v = atoi(e);
     if (v == 1 || (can && v == 4)) hpw = v;
@@ -627,7 +637,8 @@ extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *x
   const int rc = layer == 0 ? launch_dec_layer_dims<true, true>(p, st) : launch_dec_layer_dims<true, false>(p, st);
   {   // MFMA part: Q|K|V projection + out-projection of the bucket's rows (the attention itself depends on device state)
     const double M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
-    sc_prof_end(prof, SC_PROF_LAYER_SELF, 8.0 * M * sb.d * sb.d, 4.0 * sb.d * sb.d * 4.0);
+    // algorithmic bytes without the K|V rows (bench.py adds them from the device counter): Wqkv + Wo once, x in, x out
+    sc_prof_end(prof, SC_PROF_LAYER_SELF, 8.0 * M * sb.d * sb.d, 4.0 * (4.0 * sb.d * sb.d + 2.0 * M * sb.d));
   }
   return rc;
 }
@@ -647,7 +658,7 @@ extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *
   const int rc = launch_dec_layer_dims<false, false>(p, st);
   {   // MFMA part: q projection + out-projection; K|V bytes = sum_s T_s * 2d * 4: the host knows T (bench.py)
     const double M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
-    sc_prof_end(prof, SC_PROF_LAYER_CROSS, 4.0 * M * sb.d * sb.d, 2.0 * sb.d * sb.d * 4.0);
+    sc_prof_end(prof, SC_PROF_LAYER_CROSS, 4.0 * M * sb.d * sb.d, 4.0 * (2.0 * sb.d * sb.d + 2.0 * M * sb.d));
   }
   return rc;
 }

@@ -842,6 +842,9 @@ extern "C" int sc_gemm_ln(const float *A, const int32_t *a_rows, int lda, const 
 // partial round trip 2*D*4*F/128/CPW).
 // ===========================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SC_FFN_EARLY_B2
+#define SC_FFN_EARLY_B2 1
+#endif
 
 __device__ __forceinline__ f32x4 ffn_mfma8(f32x4 acc, const float4 &a0, const float4 &a1, const float4 &b0,
                                            const float4 &b1) {
@@ -989,6 +992,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.pbias) pb = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.nph == 2) {   // four heads per workgroup upstream (decoder_layer.hip: HPW): two partial products per row
+        const float4 p0 = *reinterpret_cast<const float4 *>(p.PH + (row * 2) * D + 4 * c4);
+        const float4 p1 = *reinterpret_cast<const float4 *>(p.PH + (row * 2 + 1) * D + 4 * c4);
+        y = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+      } else
       for (int z0 = 0; z0 < p.nph; z0 += 8) {
         float4 pv[8];
 #pragma unroll
@@ -1005,6 +1013,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       if (grp == 0 && m0 + i < p.M) *reinterpret_cast<float4 *>(p.Xout + row * D + 4 * c4) = x;
       *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * c4) = x;
     }
+    load_b1(grp * p.cpw);   // GEMM 1's first weight fragments travel during the LayerNorm (the partial sums have arrived)
     __syncthreads();
     for (int i = threadIdx.x >> 4; i < RT; i += 32) {   // uniform per 16-lane row group
       float4 x[Q4];
@@ -1076,13 +1085,19 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       if (WS) acc2c[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-  load_b1(grp * p.cpw);
+  if (!PRO) load_b1(grp * p.cpw);
   __syncthreads();
   SC_STAMP(PRO ? 2 : 3, 1);
 
   for (int cc = 0; cc < p.cpw; ++cc) {
     const int chunk = grp * p.cpw + cc;
     const float bias = p.b1 ? p.b1[chunk * FC + wave * 16 + r] : 0.f;
+#if SC_FFN_EARLY_B2
+    // GEMM 2's weight fragments of this chunk are requested BEFORE GEMM 1: they travel behind its MFMAs.  Requested
+    // after it (round 1-3) only the short epilogue lay between the request and their first use, and both waves of a
+    // SIMD reach that point together (barrier): the matrix pipe idled for an L2 round trip per chunk.
+    load_b2(chunk);
+#endif
     // ---- GEMM 1: h[RT x 16] of this wave ----
     f32x4 acc1[RTT];
     f32x4 acc1c[WS ? RTT : 1];
@@ -1140,8 +1155,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
         a1 = n1;
       }
     }
+#if !SC_FFN_EARLY_B2
     // GEMM 2 weights of this chunk: in flight during the epilogue
     load_b2(chunk);
+#endif
     if (cc > 0) __syncthreads();  // previous chunk's GEMM 2 is done reading Hs
 #pragma unroll
     for (int rt = 0; rt < RTT; ++rt)
