@@ -75,7 +75,10 @@ def make_weights(device, ffn_dtype=None):
     sd = synth.make_state_dict(XL, 1234)
     mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
     return PackedWeights(sd, XL, device, mean, std, ffn_dtype=ffn_dtype,
-                         proj_dtype=ffn_dtype)   # the encoder's attention projections in the same form
+                         proj_dtype=ffn_dtype,   # the encoder's attention projections in the same form
+                         # float16 = the whole fp16 mode of BASELINE configs[4]: the decoder's projections / output layer and
+                         # the partial products between its kernels as well (effective together with --kv-dtype float16)
+                         dec_dtype="float16" if ffn_dtype == "float16" else "float32")
 
 
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None, kv_dtype=None):
@@ -740,6 +743,19 @@ def main():
                         "all scores fp32; opt-in `kv_dtype`): tools/fp16_mode_stats.py - 256 streams x 7 chunks, no hypothesis of any "
                         "stream changes, best scores within 7e-5 of the fp32 run")
 
+    fp16_mode = None
+    if not args.no_other_mode and world == 1 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
+        w_half = make_weights(device, "float16")
+        fp16_mode = leg(args.mode, weights=w_half, kv_dtype="float16")
+        del w_half
+        fp16_mode["over_headline"] = round(fp16_mode["value"] / value, 4)
+        fp16_mode["dtype"] = ("fp16 weights + fp16 MFMA inputs (feed-forward, encoder and decoder attention projections), fp16 K|V "
+                              "caches, fp16 partial products between the decoder's kernels; fp32 accumulation, LayerNorm, softmax, "
+                              "output layer, log-softmax, CTC scan and scores")
+        fp16_mode["note"] = ("NOT the headline: BASELINE configs[4]'s mode (`--ffn-dtype float16 --kv-dtype float16`).  No fp16 run of the "
+                             "reference's native decoder exists (speechcatcher.py:205-210 disables it): parity for this mode is the ids of the "
+                             "six XL fixtures + a bound on the share of streams whose best hypothesis moves (tests/test_gpu_baseline_size.py)")
+
     bbd_on = None
     if not args.no_other_mode and world == 1 and not args.bbd:
         bbd_on = leg(args.mode, bbd=True)
@@ -818,8 +834,9 @@ def main():
         "vs_baseline": None,
         "dtype": ("f32" if KV_DTYPE == "float32" and FFN_DTYPE == "float32" else
                   "f32 except: " + ", ".join(x for x in (("fp16 K|V caches" if KV_DTYPE != "float32" else ""),
-                                                         ("fp16 feed-forward + encoder attention-projection weights and MFMA inputs (fp32 accumulation)"
-                                                          if FFN_DTYPE == "float16" else ""),
+                                                         ("fp16 weights and MFMA inputs in the feed-forward, the encoder's and (with fp16 K|V caches) the decoder's "
+                                                          "attention projections, fp16 partial products between the decoder's kernels "
+                                                          "(fp32 accumulation)" if FFN_DTYPE == "float16" else ""),
                                                          ("feed-forward and encoder attention-projection product sums from fp16 hi + lo splits of both "
                                                           "fp32 operands on the fp16 matrix pipe (three MFMAs per sum, fp32 accumulation; ~2^-22 "
                                                           "relative per product)"
@@ -847,7 +864,7 @@ def main():
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
-        "kv_cache_fp16": kv16, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "long_context": long_ctx,
+        "kv_cache_fp16": kv16, "fp16_mode": fp16_mode, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "long_context": long_ctx,
     }
     if args.mode == "continuous":
         out["continuous"] = {k: head[k] for k in ("iterations_per_step", "polls_per_step", "chunks_per_stream_min_max")}

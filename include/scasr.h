@@ -92,6 +92,9 @@ typedef struct sc_dec_layer {
   const float *wqkv_pp, *wq_pp, *wo_pp, *wo2_pp; /* sc_pack_panel_weight of wqkv, wq, wo, wo2 (sc_dec_layer_self / _cross), or NULL */
   const void *w1_h, *w2_h;          /* fp16 copies of w1_p / w2_p or NULL (see sc_enc_layer) */
   const void *w1_s, *w2_s;          /* fp16 hi | lo split of w1_p / w2_p or NULL (see sc_enc_layer) */
+  const void *wqkv_pph, *wq_pph, *wo_pph, *wo2_pph; /* fp16 copies of wqkv_pp / wq_pp / wo_pp / wo2_pp (same fragment order)
+                                       or NULL: the layer kernels' projections with fp16 MFMA inputs, fp32 accumulation
+                                       (BASELINE configs[4], with sc_search.act_half / out_w_qh; needs kv_half) */
 } sc_dec_layer;
 
 /* Search-side buffers of one StreamBatch (S streams, beam W, pre-beam K). */
@@ -150,6 +153,13 @@ typedef struct sc_search {
    * adds the DISTINCT (position, slot) K|V rows it walked for a stream (plus its new rows) to stat_rows[0]
    * (sc_dec_self_attn) / stat_rows[1] (sc_dec_layer_self) - one atomic per (stream, layer), by head 0 */
   unsigned long long *stat_rows;
+  /* fp16 decoder mode (BASELINE configs[4]; opt-in, never the parity mode): out_w_qh = fp16 copy of out_w_q (the
+   * output layer with fp16 MFMA inputs) or NULL; act_half bit 0 (1): the layer kernels use the fp16 weight copies
+   * (*_pph) with fp16 MFMA inputs; bit 1 (2): the partial products between the decoder's kernels (ph1, ph2, ffn_part)
+   * hold fp16 elements (same element offsets); bit 2 (4): the output layer uses out_w_qh.  LayerNorm, softmax,
+   * log-softmax, CTC, scores: fp32. */
+  const void *out_w_qh;
+  int32_t act_half;
   int32_t kv_rows;   /* rows of the self-attention K|V pool per (stream, layer), <= 65536 */
   int32_t *kvflags;  /* [S] written by sc_kv_alloc: 1 = the stream's pool is exhausted (its step computes garbage: the
                         host fails the stream with SC_ERR_CAPACITY), 0 = fine */

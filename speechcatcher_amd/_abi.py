@@ -34,7 +34,7 @@ class DecLayer(C.Structure):
                                   "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2",
                                   "ln3_g", "ln3_b", "w1", "b1", "w2", "b2",
                                   "wo_p", "wq_p", "wo2_p", "w1_p", "w2_p", "wqkv_q", "wqkv_pp", "wq_pp", "wo_pp", "wo2_pp", "w1_h", "w2_h",
-                                  "w1_s", "w2_s")]
+                                  "w1_s", "w2_s", "wqkv_pph", "wq_pph", "wo_pph", "wo2_pph")]
 
 
 class Search(C.Structure):
@@ -49,7 +49,7 @@ class Search(C.Structure):
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
            ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32), ("stat_rows", vp),
-           ("kv_rows", C.c_int32), ("kvflags", vp)]
+           ("out_w_qh", vp), ("act_half", C.c_int32), ("kv_rows", C.c_int32), ("kvflags", vp)]
     )
 
 

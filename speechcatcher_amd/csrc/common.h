@@ -52,7 +52,7 @@ int sc_dec_layer_hpw(const sc_search &sb);
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,
                              float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st,
-                             int by_row = 0);
+                             int by_row = 0, int half_mode = 0);
 
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
 // DPP lane permutations (no LDS round trip, unlike the ds_bpermute behind __shfl)

@@ -42,6 +42,38 @@
 #define ANC(pp, s) (sb.anc + ((long)(pp) * sb.S + (s)) * sb.LCAP * sb.W)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dl_h4 __attribute__((ext_vector_type(4)));
+
+// fp16 decoder mode (WH; BASELINE configs[4], scasr.h: sc_dec_layer.wqkv_pph ...): the weight fragments are the fp16
+// copies (same fragment order, 8 bytes per lane and half k-block instead of 16), the A operands are rounded to fp16 on
+// their way from LDS, two v_mfma_f32_16x16x16_f16 cover the 8 k values a lane holds per 32-wide k block (fp32
+// accumulation).  The same 8 k-steps for NA independent accumulators, as dl_mfma8_il below.
+template <int NA>
+__device__ __forceinline__ void dl_mfma8_il_h(f32x4 (&acc)[NA], const float4 &a0, const float4 &a1, const dl_h4 (&b0)[NA],
+                                              const dl_h4 (&b1)[NA]) {
+  const dl_h4 h0{(_Float16)a0.x, (_Float16)a0.y, (_Float16)a0.z, (_Float16)a0.w};
+  const dl_h4 h1{(_Float16)a1.x, (_Float16)a1.y, (_Float16)a1.z, (_Float16)a1.w};
+#pragma unroll
+  for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(h0, b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(h1, b1[t], acc[t], 0, 0, 0);
+}
+
+// partial products between the decoder's kernels: fp32, or fp16 elements at the same element offsets (sc_search.act_half)
+__device__ __forceinline__ float4 dl_load_part(const float *base, long elem, bool half) {
+  if (half) {
+    const dl_h4 h = *reinterpret_cast<const dl_h4 *>(reinterpret_cast<const _Float16 *>(base) + elem);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  }
+  return *reinterpret_cast<const float4 *>(base + elem);
+}
+__device__ __forceinline__ void dl_store_part(float *base, long elem, const float4 &v, bool half) {
+  if (half)
+    *reinterpret_cast<dl_h4 *>(reinterpret_cast<_Float16 *>(base) + elem) =
+        dl_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  else
+    *reinterpret_cast<float4 *>(base + elem) = v;
+}
 
 __device__ __forceinline__ f32x4 dl_mfma8(f32x4 acc, const float4 &a0, const float4 &a1, const float4 &b0,
                                           const float4 &b1) {
@@ -115,8 +147,10 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #ifndef SC_LAYER_NTW
 #define SC_LAYER_NTW 4
 #endif
-template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1>
+template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1, bool WH = false>
 __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
+  typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
+  const bool acth = (p.sb.act_half & 2) != 0;                       // partial products in fp16
   constexpr int NTH = 256 * HPW;   // threads: HPW head groups of 4 waves
   constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
   constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // requested as soon as the x rows are in LDS and travels during the LayerNorm; the output projection's fragments
   // travel during the merge of the attention's partial states.
   constexpr bool EARLY = HPW > 1;
-  float4 pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
+  BF pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
   int slp[(PF && SELF) ? WM : 1];
   if (PF && SELF) {
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
-      const float4 *wq = reinterpret_cast<const float4 *>(p.wp) + ((long)tile * KI + wave * KPW) * 128 + lane;
+      const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + wave * KPW) * 128 + lane;
       pfb[t * 2] = wq[0];
       pfb[t * 2 + 1] = wq[64];
     }
@@ -191,13 +225,18 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       const int ofs = gt * 32;   // floats: 128 B per thread, 32 KB per head group and instruction
 #pragma unroll
       for (int wh = 0; wh < NW; ++wh) {
-        const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
-        if (ofs < NTQ * KI * 512) touch += base[ofs];
+        if (WH) {   // 2-byte elements: the same fragments are half as many bytes
+          const _Float16 *base = reinterpret_cast<const _Float16 *>(p.wp) + ((long)((wh * D + head * DK) / 16) * KI) * 512;
+          if (2 * ofs < NTQ * KI * 512) touch += (float)base[2 * ofs];
+        } else {
+          const float *base = p.wp + ((long)((wh * D + head * DK) / 16) * KI) * 512;   // NTQ tiles x KI k-blocks x 2 KB
+          if (ofs < NTQ * KI * 512) touch += base[ofs];
+        }
       }
     }
     // output projection: D/16 tiles, k-block (head*DK)/32, 2 KB each
     constexpr int TPW = D / 16 * 16;   // lines: 16 per tile
-    if (gt < TPW) touch += p.wop[((long)((gt >> 4) * KI + (head * DK) / 32) * 2) * 256 + (gt & 15) * 32];
+    if (!WH && gt < TPW) touch += p.wop[((long)((gt >> 4) * KI + (head * DK) / 32) * 2) * 256 + (gt & 15) * 32];
   }
 
   // ------------------------------------------------------------------ prologue: x rows, LayerNorm -> Xn
@@ -235,7 +274,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
           const long row = (long)s * W + i;
 #pragma unroll
           for (int z = 0; z < ZB; ++z)
-            pv[q][z] = *reinterpret_cast<const float4 *>(p.part + (long)min(z0 + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4);
+            pv[q][z] = dl_load_part(p.part, (long)min(z0 + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4, acth);
         }
         if (PF && z0 == 0) prefetch_w();
 #pragma unroll
@@ -332,16 +371,16 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto load_b = [&](int ki, float4 (&b0)[NT], float4 (&b1)[NT]) {
+    auto load_b = [&](int ki, BF (&b0)[NT], BF (&b1)[NT]) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
-        const float4 *wq = reinterpret_cast<const float4 *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
+        const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
         b0[t] = wq[0];
         b1[t] = wq[64];
       }
     };
-    float4 b0[NT], b1[NT];
+    BF b0[NT], b1[NT];
     if (PF || EARLY) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -356,9 +395,10 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       const int ki = wave * KPW + kq;
       const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
       const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
-      float4 n0[NT], n1[NT];
+      BF n0[NT], n1[NT];
       if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
-      dl_mfma8_il<NT>(acc, a0, a1, b0, b1);
+      if constexpr (WH) dl_mfma8_il_h<NT>(acc, a0, a1, b0, b1);
+      else dl_mfma8_il<NT>(acc, a0, a1, b0, b1);
       if (kq + 1 < KPW) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -410,11 +450,11 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // take tiles round-robin and leave one partial state each (+ one for the new token's own row, SELF)
   // PF: the output projection's B fragments travel while the attention runs
   constexpr int TWO = D / 16 / 4;
-  float4 ob[(PF || EARLY) ? TWO * 2 : 1];
+  BF ob[(PF || EARLY) ? TWO * 2 : 1];
   auto prefetch_o = [&]() {
 #pragma unroll
     for (int t = 0; t < TWO; ++t) {
-      const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32) * 128 + lane;
+      const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32) * 128 + lane;
       ob[2 * t] = wq[0];
       ob[2 * t + 1] = wq[64];
     }
@@ -496,14 +536,14 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     }
     const int r = lane & 15, kk = lane >> 4;
     static_assert(TW == TWO, "tiles per wave");
-    float4 b0[TW], b1[TW];
+    BF b0[TW], b1[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
       if (PF || EARLY) {
         b0[t] = ob[2 * t];
         b1[t] = ob[2 * t + 1];
       } else {
-        const float4 *wq = reinterpret_cast<const float4 *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
+        const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
         b0[t] = wq[0];
         b1[t] = wq[64];
       }
@@ -514,7 +554,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     f32x4 oacc[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dl_mfma8_il<TW>(oacc, a0, a1, b0, b1);
+    if constexpr (WH) dl_mfma8_il_h<TW>(oacc, a0, a1, b0, b1);
+    else dl_mfma8_il<TW>(oacc, a0, a1, b0, b1);
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         const float4 t = *reinterpret_cast<const float4 *>(smem + gg * GS + 16 * LDA + w * LDO + 4 * c4);
         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
       }
-      *reinterpret_cast<float4 *>(p.ph + (((long)s * W + w) * NPH + blockIdx.y) * D + 4 * c4) = o;
+      dl_store_part(p.ph, (((long)s * W + w) * NPH + blockIdx.y) * D + 4 * c4, o, acth);
     }
   }
   if (kvtouch == 123456.789f) p.ph[0] = kvtouch;   // never true: keeps the K|V warm-up loads
@@ -559,7 +600,7 @@ int sc_dec_layer_hpw(const sc_search &sb) {
   return hpw;
 }
 
-template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW>
+template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW, bool WH = false>
 static void launch_dec_layer_variant(const DecLayerArgs &p, int ns, hipStream_t st) {
   const sc_search &sb = p.sb;
   // one or two streams: pad grid.x to 8 so that all H workgroups of a stream land on ONE XCD (linear id x + 8*y) and
@@ -569,11 +610,11 @@ static void launch_dec_layer_variant(const DecLayerArgs &p, int ns, hipStream_t 
   const size_t lds = (size_t)dl_lds_floats(D, DK, sb.W, WM, SELF, HPW) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW, WH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW><<<grid, 256 * HPW, lds, st>>>(p);
+  dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW, WH><<<grid, 256 * HPW, lds, st>>>(p);
 }
 
 template <int D, int DK, bool SELF, bool FIRST, bool KVH>
@@ -584,6 +625,21 @@ static int launch_dec_layer_kvh(const DecLayerArgs &p, hipStream_t st) {
   bool deep = (sb.rowmap && 2 * sb.n_rows <= sb.S * sb.W) || sb.S * sb.H <= 256;
   if (const char *fd = sc_hook("SC_ATTN_DEEP")) deep = atoi(fd) != 0;   // tests: force either variant at any size
   const int hpw = sc_dec_layer_hpw(sb);
+  // fp16 decoder mode (sc_search.act_half; needs the fp16 K|V caches): the *_pph fragments are in p.wp / p.wop
+  if constexpr (KVH) {
+    if (sb.act_half & 1) {
+      if constexpr (D == 256 && DK == 32) {
+        if (hpw == 4) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 4, true>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
+      }
+      if (sb.W <= 5) launch_dec_layer_variant<D, DK, 5, SELF, 4, FIRST, KVH, 1, true>(p, ns, st);
+      else if (sb.W <= 10) {
+        if (deep) launch_dec_layer_variant<D, DK, 10, SELF, 8, FIRST, KVH, 1, true>(p, ns, st);
+        else launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 1, true>(p, ns, st);
+      } else launch_dec_layer_variant<D, DK, 16, SELF, 2, FIRST, KVH, 1, true>(p, ns, st);
+      SC_CHECK_LAUNCH();
+      return SC_OK;
+    }
+  }
   if constexpr (D == 256 && DK == 32) {
     if (hpw == 4) { launch_dec_layer_variant<D, DK, 10, SELF, 2, FIRST, KVH, 4>(p, ns, st); SC_CHECK_LAUNCH(); return SC_OK; }
   }
@@ -630,8 +686,11 @@ extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *x
   SC_CHECK_ARG(layer == 0 || (xin && xin != xout && ffn_part && n_ffn_part > 0), "x_in / partial sums missing");
   const sc_dec_layer &w = sb.layers[layer];
   SC_CHECK_ARG(w.wqkv_pp && w.wo_pp, "panel-packed Wqkv / Wo missing");
+  SC_CHECK_ARG(!sb.act_half || (sb.kv_half && w.wqkv_pph && w.wo_pph), "fp16 decoder mode needs fp16 K|V caches and the *_pph weights");
+  const bool wh = (sb.act_half & 1) != 0;
   DecLayerArgs p{sb, layer, xin, xout, ffn_part, n_ffn_part, (long)sb.S * sb.W * sb.d, (long)sb.d,
-                 layer > 0 ? sb.layers[layer - 1].b2 : nullptr, w.ln1_g, w.ln1_b, w.wqkv_pp, w.bqkv, w.wo_pp, sb.ph1};
+                 layer > 0 ? sb.layers[layer - 1].b2 : nullptr, w.ln1_g, w.ln1_b,
+                 wh ? (const float *)w.wqkv_pph : w.wqkv_pp, w.bqkv, wh ? (const float *)w.wo_pph : w.wo_pp, sb.ph1};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = layer == 0 ? launch_dec_layer_dims<true, true>(p, st) : launch_dec_layer_dims<true, false>(p, st);
@@ -651,8 +710,10 @@ extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *
   const sc_dec_layer &w = sb.layers[layer];
   SC_CHECK_ARG(w.wq_pp && w.wo2_pp, "panel-packed Wq / Wo2 missing");
   const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_self (same bucket, same form)
+  SC_CHECK_ARG(!sb.act_half || (sb.kv_half && w.wq_pph && w.wo2_pph), "fp16 decoder mode needs fp16 K|V caches and the *_pph weights");
+  const bool wh = (sb.act_half & 1) != 0;
   DecLayerArgs p{sb, layer, xin, xout, sb.ph1, nph, (long)sb.d, (long)nph * sb.d, w.bo, w.ln2_g, w.ln2_b,
-                 w.wq_pp, w.bq, w.wo2_pp, sb.ph2};
+                 wh ? (const float *)w.wq_pph : w.wq_pp, w.bq, wh ? (const float *)w.wo2_pph : w.wo2_pp, sb.ph2};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = launch_dec_layer_dims<false, false>(p, st);

@@ -286,10 +286,16 @@ struct RedProjArgs {
   const float *Wq, *bq;
   float *Q; int ldq;
   int by_row;   // partial sums indexed by row id (xrow) instead of by position m (sc_dec_layer_ffn)
+  int part_half;   // the partial sums hold fp16 elements (sc_search.act_half)
 };
 
-template <int D, int RG>
+typedef _Float16 rp_h4 __attribute__((ext_vector_type(4)));
+// WH: Wq holds the fp16 copy of the lane-packed weight (sc_search.out_w_qh): one v_mfma_f32_4x4x4_16B_f16 per 4 k values
+// instead of four v_mfma_f32_4x4x1_16B_f32 (fp32 accumulation; the LayerNorm rows are rounded to fp16 on their way
+// from LDS) - the output layer of the fp16 decoder mode
+template <int D, int RG, bool WH = false>
 __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
+  typedef typename std::conditional<WH, rp_h4, float4>::type BF;
   constexpr int R = 4 * RG, NT = D / 64, KS = 8 / NT, KW = D / KS, NL = KW / 4;
   constexpr int LD = D + 4, EL = D / 64, RPW = (R + 7) / 8;
   __shared__ __attribute__((aligned(16))) float PA[R * LD];
@@ -298,9 +304,9 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
   const int tile = wave % NT, ks = wave / NT, k0 = ks * KW;
   const int m0 = blockIdx.x * R, nb = blockIdx.y;
   // projection weights of this column block: in flight during the reduce + LayerNorm
-  float4 b[NL];
+  BF b[NL];
   {
-    const float4 *wp = reinterpret_cast<const float4 *>(p.Wq) + ((long)(nb * NT + tile) * (D / 4) + k0 / 4) * 64 + lane;
+    const BF *wp = reinterpret_cast<const BF *>(p.Wq) + ((long)(nb * NT + tile) * (D / 4) + k0 / 4) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < NL; ++q) b[q] = wp[q * 64];
   }
@@ -329,8 +335,10 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
 #pragma unroll
         for (int e = 0; e < EL; ++e)
 #pragma unroll
-          for (int q = 0; q < 16; ++q)
-            pv[e][q] = p.part[((long)min(z0 + q, p.npart - 1) * p.part_M + (p.by_row ? xrow[rr] : (long)m)) * D + lane + 64 * e];
+          for (int q = 0; q < 16; ++q) {
+            const long pe = ((long)min(z0 + q, p.npart - 1) * p.part_M + (p.by_row ? xrow[rr] : (long)m)) * D + lane + 64 * e;
+            pv[e][q] = p.part_half ? (float)reinterpret_cast<const _Float16 *>(p.part)[pe] : p.part[pe];
+          }
 #pragma unroll
         for (int e = 0; e < EL; ++e)
 #pragma unroll
@@ -372,14 +380,21 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
       float4 a[RG];
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg) a[rg] = *reinterpret_cast<const float4 *>(ap + 4 * rg * LD + 4 * q);
+      if constexpr (WH) {
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].x, b[q].x, acc[rg], 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg)
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x4f16(rp_h4{(_Float16)a[rg].x, (_Float16)a[rg].y, (_Float16)a[rg].z, (_Float16)a[rg].w},
+                                                       b[q], acc[rg], 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].y, b[q].y, acc[rg], 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].x, b[q].x, acc[rg], 0, 0, 0);
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].z, b[q].z, acc[rg], 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].y, b[q].y, acc[rg], 0, 0, 0);
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].w, b[q].w, acc[rg], 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].z, b[q].z, acc[rg], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rg].w, b[q].w, acc[rg], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -402,18 +417,18 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
   }
 }
 
-template <int D>
+template <int D, bool WH = false>
 static void launch_redproj(const RedProjArgs &p, int rg, int nblocks, hipStream_t st) {
-  if (rg == 1) reduce_ln_proj_kernel<D, 1><<<dim3(cdiv(p.M, 4), nblocks), 512, 0, st>>>(p);
-  else if (rg == 2) reduce_ln_proj_kernel<D, 2><<<dim3(cdiv(p.M, 8), nblocks), 512, 0, st>>>(p);
-  else reduce_ln_proj_kernel<D, 4><<<dim3(cdiv(p.M, 16), nblocks), 512, 0, st>>>(p);
+  if (rg == 1) reduce_ln_proj_kernel<D, 1, WH><<<dim3(cdiv(p.M, 4), nblocks), 512, 0, st>>>(p);
+  else if (rg == 2) reduce_ln_proj_kernel<D, 2, WH><<<dim3(cdiv(p.M, 8), nblocks), 512, 0, st>>>(p);
+  else reduce_ln_proj_kernel<D, 4, WH><<<dim3(cdiv(p.M, 16), nblocks), 512, 0, st>>>(p);
 }
 
 // internal (common.h): called by sc_ffn_ln_proj after the fused FFN kernel wrote its partial sums
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,
                              const int32_t *rows, int M, int D, const float *ln_g, const float *ln_b, float ln_eps,
                              float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st,
-                             int by_row) {
+                             int by_row, int half_mode) {
   SC_CHECK_ARG(sc_proj_ln_proj_supported(D) && N % D == 0 && N > 0, "projection width must be a multiple of D");
   SC_CHECK_ARG(Xin != Xout, "x_in and x_out must be different buffers");
   const int nblocks = N / D;
@@ -423,9 +438,14 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
     const int v = atoi(e);
     if (v == 4 || v == 8 || v == 16) rpp = v;
   }
-  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N, by_row};
+  // half_mode (fp16 decoder mode, sc_search.act_half): bit 0 = Wq holds fp16 elements, bit 1 = the partial sums do
+  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N, by_row, (half_mode & 2) ? 1 : 0};
   ProfScope prof = sc_prof_begin(st);
-  if (D == 256) launch_redproj<256>(p, rpp / 4, nblocks, st);
+  if (half_mode & 1) {
+    SC_CHECK_ARG(D == 256 || D == 128, "fp16 output layer: d must be 128 or 256");
+    if (D == 256) launch_redproj<256, true>(p, rpp / 4, nblocks, st);
+    else launch_redproj<128, true>(p, rpp / 4, nblocks, st);
+  } else if (D == 256) launch_redproj<256>(p, rpp / 4, nblocks, st);
   else if (D == 128) launch_redproj<128>(p, rpp / 4, nblocks, st);
   else launch_redproj<64>(p, rpp / 4, nblocks, st);
   sc_prof_end(prof, SC_PROF_PROJ_LN_PROJ, 2.0 * M * D * N,
@@ -442,7 +462,10 @@ extern "C" int sc_dec_output_logits(const sc_search *sbp, const float *xin, floa
   const sc_search &sb = *sbp;
   SC_CHECK_ARG(sb.out_w_q && sb.V % sb.d == 0, "needs the lane-packed output layer (V a multiple of d)");
   const int M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
+  const bool hm = (sb.act_half & 4) != 0 && sb.out_w_qh != nullptr;
+  SC_CHECK_ARG(!(sb.act_half & 4) || hm, "fp16 output layer needs out_w_qh");
   return sc_launch_reduce_ln_proj(ffn_part, n_ffn_part, sb.S * sb.W, sb.layers[sb.n_layers - 1].b2, xin, xout,
-                                  sb.rowmap, M, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, nullptr, sb.out_w_q,
-                                  sb.out_b, sb.logits, sb.V, (hipStream_t)stream, 1);
+                                  sb.rowmap, M, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, nullptr,
+                                  hm ? (const float *)sb.out_w_qh : sb.out_w_q, sb.out_b, sb.logits, sb.V,
+                                  (hipStream_t)stream, 1, (hm ? 1 : 0) | (sb.act_half & 2));
 }

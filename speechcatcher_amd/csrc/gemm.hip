@@ -878,6 +878,7 @@ struct FfnArgs {
   int part_rows;
   int w_form;   // 0: fp32 weights; 1: W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
                 // 2: W1p / W2p hold the fp16 hi | lo SPLIT of the fp32 weights (see WF below)
+  int act_half; // PRO: PH and part hold fp16 elements (same element offsets; sc_search.act_half)
 };
 
 // WF = 1 (WH): fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
@@ -992,16 +993,23 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.pbias) pb = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      auto ldp = [&](long elem) -> float4 {
+        if (p.act_half) {
+          const h16x4 h = *reinterpret_cast<const h16x4 *>(reinterpret_cast<const _Float16 *>(p.PH) + elem);
+          return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+        return *reinterpret_cast<const float4 *>(p.PH + elem);
+      };
       if (p.nph == 2) {   // four heads per workgroup upstream (decoder_layer.hip: HPW): two partial products per row
-        const float4 p0 = *reinterpret_cast<const float4 *>(p.PH + (row * 2) * D + 4 * c4);
-        const float4 p1 = *reinterpret_cast<const float4 *>(p.PH + (row * 2 + 1) * D + 4 * c4);
+        const float4 p0 = ldp((row * 2) * D + 4 * c4);
+        const float4 p1 = ldp((row * 2 + 1) * D + 4 * c4);
         y = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
       } else
       for (int z0 = 0; z0 < p.nph; z0 += 8) {
         float4 pv[8];
 #pragma unroll
         for (int z = 0; z < 8; ++z)
-          pv[z] = *reinterpret_cast<const float4 *>(p.PH + (row * p.nph + min(z0 + z, p.nph - 1)) * D + 4 * c4);
+          pv[z] = ldp((row * p.nph + min(z0 + z, p.nph - 1)) * D + 4 * c4);
 #pragma unroll
         for (int z = 0; z < 8; ++z)
           if (z0 + z < p.nph) {
@@ -1249,8 +1257,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
     const int e = threadIdx.x + q * 512;
     const int i = e / (D / 4), c4 = e % (D / 4);
     if (m0 + i < p.M) {
-      float *o = PRO ? p.part + ((long)grp * p.part_rows + rowid[i]) * D : dst + (long)i * D;
-      *reinterpret_cast<float4 *>(o + 4 * c4) = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
+      const float4 v = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * c4);
+      if (PRO && p.act_half) {
+        *reinterpret_cast<h16x4 *>(reinterpret_cast<_Float16 *>(p.part) + ((long)grp * p.part_rows + rowid[i]) * D + 4 * c4) =
+            h16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+      } else {
+        float *o = PRO ? p.part + ((long)grp * p.part_rows + rowid[i]) * D : dst + (long)i * D;
+        *reinterpret_cast<float4 *>(o + 4 * c4) = v;
+      }
     }
   }
   SC_STAMP(PRO ? 2 : 3, 3);
@@ -1802,7 +1816,7 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   const int ngrp = nch / best_cpw;
   const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_cross (decoder_layer.hip)
   FfnArgs p{nullptr, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F,
-            best_cpw, sb.ph2, nph, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf};
+            best_cpw, sb.ph2, nph, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf, (sb.act_half & 2) ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);

@@ -1235,18 +1235,35 @@ __global__ __launch_bounds__(256) void ctc_gather_state_kernel(sc_search sb) {
       r_b = ck[((long)(j - 1) * 2 + 1) * WK + e];
       begin = t0;
     }
+    // all inputs of the segment are requested before the recurrence starts (16 frames x {table column, blank column,
+    // r of the prefix}: independent of the recurrence - issued inside the loop they cost one L2 round trip per frame)
+    float xc[SC_CTC_CK], xb[SC_CTC_CK], pn[SC_CTC_CK], pb[SC_CTC_CK];
+#pragma unroll
+    for (int q = 0; q < SC_CTC_CK / 4; ++q) {
+      const int t4 = min(t0 + 4 * q, tct - 4);   // (t0 is a multiple of 16, tct of 4: aligned; frames >= T are not used)
+      const float4 c4 = *reinterpret_cast<const float4 *>(xcol + t4), b4 = *reinterpret_cast<const float4 *>(xblk + t4);
+      xc[4 * q] = c4.x; xc[4 * q + 1] = c4.y; xc[4 * q + 2] = c4.z; xc[4 * q + 3] = c4.w;
+      xb[4 * q] = b4.x; xb[4 * q + 1] = b4.y; xb[4 * q + 2] = b4.z; xb[4 * q + 3] = b4.w;
+    }
+#pragma unroll
+    for (int q = 0; q < SC_CTC_CK; ++q) {
+      const int tp = min(max(t0 + q - 1, 0), T - 1);
+      pn[q] = has ? rp[((long)tp * 2) * W + h] : SC_LOGZERO;
+      pb[q] = has ? rp[((long)tp * 2 + 1) * W + h] : 0.f;
+    }
     float cum = 0.f;   // !has: running blank log-prob sum of the initial (state None) hypothesis, in the scan's order
     if (!has)
       for (int t = 0; t < begin && t < t1; ++t) cum += xblk[t];
-    for (int t = begin; t < t1; ++t) {
-      const float pn = has ? rp[((long)(t - 1) * 2) * W + h] : SC_LOGZERO;
-      const float pb = has ? rp[((long)(t - 1) * 2 + 1) * W + h] : cum;
-      float phi;
-      const float xb = xblk[t];
-      ctc_frame(r_n, r_b, pn, pb, same, xcol[t], xb, phi);
-      dst[((long)t * 2) * W + i] = r_n;
-      dst[((long)t * 2 + 1) * W + i] = r_b;
-      if (!has) cum += xb;
+#pragma unroll
+    for (int q = 0; q < SC_CTC_CK; ++q) {
+      const int t = t0 + q;
+      if (t >= begin && t < t1) {
+        float phi;
+        ctc_frame(r_n, r_b, pn[q], has ? pb[q] : cum, same, xc[q], xb[q], phi);
+        dst[((long)t * 2) * W + i] = r_n;
+        dst[((long)t * 2 + 1) * W + i] = r_b;
+        if (!has) cum += xb[q];
+      }
     }
   }
 }

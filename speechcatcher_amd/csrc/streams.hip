@@ -1588,7 +1588,7 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
     DEC(ln1_g) DEC(ln1_b) DEC(wqkv) DEC(bqkv) DEC(wo) DEC(bo) DEC(ln2_g) DEC(ln2_b) DEC(wq) DEC(bq) DEC(wo2) DEC(bo2)
     DEC(ln3_g) DEC(ln3_b) DEC(w1) DEC(b1) DEC(w2) DEC(b2) DEC(wo_p) DEC(wq_p) DEC(wo2_p) DEC(w1_p) DEC(w2_p) DEC(wqkv_q)
     DEC_OPT(wqkv_pp) DEC_OPT(wq_pp) DEC_OPT(wo_pp) DEC_OPT(wo2_pp) DEC_OPT(w1_h) DEC_OPT(w2_h)
-    DEC_OPT(w1_s) DEC_OPT(w2_s)
+    DEC_OPT(w1_s) DEC_OPT(w2_s) DEC_OPT(wqkv_pph) DEC_OPT(wq_pph) DEC_OPT(wo_pph) DEC_OPT(wo2_pph)
 #undef DEC
 #undef DEC_OPT
     e->wkv[i] = e->f(p + "wkv");
@@ -1794,6 +1794,18 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   sb.n_rows = S * W;
   sb.embed = e->f("embed"); sb.pe = e->f("pe"); sb.dec_norm_g = e->f("dec_norm_g"); sb.dec_norm_b = e->f("dec_norm_b");
   sb.out_w = e->f("out_w"); sb.out_b = e->f("out_b"); sb.out_w_q = e->f("out_w_q", false);
+  // fp16 decoder mode (BASELINE configs[4]): the engine carries the fp16 copies AND the K|V caches are fp16
+  sb.out_w_qh = nullptr;
+  sb.act_half = 0;
+  if (sb.kv_half && e->f("out_w_qh", false) && !e->dec.empty() && e->dec[0].wqkv_pph && e->dec[0].wq_pph && e->dec[0].wo_pph &&
+      e->dec[0].wo2_pph && sb.ph1) {
+    sb.out_w_qh = e->f("out_w_qh", false);
+    // fp16 weight fragments in the layer kernels + fp16 partial products.  NOT the output layer (bit 4): its result goes
+    // straight into the scores - measured on 256 streams x 7 chunks against the fp32 engine (tools/fp16_mode_stats.py,
+    // profiles/r04_fp16_mode_stats.txt): bits 1 | 2 move the best hypothesis of 1 stream, the fp16 output layer alone of 18
+    sb.act_half = 1 | 2;
+    if (const char *ah = sc_hook("SC_ACT_HALF")) sb.act_half = atoi(ah) & 7;   // tools/fp16_mode_stats.py: any subset
+  }
   sb.layers = e->dec.data();
   (void)sc_set_stream_workspace(b->stream, b->ws, (size_t)128 << 20);
   b->es = b->stream;

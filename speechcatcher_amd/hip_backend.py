@@ -3,6 +3,7 @@ C ABI of libscasr.so (include/scasr.h).  torch is used only as the owner of
 device memory and of the HIP stream; every pointer handed to the library is a
 raw device address."""
 import ctypes as C
+import os
 
 import torch
 
@@ -246,6 +247,12 @@ class HipBackend:
         s.out_w_q = w.out_w_q.data_ptr() if getattr(w, "out_w_q", None) is not None else None
         s.kv_half = 1 if sb.ckv.dtype == torch.float16 else 0
         s.kv_rows, s.kvflags = int(sb.kv_rows), sb.kvflags.data_ptr()
+        # fp16 decoder mode (weights.PackedWeights(dec_dtype="float16")): needs the fp16 K|V caches
+        if s.kv_half and getattr(w, "out_w_qh", None) is not None and all("wqkv_pph" in lw for lw in w.dec):
+            s.out_w_qh, s.act_half = w.out_w_qh.data_ptr(), int(os.environ.get("SC_ACT_HALF", "3")) & 7   # layer projections | partial products (| 4: output layer, see csrc/streams.hip)
+        else:
+            for i in range(len(w.dec)):
+                layers[i].wqkv_pph = layers[i].wq_pph = layers[i].wo_pph = layers[i].wo2_pph = None
         if getattr(sb, "ctcxT", None) is not None:  # column-major CTC table copy
             s.ctcxT, s.tct = sb.ctcxT.data_ptr(), sb.ctcxT.shape[-1]
         if getattr(sb, "ph1", None) is not None:   # head-parallel decoder layers (include/scasr.h)

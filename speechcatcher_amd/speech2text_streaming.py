@@ -263,7 +263,8 @@ class Speech2TextStreaming:
             self.mean, self.std = load_stats(self.model_dir)
             self.token_list = load_token_list(self.model_dir)
         self.weights = PackedWeights(sd, self.cfg, self.device, self.mean, self.std,
-                                     ffn_dtype=dtype, proj_dtype=dtype)
+                                     ffn_dtype=dtype, proj_dtype=dtype,
+                                     dec_dtype="float16" if half else "float32")
         self.model = self.weights
         # the decoder itself: the C++ engine behind the stream-level C ABI (csrc/streams.hip); raises without
         # the built library or without a GPU - there is no fallback

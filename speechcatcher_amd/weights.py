@@ -90,7 +90,8 @@ def rowtile_proj_supported(d: int, N: int) -> bool:
 
 class PackedWeights:
     def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device,
-                 mean=None, std=None, ffn_dtype: str = "float32", proj_dtype: str = "float32"):
+                 mean=None, std=None, ffn_dtype: str = "float32", proj_dtype: str = "float32",
+                 dec_dtype: str = "float32"):
         """``ffn_dtype="float16"``: additional fp16 copies of the fragment-packed feed-forward weights (w1_h / w2_h);
         the fused FFN kernels then run fp16 MFMA inputs with fp32 accumulation (BASELINE configs[4]; never the
         default - the reference computes in fp32).  ``proj_dtype="float16"``: the same for the attention projections
@@ -98,9 +99,16 @@ class PackedWeights:
         ``"split16"`` (either): fp16 hi | lo splits of the fp32 weights instead (``split_panel_weight``: w1_s / w2_s,
         wqkv_s / wo_s) - the kernels split the activations the same way and evaluate every product sum with three fp16
         MFMAs: fp32-grade results (all reference fixtures at the fp32 tolerance) at a fraction of the f32 matrix-pipe
-        time.  Opt-in as well: the default computes on the f32 MFMA path."""
+        time.  Opt-in as well: the default computes on the f32 MFMA path.
+        ``dec_dtype="float16"`` (round 4, the decoder side of BASELINE configs[4]): fp16 copies of the decoder's attention
+        projections (wqkv_pph / wq_pph / wo_pph / wo2_pph: sc_dec_layer_self / _cross) - fp16 MFMA inputs there - and the
+        partial products between the decoder's kernels are stored in fp16 (sc_search.act_half).  The fp16 copy of the
+        output layer (out_w_qh) is carried too but NOT used by the engines: logits feed the scores directly and fp16 inputs
+        there moved the best hypothesis of 18 of 256 test streams (the rest of the fp16 decoder mode: 1).  LayerNorm,
+        softmax, log-softmax, the output layer, the CTC scan and all scores stay fp32."""
         assert ffn_dtype in ("float32", "float16", "split16") and proj_dtype in ("float32", "float16", "split16")
-        self.ffn_dtype, self.proj_dtype = ffn_dtype, proj_dtype
+        assert dec_dtype in ("float32", "float16")
+        self.ffn_dtype, self.proj_dtype, self.dec_dtype = ffn_dtype, proj_dtype, dec_dtype
         self.cfg = cfg
         self.device = torch.device(device)
         d, F2 = cfg.d_model, cfg.conv_freq2
@@ -181,6 +189,9 @@ class PackedWeights:
                 lw["wq_pp"] = pack_panel_weight(lw["wq"])
                 lw["wo_pp"] = pack_panel_weight(lw["wo"])
                 lw["wo2_pp"] = pack_panel_weight(lw["wo2"])
+                if dec_dtype == "float16":   # same fragment order, 2-byte elements: fp16 MFMA inputs in the layer kernels
+                    for n in ("wqkv", "wq", "wo", "wo2"):
+                        lw[n + "_pph"] = lw[n + "_pp"].to(torch.float16).contiguous()
         for lw in self.enc:              # encoder attention projections for the row-tile kernel (sc_rowtile_proj)
             for n in ("wqkv", "wo"):
                 lw[n + "_p"] = pack_panel_weight(lw[n]) if rowtile_proj_supported(d, d) else lw[n]
@@ -202,13 +213,15 @@ class PackedWeights:
         # output layer in lane order (projected by the last layer's reduce kernel) when V is a multiple of d
         self.out_w_q = (pack_lane_weight(self.out_w) if d in PANEL_DIMS and cfg.vocab_size % d == 0
                         and ffn_fused_supported(d, cfg.ffn_dim) else None)
+        self.out_w_qh = (self.out_w_q.to(torch.float16).contiguous()
+                         if dec_dtype == "float16" and self.out_w_q is not None and d in (128, 256) else None)
         self.ctc_w = dev(g("ctc.ctc_lo.weight"))
         self.ctc_b = dev(g("ctc.ctc_lo.bias"))
 
     # ---- the flat, named view the stream-level C ABI takes (include/scasr.h: sc_engine_create / sc_engine_load)
     _TOP = ("window", "mel_fb", "twiddle", "pe", "mean64", "std64", "conv1_w", "conv1_b", "conv2_w", "conv2_b",
             "sub_out_w", "sub_out_b", "enc_norm_g", "enc_norm_b", "embed", "dec_norm_g", "dec_norm_b", "out_w", "out_b",
-            "out_w_q", "ctc_w", "ctc_b")
+            "out_w_q", "out_w_qh", "ctc_w", "ctc_b")
 
     def named_tensors(self):
         """[(name, tensor)]: "window", ..., "enc.{i}.{field}", "dec.{i}.{field}" (fields = the dict keys above)."""

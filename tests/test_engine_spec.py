@@ -19,7 +19,7 @@ CFGS = {"TINY": TINY, "XL": XL, "L_LIKE": L_LIKE, "M_DEFAULTS": M_DEFAULTS}
 
 
 def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", ffn_dtype="float32",
-               proj_dtype="float32", **kw):
+               proj_dtype="float32", dec_dtype="float32", **kw):
     """backend: None = the torch spec backend (CPU), a HipBackend = the Python engine over the HIP kernels,
     "native" = the C++ engine behind the stream-level C ABI (speechcatcher_amd.native)."""
     from oracle.kernel_spec import SpecBackend
@@ -29,9 +29,10 @@ def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, devi
     sc = SearchConfig(beam_size=beam, use_bbd=bbd)
     if isinstance(backend, str) and backend == "native":
         from speechcatcher_amd.native import NativeStreamBatch
-        return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std, ffn_dtype=ffn_dtype, proj_dtype=proj_dtype),
+        return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std, ffn_dtype=ffn_dtype, proj_dtype=proj_dtype,
+                                               dec_dtype=dec_dtype),
                                  n_streams, sc, **kw)
-    w = PackedWeights(sd, cfg, device, mean, std, ffn_dtype=ffn_dtype, proj_dtype=proj_dtype)
+    w = PackedWeights(sd, cfg, device, mean, std, ffn_dtype=ffn_dtype, proj_dtype=proj_dtype, dec_dtype=dec_dtype)
     return StreamBatch(w, backend or SpecBackend(), n_streams, sc, **kw)
 
 

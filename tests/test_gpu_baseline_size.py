@@ -206,6 +206,7 @@ def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     out = {}
     for mode in ("float32", "float16", "split16"):
         sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", ffn_dtype=mode, proj_dtype=mode,
+                        dec_dtype="float16" if mode == "float16" else "float32",      # (the whole fp16 mode, decoder included)
                         kv_dtype="float32" if mode == "split16" else mode, **kw)
         _feed(sb, audio, n)
         out[mode] = sb.hypotheses_arrays(list(range(S)))

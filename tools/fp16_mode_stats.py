@@ -10,12 +10,16 @@ S, n, beam = 256, 7, 10
 audio = np.stack([synth.synth_audio(900 + s, CHUNK * n) for s in range(S)])
 kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
 out = {}
-MODES = sys.argv[1:] or ["kv16", "ffn16", "proj16", "float16", "split16"]
+# decN: fp16 K|V caches + the fp16 decoder mode with sc_search.act_half = N (1 layer-kernel projections, 2 partial products
+# between the decoder's kernels, 4 output layer; round 4); float16 = everything
+MODES = sys.argv[1:] or ["kv16", "ffn16", "proj16", "dec1", "dec2", "dec4", "dec3", "dec7", "float16", "split16"]
 for mode in ["float32"] + MODES:
+    os.environ["SC_ACT_HALF"] = mode[3:] if mode.startswith("dec") else "7"
     sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native",
                     ffn_dtype="float16" if mode in ("ffn16", "float16") else "split16" if mode == "split16" else "float32",
                     proj_dtype="float16" if mode in ("proj16", "float16") else "split16" if mode == "split16" else "float32",
-                    kv_dtype="float16" if mode in ("kv16", "float16") else "float32", **kw)
+                    dec_dtype="float16" if mode.startswith("dec") or mode == "float16" else "float32",
+                    kv_dtype="float16" if mode in ("kv16", "float16") or mode.startswith("dec") else "float32", **kw)
     ids = np.arange(S, dtype=np.int32)
     for k in range(n):
         sb.push_block(ids, np.ascontiguousarray(audio[:, k * CHUNK:(k + 1) * CHUNK]))
