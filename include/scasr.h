@@ -321,9 +321,10 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_FUSED_MAX_ROWS 960
 /* ... with one head per workgroup; from SC_HPW_MIN_ROWS rows on with FOUR heads per workgroup (1024 threads: the
  * prologue reduce + LayerNorm once per four heads, H/4 partial products per row).  Measured on the default bench
- * (tools/ab_hpw.sh, SC_HPW_MIN = never / 0 / 160 / 320 / 640): 2967 / 3109 / 3074 / 3024 / 3094 audio-s/s - four heads
- * everywhere but the few-streams regime (<= 8 streams at beam 10), which keeps the prefetching one-head variant */
-#define SC_HPW_MIN_ROWS 96
+ * (continuous, tools/ab_hpw.sh, SC_HPW_MIN = never / 0 / 160 / 320 / 640 / 800 / 960): 2967 / 3109 / 3074 / 3024 / 3094 /
+ * 3055 / 3035 audio-s/s; strict lock-step, where the medium buckets count (tools/ab_hpw_strict.sh, 96 / 320 / 480 / 640 /
+ * 960 / never): 2038 / 2137 / 2159 / 2126 / 2195 / 2151 - four heads from half of a 128-stream batch on */
+#define SC_HPW_MIN_ROWS 640
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);

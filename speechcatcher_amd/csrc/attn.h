@@ -209,25 +209,26 @@ __host__ __device__ static inline int mattn_partial_floats(int DK, int np) { ret
 // c0 + p: duplicates among its <= WM rows are found by comparison in registers, a wave scan + the wave totals give
 // every position its place in the list.  rw [128 * W] and wtot [8] are LDS of the group; contains __syncthreads()
 // (all threads of the workgroup must call it the same number of times).  Returns the number of entries.
-template <int WM>
+// PRE: the thread's ancestor rows were loaded earlier (`pre`, a register array: it is taken by reference and selected at
+// compile time - a run-time pointer to it would force the array into scratch memory, +5 us per launch measured).
+template <int WM, bool PRE = false>
 __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *anc, int c0, int Lc, int W, int nh,
-                                                int gt, int lane, int wave, const int *preloaded = nullptr) {
+                                                int gt, int lane, int wave, const int (&pre)[WM]) {
   constexpr int PCH = 128;
   for (int e = gt; e < PCH * W; e += 256) rw[e] = 0;
   const int pp = c0 + gt;
   const bool live = gt < PCH && pp < Lc;
   int r[WM];
 #pragma unroll
-  for (int h = 0; h < WM; ++h) r[h] = preloaded ? preloaded[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
+  for (int h = 0; h < WM; ++h) r[h] = PRE ? pre[h] : anc[(long)(live ? pp : 0) * W + min(h, nh - 1)];
   unsigned first = 0;   // hypotheses that are the first to name their row
+  int rep[WM];          // ... and for every hypothesis the first one with the same row
 #pragma unroll
   for (int h = 0; h < WM; ++h) {
-    if (h < nh) {
-      bool f = true;
+    rep[h] = h;
 #pragma unroll
-      for (int h2 = 0; h2 < h; ++h2) f = f && r[h2] != r[h];
-      if (f) first |= 1u << h;
-    }
+    for (int h2 = h - 1; h2 >= 0; --h2) rep[h] = (r[h2] == r[h]) ? h2 : rep[h];
+    if (h < nh && rep[h] == h) first |= 1u << h;
   }
   const int cnt = live ? __popc(first) : 0;
   int incl = cnt;
@@ -244,11 +245,7 @@ __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *a
 #pragma unroll
     for (int h = 0; h < WM; ++h) {
       if (h < nh) {
-        int rep = h;   // the first hypothesis with the same row
-#pragma unroll
-        for (int h2 = WM - 1; h2 >= 0; --h2)
-          if (h2 < h && r[h2] == r[h]) rep = h2;
-        const int rank = __popc(first & ((1u << rep) - 1u));
+        const int rank = __popc(first & ((1u << rep[h]) - 1u));
         atomicOr(&rw[base + rank], (r[h] & 0xFFFF) | (1 << (16 + h)));
       }
     }

@@ -138,7 +138,7 @@ __host__ __device__ static inline int dl_group_floats(int D, int DK, int W, int 
 }
 // HPW head groups + LayerNorm gamma | beta + (HPW > 1) the LayerNorm tile shared by the head groups
 __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
-  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + (hpw > 1 ? 16 * (D + 4) : 0);
+  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + 16 /*pool rows of the new tokens*/ + (hpw > 1 ? 16 * (D + 4) : 0);
 }
 
 // key tiles per wave in flight in the attention walk of the few-streams variant (UNR = 8).  Measured in round 3 with 8
@@ -177,13 +177,15 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   float *kvn = qs + 16 * DK;                                 // SELF: [WM][2*DK] k|v of the new token
   float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
   float *gb = smem + HPW * GS;                               // [2][D] LayerNorm gamma | beta (shared)
-  float *Xsh = HPW > 1 ? gb + 2 * D : region;                // [16][D+4] LayerNorm tile: shared by the head groups
+  int *ancs = reinterpret_cast<int *>(gb + 2 * D);           // [16] SELF: pool rows of the new tokens (sc_kv_alloc)
+  float *Xsh = HPW > 1 ? gb + 2 * D + 16 : region;           // [16][D+4] LayerNorm tile: shared by the head groups
 
   // ------------------------------------------------------------------ L2 warm-up of this head's weight slices
   // One dword per 128-B line of the projection fragments and of the output-projection fragments, issued before
   // anything else: when few streams are active the weights come from the Infinity Cache / HBM (0.4-0.9 us per
   // dependent miss); the loads that feed the MFMAs later then hit L2.  The values only keep the loads alive.
   SC_STAMP(SELF ? 0 : 1, 0);
+  if (SELF && tid < 16) ancs[tid] = ANC(cur, s)[(long)(L - 1) * W + min(tid, nh - 1)];   // (read behind the prologue's barriers)
   // LayerNorm parameters: issued first, parked in LDS once the partial sums (issued later, returned later) are in
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < D / 2) gbv = *reinterpret_cast<const float4 *>((tid < D / 4 ? p.ln_g : p.ln_b) + 4 * (tid % (D / 4)));
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   constexpr bool EARLY = HPW > 1;
   BF pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
-  int slp[(PF && SELF) ? WM : 1];
+  int slp[WM] = {};
   if (PF && SELF) {
     const int *anc0 = ANC(cur, s);
     const bool live0 = gt < PCH && gt < L - 1;
@@ -417,7 +419,6 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 3);
   const long skv0 = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;   // element offset (fp32 or fp16 pool)
-  const int *ancn = ANC(cur, s) + (long)(L - 1) * W;   // pool rows of the new tokens (sc_kv_alloc)
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       } else if (SELF) {
         kvn[w * 2 * DK + (which - 1) * DK + c] = v;
         // append this token's K|V row into its pool row; later steps read it from the cache
-        if (w < nh) kv_store1<KVH>(sb.skv, skv0 + (long)ancn[w] * 2 * D + (which - 1) * D + c, v);
+        if (w < nh) kv_store1<KVH>(sb.skv, skv0 + (long)ancs[w] * 2 * D + (which - 1) * D + c, v);
       }
     }
   }
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
-      const int U = mattn_build_rows<WM>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave,
-                                         (PF && SELF && c0 == 0) ? slp : nullptr);   // (attn.h)
+      const int U = (PF && ch == 0) ? mattn_build_rows<WM, true>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp)
+                                    : mattn_build_rows<WM, false>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp);   // (attn.h)
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis

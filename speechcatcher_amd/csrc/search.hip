@@ -113,10 +113,17 @@ __global__ __launch_bounds__(256) void kv_alloc_kernel(sc_search sb) {
   for (int w = tid; w < nwords; w += 256) bm[w] = 0u;
   __syncthreads();
   const int n = (L - 1) * nh;
-  for (int e = tid; e < n; e += 256) {
-    const int p = e / nh, h = e % nh;
-    const int r = anc[(long)p * W + h];
-    atomicOr(&bm[(r >> 5) & (SC_KV_MAX_ROWS / 32 - 1)], 1u << (r & 31));
+  // (8 loads per thread in flight: one round trip per 2048 table entries instead of one per 256)
+  for (int e0 = tid; e0 < n; e0 += 256 * 8) {
+    int r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = min(e0 + 256 * u, n - 1);
+      r[u] = anc[(long)(e / nh) * W + e % nh];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < n) atomicOr(&bm[(r[u] >> 5) & (SC_KV_MAX_ROWS / 32 - 1)], 1u << (r[u] & 31));
   }
   __syncthreads();
   if (tid >= 64) return;
@@ -248,7 +255,8 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
-      const int U = mattn_build_rows<WM>(rows, wtot, anc, c0, Lc, W, nh, tid, lane, wave);   // (attn.h)
+      const int nopre[WM] = {};
+      const int U = mattn_build_rows<WM>(rows, wtot, anc, c0, Lc, W, nh, tid, lane, wave, nopre);   // (attn.h)
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, d, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis

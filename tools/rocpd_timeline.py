@@ -32,8 +32,8 @@ def main():
     # a decode step starts with dec_embed (six-launch layers) or with the FIRST variant of the head-parallel
     # self-attention layer kernel (last template argument true)
     import re
-    # mangled: dec_layer_attn_kernel<D, DK, WM, SELF = true, UNR, FIRST = true, KVH[, HPW]>
-    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?EEv")
+    # mangled: dec_layer_attn_kernel<D, DK, WM, SELF = true, UNR, FIRST = true, KVH[, HPW[, WH]]>
+    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?(ELb[01])?EEv")
     starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0] or first.search(r[0])]
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
     seg = rows[a:b]
