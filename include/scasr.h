@@ -107,9 +107,10 @@ typedef struct sc_search {
   const float *ctcx;   /* [S][TCAP][V]  CTC posterior table (quirk A1 rows) */
   const float *ckv;    /* [S][n_layers][TCAP][2d] cross-attention K|V */
   float *skv;          /* [S][n_layers][kv_rows][2d] self-attention K|V rows of a stream: a POOL (round 4) - a row holds
-                          the K|V of one (position, hypothesis) token; sc_kv_alloc hands every live hypothesis the row
-                          of its newest token at the start of a decode step (rows no live hypothesis descends from
-                          are free again), `anc` is the index.  Hypotheses of a beam share almost all of their
+                          the K|V of one (position, hypothesis) token; sc_beam_prune hands every NEW hypothesis the row
+                          of its newest token (the lowest rows no new hypothesis descends from: rows of pruned
+                          hypotheses are free again), `anc` is the index.  The reference keeps a per-hypothesis output
+                          cache instead and copies it when hypotheses fork (transformer_decoder.py:210-249).  Hypotheses of a beam share almost all of their
                           history (1.2 distinct rows per position at beam 10), so kv_rows ~ 1.5 x LCAP instead of the
                           W x LCAP of one slot per (position, hypothesis) */
   int32_t *yseq, *xpos; /* [2][S][W][LCAP] */
@@ -161,8 +162,8 @@ typedef struct sc_search {
   const void *out_w_qh;
   int32_t act_half;
   int32_t kv_rows;   /* rows of the self-attention K|V pool per (stream, layer), <= 65536 */
-  int32_t *kvflags;  /* [S] written by sc_kv_alloc: 1 = the stream's pool is exhausted (its step computes garbage: the
-                        host fails the stream with SC_ERR_CAPACITY), 0 = fine */
+  int32_t *kvflags;  /* [S] written by sc_beam_prune: 1 = the stream's pool is exhausted (its next step would compute
+                        garbage: the host fails the stream with SC_ERR_CAPACITY), 0 = fine */
 } sc_search;
 
 const char *sc_last_error(void);
@@ -388,13 +389,6 @@ int sc_encoder_layers(const sc_enc_layer *layers /*HOST*/, int n_layers, float *
 
 /* CTCPrefixScoreTH.extend_state (ctc_prefix_score_full.py:349-368) */
 int sc_ctc_extend_state(const sc_search *sb /*HOST*/, void *stream);
-/* Self-attention K|V pool, first launch of a decode step: every live hypothesis h of an active stream gets the pool
- * row for its newest token (position L-1) - anc[cur][s][L-1][h] - out of the rows that no live hypothesis descends
- * from (mark over the ancestor table, lowest free rows first).  The reference keeps a per-hypothesis output cache
- * instead and deep-copies it when hypotheses fork (transformer_decoder.py:210-249, hypothesis.py: states); the pool +
- * ancestor table is the same information without the copies.  Idempotent: a step that is re-run after a rollback
- * (beam_search.py:827-836) allocates again from the state it is given. */
-int sc_kv_alloc(const sc_search *sb, void *stream);
 /* embed*sqrt(d)+PE of the newest token (transformer_decoder.py:231) */
 int sc_dec_embed(const sc_search *sb, void *stream);
 /* kv_half: cross-attention K|V rows of all layers from an fp32 staging buffer [n_layers][m][d2] (the output of

@@ -257,25 +257,9 @@ class SpecBackend:
             tok = sb.yseq[cur, s, :nh, L - 1].to(torch.long)
             sb.dx[s * sb.W:s * sb.W + nh] = w.embed[tok] * sq + w.pe[L - 1]
 
-    def kv_alloc(self, sb):
-        """sc_kv_alloc: pool rows for the K|V of the newest token (position L-1) of every live hypothesis - the lowest
-        rows of the stream's pool that no live hypothesis descends from (ancestor table, positions < L-1), in
-        hypothesis order; kvflags[s] = 1 when the pool is exhausted (rows clamp to the last one)."""
-        ctrl = sb.ctrl.cpu().numpy()
-        NR = int(sb.kv_rows)
-        for s in range(sb.S):
-            act, cur, fin, T, L, nh, has, _ = [int(v) for v in ctrl[s]]
-            if not act or nh <= 0:
-                continue
-            used = set(sb.anc[cur, s, :L - 1, :nh].reshape(-1).tolist()) if L > 1 else set()
-            free = [r for r in range(NR) if r not in used][:nh]
-            sb.kvflags[s] = 1 if len(free) < nh else 0
-            free += [NR - 1] * (nh - len(free))
-            sb.anc[cur, s, L - 1, :nh] = torch.tensor(free, dtype=torch.int32)
-
     def dec_self_attn(self, sb, li):
         """decoder_layer.py:85-101 with a true K/V cache: the new K/V row goes
-        into the pool row kv_alloc gave the hypothesis (anc[L-1][h]); older rows
+        into the pool row beam_prune gave the hypothesis (anc[L-1][h]); older rows
         are found through the ancestor table.  (A14: identical to re-projecting
         the output cache.)"""
         cfg = sb.cfg
@@ -707,6 +691,15 @@ class SpecBackend:
                     if tok in sb.yseq[o, s, i, 1:L].tolist():
                         rep = True
             flags[s] = (1 if any_eos else 0) | (2 if best_eos else 0) | (4 if all_eos else 0) | (8 if rep else 0)
+            # K|V pool rows of the new hypotheses' newest tokens (position L): the lowest rows none of them descends from
+            nout = len(cands)
+            if L + 1 <= sb.LCAP:
+                NR = int(sb.kv_rows)
+                used = set(sb.anc[o, s, :L, :nout].reshape(-1).tolist())
+                free = [r for r in range(NR) if r not in used][:nout]
+                sb.kvflags[s] = 1 if len(free) < nout else 0
+                free += [NR - 1] * (nout - len(free))
+                sb.anc[o, s, L, :nout] = torch.tensor(free, dtype=torch.int32)
         sb.flags.copy_(flags)
 
     def ctc_gather_state(self, sb):
@@ -730,7 +723,6 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
-        self.kv_alloc(sb)
         if getattr(sb, "ph1", None) is not None and self.fused_layers:
             # head-parallel layer kernels, 3 ops per layer (sc_decode_step takes this path for the same models)
             xa, xb, npart = sb.dx, sb.dxn, 0

@@ -136,7 +136,6 @@ _SIGS = {
     "sc_relpos_attention_masked": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "sc_ctc_extend_state": (C.c_int, [vp, vp]),
     "sc_dec_embed": (C.c_int, [vp, vp]),
-    "sc_kv_alloc": (C.c_int, [vp, vp]),
     "sc_kv_rows_to_half": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "sc_dec_self_attn": (C.c_int, [vp, C.c_int, vp]),
     "sc_dec_cross_attn": (C.c_int, [vp, C.c_int, vp]),

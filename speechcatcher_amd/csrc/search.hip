@@ -95,72 +95,10 @@ extern "C" int sc_kv_rows_to_half(const float *stage, const int32_t *rows, int m
 }
 
 // ---------------------------------------------------------------------------
-// Self-attention K|V pool: rows for the newest tokens of the live hypotheses (scasr.h: sc_kv_alloc).  One workgroup
-// per stream: mark the rows the live hypotheses descend from (ancestor table, positions < L-1) in an LDS bit map,
-// then wave 0 hands the lowest unmarked rows to hypotheses 0 .. nh-1 in order.  No allocator state survives the
-// launch - the ancestor table of the live side IS the state - so rollbacks and re-runs need no undo.
+// Self-attention K|V pool (scasr.h: sc_search.skv / anc): rows are handed out by beam_prune_kernel below - the rows of the
+// new hypotheses' newest tokens are chosen when the hypotheses are made - so a decode step starts with its rows in
+// place and no launch of its own.
 #define SC_KV_MAX_ROWS 65536
-__global__ __launch_bounds__(256) void kv_alloc_kernel(sc_search sb) {
-  __shared__ unsigned bm[SC_KV_MAX_ROWS / 32];
-  const int s = sb.rowmap ? sb.rowmap[blockIdx.x * sb.W] / sb.W : blockIdx.x;
-  if (!CTRL(s, SC_C_ACTIVE)) return;
-  const int nh = CTRL(s, SC_C_NHYP);
-  if (nh <= 0) return;
-  const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), W = sb.W, NR = sb.kv_rows;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int nwords = (NR + 31) / 32;
-  int *anc = ANC(cur, s);
-  for (int w = tid; w < nwords; w += 256) bm[w] = 0u;
-  __syncthreads();
-  const int n = (L - 1) * nh;
-  // (8 loads per thread in flight: one round trip per 2048 table entries instead of one per 256)
-  for (int e0 = tid; e0 < n; e0 += 256 * 8) {
-    int r[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = min(e0 + 256 * u, n - 1);
-      r[u] = anc[(long)(e / nh) * W + e % nh];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (e0 + 256 * u < n) atomicOr(&bm[(r[u] >> 5) & (SC_KV_MAX_ROWS / 32 - 1)], 1u << (r[u] & 31));
-  }
-  __syncthreads();
-  if (tid >= 64) return;
-  int *out = anc + (long)(L - 1) * W;
-  int got = 0;
-  for (int w0 = 0; w0 < nwords && got < nh; w0 += 64) {
-    const int w = w0 + lane;
-    unsigned fr = w < nwords ? ~bm[w] : 0u;
-    if (w == nwords - 1 && (NR & 31)) fr &= (1u << (NR & 31)) - 1u;
-    const int c = __popc(fr);
-    int incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    int k = got + incl - c;   // index of this lane's first free row among all free rows
-    while (fr && k < nh) {
-      const int b = __ffs(fr) - 1;
-      fr &= fr - 1u;
-      out[k++] = w * 32 + b;
-    }
-    got += __shfl(incl, 63, 64);
-  }
-  if (got < nh && lane >= got && lane < nh) out[lane] = NR - 1;   // exhausted: in-bounds garbage, the host fails the stream
-  if (lane == 0 && sb.kvflags) sb.kvflags[s] = got < nh ? 1 : 0;
-}
-
-extern "C" int sc_kv_alloc(const sc_search *sbp, void *stream) {
-  SC_CHECK_ARG(sbp && sbp->anc, "null");
-  SC_CHECK_ARG(sbp->kv_rows >= sbp->W && sbp->kv_rows <= SC_KV_MAX_ROWS, "kv_rows out of range (beam .. 65536)");
-  const int ns = sbp->rowmap ? sbp->n_rows / sbp->W : sbp->S;   // streams of the compaction bucket only
-  kv_alloc_kernel<<<ns, 256, 0, (hipStream_t)stream>>>(*sbp);
-  SC_CHECK_LAUNCH();
-  return SC_OK;
-}
-
 // ---------------------------------------------------------------------------
 __global__ void dec_embed_kernel(sc_search sb, float sq) {
   const int row = blockIdx.x, s = row / sb.W, h = row % sb.W;
@@ -228,7 +166,7 @@ __global__ __launch_bounds__(256, (UNR <= 4 && WM <= 10 && DK <= 32) ? 4 : 1) vo
   const long skv0 = ((long)s * sb.n_layers + li) * sb.kv_rows * 2 * d + head * DK;
   const long ckv0 = ((long)s * sb.n_layers + li) * sb.TCAP * 2 * d + head * DK;
   if (SELF) {
-    // append this token's K|V rows into the pool rows sc_kv_alloc gave the hypotheses (anc[L-1][h]); this launch
+    // append this token's K|V rows into the pool rows beam_prune_kernel gave the hypotheses (anc[L-1][h]); this launch
     // reads them from dqkv, later steps from the cache
     const int *ancn = ANC(cur, s) + (long)(L - 1) * W;
     for (int e = tid; e < nh * DK; e += 256) {
@@ -1098,8 +1036,14 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
   extern __shared__ __attribute__((aligned(16))) double tot[];
   __shared__ int fl_any, fl_all, fl_best, fl_rep;
   __shared__ int win_h[64], win_tok[64];   // per output rank: source hypothesis, appended token
+  // K|V pool rows the NEW hypotheses descend from (bit per row): marked while their histories are copied, then the
+  // lowest unmarked rows become the rows of their newest tokens (position L) - what the next decode step appends to.
+  // No allocator state survives the launch: the ancestor table of a side IS the state.  A step that is rolled back
+  // (beam_search.py:827-836) leaves the other side as it was: its rows for position L-1 are still in ITS table.
+  __shared__ unsigned bm[SC_KV_MAX_ROWS / 32];
   const int s = blockIdx.x, tid = threadIdx.x;
   if (!CTRL(s, SC_C_ACTIVE)) return;
+  for (int w = tid; w < (sb.kv_rows + 31) / 32; w += 256) bm[w] = 0u;
   const int W = sb.W, K = sb.K;
   const int nh = CTRL(s, SC_C_NHYP), L = CTRL(s, SC_C_L), T = CTRL(s, SC_C_T);
   const int cur = CTRL(s, SC_C_CUR), o = 1 - cur;
@@ -1173,6 +1117,7 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
         xdst[p] = xv[u];
         if (p >= 1 && yv[u] == tok && tok != sb.sos && tok != sb.eos) rep = true;
         adst[(long)p * W + i] = av[u];   // pool rows of the parent's history, incl. its newest token's row (position L-1)
+        atomicOr(&bm[(av[u] >> 5) & (SC_KV_MAX_ROWS / 32 - 1)], 1u << (av[u] & 31));
       } else {
         ydst[L] = tok;
         xdst[L] = T - 1;
@@ -1184,11 +1129,38 @@ __global__ __launch_bounds__(256) void beam_prune_kernel(sc_search sb) {
   if (tid == 0)
     sb.flags[s] = (fl_any ? SC_F_ANY_EOS : 0) | (fl_best ? SC_F_BEST_EOS : 0) |
                   (fl_all ? SC_F_ALL_EOS : 0) | (fl_rep ? SC_F_REPEAT : 0);
+  if (tid >= 64 || L + 1 > sb.LCAP) return;   // (a stream at max_tokens is failed by the host before its next step)
+  // ---- pool rows for position L of the nout new hypotheses: the lowest free rows, in hypothesis order (wave 0)
+  const int lane = tid, NR = sb.kv_rows, nwords = (NR + 31) / 32;
+  int *out = adst + (long)L * W;
+  int got = 0;
+  for (int w0 = 0; w0 < nwords && got < nout; w0 += 64) {
+    const int w = w0 + lane;
+    unsigned fr = w < nwords ? ~bm[w] : 0u;
+    if (w == nwords - 1 && (NR & 31)) fr &= (1u << (NR & 31)) - 1u;
+    const int c = __popc(fr);
+    int incl = c;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      const int t = __shfl_up(incl, o2, 64);
+      if (lane >= o2) incl += t;
+    }
+    int k = got + incl - c;   // index of this lane's first free row among all free rows
+    while (fr && k < nout) {
+      const int b = __ffs(fr) - 1;
+      fr &= fr - 1u;
+      out[k++] = w * 32 + b;
+    }
+    got += __shfl(incl, 63, 64);
+  }
+  if (got < nout && lane >= got && lane < nout) out[lane] = NR - 1;   // exhausted: in-bounds garbage, the host fails the stream
+  if (lane == 0 && sb.kvflags) sb.kvflags[s] = got < nout ? 1 : 0;
 }
 
 extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   SC_CHECK_ARG(sbp->W <= 64, "beam wider than 64");
+  SC_CHECK_ARG(sbp->kv_rows >= sbp->W && sbp->kv_rows <= SC_KV_MAX_ROWS, "kv_rows out of range (beam .. 65536)");
   size_t smem = (size_t)sbp->W * sbp->W * sizeof(double);
   beam_prune_kernel<<<sbp->S, 256, smem, (hipStream_t)stream>>>(*sbp);
   SC_CHECK_LAUNCH();
@@ -1316,7 +1288,6 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
-  SC_TRY(sc_kv_alloc(sbp, stream));   // pool rows for the K|V of this step's tokens
   if (dec_fused_ok(sb)) {
     // 3 launches per layer; x ping-pongs dx <-> dxn
     float *xa = sb.dx, *xb = sb.dxn;

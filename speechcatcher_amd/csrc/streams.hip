@@ -360,6 +360,7 @@ __global__ void init_hyp_kernel(sc_search sb, int s) {
   const size_t o = ((size_t)0 * sb.S + s) * sb.W + 0;
   sb.yseq[o * sb.LCAP] = sb.sos;
   sb.xpos[o * sb.LCAP] = 0;
+  sb.anc[((size_t)0 * sb.S + s) * sb.LCAP * sb.W] = 0;   // K|V pool row of the sos token (position 0, hypothesis 0): row 0
   sb.score[o] = 0.0;
   sb.sc_dec[o] = 0.0;
   sb.sc_ctc[o] = 0.0;
@@ -1195,7 +1196,7 @@ int tick_collect(sc_streams *b) {
   // ---- the accept / stop rules of the step loop (:759-821)
   for (int s : b->tick_active) {
     Run &r = b->run[s];
-    if (b->flags_host[S + s]) {   // sc_kv_alloc found no free row: the step computed garbage for this stream
+    if (b->flags_host[S + s]) {   // the prune kernel found no free K|V pool row for the new hypotheses: the stream cannot go on
       b->flags_host[S + s] = 0;
       fault_stream(b, s, SC_ERR_CAPACITY, "self-attention K|V pool exhausted (kv_pool_rows / max_tokens)");
       continue;
@@ -1747,7 +1748,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   }
   sb.tct = (b->TCAP + 3) / 4 * 4;
   A(sb.ctcxT, (size_t)S * V * sb.tct);
-  // self-attention K|V: a pool of rows per stream and layer (scasr.h: sc_kv_alloc) - a beam's hypotheses share almost all
+  // self-attention K|V: a pool of rows per stream and layer (scasr.h: sc_search.skv) - a beam's hypotheses share almost all
   // of their history, so 1.5 rows per token position (+ the W rows a step appends, with slack) instead of W
   {
     const long full = (long)b->LCAP * W;

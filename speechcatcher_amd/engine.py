@@ -174,7 +174,7 @@ class StreamBatch:
         if kvt != f32 and not hasattr(backend, "kv_rows_to_half"):
             raise EngineError("half-precision K|V caches need the HIP backend")
         self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d, dtype=kvt)
-        # self-attention K|V: a pool of rows per stream and layer (include/scasr.h: sc_kv_alloc); `anc` holds pool rows
+        # self-attention K|V: a pool of rows per stream and layer (include/scasr.h: sc_search.skv); `anc` holds pool rows
         self.kv_rows = max(2 * W, min(self.LCAP * W, kv_pool_rows if kv_pool_rows > 0 else self.LCAP + self.LCAP // 2 + 4 * W))
         if self.kv_rows > 65536:
             raise EngineError("the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)")
@@ -349,6 +349,7 @@ class StreamBatch:
         # create_initial_hypothesis (hypothesis.py:75-91): yseq=[sos], xpos=[0]
         self.yseq[0, s, 0, 0] = self.cfg.sos_id
         self.xpos[0, s, 0, 0] = 0
+        self.anc[0, s, 0, 0] = 0          # K|V pool row of the sos token
         self.score[0, s, 0] = 0.0
         self.sc_dec[0, s, 0] = 0.0
         self.sc_ctc[0, s, 0] = 0.0
@@ -1001,7 +1002,7 @@ class StreamBatch:
             t_st = time.perf_counter()
             f = self._read_flags()[ids]
             self._tick("decode_wait_flags", t_st)
-            full = act & (self._flags_np[self.S:][ids] != 0)    # sc_kv_alloc found no free K|V pool row: garbage step
+            full = act & (self._flags_np[self.S:][ids] != 0)    # the prune kernel found no free K|V pool row
             if full.any():
                 err = EngineError(f"self-attention K|V pool exhausted (kv_pool_rows={self.kv_rows}, max_tokens={self.LCAP})")
                 if not self._isolate:

@@ -272,9 +272,6 @@ class HipBackend:
     def dec_embed(self, sb):
         self._sb_call("sc_dec_embed", sb)
 
-    def kv_alloc(self, sb):
-        self._sb_call("sc_kv_alloc", sb)
-
     def dec_self_attn(self, sb, li):
         self._sb_call("sc_dec_self_attn", sb, li)
 

@@ -9,7 +9,7 @@ from oracle.kernel_spec import SpecBackend
 FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "ffn_ln_proj", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
             "ctx_handoff", "enc_attention", "ctc_extend_state", "dec_embed", "dec_self_attn",
             "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw", "beam_prune",
-            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits", "kv_alloc"]
+            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits"]
 
 
 class LockstepBackend(SpecBackend):
@@ -66,8 +66,8 @@ class LockstepBackend(SpecBackend):
         "dec_cross_attn": ["datt"], "logsoftmax_topk": ["logp", "pre_ids"],
         "ctc_prefix_scan": ["psi", "psi_eos", "ctc_rnew"],
         "fuse_topw": ["cand_tok", "cand_score", "cand_ctc"],
-        "beam_prune": ["yseq", "xpos", "score", "sc_dec", "sc_ctc", "anc", "ctc_s", "sel", "flags"],
-        "ctc_gather_state": ["ctc_r"], "kv_alloc": ["anc", "kvflags"],
+        "beam_prune": ["yseq", "xpos", "score", "sc_dec", "sc_ctc", "anc", "ctc_s", "sel", "flags", "kvflags"],
+        "ctc_gather_state": ["ctc_r"],
         # head-parallel decoder layers: (sb, li, xin, xout[, npart]) / (sb, xin, xout, npart)
         "dec_layer_self": [3, "skv", "ph1"], "dec_layer_cross": [3, "ph2"], "dec_layer_ffn": [3, "ffn_part"],
         "dec_output_logits": [2, "logits"],

@@ -248,7 +248,7 @@ def test_engine_calls_after_final_without_reset(bbd):
 
 
 def run_kv_pool_exhaustion(backend=None, device="cpu"):
-    """The self-attention K|V pool (include/scasr.h: sc_kv_alloc): rows are handed out per step and reclaimed when no
+    """The self-attention K|V pool (include/scasr.h: sc_search.skv): rows are handed out per step and reclaimed when no
     live hypothesis descends from them.  A pool of one row per (position, hypothesis) can never run out; the default
     (1.5 rows per position) serves the fixture utterance with the same results; a pool that is too small fails the
     stream with a capacity error - alone, when faults are isolated."""

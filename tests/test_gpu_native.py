@@ -130,7 +130,7 @@ def test_native_final_chunk_that_faults_on_a_running_stream():
 
 @pytest.mark.parametrize("engine", ["native", "python"])
 def test_kv_pool_exhaustion_on_the_gpu(engine):
-    """self-attention K|V pool (sc_kv_alloc) on both engines: default pool = full pool = fixture; too small a pool is a
+    """self-attention K|V pool (sc_search.skv / anc) on both engines: default pool = full pool = fixture; too small a pool is a
     per-stream capacity fault"""
     from test_engine_spec import run_kv_pool_exhaustion
     if engine == "native":

@@ -547,7 +547,7 @@ def _dump(ls, name):
 ALL_OPS = {"logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "layernorm", "block_pack", "ctx_handoff", "enc_attention",
            "dec_self_attn", "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw",
            "beam_prune", "ctc_gather_state", "ctc_extend_state", "dec_embed", "copy_rows",
-           "log_softmax_rows", "kv_alloc"}
+           "log_softmax_rows"}
 
 
 def test_every_kernel_lockstep_tiny(hip):
