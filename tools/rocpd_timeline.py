@@ -8,7 +8,7 @@ import sys
 
 def main():
     con = sqlite3.connect(sys.argv[1])
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+    which = sys.argv[2] if len(sys.argv) > 2 else "-3"      # a step index, or "hpw4": the last step that starts with a four-heads-per-workgroup kernel
     max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -21,7 +21,9 @@ def main():
     rows = list(cur.execute(f"select s.{name_col}, d.start, d.end, {('d.' + qcol) if qcol else '0'} from {kd} d "
                             f"join {ks} s on d.kernel_id = s.id order by d.start"))
     # only the decode stream's queue (continuous batching: encoder groups run beside it on another stream)
-    dq = [r[3] for r in rows if "dec_embed" in r[0]]
+    import re
+    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?(ELb[01])?EEv")
+    dq = [r[3] for r in rows if "dec_embed" in r[0] or first.search(r[0])]
     if dq:
         q = max(set(dq), key=dq.count)
         n_other = sum(1 for r in rows if r[3] != q)
@@ -31,10 +33,12 @@ def main():
         rows = [r[:3] for r in rows]
     # a decode step starts with dec_embed (six-launch layers) or with the FIRST variant of the head-parallel
     # self-attention layer kernel (last template argument true)
-    import re
     # mangled: dec_layer_attn_kernel<D, DK, WM, SELF = true, UNR, FIRST = true, KVH[, HPW[, WH]]>
-    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?(ELb[01])?EEv")
     starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0] or first.search(r[0])]
+    if which == "hpw4":
+        cand = [k for k, i in enumerate(starts[:-1]) if "ELi4ELb" in rows[i][0]]
+        which = cand[-2] - len(starts) if len(cand) > 1 else -3
+    which = int(which)
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
     seg = rows[a:b]
     busy = sum(r[2] - r[1] for r in seg)
