@@ -66,6 +66,7 @@ def capacities(n_steps_total):
 
 
 FFN_DTYPE = "float32"  # --ffn-dtype float16: fp16 feed-forward weights + fp16 MFMA inputs (configs[4]), never the default
+ENCODER_BATCH = 0      # --encoder-batch N: sc_streams_set_encoder_batch (0: the engine's default, half of the streams)
 KV_DTYPE = "float32"   # --kv-dtype float16: K|V caches in fp16 (BASELINE configs[4]'s storage mode), never the default
 
 
@@ -84,9 +85,12 @@ def make_weights(device, ffn_dtype=None):
 def build_native(w, n_streams, beam, bbd, n_steps_total, engine=None, kv_dtype=None):
     from speechcatcher_amd.native import NativeStreamBatch
     frames, tokens = capacities(n_steps_total)
-    return NativeStreamBatch(w, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
-                             max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
-                             engine=engine, kv_dtype=kv_dtype or KV_DTYPE)
+    sb = NativeStreamBatch(w, n_streams, SearchConfig(beam_size=beam, use_bbd=bbd), max_frames=frames,
+                           max_tokens=tokens, pcm_capacity=CHUNK * (n_steps_total + 2), max_chunk_samples=CHUNK,
+                           engine=engine, kv_dtype=kv_dtype or KV_DTYPE)
+    if ENCODER_BATCH > 0:
+        sb.set_encoder_batch(min(ENCODER_BATCH, n_streams))
+    return sb
 
 
 def make_audio(n_streams, n_steps, stream_offset=0, shared=False):
@@ -471,6 +475,9 @@ def main():
     ap.add_argument("--queue-depth", type=int, default=1,
                     help="continuous mode: chunks a stream keeps with the engine (sc_streams_set_queue_depth); 1 = call -> reply -> "
                          "next call (the headline), 2+ = the next chunk is submitted while the previous one decodes (file / backlog hosts)")
+    ap.add_argument("--encoder-batch", type=int, default=0,
+                    help="continuous mode: merged encoder groups are issued when they hold this many streams "
+                         "(sc_streams_set_encoder_batch; 0 = the engine's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the leg of the mode that is not the headline")
@@ -495,7 +502,8 @@ def main():
         mine = [int(c) for c in os.environ["SC_BENCH_CPUS"].split(",")]
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(8, len(mine))))
-    global CHUNK, KV_DTYPE, FFN_DTYPE
+    global CHUNK, KV_DTYPE, FFN_DTYPE, ENCODER_BATCH
+    ENCODER_BATCH = args.encoder_batch
     CHUNK = args.chunk
     KV_DTYPE = args.kv_dtype
     FFN_DTYPE = args.ffn_dtype
