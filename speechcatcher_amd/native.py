@@ -244,11 +244,13 @@ class NativeStreamBatch:
                 out[s] = exc
         return out
 
-    def poll_ids(self, min_done: int = 1):
-        """``poll`` without Python objects: (stream ids, statuses) as int32 arrays."""
+    def poll_ids(self, min_done: int = 1, max_done: int = 0):
+        """``poll`` without Python objects: (stream ids, statuses) as int32 arrays; at most ``max_done`` replies
+        (0: all that are ready), oldest completion first."""
         ids = np.zeros(self.S, np.int32)
         st = np.zeros(self.S, np.int32)
-        n = self.lib.sc_poll(self.handle, int(min_done), self.S, ids.ctypes.data_as(_abi.c_int_p), st.ctypes.data_as(_abi.c_int_p))
+        n = self.lib.sc_poll(self.handle, int(min_done), int(max_done) if max_done > 0 else self.S,
+                             ids.ctypes.data_as(_abi.c_int_p), st.ctypes.data_as(_abi.c_int_p))
         if n < 0:
             _abi.check(n, "sc_poll")
         return ids[:n], st[:n]

@@ -140,6 +140,33 @@ def test_kv_pool_exhaustion_on_the_gpu(engine):
         run_kv_pool_exhaustion(backend=HipBackend("cuda:0"), device="cuda:0")
 
 
+def test_poll_reports_the_oldest_completions_first():
+    """sc_poll with a small max_done: streams are reported in the order their chunks completed, not
+    by stream index.  Six streams get one chunk each in one admission; the engine decodes until ALL are complete
+    (min_done = 6) but may only report one per call: the sequence must be ordered by the decode steps each stream needed
+    for its chunk (a stream that needs fewer steps completes in an earlier tick), ties by index; every stream exactly once."""
+    from test_engine_spec import make_batch
+    S = 6
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, n_streams=S, backend="native", max_frames=200, max_tokens=300,
+                    pcm_capacity=1 << 17)
+    audio = [synth.synth_audio(40 + s, 10240 * 4) for s in range(S)]
+    for k in range(3):                       # bring every stream to its first decode blocks, in lock-step
+        sb.push([(s, audio[s][k * 10240:(k + 1) * 10240], False) for s in range(S)])
+    before = [sb.st[s].n_steps_total for s in range(S)]
+    # reversed submission order: the reporting order must not depend on it either
+    sb.submit([(s, audio[s][3 * 10240:4 * 10240], False) for s in reversed(range(S))])
+    order = []
+    ids, st = sb.poll_ids(S, max_done=1)     # decodes until all six are complete, reports one
+    while len(ids):
+        assert len(ids) == 1 and st[0] >= 0
+        order.append(int(ids[0]))
+        ids, st = sb.poll_ids(0, max_done=1)
+    assert sorted(order) == list(range(S))
+    steps = [sb.st[s].n_steps_total - before[s] for s in range(S)]
+    assert len(set(steps)) > 1, steps        # (the streams do need different numbers of steps)
+    assert order == sorted(range(S), key=lambda s: (steps[s], s)), (order, steps)
+
+
 def test_native_batch_of_distinct_streams_equals_one_by_one():
     """32 different utterances of different lengths in one batch (ragged-batch compaction, per-bucket graphs,
     head-parallel and six-launch layer forms by bucket size) = every stream alone = the same streams served by
