@@ -211,11 +211,15 @@ __host__ __device__ static inline int mattn_partial_floats(int DK, int np) { ret
 // (all threads of the workgroup must call it the same number of times).  Returns the number of entries.
 // PRE: the thread's ancestor rows were loaded earlier (`pre`, a register array: it is taken by reference and selected at
 // compile time - a run-time pointer to it would force the array into scratch memory, +5 us per launch measured).
-template <int WM, bool PRE = false>
+// NTHR threads cooperate (gt = index among them, wave = gt / 64) on PCH positions: 256 / 128 = the four waves of one head
+// group and its own list; 1024 / 512 = a whole four-head workgroup building ONE list that its head groups share (the
+// list depends on the stream only) - a 400-token hypothesis then costs one build phase (two barriers, one dependent
+// round trip for the ancestor rows) instead of four, and the walk runs over all its tiles without draining in between.
+template <int WM, bool PRE = false, int NTHR = 256, int PCH = 128>
 __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *anc, int c0, int Lc, int W, int nh,
                                                 int gt, int lane, int wave, const int (&pre)[WM]) {
-  constexpr int PCH = 128;
-  for (int e = gt; e < PCH * W; e += 256) rw[e] = 0;
+  static_assert(PCH % 64 == 0 && PCH <= NTHR, "positions: whole waves of the cooperating threads");
+  for (int e = gt; e < PCH * W; e += NTHR) rw[e] = 0;
   const int pp = c0 + gt;
   const bool live = gt < PCH && pp < Lc;
   int r[WM];
@@ -237,10 +241,15 @@ __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *a
     const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  if (lane == 63) wtot[wave] = incl;
+  if (lane == 63 && wave < PCH / 64) wtot[wave] = incl;
   __syncthreads();   // also orders the zero fill before the ORs
-  const int base = incl - cnt + (wave >= 1 ? wtot[0] : 0);
-  const int U = wtot[0] + wtot[1];
+  int base = incl - cnt, U = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < PCH / 64; ++w2) {
+    const int t = wtot[w2];
+    if (w2 < wave) base += t;
+    U += t;
+  }
   if (live) {
 #pragma unroll
     for (int h = 0; h < WM; ++h) {

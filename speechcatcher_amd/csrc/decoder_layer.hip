@@ -138,7 +138,10 @@ __host__ __device__ static inline int dl_group_floats(int D, int DK, int W, int 
 }
 // HPW head groups + LayerNorm gamma | beta + (HPW > 1) the LayerNorm tile shared by the head groups
 __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
-  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + 16 /*pool rows of the new tokens*/ + (hpw > 1 ? 16 * (D + 4) : 0);
+  // hpw > 1: the LayerNorm tile shared by the head groups; the self-attention's shared row list (128 * hpw positions x W
+  // entries + 16 wave totals) takes its place once the projection is done
+  const int shared = hpw > 1 ? ((self && 128 * hpw * W + 16 > 16 * (D + 4)) ? 128 * hpw * W + 16 : 16 * (D + 4)) : 0;
+  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + 16 /*pool rows of the new tokens*/ + shared;
 }
 
 // key tiles per wave in flight in the attention walk of the few-streams variant (UNR = 8).  Measured in round 3 with 8
@@ -477,6 +480,22 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     const int Lc = L - 1;  // cached positions; the new token's row is the fifth partial state
     const int nchunk = cdiv(Lc, PCH);
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
+    if constexpr (HPW > 1) {
+      // ONE row list per workgroup, 128 * HPW positions at a time, built by all its threads and walked by every head
+      // group (it lives where the LayerNorm tile was: the projection is done)
+      constexpr int PCS = 128 * HPW;
+      int *srows = reinterpret_cast<int *>(Xsh), *swtot = srows + PCS * W;
+      for (int c0 = 0; c0 < Lc; c0 += PCS) {
+        const int U = mattn_build_rows<WM, false, NTH, PCS>(srows, swtot, anc, c0, Lc, W, nh, tid, lane, tid >> 6, slp);
+        urows += U;
+        mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+          const int e = srows[min(idx, PCS * W - 1)];   // entries >= U are zero: no hypothesis
+          hm = (unsigned)e >> 16;
+          ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
+        });
+        if (c0 + PCS < Lc) __syncthreads();  // the list is rebuilt for the next positions
+      }
+    } else
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
       const int U = (PF && ch == 0) ? mattn_build_rows<WM, true>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp)

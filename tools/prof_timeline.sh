@@ -10,6 +10,6 @@ ARGS="--no-cpu-baseline --no-single-stream --no-other-mode --no-resident --no-lo
 rm -rf /tmp/pk; rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pk -- python3 bench.py $ARGS > gpurun_out/${TAG}_prof_kernel.log 2>&1
 DB=$(find /tmp/pk -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB gpurun_out/${TAG}_kernel_stats.csv > /dev/null
-for w in hpw4 -300 -120; do python tools/rocpd_timeline.py $DB $w 120 > gpurun_out/${TAG}_timeline_$w.txt 2>&1; done
+for w in full hpw4 -300; do python tools/rocpd_timeline.py $DB $w 120 > gpurun_out/${TAG}_timeline_$w.txt 2>&1; done
 python tools/rocpd_busy.py $DB > gpurun_out/${TAG}_busy.txt 2>&1
 head -30 gpurun_out/${TAG}_kernel_stats.csv

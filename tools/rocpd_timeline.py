@@ -8,7 +8,7 @@ import sys
 
 def main():
     con = sqlite3.connect(sys.argv[1])
-    which = sys.argv[2] if len(sys.argv) > 2 else "-3"      # a step index, or "hpw4": the last step that starts with a four-heads-per-workgroup kernel
+    which = sys.argv[2] if len(sys.argv) > 2 else "-3"      # a step index, "hpw4": the last step that starts with a four-heads-per-workgroup kernel, "full": of a full bucket
     max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -37,6 +37,10 @@ def main():
     starts = [i for i, r in enumerate(rows) if "dec_embed" in r[0] or first.search(r[0])]
     if which == "hpw4":
         cand = [k for k, i in enumerate(starts[:-1]) if "ELi4ELb" in rows[i][0]]
+        which = cand[-2] - len(starts) if len(cand) > 1 else -3
+    if which == "full":   # the last step of a (nearly) full bucket: its decoder FFN runs 48-row tiles (RTT = 3)
+        cand = [k for k, i in enumerate(starts[:-1])
+                if any("ffn_fused_kernelILi256ELi3ELb1" in r[0] for r in rows[i:starts[k + 1]])]
         which = cand[-2] - len(starts) if len(cand) > 1 else -3
     which = int(which)
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
