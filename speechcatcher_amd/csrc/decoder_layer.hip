@@ -126,7 +126,7 @@ __host__ __device__ static inline int dl_region_floats(int D, int DK, int W, boo
   const int nt = (self ? 3 : 1) * (DK / 16);
   const int xn = 16 * (D + 4);
   const int ps = 4 * 16 * (nt * 16 + 4);
-  const int attn = mattn_partial_floats(DK, self ? 5 : 4) + (self ? 128 * W : 0) + 8;   // partial states, row list, wtot
+  const int attn = mattn_partial_floats(DK, self ? 5 : 4) + (self ? 256 * W : 0) + 8;   // partial states, row list, wtot
   const int outp = 16 * 36 + 16 * (D + 4);
   int r = xn > ps ? xn : ps;
   r = r > outp ? r : outp;
@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
   const bool acth = (p.sb.act_half & 2) != 0;                       // partial products in fp16
   constexpr int NTH = 256 * HPW;   // threads: HPW head groups of 4 waves
-  constexpr int PCH = 128;       // positions per chunk of the row list (SELF)
+  constexpr int PCH = 256;       // positions per chunk of a head group's own row list (SELF, one head per workgroup): every
+                                 // thread one position (128 until round 4: half as many build phases per walk now)
   constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
   constexpr int NTQ = DK / 16, NT = (SELF ? 3 : 1) * NTQ, LDP = NT * 16 + 4;
   static_assert(KI % 4 == 0 && (DK == 16 || DK == 32), "d_model must be a multiple of 128, head dim 16 or 32");
@@ -498,8 +499,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     } else
     for (int ch = 0; ch < nchunk; ++ch) {
       const int c0 = ch * PCH;
-      const int U = (PF && ch == 0) ? mattn_build_rows<WM, true>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp)
-                                    : mattn_build_rows<WM, false>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp);   // (attn.h)
+      const int U = (PF && ch == 0) ? mattn_build_rows<WM, true, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp)
+                                    : mattn_build_rows<WM, false, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp);   // (attn.h)
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis

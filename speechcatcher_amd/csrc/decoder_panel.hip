@@ -287,6 +287,7 @@ struct RedProjArgs {
   float *Q; int ldq;
   int by_row;   // partial sums indexed by row id (xrow) instead of by position m (sc_dec_layer_ffn)
   int part_half;   // the partial sums hold fp16 elements (sc_search.act_half)
+  int cb;          // column blocks per workgroup (grid.y = N / D / cb): the reduce + LayerNorm of a panel is done once for them
 };
 
 typedef _Float16 rp_h4 __attribute__((ext_vector_type(4)));
@@ -302,21 +303,21 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
   __shared__ __attribute__((aligned(16))) float PC[KS][R * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = wave % NT, ks = wave / NT, k0 = ks * KW;
-  const int m0 = blockIdx.x * R, nb = blockIdx.y;
-  // projection weights of this column block: in flight during the reduce + LayerNorm
+  const int m0 = blockIdx.x * R, nb0 = blockIdx.y * p.cb;
+  // projection weights of the first column block: in flight during the reduce + LayerNorm
   BF b[NL];
-  {
+  auto load_w = [&](int nb) {
     const BF *wp = reinterpret_cast<const BF *>(p.Wq) + ((long)(nb * NT + tile) * (D / 4) + k0 / 4) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < NL; ++q) b[q] = wp[q * 64];
-  }
-  float gam[EL], bet[EL], bia2[EL], biaq[EL];
+  };
+  load_w(nb0);
+  float gam[EL], bet[EL], bia2[EL];
 #pragma unroll
   for (int e = 0; e < EL; ++e) {
     gam[e] = p.g[lane + 64 * e];
     bet[e] = p.be[lane + 64 * e];
     bia2[e] = p.b2 ? p.b2[lane + 64 * e] : 0.f;
-    biaq[e] = p.bq ? p.bq[nb * D + lane + 64 * e] : 0.f;
   }
   long xrow[RPW];
 #pragma unroll
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
       for (int e = 0; e < EL; ++e) {
         const int c = lane + 64 * e;
         x[e] = p.Xin[xrow[rr] * D + c] + (y[e] + bia2[e]);
-        if (live && nb == 0) p.Xout[xrow[rr] * D + c] = x[e];
+        if (live && blockIdx.y == 0) p.Xout[xrow[rr] * D + c] = x[e];
         s += x[e];
       }
       const float mean = wave_sum(s) / (float)D;
@@ -365,11 +366,17 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
         const int c = lane + 64 * e;
         const float y = (x[e] - mean) * rstd * gam[e] + bet[e];
         PA[i * LD + c] = y;
-        if (p.XN && live && nb == 0) p.XN[xrow[rr] * D + c] = y;
+        if (p.XN && live && blockIdx.y == 0) p.XN[xrow[rr] * D + c] = y;
       }
     }
   }
   __syncthreads();
+  for (int cbi = 0; cbi < p.cb; ++cbi) {
+  const int nb = nb0 + cbi;
+  if (cbi > 0) load_w(nb);   // (the fragments of a column block fill the register budget: no double buffering)
+  float biaq[EL];
+#pragma unroll
+  for (int e = 0; e < EL; ++e) biaq[e] = p.bq ? p.bq[nb * D + lane + 64 * e] : 0.f;
   f32x4 acc[RG];
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -415,13 +422,15 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
       }
     }
   }
+  if (cbi + 1 < p.cb) __syncthreads();   // PC is rewritten by the next column block
+  }
 }
 
 template <int D, bool WH = false>
 static void launch_redproj(const RedProjArgs &p, int rg, int nblocks, hipStream_t st) {
-  if (rg == 1) reduce_ln_proj_kernel<D, 1, WH><<<dim3(cdiv(p.M, 4), nblocks), 512, 0, st>>>(p);
-  else if (rg == 2) reduce_ln_proj_kernel<D, 2, WH><<<dim3(cdiv(p.M, 8), nblocks), 512, 0, st>>>(p);
-  else reduce_ln_proj_kernel<D, 4, WH><<<dim3(cdiv(p.M, 16), nblocks), 512, 0, st>>>(p);
+  if (rg == 1) reduce_ln_proj_kernel<D, 1, WH><<<dim3(cdiv(p.M, 4), nblocks / p.cb), 512, 0, st>>>(p);
+  else if (rg == 2) reduce_ln_proj_kernel<D, 2, WH><<<dim3(cdiv(p.M, 8), nblocks / p.cb), 512, 0, st>>>(p);
+  else reduce_ln_proj_kernel<D, 4, WH><<<dim3(cdiv(p.M, 16), nblocks / p.cb), 512, 0, st>>>(p);
 }
 
 // internal (common.h): called by sc_ffn_ln_proj after the fused FFN kernel wrote its partial sums
@@ -439,7 +448,11 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
     if (v == 4 || v == 8 || v == 16) rpp = v;
   }
   // half_mode (fp16 decoder mode, sc_search.act_half): bit 0 = Wq holds fp16 elements, bit 1 = the partial sums do
-  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N, by_row, (half_mode & 2) ? 1 : 0};
+  // more than one round of workgroups even with 16-row panels (a full bucket's output layer: 80 panels x 4 column
+  // blocks): two column blocks per workgroup - the panel's partial sums are reduced half as often and the launch is
+  // one round (27.6 -> ~16 us at 1280 rows x 1024 columns)
+  const int cb = (rpp == 16 && (long)cdiv(M, 16) * nblocks > 256 && nblocks % 2 == 0) ? 2 : 1;
+  RedProjArgs p{part, npart, part_M, b2, Xin, Xout, rows, M, ln_g, ln_b, ln_eps, XN, Wq, bq, Q, N, by_row, (half_mode & 2) ? 1 : 0, cb};
   ProfScope prof = sc_prof_begin(st);
   if (half_mode & 1) {
     SC_CHECK_ARG(D == 256 || D == 128, "fp16 output layer: d must be 128 or 256");

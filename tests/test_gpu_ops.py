@@ -430,7 +430,8 @@ def test_rowtile_proj_split_weights(hip, M, D):
 
 
 @pytest.mark.parametrize("M,D,F,N", [(10, 256, 2048, 768), (1280, 256, 2048, 768), (533, 256, 2048, 1024),
-                                     (77, 128, 256, 384), (2100, 256, 2048, 768)])
+                                     (77, 128, 256, 384), (2100, 256, 2048, 768),
+                                     (1280, 256, 2048, 1024), (1093, 256, 2048, 1024)])   # (two column blocks per workgroup)
 def test_ffn_ln_proj_chain(hip, M, D, F, N):
     """Fused FFN whose reduce kernel also applies the LayerNorm and the next projection
     (x_in / x_out ping-pong, 4x4x1-MFMA row panels, N/D column blocks), with and without a row table."""
