@@ -1813,6 +1813,14 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
     }
   }
   SC_CHECK_ARG(best < 1e29, "max_part too small");
+  if (const char *f = sc_hook("SC_DEC_FFN_FORCE")) {   // A/B runs: "min_rows,rtt,cpw" for buckets of at least min_rows rows
+    int mr = 0, r = 0, c = 0;
+    if (sscanf(f, "%d,%d,%d", &mr, &r, &c) == 3 && M >= mr && r >= 1 && r <= ffn_rtt_max(D, wf) && c >= 1 && nch % c == 0 &&
+        nch / c <= max_part) {
+      best_rtt = r;
+      best_cpw = c;
+    }
+  }
   const int ngrp = nch / best_cpw;
   const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_cross (decoder_layer.hip)
   FfnArgs p{nullptr, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F,
