@@ -550,7 +550,9 @@ int sc_streams_outstanding(const sc_streams *streams);
  * hop behind the encoder, beam_search.py:590-634), so its frontend + encoder stage has a whole chunk period of slack:
  * the stages of successive admissions are merged and issued as ONE group when it holds min_streams streams (default:
  * half of the streams) or as soon as a queued decode block needs its frames.  1: every admission is issued at once.
- * Results do not depend on it. */
+ * Results do not depend on it in the fp32 form.  With split-precision projections ("split16") the group's row count
+ * selects between the tiled GEMM (split operands) and the small-M kernels (fp32) for the subsampling / CTC / cross-K|V
+ * projections: both are fp32-grade, results can differ in the last bits of fp32 between group sizes. */
 int sc_streams_set_encoder_batch(sc_streams *streams, int min_streams);
 /* Chunks a stream may have outstanding at a time (1..8; default 1 = the reference's call -> reply -> next call,
  * speechcatcher_server.py:359-397).  depth > 1: sc_submit accepts the next chunk(s) of a stream while an earlier one

@@ -218,8 +218,9 @@ struct sc_streams {
   int graph_key() const { return n_rows_step * 2 + (step_split_min() > 0 ? 1 : 0); }
   int enc_start_thr = 0;         // sc_push: launch the planned encoder group when at most this many streams are still decoding
   int enc_batch_min = 0;         // sc_submit: launch the open encoder group when it holds this many streams (sc_streams_set_encoder_batch)
-  int gemm_flags = 0;            // SC_GEMM_SPLIT16 when the engine carries split-precision weight copies: the tiled GEMMs of the
-                                 // encoder stage (conv2, subsampling Linear, CTC / cross-K|V projections) in the same form
+  int gemm_flags = 0;            // SC_GEMM_SPLIT16 when the engine carries split-precision copies of the PROJECTIONS (wqkv_s): the tiled
+                                 // GEMMs of the encoder stage (conv2, subsampling Linear, CTC / cross-K|V projections) in the same form
+                                 // (weights.py checks the range of their operands at load time)
   void *ws = nullptr, *ws_enc = nullptr;
   std::vector<void *> owned, owned_host;
   // device buffers
@@ -1878,7 +1879,8 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->rowmap_key.resize(S);
   for (int s = 0; s < S; ++s) b->rowmap_key[s] = s;
   b->enc_batch_min = std::max(1, S / 2);
-  b->gemm_flags = (!b->eng->enc.empty() && b->eng->enc[0].w1_s) ? SC_GEMM_SPLIT16 : 0;
+  // (the projections' split copies, i.e. proj_dtype = "split16": the feed-forward's alone leave every projection fp32)
+  b->gemm_flags = (!b->eng->enc.empty() && b->eng->enc[0].wqkv_s) ? SC_GEMM_SPLIT16 : 0;
   b->row_bucket = std::max(1, S / 32);   // 32 compaction buckets (graphs): 16 -> 32 measured +1 % at 128 streams, 64 nothing more
   if (const char *rb = sc_hook("SC_ROW_BUCKETS")) b->row_bucket = std::max(1, S / std::max(1, atoi(rb)));   // tools: sweep
   b->n_rows_step = S * W;

@@ -58,6 +58,23 @@ def split_panel_weight(Wp: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], dim=1).contiguous().reshape(N, 2 * K)
 
 
+def split16_operand_bounds(lw: Dict[str, torch.Tensor], ln: str, d: int) -> Dict[str, float]:
+    """Upper bounds of the ACTIVATIONS the split-precision kernels split into fp16 hi | lo (ffn_fused_kernel /
+    rowtile_proj_kernel, WF = 2: "operands must lie within fp16's range"), from the weights alone: a LayerNorm output is at
+    most sqrt(d-1)*|g_i| + |b_i| in element i (the largest z-score d values can hold), a Linear's output at most
+    |W| @ that + |bias|.  ``ln``: the LayerNorm in front of the feed-forward ("ln2" encoder, "ln3" decoder)."""
+    z = float(np.sqrt(d - 1.0))
+    out = {}
+    bx = z * lw[ln + "_g"].abs() + lw[ln + "_b"].abs()
+    out["ffn_in"] = float(bx.max())
+    out["ffn_hidden"] = float((lw["w1"].abs() @ bx + lw["b1"].abs()).max())
+    if ln == "ln2":   # encoder layer: Q|K|V projection behind norm1, output projection behind the attention (a convex
+        b1 = z * lw["ln1_g"].abs() + lw["ln1_b"].abs()   # combination of V rows)
+        out["proj_in"] = float(b1.max())
+        out["attn_context"] = float((lw["wqkv"][2 * d:].abs() @ b1 + lw["bqkv"][2 * d:].abs()).max())
+    return out
+
+
 def pack_lane_weight(W: torch.Tensor) -> torch.Tensor:
     """[N][K] Linear weight -> lane order of sc_proj_ln_proj (include/scasr.h:
     out[tile][q][lane][c] = W[tile*64 + lane][4*q + c]); a pure permutation."""
@@ -206,6 +223,33 @@ class PackedWeights:
                     lw[n + "_h"] = lw[n + "_p"].to(torch.float16).contiguous()   # same fragment order, 2-byte elements
                 if ffn_dtype == "split16" and ffn_fused_supported(d, cfg.ffn_dim):
                     lw[n + "_s"] = split_panel_weight(lw[n + "_p"])
+        # split16: no activation the kernels split may leave fp16's range (it would become inf silently) - decided here,
+        # from the weights, for every layer that takes the split path; a model that fails it must use float32 / float16
+        if "split16" in (ffn_dtype, proj_dtype):
+            for kind, layers, ln in (("enc", self.enc, "ln2"), ("dec", self.dec, "ln3")):
+                for i, lw in enumerate(layers):
+                    if "w1_s" not in lw and "wqkv_s" not in lw:
+                        continue
+                    bounds = split16_operand_bounds(lw, ln, d)
+                    keys = (["ffn_in", "ffn_hidden"] if "w1_s" in lw else []) + \
+                           (["proj_in", "attn_context"] if "wqkv_s" in lw else [])
+                    worst = max(keys, key=lambda k: bounds[k])
+                    if bounds[worst] >= 65504.0:
+                        raise ValueError(f"split16 is not usable for this model: {kind} layer {i}: |{worst}| can reach "
+                                         f"{bounds[worst]:.3g}, beyond fp16's range (use ffn_dtype / proj_dtype float32)")
+            if proj_dtype == "split16" and self.enc and "wqkv_s" in self.enc[0]:
+                # ... and the tiled GEMMs of the encoder stage, which split BOTH operands on the fly (SC_GEMM_SPLIT16 in
+                # csrc/streams.hip): conv2 reads relu(conv1), the subsampling Linear relu(conv2), the CTC / cross-K|V
+                # projections the after_norm output.  A log-mel feature lies in [log 1e-10, log FLT_MAX] before the MVN.
+                mean, std = self.mean64.abs().cpu().numpy(), self.std64.abs().cpu().numpy()
+                feat = float(np.max((88.8 + mean) / np.maximum(std, 1e-30)))
+                c1 = float(self.conv1_w.abs().sum(1).max()) * feat + float(self.conv1_b.abs().max())
+                c2 = float(self.conv2_w.abs().sum(1).max()) * c1 + float(self.conv2_b.abs().max())
+                enc_out = float((np.sqrt(d - 1.0) * self.enc_norm_g.abs() + self.enc_norm_b.abs()).max())
+                for name, v in (("relu(conv1)", c1), ("relu(conv2)", c2), ("encoder output", enc_out)):
+                    if v >= 65504.0:
+                        raise ValueError(f"split16 projections are not usable for this model: |{name}| can reach {v:.3g}, "
+                                         "beyond fp16's range (use proj_dtype float32)")
         self.dec_norm_g = dev(g("decoder.after_norm.weight"))
         self.dec_norm_b = dev(g("decoder.after_norm.bias"))
         self.out_w = dev(g("decoder.output_layer.weight"))

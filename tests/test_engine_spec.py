@@ -290,3 +290,27 @@ def run_kv_pool_exhaustion(backend=None, device="cpu"):
 
 def test_kv_pool_exhaustion_is_a_capacity_fault():
     run_kv_pool_exhaustion()
+
+
+def test_split16_is_refused_for_weights_whose_activations_can_leave_the_fp16_range():
+    """weights.py split16_operand_bounds: the split-precision kernels split activations into fp16 hi | lo; the bound of
+    every such activation follows from the weights (LayerNorm outputs, |W| @ bound + |bias|), and a model that could
+    overflow fp16 there is refused at load time instead of producing inf on the device."""
+    from speechcatcher_amd.weights import split16_operand_bounds
+    sd = synth.make_state_dict(XL, 1234)
+    w = PackedWeights(sd, XL, "cpu", ffn_dtype="split16", proj_dtype="split16")
+    b = split16_operand_bounds(w.enc[0], "ln2", XL.d_model)
+    assert set(b) == {"ffn_in", "ffn_hidden", "proj_in", "attn_context"} and 0 < max(b.values()) < 65504.0
+    # the bound holds on actual data: LayerNorm of extreme rows, through the first Linear
+    import torch
+    torch.manual_seed(0)
+    x = torch.randn(64, XL.d_model) * torch.logspace(-3, 3, 64)[:, None]
+    x[0, 1:] = 0.0                                                    # one-hot row: the largest z-score
+    xn = torch.nn.functional.layer_norm(x, (XL.d_model,), w.enc[0]["ln2_g"], w.enc[0]["ln2_b"], 1e-12)
+    h = xn @ w.enc[0]["w1"].T + w.enc[0]["b1"]
+    assert float(xn.abs().max()) <= b["ffn_in"] * (1 + 1e-5) and float(h.abs().max()) <= b["ffn_hidden"] * (1 + 1e-5)
+    sd2 = dict(sd)
+    sd2["encoder.encoders.3.norm2.weight"] = sd["encoder.encoders.3.norm2.weight"] * 3.0e4
+    with pytest.raises(ValueError, match="enc layer 3"):
+        PackedWeights(sd2, XL, "cpu", ffn_dtype="split16")
+    PackedWeights(sd2, XL, "cpu")                                   # the fp32 path has no such limit
