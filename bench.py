@@ -502,6 +502,19 @@ def main():
         mine = [int(c) for c in os.environ["SC_BENCH_CPUS"].split(",")]
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(8, len(mine))))
+    elif int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) > 1:
+        # ranks started by an external launcher (torch.distributed.run): the same slicing - rank i of the node feeds its GPU
+        # from its own contiguous share of the allowed cores instead of migrating over all of them beside 7 other feeders
+        try:
+            nloc = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            cpus = sorted(os.sched_getaffinity(0))
+            per = len(cpus) // nloc
+            if per >= 2:
+                os.sched_setaffinity(0, cpus[lr * per:(lr + 1) * per])
+                torch.set_num_threads(max(1, min(8, per)))
+        except (OSError, ValueError, KeyError):
+            pass
     global CHUNK, KV_DTYPE, FFN_DTYPE, ENCODER_BATCH
     ENCODER_BATCH = args.encoder_batch
     CHUNK = args.chunk
