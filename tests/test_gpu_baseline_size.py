@@ -118,16 +118,20 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
     """The regime and the mode bench.py times: XL dims, 128 streams, beam 10, no block-boundary
     detection, CONTINUOUS batching (sc_submit / sc_poll(16)) on the C++ engine, 60 chunks per stream so that the streams
     reach T >= 700 encoder frames and >= 330 tokens with full compaction buckets (large-bucket kernels, multi-chunk K/V
-    walks).  Three streams are compared CALL BY CALL with the oracle run solo on the same audio: token ids / positions /
-    process_idx exact after every reply, cumulative scores within 1e-3 (north star), drift per decode step <= 1e-4 (a
-    stream may leave the oracle's path only where the ORACLE cut its beam by less than that tolerance - a near-tie); all
-    128 streams well formed.  The same run in the split-precision form and with fp16 K|V storage against the f32 engine."""
+    walks).  Six streams are compared CALL BY CALL with the oracle run solo on the same audio: token ids / positions /
+    process_idx exact after every reply, cumulative scores within 1e-3 (north star), drift per decode step <= 1e-4; all
+    128 streams well formed.
+    Near-ties: the oracle's own beam cuts of these streams come as close as 3e-6 (stream 3, call 35: `margins` of
+    ref_port.py), and which kernel form a stream's bucket takes - hence its fp32 summation order - depends on the host's
+    timing in this mode.  A stream may therefore leave the oracle's path, but ONLY at a call where the oracle cut its beam
+    by less than 1e-4 (ten times the measured drift; seen once in nine runs: stream 3, call 37, margin 1.5e-5), and at least
+    four of the six must stay on it to the end.  The same run in the split-precision form and with fp16 K|V storage against the f32 engine."""
     import json
     import os
     from helpers import oracle_calls_parallel
     from test_engine_spec import check_hyps
     S, n, beam, poll = 128, 60, 10, 16
-    tracked = (3, 64, 125)
+    tracked = (3, 29, 64, 90, 111, 125)
     audio = np.stack([synth.synth_audio(4000 + s, CHUNK * n) for s in range(S)])
     a3 = audio.reshape(S, n, CHUNK)
     kw = dict(n_streams=S, max_frames=16 * n + 80, max_tokens=640, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
@@ -157,10 +161,10 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
             try:
                 check_hyps(hyps, pidx, ref, 1e-3)
             except AssertionError:
-                # A beam cut the ORACLE itself decided by less than the score tolerance can fall the other way in any fp32
-                # implementation (which kernel form a stream's bucket takes changes the summation order): from there on the
-                # two runs follow different, equally valid paths.  Anything else is a parity failure.
-                if ref["min_margin"] >= 1e-3:
+                # A beam cut the ORACLE itself decided by less than 1e-4 can fall the other way in any fp32 implementation
+                # (which kernel form a stream's bucket takes changes the summation order): from there on the two runs
+                # follow different, equally valid paths.  Anything else is a parity failure.
+                if ref["min_margin"] >= 1e-4:
                     raise
                 near_tie = {"call": k, "oracle_beam_cut_margin": ref["min_margin"]}
                 print(f"stream {s}: diverged from the oracle at call {k}, where the oracle cut its beam by {ref['min_margin']:.2e}")
@@ -173,9 +177,9 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
         assert worst_step <= 1e-4 and (near_tie is not None or compared >= n * 3 // 4), (s, compared, worst_step)   # (calls without a decode step are skipped)
         report[s] = {"calls_compared": compared, "max_abs_total_score_diff": worst, "max_drift_per_decode_step": worst_step,
                      "T_end": seen[s][-1][2], "tokens_end": len(seen[s][-1][0][0]["yseq"]), "near_tie_divergence": near_tie}
-    # at most one of the three tracked streams may leave the oracle's path at a near-tie, and not before half of the run
+    # at least four of the six tracked streams stay on the oracle's path through the whole run
     ties = [r["near_tie_divergence"] for r in report.values() if r["near_tie_divergence"]]
-    assert len(ties) <= 1 and all(t["call"] >= n // 2 for t in ties), ties
+    assert len(ties) <= len(tracked) - 4, ties
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "r04_xl_continuous_128_parity.json"), "w") as f:
         json.dump({"streams": S, "chunks": n, "poll": poll, "T_min_max": [min(T), max(T)],
