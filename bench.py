@@ -846,7 +846,7 @@ def main():
                  "concurrency model: one independent call loop per stream, speechcatcher_server.py:331-397)" if args.queue_depth == 1 else
                  f"{args.queue_depth} chunks per stream at the engine (the next chunk is submitted while the previous one decodes: a "
                  "host that has the audio already)") + "; per call the "
-                 "results are those of the strict lock-step run" if args.mode == "continuous" else
+                 "results are those of the strict lock-step run (same blocks, steps and kernels; a stream's fp32 summation order follows the kernel form of its bucket, DESIGN.md section 2)" if args.mode == "continuous" else
                  "strict lock-step: one batched call per chunk step, every block completes inside its call")
     out = {
         "metric": f"concurrent real-time streams (audio-seconds/s), de_xl dims, {CHUNK * 1000 // 16000} ms ({CHUNK}-sample) chunk steps, beam 10 CTC+attention",

@@ -541,7 +541,8 @@ int sc_push_features(sc_streams *streams, const int *stream_ids, const float *co
  * outstanding) and reports up to max_done of them: done_ids[i] = stream, status[i] as in sc_push.  Returns the
  * number reported, < 0 on error.  A stream's reply is ready when ITS blocks are done; streams that finish early
  * get their next chunk while the stragglers of the previous one are still decoding.  Per stream the blocks, steps
- * and results are those of sc_push.  sc_push may be mixed in: it also advances the submitted streams. */
+ * and results are those of sc_push (the kernel form of a decode step follows the number of streams in it, and with it the
+ * fp32 summation order: scores agree to ~1e-5, a beam cut closer than that can fall either way).  sc_push may be mixed in: it also advances the submitted streams. */
 int sc_submit(sc_streams *streams, const int *stream_ids, const float *const *pcm, const int *n_samples,
               const uint8_t *is_final, int n);
 int sc_poll(sc_streams *streams, int min_done, int max_done, int *done_ids /*HOST out*/, int *status /*HOST out, may be NULL*/);

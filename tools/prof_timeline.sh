@@ -12,4 +12,6 @@ DB=$(find /tmp/pk -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB gpurun_out/${TAG}_kernel_stats.csv > /dev/null
 for w in full hpw4 -300; do python tools/rocpd_timeline.py $DB $w 120 > gpurun_out/${TAG}_timeline_$w.txt 2>&1; done
 python tools/rocpd_busy.py $DB > gpurun_out/${TAG}_busy.txt 2>&1
+# ... and of the timed window alone (8 steps of ~25 ms at the end of the run, behind the lock-step pre-roll and the warm-up)
+python tools/rocpd_busy.py $DB 180ms > gpurun_out/${TAG}_busy_timed_window.txt 2>&1
 head -30 gpurun_out/${TAG}_kernel_stats.csv

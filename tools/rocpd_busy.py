@@ -2,7 +2,7 @@
 """GPU occupancy over time from a rocprofv3 rocpd (.db) kernel trace: per queue and for all queues together, the
 fraction of the wall time (between the first and the last kernel of the LAST `frac` of the trace) during which at least
 one kernel was running, and the share of that time with kernels of two queues running at once.
-Usage: python tools/rocpd_busy.py <results.db> [frac=0.4]"""
+Usage: python tools/rocpd_busy.py <results.db> [frac=0.4 | <N>ms = the last N milliseconds of the trace]"""
 import sqlite3
 import sys
 
@@ -23,7 +23,9 @@ def union(iv):
 
 def main():
     con = sqlite3.connect(sys.argv[1])
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+    arg = sys.argv[2] if len(sys.argv) > 2 else "0.4"
+    last_ns = float(arg[:-2]) * 1e6 if arg.endswith("ms") else None
+    frac = 0.4 if last_ns else float(arg)
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
@@ -31,7 +33,7 @@ def main():
     qcol = "queue_id" if "queue_id" in kcols else "stream_id"
     rows = list(cur.execute(f"select start, end, {qcol} from {kd} order by start"))
     t_end = rows[-1][1]
-    t_beg = rows[0][0] + (1.0 - frac) * (t_end - rows[0][0])
+    t_beg = t_end - last_ns if last_ns else rows[0][0] + (1.0 - frac) * (t_end - rows[0][0])
     rows = [r for r in rows if r[0] >= t_beg]
     wall = rows[-1][1] - rows[0][0]
     qs = sorted(set(r[2] for r in rows), key=lambda q: -sum(r[1] - r[0] for r in rows if r[2] == q))
