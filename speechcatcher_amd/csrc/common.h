@@ -54,6 +54,13 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
                              float *XN, const float *Wq, const float *bq, float *Q, int N, hipStream_t st,
                              int by_row = 0, int half_mode = 0);
 
+// gemm.hip: sc_ffn_ln / _h / _s (w_form 0 / 1 / 2) whose split-sum reduce also does the encoder's context hand-off of layer
+// `layer` (sc_ctx_handoff fused into the reduce: one launch less per encoder layer).  blkinfo [nblk][4] comes from
+// sc_ctx_blkinfo (encoder.hip); rows are the nblk * R rows of the block buffer, all in one slab of the workspace.
+struct ScHandoff { const int32_t *blkinfo; int R; float *state; int layer; };
+int sc_ffn_ln_handoff(const float *XN, int M, int D, int F, const void *W1, const float *b1, const void *W2, const float *b2,
+                      float *X, int w_form, const ScHandoff &ho, void *stream);
+
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
 // DPP lane permutations (no LDS round trip, unlike the ds_bpermute behind __shfl)
 template <int CTRL>

@@ -346,6 +346,20 @@ __global__ void ctx_handoff_kernel(float *x, int R, const int *jobs, float *stat
   }
 }
 
+// per-block table of the hand-off chains for ffn_reduce_handoff_kernel (gemm.hip); jobs as for ctx_handoff_kernel
+__global__ void ctx_blkinfo_kernel(const int *jobs, int ns, int nblk, int *blkinfo) {
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) reinterpret_cast<int4 *>(blkinfo)[b] = make_int4(-1, 0, -1, -1);
+  __syncthreads();
+  for (int j = threadIdx.x; j < ns; j += blockDim.x) {
+    const int b0 = jobs[j * 4], nbk = jobs[j * 4 + 1], srow = jobs[j * 4 + 2], has = jobs[j * 4 + 3];
+    for (int i = 0; i < nbk; ++i) {
+      const bool last = i == nbk - 1;
+      reinterpret_cast<int4 *>(blkinfo)[b0 + i] =
+          make_int4(last ? -1 : b0 + i + 1, (i == 0 && !has) ? 1 : 0, last ? srow : -1, (last && has) ? b0 : -1);
+    }
+  }
+}
+
 extern "C" int sc_ctx_handoff(float *x, int R, const int32_t *jobs, int ns, float *state, int layer,
                               int d, void *stream) {
   SC_CHECK_ARG(x && jobs && state, "null pointer");
@@ -566,6 +580,18 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   const bool rowtile_ok = sc_rowtile_proj_supported(d, d) && !(re && atoi(re) == 0);
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
+  // the context hand-off behind every layer rides on the reduce of the fused feed-forward's split sums (one launch less
+  // per layer) when all rows fit one slab of the split-sum workspace; its per-block table lives at the head of `ffh`,
+  // which the fused path does not use.  SC_ENC_HANDOFF=0: separate sc_ctx_handoff launches (A/B switch)
+  const char *he = sc_hook("SC_ENC_HANDOFF");
+  const bool fused_handoff = masked && ns > 0 && ffn_fused && !(he && atoi(he) == 0) && R > 1 &&
+                             sc_workspace_bytes(stream) >= (size_t)(F / 128) * M * d * sizeof(float) &&
+                             (size_t)M * F >= (size_t)nblk * 4;
+  int32_t *blkinfo = reinterpret_cast<int32_t *>(ffh);
+  if (fused_handoff) {
+    ctx_blkinfo_kernel<<<1, 256, 0, (hipStream_t)stream>>>(jobs, ns, nblk, blkinfo);
+    SC_CHECK_LAUNCH();
+  }
   for (int li = 0; li < n_layers; ++li) {
     const sc_enc_layer &w = L[li];
     const bool rowtile = rowtile_ok && w.wqkv_p && w.wo_p;
@@ -597,6 +623,13 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
     } else {
       SC_TRY(sc_gemm(att, nullptr, d, w.wo, w.bo, x, nullptr, d, M, d, d, SC_GEMM_RESIDUAL, 0, stream));
       SC_TRY(sc_layernorm(x, nullptr, d, xn, nullptr, d, M, d, w.ln2_g, w.ln2_b, eps, stream));
+    }
+    if (fused_handoff) {
+      const int wf = (w.w1_s && w.w2_s) ? 2 : (w.w1_h && w.w2_h) ? 1 : 0;
+      const ScHandoff ho{blkinfo, R, past_ctx, li};
+      SC_TRY(sc_ffn_ln_handoff(xn, M, d, F, wf == 2 ? w.w1_s : wf == 1 ? w.w1_h : (const void *)w.w1_p, w.b1,
+                               wf == 2 ? w.w2_s : wf == 1 ? w.w2_h : (const void *)w.w2_p, w.b2, x, wf, ho, stream));
+      continue;
     }
     if (ffn_fused) {
       if (w.w1_s && w.w2_s)   // fp16 hi | lo split of the fp32 weights: fp32-grade on the fp16 matrix pipe

@@ -428,6 +428,55 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
   *dst = acc;
 }
 
+// ... of the fused feed-forward's split sums (residual add into x) TOGETHER with the context hand-off of the contextual
+// block encoder (contextual_block_encoder_layer.py:252-267; ctx_handoff_kernel, encoder.hip: slot 0 of every block <- last row of the stream's previous block, the
+// first block's from / the last block's to the per-stream state): the thread that owns element n of a block's LAST row
+// also writes it where the chain sends it; slot-0 rows are written by nobody else (their own sums are discarded by the
+// hand-off anyway).  blkinfo[blk] = {next block of the chain or -1, 1 if first block of a chain without saved state,
+// state row base (stream * n_layers) if last block else -1, first block of the chain if last and the state is valid else -1}
+__global__ __launch_bounds__(256) void ffn_reduce_handoff_kernel(GemmArgs g, int ksplit, ScHandoff h) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = g.N >> 2;
+  if (idx >= (long)g.M * n4) return;
+  const int m = idx / n4, n = (idx % n4) * 4;
+  const int blk = m / h.R, r = m % h.R;
+  if (r == 0) return;
+  int4 info = make_int4(-1, 0, -1, -1);
+  if (r == h.R - 1) info = *reinterpret_cast<const int4 *>(h.blkinfo + 4 * blk);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z0 = 0; z0 < ksplit; z0 += 8) {
+    float4 p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int z = min(z0 + i, ksplit - 1);
+      p[i] = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (z0 + i < ksplit) {
+        if (z0 + i == 0) acc = p[0];
+        else { acc.x += p[i].x; acc.y += p[i].y; acc.z += p[i].z; acc.w += p[i].w; }
+      }
+    }
+  }
+  if (g.bias) {
+    const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  float4 *dst = reinterpret_cast<float4 *>(g.C + (long)m * g.ldc + n);
+  const float4 o = *dst;
+  acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+  *dst = acc;
+  if (r != h.R - 1) return;
+  if (info.x >= 0) *reinterpret_cast<float4 *>(g.C + (long)info.x * h.R * g.ldc + n) = acc;
+  if (info.y) *reinterpret_cast<float4 *>(g.C + (long)blk * h.R * g.ldc + n) = acc;
+  if (info.z >= 0) {
+    float4 *st = reinterpret_cast<float4 *>(h.state + (long)(info.z + h.layer) * g.N + n);
+    if (info.w >= 0) *reinterpret_cast<float4 *>(g.C + (long)info.w * h.R * g.ldc + n) = *st;
+    *st = acc;
+  }
+}
+
 // split-K reduce fused with the LayerNorm that follows the residual add:
 // one wave per row (N <= 1024).  C[m] = epilogue(sum_z part[z][m]),
 // ln_out[m] = LN(C[m]) * gamma + beta.
@@ -1646,7 +1695,8 @@ extern "C" int sc_ffn_ln_supported(int D, int F) { return (D == 256 || D == 128)
 static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, const float *W1p,
                    const float *b1, const float *W2p, const float *b2, float *X, const float *ln_g,
                    const float *ln_b, float ln_eps, float *ln_out, float *Xout, const float *Wq,
-                   const float *bq, float *Q, int N, void *stream, int w_form = 0) {   // FfnArgs.w_form
+                   const float *bq, float *Q, int N, void *stream, int w_form = 0,   // FfnArgs.w_form
+                   const ScHandoff *ho = nullptr) {
   SC_CHECK_ARG(XN && W1p && W2p && X, "null pointer");
   SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
   SC_CHECK_ARG(!ln_out || (ln_g && ln_b), "LayerNorm parameters missing");
@@ -1683,6 +1733,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     }
     SC_CHECK_ARG(best < 1e29, "workspace too small for sc_ffn_ln");
     SC_CHECK_ARG(!Wq || slab == M, "workspace too small for the fused projection (rows do not fit one slab)");
+    SC_CHECK_ARG(!ho || (slab == M && !rows && !ln_out && !Wq), "context hand-off: all rows in one slab, no row table / LayerNorm");
     if (const char *f = sc_hook("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
       int r = 0, c = 0;
       if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && nch % c == 0 &&
@@ -1712,6 +1763,9 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
       int rc = sc_launch_reduce_ln_proj(g_ws, ngrp, (int)slab, b2, X, Xout, rows, M, D, ln_g, ln_b, ln_eps, ln_out,
                                         Wq, bq, Q, N, st);
       if (rc != SC_OK) return rc;
+    } else if (ho) {
+      const long n4 = (long)slab * (D / 4);
+      ffn_reduce_handoff_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ngrp, *ho);
     } else if (ln_out) {
       float *lo = rows ? ln_out : ln_out + (long)m_done * D;
       gemm_splitk_reduce_ln_kernel<<<cdiv((int)slab, 4), 256, 0, st>>>(g, ngrp, ln_g, ln_b, ln_eps, lo, D);
@@ -1730,6 +1784,13 @@ extern "C" int sc_ffn_ln(const float *XN, const int32_t *rows, int M, int D, int
                          const float *ln_b, float ln_eps, float *ln_out, void *stream) {
   return ffn_run(XN, rows, M, D, F, W1p, b1, W2p, b2, X, ln_g, ln_b, ln_eps, ln_out, nullptr, nullptr, nullptr,
                  nullptr, 0, stream);
+}
+
+int sc_ffn_ln_handoff(const float *XN, int M, int D, int F, const void *W1, const float *b1, const void *W2, const float *b2,
+                      float *X, int w_form, const ScHandoff &ho, void *stream) {
+  SC_CHECK_ARG(ho.blkinfo && ho.state && ho.R > 1 && M % ho.R == 0, "hand-off table");
+  return ffn_run(XN, nullptr, M, D, F, (const float *)W1, b1, (const float *)W2, b2, X, nullptr, nullptr, 0.f, nullptr, nullptr,
+                 nullptr, nullptr, nullptr, 0, stream, w_form, &ho);
 }
 
 // fp16 weights (fragment-packed like W1p / W2p, 2-byte elements): fp16 MFMA inputs, fp32 accumulation and output
