@@ -61,12 +61,6 @@ struct ScHandoff { const int32_t *blkinfo; int R; float *state; int layer; };
 int sc_ffn_ln_handoff(const float *XN, int M, int D, int F, const void *W1, const float *b1, const void *W2, const float *b2,
                       float *X, int w_form, const ScHandoff &ho, void *stream);
 
-// gemm.hip: first launch of an encoder layer - norm1 + Q|K|V projection of one head + the block's masked attention, one
-// workgroup per (block, head); att [nblk * R][d] as sc_enc_attention leaves it (fp32 weights, d in {128, 256}, head dim 16 / 32)
-int sc_enc_qkv_attn_supported(int d, int H);
-int sc_enc_qkv_attn(const float *x, int nblk, int R, int d, int H, const float *ln_g, const float *ln_b, float eps,
-                    const float *wqkv_p, const float *bqkv, int masked, float *att, void *stream);
-
 // ---- device helpers (wave = 64 lanes on gfx950) ---------------------------
 // DPP lane permutations (no LDS round trip, unlike the ds_bpermute behind __shfl)
 template <int CTRL>

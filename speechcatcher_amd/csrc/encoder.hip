@@ -578,9 +578,6 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
   // SC_ENC_ROWTILE=0: LayerNorm + GEMM launches instead (A/B switch)
   const char *re = sc_hook("SC_ENC_ROWTILE");
   const bool rowtile_ok = sc_rowtile_proj_supported(d, d) && !(re && atoi(re) == 0);
-  // SC_ENC_QKVATTN=0: the row-tile Q|K|V launch + the attention launch instead of the fused one (A/B switch)
-  const char *qa = sc_hook("SC_ENC_QKVATTN");
-  const bool qkv_attn_ok = sc_enc_qkv_attn_supported(d, H) && R <= 64 && qa && atoi(qa) == 1;   // experiment: off unless asked for
   int rc;
 #define SC_TRY(call) do { rc = (call); if (rc != SC_OK) return rc; } while (0)
   // the context hand-off behind every layer rides on the reduce of the fused feed-forward's split sums (one launch less
@@ -600,9 +597,6 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
     const bool rowtile = rowtile_ok && w.wqkv_p && w.wo_p;
     const bool proj_h = rowtile && w.wqkv_h && w.wo_h;   // fp16 attention projections (fp16 MFMA inputs, fp32 sums)
     const bool proj_s = rowtile && w.wqkv_s && w.wo_s;   // fp16 hi | lo split: fp32-grade on the fp16 matrix pipe
-    if (rowtile && !proj_s && !proj_h && qkv_attn_ok) {   // norm1 + q|k|v of a head + its block attention in one launch
-      SC_TRY(sc_enc_qkv_attn(x, nblk, R, d, H, w.ln1_g, w.ln1_b, eps, w.wqkv_p, w.bqkv, masked, att, stream));
-    } else {
     if (proj_s) {
       SC_TRY(sc_rowtile_proj_s(x, d, M, d, w.ln1_g, w.ln1_b, eps, w.wqkv_s, w.bqkv, 3 * d, nullptr, qkv, 3 * d,
                                nullptr, nullptr, nullptr, stream));
@@ -617,7 +611,6 @@ extern "C" int sc_encoder_layers(const sc_enc_layer *L, int n_layers, float *x, 
       SC_TRY(sc_gemm(xn, nullptr, d, w.wqkv, w.bqkv, qkv, nullptr, 3 * d, M, 3 * d, d, 0, 0, stream));
     }
     SC_TRY(sc_enc_attention(qkv, att, nblk, R, H, d, masked, stream));
-    }
     if (proj_s) {
       SC_TRY(sc_rowtile_proj_s(att, d, M, d, nullptr, nullptr, eps, w.wo_s, w.bo, d, x, x, d, w.ln2_g, w.ln2_b, xn,
                                stream));

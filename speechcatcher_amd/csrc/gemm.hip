@@ -1685,253 +1685,6 @@ extern "C" int sc_rowtile_proj_s(const float *A, int lda, int M, int D, const fl
 }
 
 
-// ===========================================================================
-// Encoder layer, first launch (round 4): norm1 + the Q | K | V projection of ONE head + the block's masked attention
-// for that head, one workgroup per (block, head)  (contextual_block_encoder_layer.py:212-250: x = norm1(x);
-// self_attn(x, x, x, mask); multi_head_attention.py:60-110).  Replaces the row-tile Q|K|V launch + the attention launch
-// (22.7 us per layer at 1344 rows -> one launch): q, k, v never leave LDS.
-//   two waves per 16-column tile of the head's q | k | v (one half of K each; the B fragments - 8 KB per wave - sit in
-//   registers, requested first), all 16 * RTT rows of the block; the second half's sums are added to the first's in
-//   LDS.  Then lane = query row, the 6 * DK / 16 waves take the keys round-robin (online softmax) and their partial
-//   states are merged in wave order, as in enc_attention_split_kernel.
-// x rows of the block: x + (blk * R + r) * D;  att[(blk * R + r) * D + head * DK + c].
-// ===========================================================================
-struct EncQkvAttnArgs {
-  const float *x, *ln_g, *ln_b, *Wp, *bias;
-  float *att;
-  int R, H, masked;
-  float eps;
-};
-
-// first region: the row tile [RT][D+4], later the merge buffer [6*DK/16][RT][DK+2] - whichever is larger
-__host__ __device__ static inline int enc_qkv_attn_region(int D, int DK, int RT) {
-  const int a = RT * (D + 4), b = 6 * (DK / 16) * RT * (DK + 2);
-  return a > b ? a : b;
-}
-__host__ __device__ static inline size_t enc_qkv_attn_lds_bytes(int D, int DK, int RT) {
-  return (size_t)(enc_qkv_attn_region(D, DK, RT) + RT * (DK + 1) + 2 * RT * DK) * sizeof(float);
-}
-
-template <int D, int DK, int RTT>
-__global__ __launch_bounds__(64 * 6 * (DK / 16)) void enc_qkv_attn_kernel(EncQkvAttnArgs p) {
-  // NC column tiles of q | k | v per head, two waves per tile (k-blocks [0, KI1/2) and [KI1/2, KI1)): NW waves
-  constexpr int NC = 3 * (DK / 16), NW = 2 * NC, NT = 64 * NW, RT = 16 * RTT, KI1 = D / 32, KH = KI1 / 2;
-  constexpr int LDX = D + 4, LQ = DK + 1, LM = DK + 2;
-  extern __shared__ __attribute__((aligned(16))) float eqa_smem[];
-  float *Xs = eqa_smem;                  // [RT][LDX] norm1(x) of the block, rows >= R zero
-  float *Qs = eqa_smem + enc_qkv_attn_region(D, DK, RT);   // [RT][LQ]
-  float *Ks = Qs + RT * LQ;              // [RT][DK]
-  float *Vs = Ks + RT * DK;              // [RT][DK]
-  float *Ms = eqa_smem;                  // [NW][RT][LM] partial softmax states (the row tile is dead by then)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, kk = lane >> 4;
-  const int blk = blockIdx.x / p.H, head = blockIdx.x % p.H, R = p.R;
-  const int ct = wave % NC, kh = wave / NC;             // column tile of the head's q | k | v, K half
-  const int which = ct / (DK / 16), half = ct % (DK / 16);
-  const int tile = (which * D + head * DK) / 16 + half;   // 16-column tile of [3D] this wave projects
-  float4 bf[KH][2];
-  {
-    const float4 *wp = reinterpret_cast<const float4 *>(p.Wp) + ((long)tile * KI1 + kh * KH) * 128 + lane;
-#pragma unroll
-    for (int ki = 0; ki < KH; ++ki) {
-      bf[ki][0] = wp[ki * 128];
-      bf[ki][1] = wp[ki * 128 + 64];
-    }
-  }
-  const float bias = (p.bias && kh == 0) ? p.bias[which * D + head * DK + half * 16 + r] : 0.f;
-  // LayerNorm parameters of the 16 columns-of-four a lane owns in the 16-lanes-per-row pass below
-  constexpr int Q4 = D / 64;
-  const int sub = tid & 15;
-  float4 gm[Q4], bt[Q4];
-#pragma unroll
-  for (int q = 0; q < Q4; ++q) {
-    gm[q] = *reinterpret_cast<const float4 *>(p.ln_g + 4 * (sub + 16 * q));
-    bt[q] = *reinterpret_cast<const float4 *>(p.ln_b + 4 * (sub + 16 * q));
-  }
-  {
-    constexpr int NQ = (RT * (D / 4) + NT - 1) / NT;
-    float4 stage[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int e = tid + q * NT, i = e / (D / 4), c4 = e % (D / 4);
-      stage[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < R) stage[q] = *reinterpret_cast<const float4 *>(p.x + ((long)blk * R + i) * D + 4 * c4);
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int e = tid + q * NT, i = e / (D / 4), c4 = e % (D / 4);
-      if (e < RT * (D / 4)) *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * c4) = stage[q];
-    }
-  }
-  __syncthreads();
-  for (int i = tid >> 4; i < R; i += NT / 16) {   // LayerNorm in place: 16 lanes per row (uniform per 16-lane group)
-    float4 x[Q4];
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q4; ++q) {
-      x[q] = *reinterpret_cast<const float4 *>(Xs + i * LDX + 4 * (sub + 16 * q));
-      sum += (x[q].x + x[q].y) + (x[q].z + x[q].w);
-    }
-    const float mean = group_sum<16>(sum) / (float)D;
-    float q2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q4; ++q) {
-      const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, e = x[q].w - mean;
-      q2 += (a * a + b * b) + (c * c + e * e);
-    }
-    const float rstd = 1.0f / sqrtf(group_sum<16>(q2) / (float)D + p.eps);
-#pragma unroll
-    for (int q = 0; q < Q4; ++q)
-      *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * (sub + 16 * q)) =
-          make_float4((x[q].x - mean) * rstd * gm[q].x + bt[q].x, (x[q].y - mean) * rstd * gm[q].y + bt[q].y,
-                      (x[q].z - mean) * rstd * gm[q].z + bt[q].z, (x[q].w - mean) * rstd * gm[q].w + bt[q].w);
-  }
-  __syncthreads();
-  float *dst = which == 0 ? Qs : which == 1 ? Ks : Vs;
-  const int ld = which == 0 ? LQ : DK;
-  {
-    f32x4 acc[RTT];
-#pragma unroll
-    for (int rt = 0; rt < RTT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NS = RTT * KH;
-    const float *ab = Xs + r * LDX + kh * KH * 32 + 8 * kk;
-    float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      const int ki = st / RTT, rt = st % RTT;
-      float4 n0 = a0, n1 = a1;
-      if (st + 1 < NS) {
-        const float *ap = ab + ((st + 1) % RTT) * 16 * LDX + ((st + 1) / RTT) * 32;
-        n0 = *reinterpret_cast<const float4 *>(ap);
-        n1 = *reinterpret_cast<const float4 *>(ap + 4);
-      }
-      acc[rt] = ffn_mfma8(acc[rt], a0, a1, bf[ki][0], bf[ki][1]);
-      a0 = n0;
-      a1 = n1;
-    }
-    // the two K halves of a tile: the first half's wave stores, the second adds (fixed order)
-    if (kh == 0) {
-#pragma unroll
-      for (int rt = 0; rt < RTT; ++rt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[(rt * 16 + 4 * kk + j) * ld + half * 16 + r] = acc[rt][j] + bias;
-    }
-    __syncthreads();
-    if (kh == 1) {
-#pragma unroll
-      for (int rt = 0; rt < RTT; ++rt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[(rt * 16 + 4 * kk + j) * ld + half * 16 + r] += acc[rt][j];
-    }
-  }
-  __syncthreads();
-  float acc[DK];
-#pragma unroll
-  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const bool live = lane < R && !(p.masked && lane == 0);
-  if (live) {
-    float q[DK];
-#pragma unroll
-    for (int c = 0; c < DK; ++c) q[c] = Qs[lane * LQ + c];
-    const float scale = sqrtf((float)DK);
-    const int nkeys = p.masked ? R - 1 : R;
-    for (int j = wave; j < nkeys; j += NW) {
-      float sdot = 0.f;
-#pragma unroll
-      for (int c = 0; c < DK; ++c) sdot = fmaf(q[c], Ks[j * DK + c], sdot);
-      sdot = sdot / scale;
-      if (sdot > m) {
-        const float corr = expf(m - sdot);
-        l *= corr;
-#pragma unroll
-        for (int c = 0; c < DK; ++c) acc[c] *= corr;
-        m = sdot;
-      }
-      const float pj = expf(sdot - m);
-      l += pj;
-#pragma unroll
-      for (int c = 0; c < DK; ++c) acc[c] = acc[c] + pj * Vs[j * DK + c];
-    }
-  }
-  if (lane < RT) {   // (Xs is dead: every wave passed the barriers behind the projection)
-    float *ms = Ms + (wave * RT + lane) * LM;
-    ms[0] = m;
-    ms[1] = l;
-#pragma unroll
-    for (int c = 0; c < DK; ++c) ms[2 + c] = acc[c];
-  }
-  __syncthreads();
-  for (int e = tid; e < R * (DK / 4); e += NT) {
-    const int i = e / (DK / 4), c4 = e % (DK / 4);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!(p.masked && i == 0)) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) mx = fmaxf(mx, Ms[(w * RT + i) * LM]);
-      float lt = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const float *ms = Ms + (w * RT + i) * LM;
-        const float f = expf(ms[0] - mx);  // 0 for a wave without keys (max = -inf)
-        lt += ms[1] * f;
-        o.x += ms[2 + 4 * c4] * f;
-        o.y += ms[3 + 4 * c4] * f;
-        o.z += ms[4 + 4 * c4] * f;
-        o.w += ms[5 + 4 * c4] * f;
-      }
-      const float inv = 1.0f / lt;
-      o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-    }
-    reinterpret_cast<float4 *>(p.att + ((long)blk * R + i) * D + head * DK)[c4] = o;
-  }
-}
-
-template <int D, int DK, int RTT>
-static void launch_enc_qkv_attn_rtt(const EncQkvAttnArgs &p, int nblk, hipStream_t st) {
-  const size_t lds = enc_qkv_attn_lds_bytes(D, DK, 16 * RTT);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&enc_qkv_attn_kernel<D, DK, RTT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  enc_qkv_attn_kernel<D, DK, RTT><<<nblk * p.H, 64 * 6 * (DK / 16), lds, st>>>(p);
-}
-template <int D, int DK>
-static void launch_enc_qkv_attn(const EncQkvAttnArgs &p, int nblk, hipStream_t st) {
-  switch (cdiv(p.R, 16)) {
-    case 1: launch_enc_qkv_attn_rtt<D, DK, 1>(p, nblk, st); break;
-    case 2: launch_enc_qkv_attn_rtt<D, DK, 2>(p, nblk, st); break;
-    case 3: launch_enc_qkv_attn_rtt<D, DK, 3>(p, nblk, st); break;
-    default: launch_enc_qkv_attn_rtt<D, DK, 4>(p, nblk, st); break;
-  }
-}
-
-int sc_enc_qkv_attn_supported(int d, int H) {
-  return (d == 256 || d == 128) && d % H == 0 && (d / H == 32 || d / H == 16);
-}
-
-int sc_enc_qkv_attn(const float *x, int nblk, int R, int d, int H, const float *ln_g, const float *ln_b, float eps,
-                    const float *wqkv_p, const float *bqkv, int masked, float *att, void *stream) {
-  SC_CHECK_ARG(x && wqkv_p && att && ln_g && ln_b, "null pointer");
-  SC_CHECK_ARG(sc_enc_qkv_attn_supported(d, H) && R >= 1 && R <= 64, "unsupported dimensions");
-  if (nblk <= 0) return SC_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const EncQkvAttnArgs p{x, ln_g, ln_b, wqkv_p, bqkv, att, R, H, masked, eps};
-  ProfScope prof = sc_prof_begin(st);
-  const int dk = d / H;
-  if (d == 256 && dk == 32) launch_enc_qkv_attn<256, 32>(p, nblk, st);
-  else if (d == 256) launch_enc_qkv_attn<256, 16>(p, nblk, st);
-  else if (dk == 32) launch_enc_qkv_attn<128, 32>(p, nblk, st);
-  else launch_enc_qkv_attn<128, 16>(p, nblk, st);
-  const double M = (double)nblk * R;
-  // algorithmic: Q|K|V projection + q.k / p.v of the block attention; x in, att out, Wqkv once
-  sc_prof_end(prof, SC_PROF_ROWTILE_PROJ, 2.0 * M * d * 3 * d + 4.0 * M * R * d, 4.0 * (2.0 * M * d + 3.0 * (double)d * d));
-  SC_CHECK_LAUNCH();
-  return SC_OK;
-}
-
 // tallest row tile (16 * rtt rows) per weight form: the split form carries two sets of accumulators and spills
 // beyond 48 rows at D = 256 (tools/kernel_resources.py)
 static inline int ffn_rtt_max(int D, int w_form) { return (w_form == 2 && D == 256) ? 3 : 5; }
