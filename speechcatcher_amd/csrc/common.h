@@ -139,11 +139,19 @@ static __device__ long long sc_phase_stamps[4][32];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (int)(gridDim.x * gridDim.y) >= SC_PHASE_MIN_GRID) \
       sc_phase_stamps[k][i] = (long long)__builtin_amdgcn_s_memtime();                       \
   } while (0)
+// ... behind a wait for everything the wave has in flight: the stamp then closes a memory round trip (changes the timing
+// a little: the loads of the next stage are not under way yet)
+#define SC_STAMP_WAIT(k, i)                                                                   \
+  do {                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0);                                                            \
+    SC_STAMP(k, i);                                                                           \
+  } while (0)
 #define SC_PHASE_GETTER(name)                                                                 \
   extern "C" int name(long long *out) {                                                       \
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_phase_stamps), sizeof(long long) * 4 * 32) == hipSuccess ? 0 : -1; \
   }
 #else
 #define SC_STAMP(k, i) do {} while (0)
+#define SC_STAMP_WAIT(k, i) do {} while (0)
 #define SC_PHASE_GETTER(name)
 #endif

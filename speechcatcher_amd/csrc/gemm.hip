@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       const int m = min(m0 + (threadIdx.x + q * 512) / C4, p.M - 1);
       rowv[q] = p.rows ? p.rows[m] : m;
     }
+    SC_STAMP_WAIT(2, 1);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int e = threadIdx.x + q * 512, i = e / C4, c4 = e % C4;
@@ -1070,8 +1071,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       if (grp == 0 && m0 + i < p.M) *reinterpret_cast<float4 *>(p.Xout + row * D + 4 * c4) = x;
       *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * c4) = x;
     }
+    SC_STAMP_WAIT(2, 2);
     load_b1(grp * p.cpw);   // GEMM 1's first weight fragments travel during the LayerNorm (the partial sums have arrived)
     __syncthreads();
+    SC_STAMP(2, 3);
     for (int i = threadIdx.x >> 4; i < RT; i += 32) {   // uniform per 16-lane row group
       float4 x[Q4];
       float sum = 0.f;
@@ -1105,6 +1108,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
           *reinterpret_cast<float4 *>(Xs + i * LDX + 4 * (sub + 16 * q)) = o;
       }
     }
+    SC_STAMP(2, 4);
   } else {
     long rowv[NQ];
 #pragma unroll
@@ -1144,7 +1148,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 
   if (!PRO) load_b1(grp * p.cpw);
   __syncthreads();
-  SC_STAMP(PRO ? 2 : 3, 1);
+  SC_STAMP(PRO ? 2 : 3, PRO ? 5 : 1);
+  if (PRO) SC_STAMP_WAIT(2, 6);   // (the first weight fragments are in)
 
   for (int cc = 0; cc < p.cpw; ++cc) {
     const int chunk = grp * p.cpw + cc;
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
         Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] =
             WS ? acc2[rt][t][j] + acc2c[WS ? rt : 0][WS ? t : 0][j] * (1.f / 2048.f) : acc2[rt][t][j];
   __syncthreads();
-  SC_STAMP(PRO ? 2 : 3, 2);
+  SC_STAMP(PRO ? 2 : 3, PRO ? 7 : 2);
   float *dst = p.part + ((long)grp * p.M + m0) * D;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
     }
   }
-  SC_STAMP(PRO ? 2 : 3, 3);
+  SC_STAMP(PRO ? 2 : 3, PRO ? 8 : 3);
 }
 SC_PHASE_GETTER(sc_phase_debug_ffn)
 

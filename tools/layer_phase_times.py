@@ -19,7 +19,8 @@ bench.roll(sb, bench.make_audio(S, 50), 36)      # (the bench's window: T ~ 600 
 torch.cuda.synchronize()
 names = {0: ["touch+partials+x", "LayerNorm", "QKV proj MFMA", "split-K reduce+cache append", "attention walk", "merge", "out-proj MFMA", "store"],
          1: ["touch+partials+x", "LayerNorm", "q proj MFMA", "split-K reduce", "attention walk", "merge", "out-proj MFMA", "store"],
-         2: ["reduce heads + LN3 + W1 frags", "GEMM1+GEMM2 (cpw chunks)", "store partial"]}
+         2: ["row ids (round trip)", "residual + head partials -> LDS (round trip)", "barrier", "LayerNorm3", "barrier",
+             "W1 fragments still under way", "GEMM1+GEMM2 (cpw chunks)", "store partial"]}
 for fn, kinds in (("sc_phase_debug_layer", (0, 1)), ("sc_phase_debug_ffn", (2,))):
     buf = (C.c_longlong * 128)()
     f = getattr(sb.lib, fn)
