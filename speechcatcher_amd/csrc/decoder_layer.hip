@@ -271,6 +271,16 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       }
     }
     if (!FIRST) {
+      // the residual rows and the bias are requested TOGETHER with the first batch of partial sums: behind them they were
+      // one more dependent round trip of ~2 us (rows another XCD wrote; tools/boundary_probe.hip)
+      float4 xi[QN], pbv[QN];
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        const int e = tid + NTH * q, i = min(e / C4, W - 1), c4 = e % C4;
+        xi[q] = *reinterpret_cast<const float4 *>(p.xin + ((long)s * W + i) * D + 4 * c4);
+        pbv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.pbias) pbv[q] = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
+      }
       float4 yv[QN];
       for (int z0 = 0; z0 < p.npart; z0 += ZB) {
         float4 pv[QN][ZB];
@@ -297,14 +307,9 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
         const int e = tid + NTH * q, i = e / C4, c4 = e % C4;
-        if (i < W) {
-          const long row = (long)s * W + i;
-          const float4 xi = *reinterpret_cast<const float4 *>(p.xin + row * D + 4 * c4);
-          float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.pbias) pb = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
-          xv[q] = make_float4(xi.x + (yv[q].x + pb.x), xi.y + (yv[q].y + pb.y), xi.z + (yv[q].z + pb.z),
-                              xi.w + (yv[q].w + pb.w));
-        }
+        if (i < W)
+          xv[q] = make_float4(xi[q].x + (yv[q].x + pbv[q].x), xi[q].y + (yv[q].y + pbv[q].y), xi[q].z + (yv[q].z + pbv[q].z),
+                              xi[q].w + (yv[q].w + pbv[q].w));
       }
     }
     if (PF && !SELF) {
