@@ -1,0 +1,126 @@
+// Kernel boundary against a grid-wide barrier inside ONE persistent kernel (lead 0): what does a phase
+// change cost on this part when every workgroup hands a few KB to a workgroup of another XCD?
+//   hipcc --offload-arch=gfx950 -O3 [-DFENCE_ALL=1] tools/grid_barrier_probe.hip -o /tmp/grid_barrier_probe && timeout 120 /tmp/grid_barrier_probe
+// 256 workgroups x 1024 threads (one per CU, the launch shape of the four-head decoder layer kernels).  A "phase": every
+// workgroup writes `kb` KB (its partial products), then reads the `kb` KB its neighbour (workgroup id + 1: another XCD) wrote
+// in the same phase and checks them.
+//   graph      : phase = two kernels (write, read) of a captured hipGraph, N phases per graph launch
+//   persistent : phase = write, grid barrier, read, grid barrier inside one kernel.  Barrier = __threadfence() (release),
+//                one atomicAdd per workgroup on a device counter, spin on it, __threadfence() (acquire)
+// Prints us per phase for both, and the barrier alone (persistent kernel without the copies).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// FENCE_ALL = 1: every thread fences (the textbook form); 0: the workgroup barrier orders the stores of the workgroup
+// before ONE thread's device-scope release / acquire (one L2 write-back + invalidate per workgroup instead of one per wave)
+#ifndef FENCE_ALL
+#define FENCE_ALL 0
+#endif
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned target) {
+  if (FENCE_ALL) __threadfence();   // release: this workgroup's stores are visible device-wide
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!FENCE_ALL) __threadfence();
+    atomicAdd(counter, 1u);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    if (!FENCE_ALL) __threadfence();
+  }
+  __syncthreads();
+  if (FENCE_ALL) __threadfence();   // acquire: no stale lines of the other workgroups' slices
+}
+
+__global__ __launch_bounds__(1024) void write_k(float4 *buf, int n4, int phase) {
+  float4 *d = buf + (long)blockIdx.x * n4;
+  for (int i = threadIdx.x; i < n4; i += 1024) d[i] = make_float4(phase, blockIdx.x, i, 1.f);
+}
+__global__ __launch_bounds__(1024) void read_k(const float4 *buf, int n4, int phase, unsigned *bad) {
+  const int src = (blockIdx.x + 1) % gridDim.x;
+  const float4 *s = buf + (long)src * n4;
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = s[i];
+    if (v.x != (float)phase || v.y != (float)src || v.z != (float)i) atomicAdd(bad, 1u);
+  }
+}
+
+__global__ __launch_bounds__(1024) void persistent_k(float4 *buf, int n4, int phases, unsigned *counter, unsigned *bad, int copies) {
+  const unsigned G = gridDim.x;
+  unsigned epoch = 0;
+  for (int ph = 0; ph < phases; ++ph) {
+    if (copies) {
+      float4 *d = buf + (long)blockIdx.x * n4;
+      for (int i = threadIdx.x; i < n4; i += 1024) d[i] = make_float4(ph, blockIdx.x, i, 1.f);
+    }
+    grid_barrier(counter, ++epoch * G);
+    if (copies) {
+      const int src = (blockIdx.x + 1) % G;
+      const float4 *s = buf + (long)src * n4;
+      for (int i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = s[i];
+        if (v.x != (float)ph || v.y != (float)src || v.z != (float)i) atomicAdd(bad, 1u);
+      }
+    }
+    grid_barrier(counter, ++epoch * G);   // nobody overwrites a slice that is still being read
+  }
+}
+
+int main() {
+  const int G = 256, N = 100;
+  hipStream_t st;
+  CHECK(hipStreamCreate(&st));
+  unsigned *counter, *bad;
+  CHECK(hipMalloc(&counter, 4));
+  CHECK(hipMalloc(&bad, 4));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int kb : {4, 16, 40}) {
+    const int n4 = kb * 1024 / 16;
+    float4 *buf;
+    CHECK(hipMalloc(&buf, (size_t)G * n4 * 16));
+    CHECK(hipMemset(bad, 0, 4));
+    // ---- graph of 2 N kernels
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int ph = 0; ph < N; ++ph) {
+      write_k<<<G, 1024, 0, st>>>(buf, n4, ph);
+      read_k<<<G, 1024, 0, st>>>(buf, n4, ph, bad);
+    }
+    CHECK(hipStreamEndCapture(st, &g));
+    CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    float best_g = 1e30f, best_p = 1e30f, best_b = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+      CHECK(hipEventRecord(e0, st));
+      CHECK(hipGraphLaunch(ge, st));
+      CHECK(hipEventRecord(e1, st));
+      CHECK(hipStreamSynchronize(st));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) best_g = ms < best_g ? ms : best_g;
+    }
+    // ---- persistent kernel, with and without the copies
+    for (int copies = 1; copies >= 0; --copies)
+      for (int rep = 0; rep < 6; ++rep) {
+        CHECK(hipMemsetAsync(counter, 0, 4, st));
+        CHECK(hipEventRecord(e0, st));
+        persistent_k<<<G, 1024, 0, st>>>(buf, n4, N, counter, bad, copies);
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) (copies ? best_p : best_b) = ms < (copies ? best_p : best_b) ? ms : (copies ? best_p : best_b);
+      }
+    unsigned hb = 0;
+    CHECK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
+    printf("%3d KB per workgroup and phase: graph of two kernels %6.2f us per phase | persistent kernel, two grid barriers %6.2f us per phase "
+           "(barriers alone %5.2f us = %4.2f us each) | wrong values read: %u\n",
+           kb, best_g * 1000.f / N, best_p * 1000.f / N, best_b * 1000.f / N, best_b * 1000.f / N / 2, hb);
+    CHECK(hipGraphExecDestroy(ge));
+    CHECK(hipGraphDestroy(g));
+    CHECK(hipFree(buf));
+  }
+  return 0;
+}
