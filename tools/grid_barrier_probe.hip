@@ -1,6 +1,6 @@
 // Kernel boundary against a grid-wide barrier inside ONE persistent kernel (lead 0): what does a phase
 // change cost on this part when every workgroup hands a few KB to a workgroup of another XCD?
-//   hipcc --offload-arch=gfx950 -O3 [-DFENCE_ALL=1] tools/grid_barrier_probe.hip -o /tmp/grid_barrier_probe && timeout 120 /tmp/grid_barrier_probe
+//   hipcc --offload-arch=gfx950 -O3 [-DFENCE_ALL=1|2] tools/grid_barrier_probe.hip -o /tmp/grid_barrier_probe && timeout 120 /tmp/grid_barrier_probe
 // 256 workgroups x 1024 threads (one per CU, the launch shape of the four-head decoder layer kernels).  A "phase": every
 // workgroup writes `kb` KB (its partial products), then reads the `kb` KB its neighbour (workgroup id + 1: another XCD) wrote
 // in the same phase and checks them.
@@ -20,16 +20,23 @@
 #define FENCE_ALL 0
 #endif
 __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned target) {
-  if (FENCE_ALL) __threadfence();   // release: this workgroup's stores are visible device-wide
+  if (FENCE_ALL == 1) __threadfence();   // release: this workgroup's stores are visible device-wide
   __syncthreads();
   if (threadIdx.x == 0) {
+#if FENCE_ALL == 2   // release-only before, acquire-only behind the counter (L2 write-back, then invalidate: half of two full fences)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    atomicAdd(counter, 1u);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
     if (!FENCE_ALL) __threadfence();
     atomicAdd(counter, 1u);
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
     if (!FENCE_ALL) __threadfence();
+#endif
   }
   __syncthreads();
-  if (FENCE_ALL) __threadfence();   // acquire: no stale lines of the other workgroups' slices
+  if (FENCE_ALL == 1) __threadfence();   // acquire: no stale lines of the other workgroups' slices
 }
 
 __global__ __launch_bounds__(1024) void write_k(float4 *buf, int n4, int phase) {
