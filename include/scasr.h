@@ -500,8 +500,12 @@ typedef struct sc_stream_options {
   int32_t max_chunk_samples; /* longest single call (0: 32768) */
   int32_t strict_reference;  /* reset() leaves the stale CTC table / PE counter like the reference (scorers.py:342-350) */
   int32_t kv_half;           /* K|V caches in fp16 (fp32 arithmetic): BASELINE configs[4]'s storage mode; 0 = fp32 */
-  int32_t kv_pool_rows;      /* rows of the self-attention K|V pool per stream and layer (capacity; 0: 1.5 x max_tokens + 4 x beam,
-                                at most max_tokens x beam = one row per (position, hypothesis)) */
+  int32_t kv_pool_rows;      /* rows of the self-attention K|V pool per stream and layer (capacity; at most max_tokens x beam =
+                                one row per (position, hypothesis)).  0 = default: that maximum - a stream can then never run out
+                                of rows before max_tokens - unless it would take more than a quarter of the device's free memory
+                                (thousands of streams): then what that budget holds, at least 1.5 x max_tokens + 4 x beam.  A
+                                stream that needs more rows than the pool has fails with SC_ERR_CAPACITY at the step that is
+                                actually TAKEN (a step that is rolled back or rewound never fails) and is reset */
 } sc_stream_options;
 
 typedef struct sc_stream_info_t {

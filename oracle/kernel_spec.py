@@ -627,6 +627,13 @@ class SpecBackend:
                 continue
             rows = slice(s * W, s * W + nh)
             ids = sb.pre_ids[rows].to(torch.long)
+            if not float(wc) > 0.0:     # no CTC scorer (beam_search.py:925): decoder-only, "ctc" never enters the scores
+                comb = wd * sb.logp[rows]
+                order = torch.sort(comb, dim=-1, descending=True, stable=True).indices[:, :W]
+                sb.cand_tok[rows] = order.to(torch.int32)
+                sb.cand_score[rows] = comb.gather(1, order)
+                sb.cand_ctc[rows] = 0.0
+                continue
             lpsi = torch.full((nh, V), LOGZERO)
             lpsi.scatter_(1, ids, sb.psi[rows])
             lpsi[:, cfg.eos_id] = sb.psi_eos[rows]
@@ -737,7 +744,10 @@ class SpecBackend:
             if not self.decoder_layers(sb, fuse_logits=True):      # logits, or after_norm(x) in dxn
                 self.gemm(sb.dxn, rows, d, w.out_w, w.out_b, sb.logits, rows, cfg.vocab_size, n, cfg.vocab_size, d)
         self.logsoftmax_topk(sb)
-        self.ctc_prefix_scan(sb)
+        use_ctc = sb.search.ctc_weight > 0
+        if use_ctc:
+            self.ctc_prefix_scan(sb)
         self.fuse_topw(sb)
         self.beam_prune(sb)
-        self.ctc_gather_state(sb)
+        if use_ctc:
+            self.ctc_gather_state(sb)

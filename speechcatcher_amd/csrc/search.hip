@@ -948,6 +948,18 @@ __global__ __launch_bounds__(256) void fuse_topw_kernel(sc_search sb) {
   if (!CTRL(s, SC_C_ACTIVE) || h >= CTRL(s, SC_C_NHYP)) return;
   const int V = sb.V, K = sb.K, W = sb.W, tid = threadIdx.x;
   float *comb = smem, *ctc = smem + V;
+  if (!(sb.w_ctc > 0.f)) {
+    // ctc_weight <= 0: the reference builds NO CTC scorer (beam_search.py:925) - the search is decoder-only, the top-W of
+    // w_dec * logp are the first W pre-beam candidates (the same composite keys: ties towards the lowest id), and
+    // Hypothesis.scores never gets a "ctc" entry (cand_ctc = 0 keeps sc_ctc at 0)
+    if (tid < W) {
+      const int c = sb.pre_ids[(long)row * K + tid];
+      sb.cand_tok[(long)row * W + tid] = c;
+      sb.cand_score[(long)row * W + tid] = __fmul_rn(sb.w_dec, sb.logp[(long)row * V + c]);
+      sb.cand_ctc[(long)row * W + tid] = 0.f;
+    }
+    return;
+  }
   const float s_prev = CTRL(s, SC_C_HAS) ? sb.ctc_s[((long)CTRL(s, SC_C_CUR) * sb.S + s) * W + h] : 0.f;
   // ---- fast path: only the K pre-beam candidates and eos carry a CTC score
   // above logzero, so the top-W of the fused scores over V is the top-W over
@@ -1307,9 +1319,10 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
     SC_TRY(sc_gemm(sb.dxn, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, n, sb.V, sb.d, 0, 0, stream));
   }
   SC_TRY(sc_logsoftmax_topk(sbp, stream));
-  SC_TRY(sc_ctc_prefix_scan_split(sbp, scan_split_min, stream));
+  const bool use_ctc = sb.w_ctc > 0.f;   // ctc_weight <= 0: decoder-only search (beam_search.py:925), no scan, no CTC state
+  if (use_ctc) SC_TRY(sc_ctc_prefix_scan_split(sbp, scan_split_min, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));
   SC_TRY(sc_beam_prune(sbp, stream));
-  SC_TRY(sc_ctc_gather_state(sbp, stream));
+  if (use_ctc) SC_TRY(sc_ctc_gather_state(sbp, stream));
   return SC_OK;
 }

@@ -1197,11 +1197,11 @@ int tick_collect(sc_streams *b) {
   // ---- the accept / stop rules of the step loop (:759-821)
   for (int s : b->tick_active) {
     Run &r = b->run[s];
-    if (b->flags_host[S + s]) {   // the prune kernel found no free K|V pool row for the new hypotheses: the stream cannot go on
-      b->flags_host[S + s] = 0;
-      fault_stream(b, s, SC_ERR_CAPACITY, "self-attention K|V pool exhausted (kv_pool_rows / max_tokens)");
-      continue;
-    }
+    // the prune kernel found no free K|V pool row for the new hypotheses' newest tokens: the side it wrote cannot be
+    // decoded from.  That only matters if the step is TAKEN and stays taken (see below): a step that is rolled back
+    // (stop_bbd) or rewound when the block closes leaves the current side, which is fully valid.
+    const bool kv_full = b->flags_host[S + s] != 0;
+    b->flags_host[S + s] = 0;
     const int f = b->flags_host[s];
     const bool f_any = f & F_ANY_EOS, f_best = f & F_BEST_EOS, f_all = f & F_ALL_EOS, f_rep = f & F_REPEAT;
     r.out += 1;
@@ -1211,6 +1211,10 @@ int tick_collect(sc_streams *b) {
     const bool stop_all = !stop_eos && !stop_bbd && f_all && r.fin;
     const bool accept = !(stop_eos || stop_bbd || stop_all);
     const bool take = stop_eos || stop_all || accept;
+    if (kv_full && take && !(!accept && r.pidx > 1 && r.pvalid)) {   // (not accepted + rewind pending: finish_block goes back to H_in)
+      fault_stream(b, s, SC_ERR_CAPACITY, "self-attention K|V pool exhausted (kv_pool_rows / max_tokens)");
+      continue;
+    }
     if (stop_bbd) r.out -= 1;
     if (take) {
       r.nhp = r.nhyp;
@@ -1749,16 +1753,34 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   }
   sb.tct = (b->TCAP + 3) / 4 * 4;
   A(sb.ctcxT, (size_t)S * V * sb.tct);
-  // self-attention K|V: a pool of rows per stream and layer (scasr.h: sc_search.skv) - a beam's hypotheses share almost all
-  // of their history, so 1.5 rows per token position (+ the W rows a step appends, with slack) instead of W
+  // self-attention K|V: a pool of rows per stream and layer (scasr.h: sc_search.skv).  A beam's hypotheses share almost
+  // all of their history (1.05-1.2 distinct rows per token position measured), but nothing bounds that: two or three
+  // alternatives that survive a whole utterance need 2-3 rows per position.  Default: ONE ROW PER (position, hypothesis)
+  // - a stream can then never run out of rows before max_tokens - unless that takes more than a quarter of the device's
+  // free memory (thousands of streams): then as many rows as that budget holds, never fewer than 1.5 per position + 4W.
+  // Rows are handed out lowest-first, so a larger pool costs address space, not traffic.
   {
     const long full = (long)b->LCAP * W;
-    long rows = o->kv_pool_rows > 0 ? o->kv_pool_rows : (long)b->LCAP + b->LCAP / 2 + 4 * W;
+    long rows = o->kv_pool_rows;
+    if (rows <= 0) {
+      const long floor_rows = (long)b->LCAP + b->LCAP / 2 + 4 * W;
+      size_t free_b = 0, total_b = 0;
+      rows = floor_rows;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t per_row = (size_t)S * c.dec_layers * 2 * d * sizeof(float) / kvdiv;
+        rows = std::max<long>(floor_rows, (long)std::min<size_t>((size_t)full, free_b / 4 / per_row));
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     rows = std::max<long>(std::min(rows, full), 2 * W);
     if (rows > 65536) {
-      sc_set_error("sc_streams_create: the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)");
-      delete b;
-      return SC_ERR_ARG;
+      if (o->kv_pool_rows > 0) {
+        sc_set_error("sc_streams_create: the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)");
+        delete b;
+        return SC_ERR_ARG;
+      }
+      rows = 65536;
     }
     sb.kv_rows = (int32_t)rows;
   }

@@ -175,7 +175,16 @@ class StreamBatch:
             raise EngineError("half-precision K|V caches need the HIP backend")
         self.ckv = z(S * cfg.dec_layers * self.TCAP, 2 * d, dtype=kvt)
         # self-attention K|V: a pool of rows per stream and layer (include/scasr.h: sc_search.skv); `anc` holds pool rows
-        self.kv_rows = max(2 * W, min(self.LCAP * W, kv_pool_rows if kv_pool_rows > 0 else self.LCAP + self.LCAP // 2 + 4 * W))
+        # default (csrc/streams.hip: sc_streams_create): one row per (position, hypothesis) - never exhausted before max_tokens -
+        # unless that takes more than a quarter of the device's free memory; never fewer than 1.5 rows per position + 4W
+        if kv_pool_rows <= 0:
+            kv_pool_rows = self.LCAP * W
+            if torch.device(dev).type == "cuda":
+                per_row = S * cfg.dec_layers * 2 * d * (2 if kvt == torch.float16 else 4)
+                kv_pool_rows = max(self.LCAP + self.LCAP // 2 + 4 * W,
+                                   min(kv_pool_rows, torch.cuda.mem_get_info(torch.device(dev))[0] // 4 // per_row))
+            kv_pool_rows = min(kv_pool_rows, 65536)
+        self.kv_rows = max(2 * W, min(self.LCAP * W, kv_pool_rows))
         if self.kv_rows > 65536:
             raise EngineError("the self-attention K|V pool is limited to 65536 rows per stream (max_tokens / kv_pool_rows)")
         self.skv = z(S * cfg.dec_layers * self.kv_rows, 2 * d, dtype=kvt)
@@ -1002,7 +1011,16 @@ class StreamBatch:
             t_st = time.perf_counter()
             f = self._read_flags()[ids]
             self._tick("decode_wait_flags", t_st)
-            full = act & (self._flags_np[self.S:][ids] != 0)    # the prune kernel found no free K|V pool row
+            kv_full = act & (self._flags_np[self.S:][ids] != 0)    # the prune kernel found no free K|V pool row
+            f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
+            stop_eos = act & f_any & (~fin | f_best)
+            stop_bbd = act & ~stop_eos & f_rep & ~fin if use_bbd else np.zeros(n, bool)
+            stop_all = act & ~stop_eos & ~stop_bbd & f_all & fin
+            accept = act & ~(stop_eos | stop_bbd | stop_all)
+            take = stop_eos | stop_all | accept
+            # ... which only matters if the step is taken and stays taken: a step that is rolled back (stop_bbd) or rewound
+            # when the block closes (not accepted, pidx > 1, prev_hyps valid) leaves the current side, which is fully valid
+            full = kv_full & take & ~(~accept & (pidx > 1) & pvalid)
             if full.any():
                 err = EngineError(f"self-attention K|V pool exhausted (kv_pool_rows={self.kv_rows}, max_tokens={self.LCAP})")
                 if not self._isolate:
@@ -1011,15 +1029,9 @@ class StreamBatch:
                     self._faults[int(ids[i])] = err
                 live &= ~full
                 act = act & ~full
-                f = np.where(full, 0, f)
-            f_any, f_best, f_all, f_rep = (f & F_ANY_EOS) != 0, (f & F_BEST_EOS) != 0, (f & F_ALL_EOS) != 0, (f & F_REPEAT) != 0
+                stop_eos, stop_bbd, stop_all, accept, take = (v & ~full for v in (stop_eos, stop_bbd, stop_all, accept, take))
             out_idx += act
             nsteps += act
-            stop_eos = act & f_any & (~fin | f_best)
-            stop_bbd = act & ~stop_eos & f_rep & ~fin if use_bbd else np.zeros(n, bool)
-            stop_all = act & ~stop_eos & ~stop_bbd & f_all & fin
-            accept = act & ~(stop_eos | stop_bbd | stop_all)
-            take = stop_eos | stop_all | accept
             out_idx -= stop_bbd
             nh_out = np.minimum(W, nhyp * W)
             nhyp_prev = np.where(take, nhyp, nhyp_prev)

@@ -249,7 +249,10 @@ class HipBackend:
         s.kv_rows, s.kvflags = int(sb.kv_rows), sb.kvflags.data_ptr()
         # fp16 decoder mode (weights.PackedWeights(dec_dtype="float16")): needs the fp16 K|V caches
         if s.kv_half and getattr(w, "out_w_qh", None) is not None and all("wqkv_pph" in lw for lw in w.dec):
-            s.out_w_qh, s.act_half = w.out_w_qh.data_ptr(), int(os.environ.get("SC_ACT_HALF", "3")) & 7   # layer projections | partial products (| 4: output layer, see csrc/streams.hip)
+            # layer projections | partial products (| 4: output layer, measured and rejected: csrc/streams.hip).  SC_ACT_HALF is a
+            # test hook like every SC_* switch: honoured only under SC_TEST_HOOKS=1, exactly as the C++ engine reads it (sc_hook)
+            hooks = os.environ.get("SC_TEST_HOOKS", "0") not in ("", "0")
+            s.out_w_qh, s.act_half = w.out_w_qh.data_ptr(), (int(os.environ.get("SC_ACT_HALF", "3")) & 7) if hooks else 3
         else:
             for i in range(len(w.dec)):
                 layers[i].wqkv_pph = layers[i].wq_pph = layers[i].wo_pph = layers[i].wo2_pph = None

@@ -100,8 +100,9 @@ class NativeStreamBatch:
         """``kv_dtype``: "float32" (the reference's arithmetic) or "float16" - the self- and cross-attention K|V
         caches in fp16 (half the HBM stream of the attention kernels and half the cache memory; arithmetic,
         softmax and all scores stay fp32): the storage mode of BASELINE configs[4], opt-in, never the parity mode.
-        ``kv_pool_rows``: rows of the self-attention K|V pool per stream and layer (0: 1.5 x max_tokens + 4 x beam; a stream
-        that needs more fails with a capacity error)."""
+        ``kv_pool_rows``: rows of the self-attention K|V pool per stream and layer (0: one row per (position, hypothesis) -
+        never exhausted before max_tokens - unless that takes more than a quarter of the free device memory, then what the
+        budget holds, at least 1.5 x max_tokens + 4 x beam; a stream that needs more fails with a capacity error)."""
         if not torch.cuda.is_available():
             raise _abi.ScasrError("NativeStreamBatch needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.engine = engine or NativeEngine(weights, device=weights.device)

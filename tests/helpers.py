@@ -21,9 +21,9 @@ def oracle_model(cfg_name="TINY", seed=1234, stats="meanstd"):
     return RefPortModel(sd, cfg, mel, mean, std)
 
 
-def run_oracle_stream(model, audio, chunk, beam, bbd, finalize_all=True, **kw):
+def run_oracle_stream(model, audio, chunk, beam, bbd, finalize_all=True, ctc_weight=0.3, **kw):
     from oracle.ref_port import RefPortStreaming
-    s = RefPortStreaming(model, beam_size=beam, ctc_weight=0.3, use_bbd=bbd, **kw)
+    s = RefPortStreaming(model, beam_size=beam, ctc_weight=ctc_weight, use_bbd=bbd, **kw)
     s.trace = []
     feats, encs, calls = [], [], []
     pos, n = 0, len(audio)

@@ -19,14 +19,14 @@ CFGS = {"TINY": TINY, "XL": XL, "L_LIKE": L_LIKE, "M_DEFAULTS": M_DEFAULTS}
 
 
 def make_batch(cfg_name, seed, stats, beam, bbd, n_streams=1, backend=None, device="cpu", ffn_dtype="float32",
-               proj_dtype="float32", dec_dtype="float32", **kw):
+               proj_dtype="float32", dec_dtype="float32", ctc_weight=0.3, **kw):
     """backend: None = the torch spec backend (CPU), a HipBackend = the Python engine over the HIP kernels,
     "native" = the C++ engine behind the stream-level C ABI (speechcatcher_amd.native)."""
     from oracle.kernel_spec import SpecBackend
     cfg = CFGS[cfg_name]
     sd = synth.make_state_dict(cfg, seed)
     mean, std = synth.stats_to_mean_std(synth.make_stats(cfg, kind=stats))
-    sc = SearchConfig(beam_size=beam, use_bbd=bbd)
+    sc = SearchConfig(beam_size=beam, use_bbd=bbd, ctc_weight=ctc_weight)
     if isinstance(backend, str) and backend == "native":
         from speechcatcher_amd.native import NativeStreamBatch
         return NativeStreamBatch(PackedWeights(sd, cfg, "cuda:0", mean, std, ffn_dtype=ffn_dtype, proj_dtype=proj_dtype,
@@ -66,6 +66,8 @@ def run_case(name, n_streams=1, stream=0, score_tol=1e-3, **kw):
     js, npz = load_case(name)
     meta = js["meta"]
     kw.setdefault("max_tokens", 200 if meta["model"] == "XL" else 160)
+    if "ctc_weight" in meta:
+        kw.setdefault("ctc_weight", meta["ctc_weight"])
     sb = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"],
                     n_streams=n_streams, max_frames=256, pcm_capacity=1 << 18, **kw)
     audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
@@ -93,6 +95,16 @@ def test_engine_matches_reference_trajectories(name):
         T = sb.st[0].T_enc
         enc = sb.enc[:T].numpy()
         np.testing.assert_allclose(enc, npz["enc"][:T], atol=5e-4, rtol=0)
+
+
+CTC_WEIGHT_CASES = [f"tiny_c10240_b10_bbd{d}_cw{w}" for d in (0, 1) for w in ("00", "05")]
+
+
+@pytest.mark.parametrize("name", CTC_WEIGHT_CASES)
+def test_engine_ctc_weight_fixtures(name):
+    """Speech2TextStreaming(ctc_weight=...): 0.5, and 0.0 = no CTC scorer at all (beam_search.py:925).  The decoder-only
+    tiny fixtures run into max_length = 500 (beam_search.py:701): the step loop's bound is part of the case."""
+    run_case(name, max_tokens=520)
 
 
 def test_engine_other_stream_slot_and_float64_stats():
@@ -286,6 +298,35 @@ def run_kv_pool_exhaustion(backend=None, device="cpu"):
         failed |= {s for s, r in out.items() if isinstance(r, EngineError)}
     assert failed == {0, 1}
     assert two.st[0].T_enc == 0 and two.st[1].T_enc == 0       # both have been reset
+    # ONE stream runs out: the fault is that stream's alone - the other stream of the batch, on a short
+    # utterance, decodes exactly what it decodes in a batch with the default pool - and the failed stream, reset by the
+    # fault, is usable again: the same short utterance on it gives the same hypotheses
+    short = synth.synth_audio(3, 9000)
+    ref = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], **kw)
+    ref.push([(0, short, True)])
+    want = ref.hypotheses(0)
+    assert 1 < len(want[0]["yseq"]) < 16           # well inside a 40-row pool
+    mix = make_batch(meta["model"], meta["seed"], meta["stats"], meta["beam"], meta["bbd"], n_streams=2, kv_pool_rows=40,
+                     strict_reference=False, **kw)   # (strict: the next utterance would meet the stale CTC table, quirk A1)
+    failed_at = None
+    for k, pos in enumerate(range(0, len(audio), meta["chunk"])):
+        end = min(pos + meta["chunk"], len(audio))
+        items = [(0, audio[pos:end], end >= len(audio))] + ([(1, short, True)] if k == 0 else [])
+        out = mix.push(items, isolate_faults=True)
+        assert not isinstance(out.get(1), EngineError)
+        if isinstance(out[0], EngineError):
+            assert "pool" in str(out[0])
+            failed_at = k
+            break
+    assert failed_at is not None and failed_at > 0
+    got = mix.hypotheses(1)
+    assert [h["yseq"] for h in got] == [h["yseq"] for h in want]
+    np.testing.assert_allclose([h["score"] for h in got], [h["score"] for h in want], rtol=0, atol=1e-4)
+    assert mix.st[0].T_enc == 0                                 # reset by the fault
+    mix.push([(0, short, True)])
+    again = mix.hypotheses(0)
+    assert [h["yseq"] for h in again] == [h["yseq"] for h in want]
+    np.testing.assert_allclose([h["score"] for h in again], [h["score"] for h in want], rtol=0, atol=1e-4)
 
 
 def test_kv_pool_exhaustion_is_a_capacity_fault():

@@ -33,6 +33,22 @@ def test_native_engine_matches_reference_xl(name):
     run_case(name, backend="native", score_tol=1e-3)
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
+@pytest.mark.parametrize("name", [f"tiny_c10240_b10_bbd{d}_cw{w}" for d in (0, 1) for w in ("00", "05")] +
+                         ["xl_c10240_b10_bbd0_cw00", "xl_c10240_b10_bbd0_cw05"])
+def test_ctc_weight_fixtures_on_the_gpu(name, engine):
+    """Speech2TextStreaming(ctc_weight=...) is part of the surface (speech2text_streaming.py:143-150): fixtures of the
+    real reference at 0.5 and at 0.0 - where it builds NO CTC scorer (beam_search.py:925: decoder-only search, no scan,
+    score_ctc stays 0; the tiny cases then run into max_length = 500, beam_search.py:701) - on both engines."""
+    from test_engine_spec import run_case
+    kw = dict(max_tokens=520) if name.startswith("tiny") else {}
+    if engine == "native":
+        run_case(name, backend="native", score_tol=1e-3, **kw)
+    else:
+        from speechcatcher_amd.hip_backend import HipBackend
+        run_case(name, backend=HipBackend("cuda:0"), device="cuda:0", score_tol=1e-3, **kw)
+
+
 @pytest.mark.parametrize("name", ["tiny_c10240_b10_bbd0", "tiny_c8192_b10_bbd1", "xl_c10240_b10_bbd0"])
 def test_native_engine_with_the_t_parallel_ctc_scan(name, monkeypatch):
     """the same fixtures with the CTC prefix scan split over T from 32 frames on (default: 256): every block after

@@ -149,6 +149,25 @@ def test_reset_quirk_matches_reference():
     assert [r[2] for r in js["final"]] == [g[0] for g in res]
 
 
+CTC_WEIGHT_CASES = [f"tiny_c10240_b10_bbd{d}_cw{w}" for d in (0, 1) for w in ("00", "05")]
+
+
+@pytest.mark.parametrize("name", CTC_WEIGHT_CASES + [pytest.param(f"xl_c10240_b10_bbd0_cw{w}", marks=pytest.mark.slow) for w in ("00", "05")])
+def test_ctc_weight_is_part_of_the_surface(name):
+    """Speech2TextStreaming(ctc_weight=...) (speech2text_streaming.py:143-150): 0.5, and 0.0 = NO CTC scorer at all
+    (beam_search.py:925: decoder-only search, score_ctc stays 0).  Fixtures: tools/gen_golden.py --ctc-weights."""
+    js, _ = load_case(name)
+    meta = js["meta"]
+    model = oracle_model(meta["model"], meta["seed"], meta["stats"])
+    audio = synth.synth_audio(meta["audio_stream"], meta["n_samples"])
+    s, feats, encs, calls = run_oracle_stream(model, audio, meta["chunk"], meta["beam"], bool(meta["bbd"]),
+                                              ctc_weight=meta["ctc_weight"])
+    _check_blocks(s.trace, js["blocks"])
+    assert [r[2] for r in js["calls"][-1]["results"]] == [g[0] for g in calls[-1]["results"]]
+    if meta["ctc_weight"] <= 0:
+        assert all(v == 0.0 for b in js["blocks"] for v in b["score_ctc"])
+
+
 XL_CASES = ["xl_c10240_b10_bbd0", "xl_c10240_b10_bbd1", "xl_c25600_b10_bbd0", "xl_c8192_b10_bbd1",
             "xl_c8192_b5_bbd1", "xl_c10240_b1_bbd0"]
 

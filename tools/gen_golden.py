@@ -111,8 +111,8 @@ def results_to_json(res):
     return [[text, list(toks), [int(t) for t in ids]] for text, toks, ids in res]
 
 
-def run_stream(model_dir, audio, chunk, beam, bbd, record_steps=0, finalize_all=True):
-    s2t = Speech2TextStreaming(model_dir, beam_size=beam, ctc_weight=0.3, device="cpu", use_bbd=bbd)
+def run_stream(model_dir, audio, chunk, beam, bbd, record_steps=0, finalize_all=True, ctc_weight=0.3):
+    s2t = Speech2TextStreaming(model_dir, beam_size=beam, ctc_weight=ctc_weight, device="cpu", use_bbd=bbd)
     rec = Recorder(s2t, record_steps)
     n = len(audio)
     calls = []
@@ -330,8 +330,34 @@ def xl_extra():
         print(name, "blocks", len(rec.blocks))
 
 
+def ctc_weights():
+    """``Speech2TextStreaming(ctc_weight=...)`` is part of the surface (speech2text_streaming.py:143-150); with
+    ``ctc_weight <= 0`` the reference builds NO CTC scorer at all (beam_search.py:925: decoder-only search, no "ctc"
+    entry in Hypothesis.scores).  ``python tools/gen_golden.py --ctc-weights`` records tiny and XL trajectories at
+    ctc_weight 0.0 and 0.5 (the other fixtures all use 0.3)."""
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tmp = Path(tempfile.mkdtemp(prefix="golden_"))
+    tiny_dir = synth.write_model_dir(tmp / "tiny", TINY, seed=1234, stats_kind="meanstd")
+    xl_dir = synth.write_model_dir(tmp / "xl", XL, seed=1234, stats_kind="meanstd")
+    for tag, mdir, stream, n in (("tiny", tiny_dir, 0, 16000 * 6 + 3217), ("xl", xl_dir, 7, 16000 * 8)):
+        audio = synth.synth_audio(stream, n)
+        for cw, bbd in ((0.0, False), (0.5, False), (0.5, True), (0.0, True)):
+            if tag == "xl" and bbd:
+                continue
+            name = f"{tag}_c10240_b10_bbd{int(bbd)}_cw{int(round(cw * 10)):02d}"
+            s2t, rec, calls = run_stream(mdir, audio, 10240, 10, bbd, ctc_weight=cw)
+            meta = {"model": tag.upper(), "seed": 1234, "stats": "meanstd", "audio_stream": stream,
+                    "n_samples": len(audio), "chunk": 10240, "beam": 10, "bbd": bbd, "ctc_weight": cw}
+            save_case(name, meta, rec, calls, with_tensors=False)
+            print(name, "blocks", len(rec.blocks), "final", calls[-1]["results"][:1])
+
+
 if __name__ == "__main__":
-    if "--xl-extra" in sys.argv[1:]:
+    if "--ctc-weights" in sys.argv[1:]:
+        ctc_weights()
+    elif "--xl-extra" in sys.argv[1:]:
         xl_extra()
     elif "--after-final" in sys.argv[1:]:
         after_final()
