@@ -167,7 +167,7 @@ def strict_window(sb, audio, k0, steps, dist=None, before_timing=None):
     return elapsed, (n_dec_steps(sb) - steps0) / float(sb.S) / max(steps, 1), last, extra
 
 
-def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None, depth=1):
+def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=None, at_target=None, depth=1, exact=False):
     """CONTINUOUS batching, closed loop: every stream is served on its own - sc_submit its chunk, sc_poll until replies
     are ready, read the best hypothesis of the streams that answered (sc_get_hyps_batch), submit THEIR next chunks
     (stream i continues at chunk nxt[i] of a3 [S][chunks][CHUNK]).  boundary: host PCM in (pinned staging, one H2D
@@ -175,7 +175,9 @@ def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=Non
     The clock stops when S x steps replies have been delivered - `steps` chunk steps' worth of audio; a stream whose
     blocks need fewer decode steps gets further than one that needs more (a3 must hold spare chunks).  What is in
     flight then is drained untimed.  depth > 1 (sc_streams_set_queue_depth): every stream keeps `depth` chunks with the
-    engine - its next chunk is submitted while the previous one is still decoding (a host that has the audio already)."""
+    engine - its next chunk is submitted while the previous one is still decoding (a host that has the audio already).
+    exact: EVERY stream gets exactly `steps` chunks (a stream that has had its share is not fed again): the same S x steps
+    replies, every stream with the same weight - the tail runs at thinning buckets like any real end of a batch of calls."""
     S = sb.S
     end = a3.shape[1]
     k_start = nxt.copy()
@@ -189,6 +191,8 @@ def serve(sb, a3, nxt, steps, group, dist=None, boundary=True, before_timing=Non
 
     def submit(streams):
         streams = streams[nxt[streams] < end]
+        if exact:
+            streams = streams[nxt[streams] - k_start[streams] < steps]
         if len(streams):
             if boundary:
                 sb.submit_block(streams, a3[streams, nxt[streams]])
@@ -343,7 +347,7 @@ def cpu_baseline(k0, budget_s=10.0, beam=10, bbd=False, max_steps=20):
 
 
 def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, total, dist=None, boundary=True, kv_dtype=None,
-            depth=1):
+            depth=1, exact=False):
     """one fresh batch: pre-roll (lock-step, resident audio, untimed), warm-up in the timed mode, then the timed leg"""
     sb = build_native(w, streams, beam, bbd, total, kv_dtype=kv_dtype)
     if depth > 1:
@@ -361,7 +365,7 @@ def measure(w, audio, streams, beam, bbd, preroll, warmup, steps, group, mode, t
             preload_audio(sb, audio, a3.shape[1])
         if warmup > 0:
             serve(sb, a3, nxt, warmup, group, boundary=boundary, depth=depth)
-        out = serve(sb, a3, nxt, steps, group, dist, boundary=boundary, depth=depth)
+        out = serve(sb, a3, nxt, steps, group, dist, boundary=boundary, depth=depth, exact=exact)
         out["next_chunk"] = nxt
     out["value"] = streams * steps * CHUNK / 16000.0 / out["elapsed"]
     return sb, out
@@ -389,6 +393,57 @@ def long_context_leg(w, streams, beam, target_T, bbd, steps, group):
     return out
 
 
+def chunk_leg(w, streams, beam, bbd, chunk, group, audio_s_pre, audio_s_timed):
+    """the headline's two modes at ANOTHER call size: 25 600 samples = the model's block size (2-3 encoder
+    blocks and decode blocks per call), 8 192 = the reference CLI's chunk loop (speechcatcher.py:796).  Same position in the
+    utterance as the headline's window (pre-roll / timed region given in audio seconds), chunk-steps/s and audio-s/s."""
+    global CHUNK
+    keep = CHUNK
+    CHUNK = chunk
+    try:
+        pre = max(2, int(round(audio_s_pre * 16000.0 / chunk)) - 2)
+        warm = 2
+        steps = max(4, int(round(audio_s_timed * 16000.0 / chunk)))
+        total = pre + warm + steps + max(4, SERVED_SPARE * 10240 // chunk)
+        audio = make_audio(streams, total)
+        out = {"chunk_samples": chunk, "chunk_ms": chunk * 1000 // 16000, "steps": steps,
+               "window": f"chunks {pre + warm}..{pre + warm + steps - 1} of every stream ({pre} lock-step pre-roll + {warm} warm-up steps untimed)"}
+        for mode in ("continuous", "strict"):
+            sb, r = measure(w, audio, streams, beam, bbd, pre, warm, steps, group, mode, total)
+            ent = {"value": round(r["value"], 2), "unit": "audio_s/s", "chunk_steps_per_s": round(streams * steps / r["elapsed"], 2),
+                   "ms_per_step": round(r["elapsed"] / steps * 1e3, 3), "decode_steps_per_chunk": round(r["dec_steps_per_hop"], 2)}
+            if mode == "continuous":
+                ent["decode_iterations_per_step"] = round(r["iterations_per_step"], 2)
+                out.update(ent)
+                out.update(state_of(sb))
+            else:
+                out["strict_lock_step"] = ent
+            sb.close()
+            del sb
+        return out
+    finally:
+        CHUNK = keep
+
+
+def pinned_leg(argv_core, frac=8):
+    """the headline leg in a child process that is confined to 1/`frac` of the host cores - what a rank gets on a node with
+    `frac` GPUs (launch_ranks / the slicing under an external launcher): the open question of DESIGN section 7 is host-side
+    contention of the feeder processes.  The child is started BEFORE it touches a GPU; this process only parses its line."""
+    import subprocess
+    cpus = sorted(os.sched_getaffinity(0))
+    mine = cpus[:max(1, len(cpus) // frac)]
+    env = dict(os.environ, SC_BENCH_CPUS=",".join(map(str, mine)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv_core + ["--legs", "none", "--roofline-steps", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if res.returncode != 0:
+        return {"error": res.stderr[-400:]}
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    return {"value": line["value"], "unit": "audio_s/s", "ms_per_step": line["ms_per_step"], "host_cores_used": len(mine),
+            "host_cores_total": len(cpus),
+            "note": f"the headline leg (same window, same mode) with the process confined to {len(mine)} of the {len(cpus)} host cores "
+                    f"= a rank's share on a node with {frac} GPUs; no multi-GPU node was available: this is NOT a scaling measurement"}
+
+
 _PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",   # <256, RTT, PRO = false, WF = 0 (fp32 weights)>
                "ffn_fused_kernel<256,*,PRO>": "ffn_fused_kernelILi256ELi{}ELb1ELi0",
                "dec_layer_attn_kernel<self>": "dec_layer_attn_kernelILi256ELi32ELi10ELb1",
@@ -399,20 +454,26 @@ _PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",
                "rowtile_proj_kernel<256,*>": "rowtile_proj_kernelILi256"}
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary (None if unavailable)"""
+ROOFLINE_WINDOW_CSV = os.path.join("profiles", "r05_bench_default_roofline_window.csv")
+
+
+def pmc_traffic(kind_name):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE... as the guide's HBM section prescribes) of a kernel kind from the
+    COMMITTED summary of the rocprofv3 passes of this command (tools/prof_bench.sh: kernel trace + two --pmc passes, each
+    restricted to the launches between the roofline leg's sc_marker kernels, joined with this leg's own table) - a process
+    cannot read the counters of its own kernels.  Returns (bytes per launch, provenance) or (None, reason)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r04_bench_default_pmc_hbm_traffic.csv")
-    key = next((v for k, v in _PMC_FAMILY.items() if kernel_name.startswith(k)), None)
-    if key is None or not os.path.exists(path):
-        return None
-    tot = n = 0.0
+    path = os.path.join(ROOT, ROOFLINE_WINDOW_CSV)
+    if not os.path.exists(path):
+        return None, f"{ROOFLINE_WINDOW_CSV} not found"
     with open(path) as f:
-        for row in csv.reader(f):
-            if row and row[0] != "kernel" and any(key.format(r) in row[0] for r in (1, 2, 3, 4, 5)):
-                tot += float(row[1]) * float(row[6])
-                n += float(row[1])
-    return int(tot / n) if n else None
+        rows = list(csv.DictReader(r for r in f if not r.startswith("#")))
+        f.seek(0)
+        head = [r[1:].strip() for r in f if r.startswith("#")]
+    for r in rows:
+        if r["kind"] == kind_name and r.get("hbm_bytes_per_launch_pmc"):
+            return int(float(r["hbm_bytes_per_launch_pmc"])), f"{ROOFLINE_WINDOW_CSV} ({'; '.join(head[:2])})"
+    return None, f"{ROOFLINE_WINDOW_CSV} has no counter row for this kind"
 
 
 def launch_ranks(n):
@@ -478,6 +539,13 @@ def main():
     ap.add_argument("--encoder-batch", type=int, default=0,
                     help="continuous mode: merged encoder groups are issued when they hold this many streams "
                          "(sc_streams_set_encoder_batch; 0 = the engine's default)")
+    ap.add_argument("--legs", choices=["core", "all", "none"], default="core",
+                    help="core (default, <= 90 s): the headline + its roofline, strict lock-step, exact-steps, the 25 600- and 8 192-sample "
+                         "call sizes, single stream, fp16 mode, 1/8 of the host cores, CPU baseline; all: also resident audio, fp16 K|V, "
+                         "split16, block-boundary detection on, queue depth 2, long context (T ~ 1000 / 4500); none: the headline only")
+    ap.add_argument("--roofline-csv", default="",
+                    help="write the per-kernel table of the roofline leg (launches, avg us, algorithmic bytes / flops per launch) here; "
+                         "tools/prof_bench.sh joins it with the rocprofv3 passes of the SAME launches (sc_marker brackets the leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the leg of the mode that is not the headline")
@@ -515,6 +583,9 @@ def main():
                 torch.set_num_threads(max(1, min(8, per)))
         except (OSError, ValueError, KeyError):
             pass
+    if args.legs == "none":
+        args.no_cpu_baseline = args.no_single_stream = args.no_other_mode = args.no_resident = args.no_long_context = True
+    extended = args.legs == "all"
     global CHUNK, KV_DTYPE, FFN_DTYPE, ENCODER_BATCH
     ENCODER_BATCH = args.encoder_batch
     CHUNK = args.chunk
@@ -565,6 +636,9 @@ def main():
     if args.roofline_steps > 0:
         sb.set_graphs(False)
         sb.take_attn_counters()
+        torch.cuda.synchronize()
+        lib.sc_marker(0, sb.hip_stream)     # brackets THIS leg in a rocprofv3 trace / counter pass (tools/prof_bench.sh)
+        torch.cuda.synchronize()
         lib.sc_prof_enable(1)
         if args.mode == "strict":
             run_host(sb, step_blocks(audio, k0 + args.steps, k0 + args.steps + args.roofline_steps), np.arange(S, dtype=np.int32))
@@ -575,11 +649,15 @@ def main():
 
             def stop_timing(counters):
                 lib.sc_prof_enable(0)
+                lib.sc_marker(1, sb.hip_stream)     # (the device is idle here: serve() synchronises before it calls back)
                 rows_at_target.append(counters)
 
             serve(sb, a3, head["next_chunk"], args.roofline_steps, group, at_target=stop_timing, depth=args.queue_depth)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
+        if args.mode == "strict":
+            lib.sc_marker(1, sb.hip_stream)
+        torch.cuda.synchronize()
         lib.sc_prof_collect_kinds(ms, fl, by, nn, NK)
         sb.set_graphs(True)
         rows = sb.take_attn_counters()
@@ -662,6 +740,7 @@ def main():
         raw_us = ms[v] * 1e3 / nn[v]
         t_ms = max(net[v], 1e-9)
         kind, ach, frac, flops_v, bytes_v = bound_of[v]
+        traffic_v, traffic_src = pmc_traffic(names[v].split(" (")[0]) if default_workload else (None, "not the default workload")
         # traffic: HBM bytes per launch need rocprofv3 --pmc passes of this command (a process cannot read the
         # counters of its own kernels): `traffic` is taken from the committed summary of those passes
         # (profiles/r04_bench_default_pmc_hbm_traffic.csv, tools/prof_bench.sh: FETCH_SIZE x2 + WRITE_SIZE per launch,
@@ -672,15 +751,25 @@ def main():
                 "flops_per_launch_avg": round(flops_v / nn[v] / 1e6, 1),
                 "flops_unit": "MFLOP algorithmic per launch (DESIGN.md section 4)",
                 "algorithmic_bytes_per_launch_avg": int(bytes_v / nn[v]),
-                "kernel": names[v], "traffic": pmc_traffic(names[v]) if default_workload else None,
-                "traffic_source": "profiles/r04_bench_default_pmc_hbm_traffic.csv (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  "passes of this command, bytes per launch, launch-weighted over the kernel family)",
+                "kernel": names[v], "traffic": traffic_v, "traffic_source": traffic_src,
                 "avg_launch_us": round(t_ms * 1e3 / nn[v], 2), "avg_launch_us_raw_events": round(raw_us, 2),
                 "event_pair_overhead_us": round(ev_over_ms * 1e3, 2), "launches_timed": int(nn[v]),
                 "share_of_timed_kernel_time": round(net[v] / tot_ms, 4),
                 "measured_over": f"{args.roofline_steps} steps following the timed region, same workload, "
                                  "hipGraph replay off, HIP events around every launch",
                 "per_kernel": per_kernel}
+
+    if args.roofline_csv and roof is not None:
+        import csv
+        with open(args.roofline_csv, "w", newline="") as f:
+            f.write(f"# roofline leg of `python bench.py` ({args.roofline_steps} steps behind the timed region, hipGraph replay off, HIP events "
+                    "around every launch); launches between sc_marker_kernel<0> and <1>\n")
+            wr = csv.writer(f)
+            wr.writerow(["kind", "launches", "avg_launch_us_events", "algorithmic_bytes_per_launch", "algorithmic_mflop_per_launch"])
+            for i in range(NK):
+                if nn[i]:
+                    wr.writerow([names[i].split(" (")[0], int(nn[i]), round(net[i] * 1e3 / nn[i], 2),
+                                 int((by[i] + xattn_bytes.get(i, 0.0)) / nn[i]), round((fl[i] + xattn_flops.get(i, 0.0)) / nn[i] / 1e6, 2)])
 
     # whole chunk step against the matrix-core peak: algorithmic FLOPs of SURVEY 8(d) / wall time
     gflop_step = args.streams * (GFLOP_ENCODER_SIDE_PER_HOP * CHUNK / 10240.0 + GFLOP_PER_DECODE_STEP * args.beam / 10.0
@@ -742,7 +831,7 @@ def main():
         return o
 
     resident = None
-    if not args.no_resident and world == 1 and args.mode == "continuous":
+    if extended and not args.no_resident and world == 1 and args.mode == "continuous":
         resident = leg("continuous", boundary=False)
         resident["headline_over_this"] = round(value / resident["value"], 4)
         resident["note"] = "same window and mode, audio resident in HBM (sc_submit with NULL pcm), no hypothesis read-back"
@@ -756,8 +845,43 @@ def main():
                          "completes inside its call, every stream waits for the slowest stream of the batch" if om == "strict" else
                          "continuous batching through sc_submit / sc_poll, same window")
 
+    exact = None
+    if not args.no_other_mode and world == 1 and args.mode == "continuous":
+        sbx, r = measure(w, audio, S, args.beam, bool(args.bbd), args.preroll, args.warmup, args.steps, group, "continuous", total_steps,
+                         depth=args.queue_depth, exact=True)
+        sbx.close()
+        del sbx
+        exact = {"value": round(r["value"], 2), "unit": "audio_s/s", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
+                 "chunks_per_stream_min_max": r["chunks_per_stream_min_max"], "headline_over_this": round(value / r["value"], 4),
+                 "note": "the same leg with every stream served EXACTLY `steps` chunks (a stream that has had its share is not fed "
+                         "again; the clock stops with the last reply): in the headline's closed loop the clock stops after S x steps "
+                         "replies whoever sent them, so streams whose blocks need fewer decode steps contribute more chunks "
+                         "(chunks_per_stream_min_max of `continuous`) - this is the equal-weight variant; its tail runs at thinning "
+                         "buckets like strict lock-step does in every step"}
+
+    chunk_legs = None
+    if not args.no_other_mode and world == 1 and CHUNK == 10240 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
+        chunk_legs = {}
+        for ch in (25600, 8192):
+            try:
+                chunk_legs[f"chunk_{ch}"] = chunk_leg(w, S, args.beam, bool(args.bbd), ch, group, k0 * 0.64, args.steps * 0.64)
+            except Exception as e:  # noqa: BLE001
+                chunk_legs[f"chunk_{ch}"] = {"error": repr(e)}
+
+    pinned = None
+    if not args.no_other_mode and world == 1 and "SC_BENCH_CPUS" not in os.environ:
+        try:
+            core = ["--streams", str(S), "--steps", str(args.steps), "--warmup", str(args.warmup), "--preroll", str(args.preroll),
+                    "--beam", str(args.beam), "--bbd", str(args.bbd), "--chunk", str(CHUNK), "--mode", args.mode,
+                    "--kv-dtype", KV_DTYPE, "--ffn-dtype", FFN_DTYPE, "--queue-depth", str(args.queue_depth)]
+            pinned = pinned_leg(core)
+            if "value" in pinned:
+                pinned["over_headline"] = round(pinned["value"] / value, 4)
+        except Exception as e:  # noqa: BLE001
+            pinned = {"error": repr(e)}
+
     kv16 = None
-    if not args.no_other_mode and world == 1 and KV_DTYPE == "float32":
+    if extended and not args.no_other_mode and world == 1 and KV_DTYPE == "float32":
         kv16 = leg(args.mode, kv_dtype="float16")
         kv16["over_headline"] = round(kv16["value"] / value, 4)
         kv16["note"] = ("NOT the headline: the same leg with the self- / cross-attention K|V caches STORED in fp16 (arithmetic, softmax and "
@@ -778,7 +902,7 @@ def main():
                              "six XL fixtures + a bound on the share of streams whose best hypothesis moves (tests/test_gpu_baseline_size.py)")
 
     bbd_on = None
-    if not args.no_other_mode and world == 1 and not args.bbd:
+    if extended and not args.no_other_mode and world == 1 and not args.bbd:
         bbd_on = leg(args.mode, bbd=True)
         bbd_on["over_headline"] = round(bbd_on["value"] / value, 4)
         bbd_on["note"] = ("the other search regime of BASELINE.md section 3: the same leg WITH block-boundary detection (the reference CLI's "
@@ -786,7 +910,7 @@ def main():
                           "upper bound for a real checkpoint as the headline (detection off, ~9 steps per block) is a lower bound")
 
     queued = None
-    if not args.no_other_mode and world == 1 and args.mode == "continuous" and args.queue_depth == 1:
+    if extended and not args.no_other_mode and world == 1 and args.mode == "continuous" and args.queue_depth == 1:
         queued = leg("continuous", depth=2)
         queued["over_headline"] = round(queued["value"] / value, 4)
         queued["note"] = ("NOT the headline: the same leg with TWO chunks per stream at the engine (sc_streams_set_queue_depth(2)): a host "
@@ -799,7 +923,7 @@ def main():
                           "fewer streams (32 streams: +12 %, one stream: +6 %; DESIGN section 4)")
 
     split16 = None
-    if not args.no_other_mode and world == 1 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
+    if extended and not args.no_other_mode and world == 1 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
         w_split = make_weights(device, "split16")
         split16 = leg(args.mode, weights=w_split)
         del w_split
@@ -823,7 +947,7 @@ def main():
     del audio, a3
 
     long_ctx = None
-    if not args.no_long_context and world == 1 and CHUNK == 10240:
+    if extended and not args.no_long_context and world == 1 and CHUNK == 10240:
         long_ctx = {}
         try:
             long_ctx["T1000"] = long_context_leg(w, S, args.beam, 1000, False, 8, group)
@@ -885,7 +1009,9 @@ def main():
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
+        "exact_steps": exact, "chunk_sizes": chunk_legs, "one_eighth_of_host_cores": pinned,
         "kv_cache_fp16": kv16, "fp16_mode": fp16_mode, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "long_context": long_ctx,
+        "legs": args.legs,
     }
     if args.mode == "continuous":
         out["continuous"] = {k: head[k] for k in ("iterations_per_step", "polls_per_step", "chunks_per_stream_min_max")}

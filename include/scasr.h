@@ -170,7 +170,7 @@ const char *sc_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes incompatibly.  sc_version()
  * returns the revision the LIBRARY was built with; a host compares the two before it passes any struct
  * (speechcatcher_amd/_abi.py does at load time, the C hosts in tests/ at start-up). */
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 int sc_version(void);
 
 /* hipGraph capture / replay of any sequence of the launches below on a
@@ -592,6 +592,9 @@ int sc_streams_capture_stats(const sc_streams *streams, long *n_captures, double
 /* measurement aids (bench.py): hipGraph replay on/off (off: launches can be bracketed by the sc_prof_* events);
  * encoder K|V rows the cross-attention has read since the last call (returned and cleared) */
 int sc_streams_set_graphs(sc_streams *streams, int on);
+/* measurement aid (tools/prof_bench.sh): an empty kernel named sc_marker_kernel<id> (id 0..3) on `stream` - brackets a window
+ * of the run in a rocprofv3 trace / counter collection, so that the launches of THAT window can be told from the rest */
+int sc_marker(int id, void *stream);
 /* host seconds the decode step loop spent issuing a step (ctrl upload + graph launch) and waiting for its stop
  * flags, since the last call (returned and cleared) */
 int sc_streams_host_times(sc_streams *streams, double *launch_s, double *wait_s);

@@ -177,6 +177,7 @@ _SIGS = {
     "sc_streams_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "sc_streams_capture_stats": (C.c_int, [vp, C.POINTER(C.c_long), c_double_p]),
     "sc_streams_set_graphs": (C.c_int, [vp, C.c_int]),
+    "sc_marker": (C.c_int, [C.c_int, vp]),
     "sc_streams_host_times": (C.c_int, [vp, c_double_p, c_double_p]),
     "sc_streams_bucket_times": (C.c_int, [vp, c_double_p, C.POINTER(C.c_long)]),
     "sc_streams_take_xattn_rows": (C.c_long, [vp]),
@@ -193,7 +194,7 @@ EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 
 # revision of include/scasr.h these ctypes mirrors were written against (SC_ABI_VERSION): a library built from another
 # revision would be handed mis-laid-out structs
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

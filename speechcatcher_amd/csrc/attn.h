@@ -96,48 +96,61 @@ __device__ __forceinline__ void kv_loadn(const float *base, long elem, float *ou
 // rowfn(idx, k_elem, hyp_mask): element offset of K row `idx` of the walk (V follows vofs elements later) and the
 // bit set of hypotheses that attend to it; it must be safe for any idx (clamp) - tiles >= ntiles are masked here.
 // qs: LDS [16][DK] queries / sqrt(dk), rows of unused hypotheses zero.
+// The walk is split into its two halves so that a kernel can have the FIRST batch of a wave's tiles under way long before
+// the queries exist (round 5: the K|V rows of the cached positions do not depend on this step's x - their loads travel
+// while the projection's split sums are reduced):  mattn_load = the NT tiles wave, wave + 4, ... of a wave -> registers,
+// mattn_batch = their arithmetic.
+template <int DK, int NT>
+struct MBatch {
+  float kr[NT][DK / 4], vr[NT][4][DK / 16];
+  unsigned hm[NT][4];
+};
 template <int DK, int NT, bool KVH, class RowFn>
-__device__ __forceinline__ void mattn_walk(MAttn<DK> &st, const float *qs, const float *kv, int vofs, int ntiles,
-                                           int wave, int lane, RowFn rowfn) {
+__device__ __forceinline__ void mattn_load(MBatch<DK, NT> &b, const float *kv, int vofs, int ntiles, int t0, int lane, RowFn rowfn) {
   constexpr int DPL = DK / 4, NDT = DK / 16;
   const int n = lane & 15, kg = lane >> 4;
-  float qb[DPL];
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) qb[i] = qs[n * DK + DPL * kg + i];
-  for (int t0 = wave; t0 < ntiles; t0 += 4 * NT) {
-    float kr[NT][DPL], vr[NT][4][NDT];
-    unsigned hm[NT][4];
+  for (int i = 0; i < NT; ++i) {
+    const int t = t0 + 4 * i;
+    long ke;
+    unsigned unused;
+    rowfn(16 * t + n, ke, unused);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int t = t0 + 4 * i;
-      long ke;
-      unsigned unused;
-      rowfn(16 * t + n, ke, unused);
+    for (int q = 0; q < DPL / 4; ++q) kv_loadn<4, KVH>(kv, ke + DPL * kg + 4 * q, &b.kr[i][4 * q]);
 #pragma unroll
-      for (int q = 0; q < DPL / 4; ++q) kv_loadn<4, KVH>(kv, ke + DPL * kg + 4 * q, &kr[i][4 * q]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        long ve;
-        rowfn(16 * t + 4 * kg + j, ve, hm[i][j]);
-        kv_loadn<NDT, KVH>(kv, ve + vofs + n * NDT, vr[i][j]);
-        if (t >= ntiles) hm[i][j] = 0u;
-      }
+    for (int j = 0; j < 4; ++j) {
+      long ve;
+      rowfn(16 * t + 4 * kg + j, ve, b.hm[i][j]);
+      kv_loadn<NDT, KVH>(kv, ve + vofs + n * NDT, b.vr[i][j]);
+      if (t >= ntiles) b.hm[i][j] = 0u;
     }
-    f32x4v s[NT];
+  }
+}
+// CANONICAL BATCHES (bit-reproducible serving): the online-softmax rescale happens per batch of TWO tiles (t, t + 4) in
+// every form of the kernels - a form that has NT = 4 tiles in flight (few streams active) works them off as two
+// batches, exactly the batches the NT = 2 forms see.  A batch of masked tiles changes nothing (factor exp(0) = 1).
+template <int DK, int NT>
+__device__ __forceinline__ void mattn_batch(MAttn<DK> &st, const MBatch<DK, NT> &b, const float (&qb)[DK / 4], int lane) {
+  constexpr int DPL = DK / 4, NDT = DK / 16;
+  static_assert(NT % 2 == 0, "tiles in flight: whole canonical batches of two");
+  const int n = lane & 15;
+#pragma unroll
+  for (int b0 = 0; b0 < NT; b0 += 2) {
+    f32x4v s[2];
     float mloc = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) s[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) s[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
     // k-steps outermost: consecutive MFMAs go to different tiles' accumulators (a dependent accumulate waits 40
     // cycles, the pipe issues every 32)
 #pragma unroll
     for (int q = 0; q < DPL; ++q)
 #pragma unroll
-      for (int i = 0; i < NT; ++i) s[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i][q], qb[q], s[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.kr[b0 + i][q], qb[q], s[i], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        s[i][j] = ((hm[i][j] >> n) & 1u) ? s[i][j] : -INFINITY;
+        s[i][j] = ((b.hm[b0 + i][j] >> n) & 1u) ? s[i][j] : -INFINITY;
         mloc = fmaxf(mloc, s[i][j]);
       }
     }
@@ -151,15 +164,36 @@ __device__ __forceinline__ void mattn_walk(MAttn<DK> &st, const float *qs, const
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) st.o[dt] *= corr;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float p = (s[i][j] == -INFINITY) ? 0.f : __expf(s[i][j] - muse);
         st.l += p;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) st.o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[i][j][dt], p, st.o[dt], 0, 0, 0);
+        for (int dt = 0; dt < NDT; ++dt) st.o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.vr[b0 + i][j][dt], p, st.o[dt], 0, 0, 0);
       }
     }
+  }
+}
+// PRE: the wave's first batch (tiles wave, wave + 4, ... < 4 NT) was loaded by the caller (mattn_load with t0 = wave and the
+// same ntiles / rowfn)
+template <int DK, int NT, bool KVH, bool PRE = false, class RowFn>
+__device__ __forceinline__ void mattn_walk(MAttn<DK> &st, const float *qs, const float *kv, int vofs, int ntiles,
+                                           int wave, int lane, RowFn rowfn, const MBatch<DK, NT> *pre = nullptr) {
+  constexpr int DPL = DK / 4;
+  const int n = lane & 15, kg = lane >> 4;
+  float qb[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) qb[i] = qs[n * DK + DPL * kg + i];
+  int t0 = wave;
+  if constexpr (PRE) {
+    if (t0 < ntiles) mattn_batch<DK, NT>(st, *pre, qb, lane);
+    t0 += 4 * NT;
+  }
+  for (; t0 < ntiles; t0 += 4 * NT) {
+    MBatch<DK, NT> b;
+    mattn_load<DK, NT, KVH>(b, kv, vofs, ntiles, t0, lane, rowfn);
+    mattn_batch<DK, NT>(st, b, qb, lane);
   }
 }
 
@@ -215,11 +249,16 @@ __host__ __device__ static inline int mattn_partial_floats(int DK, int np) { ret
 // group and its own list; 1024 / 512 = a whole four-head workgroup building ONE list that its head groups share (the
 // list depends on the stream only) - a 400-token hypothesis then costs one build phase (two barriers, one dependent
 // round trip for the ancestor rows) instead of four, and the walk runs over all its tiles without draining in between.
+// ofs / zero_n: a list can be built in two passes (one-head workgroups: 256 threads on the 512-position lists that every
+// form of the layer kernels walks - the tiles, and with them the summation order, must not depend on the form): the first
+// pass zeroes the whole list (zero_n entries), the second continues behind the first's `ofs` entries (zero_n = 0).
+// Returns the number of entries in the list (ofs included).
 template <int WM, bool PRE = false, int NTHR = 256, int PCH = 128>
 __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *anc, int c0, int Lc, int W, int nh,
-                                                int gt, int lane, int wave, const int (&pre)[WM]) {
+                                                int gt, int lane, int wave, const int (&pre)[WM], int ofs = 0, int zero_n = -1) {
   static_assert(PCH % 64 == 0 && PCH <= NTHR, "positions: whole waves of the cooperating threads");
-  for (int e = gt; e < PCH * W; e += NTHR) rw[e] = 0;
+  if (zero_n < 0) zero_n = PCH * W;
+  for (int e = gt; e < zero_n; e += NTHR) rw[e] = 0;
   const int pp = c0 + gt;
   const bool live = gt < PCH && pp < Lc;
   int r[WM];
@@ -243,7 +282,7 @@ __device__ __forceinline__ int mattn_build_rows(int *rw, int *wtot, const int *a
   }
   if (lane == 63 && wave < PCH / 64) wtot[wave] = incl;
   __syncthreads();   // also orders the zero fill before the ORs
-  int base = incl - cnt, U = 0;
+  int base = ofs + incl - cnt, U = ofs;
 #pragma unroll
   for (int w2 = 0; w2 < PCH / 64; ++w2) {
     const int t = wtot[w2];

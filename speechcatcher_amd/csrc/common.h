@@ -126,19 +126,67 @@ __device__ __forceinline__ float lse2(float a, float b) {
   return m + SC_LN2 * __builtin_amdgcn_logf(1.f + sc_exp_neg(-fabsf(a - b)));
 }
 
+// ---- canonical summation of partial sums (bit-reproducible serving) ---------------------------------------------------------
+// Which tile shape a launch takes depends on how many rows are in flight, i.e. on who else is on the GPU.  A stream's result must
+// not: every sum of partial results is therefore evaluated in ONE order, whatever the decomposition that produced the partials.
+//   * split sums of the fused feed-forward (one per 128-wide hidden chunk, or per aligned PAIR of chunks added in that order
+//     by the producer): a balanced binary tree over the aligned index pairs, evaluated in batches of 8 -
+//     ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)), batches added in order (a tree again for <= 16 partials).  A missing entry
+//     is +0 (x + 0 is exact).  The same routine reduces every split-K GEMM, whose slice count is a function of (N, K) alone.
+//   * per-head partial products of the decoder's output projections: heads in aligned groups of four, each group summed in
+//     head order, the groups in order - what the four-heads-per-workgroup kernels do in LDS is what the consumer of the
+//     one-head-per-workgroup kernels does in registers.
+__device__ __forceinline__ float4 sc_add4(const float4 &a, const float4 &b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 sc_tree4(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
+  return sc_add4(sc_add4(a, b), sc_add4(c, d));
+}
+__device__ __forceinline__ float4 sc_tree8(const float4 (&v)[8]) {
+  return sc_add4(sc_tree4(v[0], v[1], v[2], v[3]), sc_tree4(v[4], v[5], v[6], v[7]));
+}
+__device__ __forceinline__ float sc_tree8f(const float (&v)[8]) {
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+__device__ __forceinline__ float4 sc_seq4(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
+  return sc_add4(sc_add4(sc_add4(a, b), c), d);
+}
+
 // Phase stamps for tools/layer_phase_times.py: compiled in only with -DSC_PHASE_DBG (make EXTRA=-DSC_PHASE_DBG, never
-// in the shipped library).  Workgroup (0,0), thread 0 stores the 100 MHz shader real-time counter at phase
-// boundaries into a per-source-file table that sc_phase_debug_<file>() copies out.
+// in the shipped library).  Thread 0 of EVERY workgroup (linear id < SC_PHASE_WGS) stores the shader clock (s_memtime:
+// one tick per shader cycle) at phase boundaries into a per-source-file table that sc_phase_debug_<file>() copies out;
+// slots 14 / 15 of a workgroup hold the 100 MHz real-time counter at its first / last stamp (the shader clocks of the
+// eight XCDs are not synchronised: workgroups are aligned on the real-time counter), slot 13 the launch's grid size.  A launch
+// overwrites the stamps of the one before: what is read is the LAST launch of every kind.  (Round 4 stamped workgroup
+// (0,0) only: the first workgroup of a launch is not representative of the 256 - phases of different workgroups do not
+// line up.)
 #ifdef SC_PHASE_DBG
 #ifndef SC_PHASE_MIN_GRID
 #define SC_PHASE_MIN_GRID 0   // -DSC_PHASE_MIN_GRID=200: only launches of at least that many workgroups leave stamps (full buckets)
 #endif
-static __device__ long long sc_phase_stamps[4][32];
-#define SC_STAMP(k, i)                                                                        \
+#define SC_PHASE_WGS 512
+#define SC_PHASE_RING 32   // the last 32 launches of every kind are kept (slot = launch number mod 32)
+static __device__ long long sc_phase_stamps[4][SC_PHASE_RING][SC_PHASE_WGS][16];
+// SC_STAMP_ON: expression in the kernel's scope (its argument struct carries the host's decision: sc_phase_debug_*_arm(n)
+// lets only the next n launches of a kind leave stamps - e.g. the 14 layers of ONE decode step, whose last launch then stays)
+#ifndef SC_STAMP_ON
+#define SC_STAMP_ON 1
+#endif
+#define SC_STAMP_AT(k, i, rt)                                                                 \
   do {                                                                                        \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (int)(gridDim.x * gridDim.y) >= SC_PHASE_MIN_GRID) \
-      sc_phase_stamps[k][i] = (long long)__builtin_amdgcn_s_memtime();                       \
+    const int wg__ = blockIdx.x + gridDim.x * blockIdx.y;                                     \
+    if (threadIdx.x == 0 && (SC_STAMP_ON) && wg__ < SC_PHASE_WGS && (int)(gridDim.x * gridDim.y) >= SC_PHASE_MIN_GRID) { \
+      long long *row__ = sc_phase_stamps[k][((SC_STAMP_ON) - 1) & (SC_PHASE_RING - 1)][wg__]; \
+      row__[i] = (long long)__builtin_amdgcn_s_memtime();                                     \
+      if ((rt) >= 0) row__[rt] = (long long)__builtin_amdgcn_s_memrealtime();                 \
+      if ((i) == 0) {                                                                         \
+        row__[13] = (long long)(gridDim.x * gridDim.y);                                       \
+        row__[12] = (long long)(SC_STAMP_ON);                                                 \
+      }                                                                                       \
+    }                                                                                         \
   } while (0)
+#define SC_STAMP(k, i) SC_STAMP_AT(k, i, ((i) == 0 ? 14 : -1))
+#define SC_STAMP_END(k, i) SC_STAMP_AT(k, i, 15)
 // ... behind a wait for everything the wave has in flight: the stamp then closes a memory round trip (changes the timing
 // a little: the loads of the next stage are not under way yet)
 #define SC_STAMP_WAIT(k, i)                                                                   \
@@ -148,10 +196,24 @@ static __device__ long long sc_phase_stamps[4][32];
   } while (0)
 #define SC_PHASE_GETTER(name)                                                                 \
   extern "C" int name(long long *out) {                                                       \
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_phase_stamps), sizeof(long long) * 4 * 32) == hipSuccess ? 0 : -1; \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_phase_stamps), sizeof(long long) * 4 * SC_PHASE_RING * SC_PHASE_WGS * 16) == hipSuccess ? 0 : -1; \
+  }                                                                                           \
+  static int sc_phase_budget[4] = {-1, -1, -1, -1};   /* launches of a kind that still leave stamps (-1: all) */ \
+  static int sc_phase_count[4] = {0, 0, 0, 0};        /* launch number of the kind (1-based; the ring slot) */   \
+  static inline int sc_phase_take(int k) {            /* 0: no stamps, else the launch number */                 \
+    if (sc_phase_budget[k] == 0) return 0;                                                    \
+    if (sc_phase_budget[k] > 0) --sc_phase_budget[k];                                         \
+    return ++sc_phase_count[k];                                                               \
+  }                                                                                           \
+  extern "C" int name##_arm(int n) {   /* clear the table; the next n launches of every kind leave stamps (-1: all) */ \
+    static long long z[4 * SC_PHASE_RING * SC_PHASE_WGS * 16];                                \
+    for (int k = 0; k < 4; ++k) { sc_phase_budget[k] = n; sc_phase_count[k] = 0; }            \
+    return hipMemcpyToSymbol(HIP_SYMBOL(sc_phase_stamps), z, sizeof z) == hipSuccess ? 0 : -1; \
   }
 #else
 #define SC_STAMP(k, i) do {} while (0)
+#define SC_STAMP_END(k, i) do {} while (0)
 #define SC_STAMP_WAIT(k, i) do {} while (0)
-#define SC_PHASE_GETTER(name)
+#define SC_PHASE_GETTER(name)                                                                 \
+  static inline int sc_phase_take(int) { return 0; }
 #endif

@@ -34,6 +34,7 @@
 // done ONCE per four heads and shared through LDS, the four heads' shares of the output projection are summed in LDS
 // before they are stored, so the next kernel reduces H / HPW = 2 partial products per row instead of 8.  256 workgroups
 // of 16 waves fill the 256 CUs of a full 128-stream bucket exactly like the 1024 workgroups of 4 waves did.
+#define SC_STAMP_ON (p.dbg_stamp)
 #include "common.h"
 #include "attn.h"
 
@@ -113,35 +114,41 @@ struct DecLayerArgs {
   // prologue:  x[row] = xin[row] + (sum_{z < npart} part[z*zs + row*rs + :] + pbias)
   const float *part;
   int npart;
+  int pgrp;          // canonical order of the sum over the partials (see the prologue): 0 tree, 4 groups of four heads, 1 in order
   long zs, rs;
   const float *pbias;
   const float *ln_g, *ln_b;
   const float *wp, *bp;  // projection behind the LayerNorm: sc_pack_panel_weight copy of Wqkv [3d][d] / Wq [d][d], bias
   const float *wop;      // output projection [d][d] (self: linear_out of self_attn, cross: of src_attn), panel-packed
   float *ph;             // [S*W][H][d] partial output projection of every head
+  int dbg_stamp;         // SC_PHASE_DBG builds: this launch leaves phase stamps (common.h)
 };
 
 // LDS floats of one workgroup (host and device use the same formula)
-__host__ __device__ static inline int dl_region_floats(int D, int DK, int W, bool self) {
+// region of a head group: a union over the phases - LayerNorm tile (one head per workgroup only: the four-head form keeps it
+// in the shared area), split-K partials of the projection, attention partial states (+ the group's own row list of 512
+// positions, one head per workgroup), A tile + staging of the output projection
+__host__ __device__ static inline int dl_region_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
   const int nt = (self ? 3 : 1) * (DK / 16);
-  const int xn = 16 * (D + 4);
-  const int ps = 4 * 16 * (nt * 16 + 4);
-  const int attn = mattn_partial_floats(DK, self ? 5 : 4) + (self ? 256 * W : 0) + 8;   // partial states, row list, wtot
-  const int outp = 16 * 36 + 16 * (D + 4);
+  const int xn = hpw > 1 ? 0 : 16 * (D + 4);
+  const int ps = 4 * WM * (nt * 16 + 4);                 // (the MFMA tiles' rows >= WM are padding: not stored)
+  const int attn = mattn_partial_floats(DK, self ? 5 : 4) + ((self && hpw == 1) ? 512 * W : 0) + 8;   // partial states, row list, wtot
+  const int outp = 16 * 36 + WM * (D + 4);
   int r = xn > ps ? xn : ps;
   r = r > outp ? r : outp;
   return r > attn ? r : attn;
 }
 // ... of one head group: region, qs, kvn, ctx
-__host__ __device__ static inline int dl_group_floats(int D, int DK, int W, int WM, bool self) {
-  return dl_region_floats(D, DK, W, self) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
+__host__ __device__ static inline int dl_group_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
+  return dl_region_floats(D, DK, W, WM, self, hpw) + 16 * DK /*qs*/ + (self ? WM * 2 * DK : 0) /*kvn*/ + WM * DK /*ctx*/;
 }
-// HPW head groups + LayerNorm gamma | beta + (HPW > 1) the LayerNorm tile shared by the head groups
+// HPW head groups + LayerNorm gamma | beta + (HPW > 1) the LayerNorm tile shared by the head groups and, behind it, the
+// self-attention's shared row list (128 * hpw positions x W entries + 16 wave totals): an area of its own since round 5 -
+// the list is built at the START of the kernel, while the producer's partial sums travel (the ancestor table does not
+// depend on this layer's x), so the LayerNorm tile and the list are alive together
 __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM, bool self, int hpw = 1) {
-  // hpw > 1: the LayerNorm tile shared by the head groups; the self-attention's shared row list (128 * hpw positions x W
-  // entries + 16 wave totals) takes its place once the projection is done
-  const int shared = hpw > 1 ? ((self && 128 * hpw * W + 16 > 16 * (D + 4)) ? 128 * hpw * W + 16 : 16 * (D + 4)) : 0;
-  return hpw * dl_group_floats(D, DK, W, WM, self) + 2 * D + 16 /*pool rows of the new tokens*/ + shared;
+  const int shared = hpw > 1 ? 16 * (D + 4) + (self ? 128 * hpw * W + 16 : 0) : 0;
+  return hpw * dl_group_floats(D, DK, W, WM, self, hpw) + 2 * D + 16 /*pool rows of the new tokens*/ + shared;
 }
 
 // key tiles per wave in flight in the attention walk of the few-streams variant (UNR = 8).  Measured in round 3 with 8
@@ -175,14 +182,16 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   if (nh <= 0) return;
   const int L = CTRL(s, SC_C_L), cur = CTRL(s, SC_C_CUR), T = CTRL(s, SC_C_T);
   const int W = sb.W, NPH = sb.H / HPW;
-  const int GS = dl_group_floats(D, DK, W, WM, SELF);        // LDS floats of one head group
+  const int GS = dl_group_floats(D, DK, W, WM, SELF, HPW);   // LDS floats of one head group
   float *region = smem + g * GS;
-  float *qs = region + dl_region_floats(D, DK, W, SELF);     // [16][DK] queries / sqrt(dk), rows >= W zero
+  float *qs = region + dl_region_floats(D, DK, W, WM, SELF, HPW);   // [16][DK] queries / sqrt(dk), rows >= W zero
   float *kvn = qs + 16 * DK;                                 // SELF: [WM][2*DK] k|v of the new token
   float *ctx = kvn + (SELF ? WM * 2 * DK : 0);               // [WM][DK] attention output of this head
   float *gb = smem + HPW * GS;                               // [2][D] LayerNorm gamma | beta (shared)
   int *ancs = reinterpret_cast<int *>(gb + 2 * D);           // [16] SELF: pool rows of the new tokens (sc_kv_alloc)
   float *Xsh = HPW > 1 ? gb + 2 * D + 16 : region;           // [16][D+4] LayerNorm tile: shared by the head groups
+  constexpr int PCS = 128 * (HPW > 1 ? HPW : 4);             // positions per row list (512 in every form: canonical tiles)
+  int *srows = reinterpret_cast<int *>(Xsh + 16 * (D + 4)), *swtot = srows + PCS * sb.W;   // HPW > 1, SELF: the shared row list
 
   // ------------------------------------------------------------------ L2 warm-up of this head's weight slices
   // One dword per 128-B line of the projection fragments and of the output-projection fragments, issued before
@@ -204,13 +213,21 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   constexpr bool EARLY = HPW > 1;
   BF pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
+  // (HPW > 1, round 5: of the first 512 positions, one per thread of the workgroup - the list is BUILT before the prologue's
+  // partial sums have arrived, see early_list below)
   int slp[WM] = {};
-  if (PF && SELF) {
+  if ((PF || HPW > 1) && SELF) {
     const int *anc0 = ANC(cur, s);
-    const bool live0 = gt < PCH && gt < L - 1;
+    const int pt = HPW > 1 ? tid : gt;
+    const bool live0 = pt < (HPW > 1 ? PCS : PCH) && pt < L - 1;
 #pragma unroll
-    for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? gt : 0) * W + min(h, nh - 1)];
+    for (int h = 0; h < WM; ++h) slp[h] = anc0[(long)(live0 ? pt : 0) * W + min(h, nh - 1)];
   }
+  int U0 = 0;   // HPW > 1, SELF: entries of the row list of the first 512 positions
+  auto early_list = [&]() {
+    if constexpr (HPW > 1 && SELF)
+      U0 = mattn_build_rows<WM, true, NTH, PCS>(srows, swtot, ANC(cur, s), 0, L - 1, W, nh, tid, lane, tid >> 6, slp);
+  };
   float touch = 0.f, kvtouch = 0.f;
   // (loads return in issue order: the fragments are requested right BEHIND the first batch of partial sums, which
   // the LayerNorm needs first)
@@ -270,6 +287,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         }
       }
     }
+    if (FIRST) early_list();
     if (!FIRST) {
       // the residual rows and the bias are requested TOGETHER with the first batch of partial sums: behind them they were
       // one more dependent round trip of ~2 us (rows another XCD wrote; tools/boundary_probe.hip)
@@ -281,28 +299,48 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         pbv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.pbias) pbv[q] = *reinterpret_cast<const float4 *>(p.pbias + 4 * c4);
       }
+      // canonical order of the producer's partial sums (common.h) - the same for every kernel form:
+      //   pgrp == 0: split sums of the fused feed-forward -> balanced tree over the aligned index pairs, 8 at a time
+      //   pgrp >= 1: per-head partial products -> aligned groups of four heads in head order (pgrp == 4; pgrp == 1: the
+      //              four-heads-per-workgroup producer has done that), the groups in order
       float4 yv[QN];
-      for (int z0 = 0; z0 < p.npart; z0 += ZB) {
-        float4 pv[QN][ZB];
+      for (int z0 = 0; z0 < p.npart; z0 += 8) {
+        float4 h8[QN];   // this batch of 8
 #pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          const int e = tid + NTH * q, i = min(e / C4, W - 1), c4 = e % C4;
-          const long row = (long)s * W + i;
+        for (int zb = 0; zb < 8; zb += ZB) {
+          if (zb > 0 && z0 + zb >= p.npart) break;
+          float4 pv[QN][ZB];
 #pragma unroll
-          for (int z = 0; z < ZB; ++z)
-            pv[q][z] = dl_load_part(p.part, (long)min(z0 + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4, acth);
-        }
-        if (PF && z0 == 0) prefetch_w();
+          for (int q = 0; q < QN; ++q) {
+            const int e = tid + NTH * q, i = min(e / C4, W - 1), c4 = e % C4;
+            const long row = (long)s * W + i;
 #pragma unroll
-        for (int q = 0; q < QN; ++q)
-#pragma unroll
-          for (int z = 0; z < ZB; ++z)
-            if (z0 + z < p.npart) {
-              if (z0 + z == 0) yv[q] = pv[q][0];
-              else {
-                yv[q].x += pv[q][z].x; yv[q].y += pv[q][z].y; yv[q].z += pv[q][z].z; yv[q].w += pv[q][z].w;
-              }
+            for (int z = 0; z < ZB; ++z) {
+              pv[q][z] = dl_load_part(p.part, (long)min(z0 + zb + z, p.npart - 1) * p.zs + row * p.rs + 4 * c4, acth);
+              if (z0 + zb + z >= p.npart) pv[q][z] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+          }
+          if (PF && z0 == 0 && zb == 0) prefetch_w();
+          if (z0 == 0 && zb == 0) early_list();   // (two barriers; the partial sums requested above travel meanwhile)
+#pragma unroll
+          for (int q = 0; q < QN; ++q) {
+            if (p.pgrp == 0) {          // tree: (p0+p1)+(p2+p3) [+ (p4+p5)+(p6+p7)]
+              float4 t = sc_tree4(pv[q][0], pv[q][1], pv[q][2], pv[q][3]);
+              if (ZB == 8) t = sc_add4(t, sc_tree4(pv[q][ZB - 4], pv[q][ZB - 3], pv[q][ZB - 2], pv[q][ZB - 1]));
+              h8[q] = zb == 0 ? t : sc_add4(h8[q], t);
+            } else if (p.pgrp == 4) {   // groups of four heads
+              float4 t = sc_seq4(pv[q][0], pv[q][1], pv[q][2], pv[q][3]);
+              h8[q] = zb == 0 ? t : sc_add4(h8[q], t);
+              if (ZB == 8 && z0 + zb + 4 < p.npart) h8[q] = sc_add4(h8[q], sc_seq4(pv[q][ZB - 4], pv[q][ZB - 3], pv[q][ZB - 2], pv[q][ZB - 1]));
+            } else {                    // in order
+#pragma unroll
+              for (int z = 0; z < ZB; ++z)
+                if (z0 + zb + z < p.npart) h8[q] = (zb + z == 0) ? pv[q][0] : sc_add4(h8[q], pv[q][z]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < QN; ++q) yv[q] = z0 == 0 ? h8[q] : sc_add4(yv[q], h8[q]);
       }
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
@@ -373,6 +411,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 2);
 
+  constexpr int NTW_ = (UNR >= 8) ? SC_LAYER_NTW : 2;   // tiles per wave in flight in the attention walk
+  MBatch<DK, NTW_> kvb0;                                 // HPW > 1, SELF: the wave's first batch, requested ahead (below)
   // ------------------------------------------------------------------ projection of the head's columns
   // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
   // straight from the fragment-packed weights (1 KB contiguous per wave load)
@@ -418,12 +458,24 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         }
       }
     }
+    // HPW > 1, SELF (round 5): the wave's FIRST batch of K|V tiles is requested here - the rows of the cached positions do not
+    // depend on this step's x, the list has been there since the prologue - and travels while the split sums are reduced
+    // and the new token's row is appended (1.4 us of a 22 us kernel during which HBM idled)
+    if constexpr (HPW > 1 && SELF) {
+      const long skv0e = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;
+      mattn_load<DK, NTW_, KVH>(kvb0, sb.skv, D, cdiv(U0, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+        const int e = srows[min(idx, PCS * W - 1)];
+        hm = (unsigned)e >> 16;
+        ke = skv0e + (long)(e & 0xFFFF) * 2 * D;
+      });
+    }
     __syncthreads();  // every wave is done reading Xn: the region becomes the partial products
-    float *Ps = region;  // [4][16][LDP]
+    float *Ps = region;  // [4][WM][LDP]
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Ps[(wave * 16 + 4 * kk + j) * LDP + t * 16 + r] = acc[t][j];
+      for (int j = 0; j < 4; ++j)
+        if (4 * kk + j < WM) Ps[(wave * WM + 4 * kk + j) * LDP + t * 16 + r] = acc[t][j];
   }
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 3);
@@ -437,10 +489,10 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       const int which = n / DK, c = n % DK;
       float v = 0.f;
       if (w < W) {
-        v = Ps[(0 * 16 + w) * LDP + n];
-        v += Ps[(1 * 16 + w) * LDP + n];
-        v += Ps[(2 * 16 + w) * LDP + n];
-        v += Ps[(3 * 16 + w) * LDP + n];
+        v = Ps[(0 * WM + w) * LDP + n];
+        v += Ps[(1 * WM + w) * LDP + n];
+        v += Ps[(2 * WM + w) * LDP + n];
+        v += Ps[(3 * WM + w) * LDP + n];
         v += p.bp[which * D + head * DK + c];
       }
       if (which == 0) {
@@ -470,13 +522,13 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     }
   };
   if (PF) prefetch_o();
-  constexpr int NTW = (UNR >= 8) ? SC_LAYER_NTW : 2;   // tiles per wave and batch
+  constexpr int NTW = NTW_;   // tiles per wave and batch
   constexpr int NP = SELF ? 5 : 4;
   float *pm = region;
   float *pl = pm + NP * 16;
   float *pO = pl + NP * 16;
   int *rows = (int *)(region + mattn_partial_floats(DK, NP));
-  int *wtot = rows + (SELF ? PCH * W : 0);
+  int *wtot = rows + (SELF ? 2 * PCH * W : 0);
   const long ckv0 = ((long)s * sb.n_layers + p.li) * sb.TCAP * 2 * D + head * DK;
   MAttn<DK> st;
   mattn_init(st);
@@ -484,35 +536,38 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   if (SELF) {
     const int *anc = ANC(cur, s);
     const int Lc = L - 1;  // cached positions; the new token's row is the fifth partial state
-    const int nchunk = cdiv(Lc, PCH);
     int urows = nh;   // distinct K|V rows of this (stream, layer): the new tokens' rows + the walked ones
     if constexpr (HPW > 1) {
       // ONE row list per workgroup, 128 * HPW positions at a time, built by all its threads and walked by every head
       // group (it lives where the LayerNorm tile was: the projection is done)
-      constexpr int PCS = 128 * HPW;
-      int *srows = reinterpret_cast<int *>(Xsh), *swtot = srows + PCS * W;
-      for (int c0 = 0; c0 < Lc; c0 += PCS) {
+      auto rowfn = [&](int idx, long &ke, unsigned &hm) {
+        const int e = srows[min(idx, PCS * W - 1)];   // entries >= U are zero: no hypothesis
+        hm = (unsigned)e >> 16;
+        ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
+      };
+      // positions [0, 512): the list was built in the prologue, every wave's first batch is in its registers
+      urows += U0;
+      mattn_walk<DK, NTW, KVH, true>(st, qs, sb.skv, D, cdiv(U0, 16), wave, lane, rowfn, &kvb0);
+      for (int c0 = PCS; c0 < Lc; c0 += PCS) {
+        __syncthreads();  // the list is rebuilt for the next positions
         const int U = mattn_build_rows<WM, false, NTH, PCS>(srows, swtot, anc, c0, Lc, W, nh, tid, lane, tid >> 6, slp);
         urows += U;
-        mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
-          const int e = srows[min(idx, PCS * W - 1)];   // entries >= U are zero: no hypothesis
-          hm = (unsigned)e >> 16;
-          ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
-        });
-        if (c0 + PCS < Lc) __syncthreads();  // the list is rebuilt for the next positions
+        mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, rowfn);
       }
     } else
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int c0 = ch * PCH;
-      const int U = (PF && ch == 0) ? mattn_build_rows<WM, true, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp)
-                                    : mattn_build_rows<WM, false, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp);   // (attn.h)
+    // one head per workgroup: the SAME lists of 512 positions (the tiles of a list, and with them the order of the sums,
+    // are what every form must share), built by the 256 threads in two passes of 256 positions
+    for (int c0 = 0; c0 < Lc; c0 += 2 * PCH) {
+      int U = (PF && c0 == 0) ? mattn_build_rows<WM, true, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp, 0, 2 * PCH * W)
+                              : mattn_build_rows<WM, false, 256, PCH>(rows, wtot, anc, c0, Lc, W, nh, gt, lane, wave, slp, 0, 2 * PCH * W);   // (attn.h)
+      if (c0 + PCH < Lc) U = mattn_build_rows<WM, false, 256, PCH>(rows, wtot, anc, c0 + PCH, Lc, W, nh, gt, lane, wave, slp, U, 0);
       urows += U;
       mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
-        const int e = rows[min(idx, PCH * W - 1)];   // entries >= U are zero: no hypothesis
+        const int e = rows[min(idx, 2 * PCH * W - 1)];   // entries >= U are zero: no hypothesis
         hm = (unsigned)e >> 16;
         ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
       });
-      if (ch + 1 < nchunk) __syncthreads();  // rows is rebuilt by the next chunk
+      if (c0 + 2 * PCH < Lc) __syncthreads();  // rows is rebuilt for the next positions
     }
     if (sb.stat_rows && head == 0 && gt == 0) atomicAdd(&sb.stat_rows[1], (unsigned long long)urows);
     // the new token: hypothesis h attends to its own row (slot h at position L-1, still in LDS) only
@@ -554,7 +609,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   {
     constexpr int LDA = 36, NTO = D / 16, TW = NTO / 4, LDO = D + 4;
     float *As = region;              // [16][LDA]
-    float *Os = region + 16 * LDA;   // [16][LDO]
+    float *Os = region + 16 * LDA;   // [WM][LDO] (the tiles' rows >= WM are padding: not stored)
     const int kb = (head * DK) / 32, koff = (head * DK) % 32;
     for (int e = gt; e < 16 * 32; e += 256) {
       const int w = e / 32, c = e % 32;
@@ -585,7 +640,8 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = oacc[t][j];
+      for (int j = 0; j < 4; ++j)
+        if (4 * kk + j < WM) Os[(4 * kk + j) * LDO + (wave * TW + t) * 16 + r] = oacc[t][j];
     __syncthreads();
     SC_STAMP(SELF ? 0 : 1, 7);
     // (HPW > 1: the head groups' shares are summed here, in head order - one partial product per workgroup)
@@ -601,7 +657,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     }
   }
   if (kvtouch == 123456.789f) p.ph[0] = kvtouch;   // never true: keeps the K|V warm-up loads
-  SC_STAMP(SELF ? 0 : 1, 8);
+  SC_STAMP_END(SELF ? 0 : 1, 8);
 }
 SC_PHASE_GETTER(sc_phase_debug_layer)
 
@@ -613,9 +669,9 @@ SC_PHASE_GETTER(sc_phase_debug_layer)
 // between the two: 3005 against 2890 / 3068 audio-s/s for one / four at every bucket size - not instantiated.)
 int sc_dec_layer_hpw(const sc_search &sb) {
   const int dk = sb.d / sb.H;
-  const bool can = sb.d == 256 && dk == 32 && sb.W > 5 && sb.W <= 10;   // the instantiated HPW > 1 variants
+  const bool can = sb.d == 256 && dk == 32 && sb.W <= 10;   // the instantiated HPW > 1 variants (beams <= 5 run in the 10-row tiles too)
   int hpw = 1;
-  int min_rows = SC_HPW_MIN_ROWS;
+  int min_rows = sb.W > 5 ? SC_HPW_MIN_ROWS : SC_FUSED_MAX_ROWS + 1;   // narrow beams: the 5-row one-head kernels up to the old limit of the form
   if (const char *e = sc_hook("SC_HPW_MIN")) min_rows = atoi(e);   // tools: threshold sweep
   if (can && (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= min_rows) hpw = 4;
   if (const char *e = sc_hook("SC_DEC_HPW")) {
@@ -714,9 +770,9 @@ extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *x
   SC_CHECK_ARG(w.wqkv_pp && w.wo_pp, "panel-packed Wqkv / Wo missing");
   SC_CHECK_ARG(!sb.act_half || (sb.kv_half && w.wqkv_pph && w.wo_pph), "fp16 decoder mode needs fp16 K|V caches and the *_pph weights");
   const bool wh = (sb.act_half & 1) != 0;
-  DecLayerArgs p{sb, layer, xin, xout, ffn_part, n_ffn_part, (long)sb.S * sb.W * sb.d, (long)sb.d,
+  DecLayerArgs p{sb, layer, xin, xout, ffn_part, n_ffn_part, 0, (long)sb.S * sb.W * sb.d, (long)sb.d,
                  layer > 0 ? sb.layers[layer - 1].b2 : nullptr, w.ln1_g, w.ln1_b,
-                 wh ? (const float *)w.wqkv_pph : w.wqkv_pp, w.bqkv, wh ? (const float *)w.wo_pph : w.wo_pp, sb.ph1};
+                 wh ? (const float *)w.wqkv_pph : w.wqkv_pp, w.bqkv, wh ? (const float *)w.wo_pph : w.wo_pp, sb.ph1, sc_phase_take(0)};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = layer == 0 ? launch_dec_layer_dims<true, true>(p, st) : launch_dec_layer_dims<true, false>(p, st);
@@ -738,8 +794,8 @@ extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *
   const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_self (same bucket, same form)
   SC_CHECK_ARG(!sb.act_half || (sb.kv_half && w.wq_pph && w.wo2_pph), "fp16 decoder mode needs fp16 K|V caches and the *_pph weights");
   const bool wh = (sb.act_half & 1) != 0;
-  DecLayerArgs p{sb, layer, xin, xout, sb.ph1, nph, (long)sb.d, (long)nph * sb.d, w.bo, w.ln2_g, w.ln2_b,
-                 wh ? (const float *)w.wq_pph : w.wq_pp, w.bq, wh ? (const float *)w.wo2_pph : w.wo2_pp, sb.ph2};
+  DecLayerArgs p{sb, layer, xin, xout, sb.ph1, nph, nph == sb.H ? 4 : 1, (long)sb.d, (long)nph * sb.d, w.bo, w.ln2_g, w.ln2_b,
+                 wh ? (const float *)w.wq_pph : w.wq_pp, w.bq, wh ? (const float *)w.wo2_pph : w.wo2_pp, sb.ph2, sc_phase_take(1)};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   const int rc = launch_dec_layer_dims<false, false>(p, st);

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
       float x[EL], y[EL];
       float s = 0.f;
       // partial sums: all EL x 16 loads of a row are issued together (one memory round trip per
-      // 16 slices), then summed in slice order (same order as gemm_splitk_reduce_ln_kernel)
+      // 16 slices), then summed in the canonical order (the same as gemm_splitk_reduce_ln_kernel)
       for (int z0 = 0; z0 < p.npart; z0 += 16) {
         float pv[EL][16];
 #pragma unroll
@@ -340,11 +340,19 @@ __global__ __launch_bounds__(512) void reduce_ln_proj_kernel(RedProjArgs p) {
             const long pe = ((long)min(z0 + q, p.npart - 1) * p.part_M + (p.by_row ? xrow[rr] : (long)m)) * D + lane + 64 * e;
             pv[e][q] = p.part_half ? (float)reinterpret_cast<const _Float16 *>(p.part)[pe] : p.part[pe];
           }
+        // canonical order (common.h): balanced tree over the aligned index pairs, 8 at a time, the batches in order
 #pragma unroll
-        for (int e = 0; e < EL; ++e)
+        for (int e = 0; e < EL; ++e) {
+          float lo[8], hi[8];
 #pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (z0 + q < p.npart) y[e] = (z0 + q == 0) ? pv[e][0] : y[e] + pv[e][q];
+          for (int q = 0; q < 8; ++q) {
+            lo[q] = z0 + q < p.npart ? pv[e][q] : 0.f;
+            hi[q] = z0 + 8 + q < p.npart ? pv[e][8 + q] : 0.f;
+          }
+          float t = sc_tree8f(lo);
+          if (z0 + 8 < p.npart) t = t + sc_tree8f(hi);
+          y[e] = z0 == 0 ? t : y[e] + t;
+        }
       }
 #pragma unroll
       for (int e = 0; e < EL; ++e) {

@@ -11,6 +11,7 @@
 //     (lane l reads [k + l/32][m + l%32]).
 // Row gather (a_rows) / scatter (c_rows) tables let ragged per-stream buffers
 // be consumed and produced without staging copies.
+#define SC_STAMP_ON (p.dbg_stamp)
 #include "common.h"
 #include <mutex>
 #include <unordered_map>
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
   const int n4 = g.N >> 2;
   if (idx >= (long)g.M * n4) return;
   const int m = idx / n4, n = (idx % n4) * 4;
-  // partials are fetched 8 at a time (independent loads in flight), summed in slice order
+  // partials are fetched 8 at a time (independent loads in flight) and summed in the canonical order (common.h: sc_tree8)
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int z0 = 0; z0 < ksplit; z0 += 8) {
     float4 p[8];
@@ -402,14 +403,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
     for (int i = 0; i < 8; ++i) {
       const int z = min(z0 + i, ksplit - 1);
       p[i] = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
+      if (z0 + i >= ksplit) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (z0 + i < ksplit) {
-        if (z0 + i == 0) acc = p[0];
-        else { acc.x += p[i].x; acc.y += p[i].y; acc.z += p[i].z; acc.w += p[i].w; }
-      }
-    }
+    const float4 t = sc_tree8(p);
+    acc = z0 == 0 ? t : sc_add4(acc, t);
   }
   if (g.bias) {
     const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
@@ -450,14 +447,10 @@ __global__ __launch_bounds__(256) void ffn_reduce_handoff_kernel(GemmArgs g, int
     for (int i = 0; i < 8; ++i) {
       const int z = min(z0 + i, ksplit - 1);
       p[i] = *reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N + n);
+      if (z0 + i >= ksplit) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (z0 + i < ksplit) {
-        if (z0 + i == 0) acc = p[0];
-        else { acc.x += p[i].x; acc.y += p[i].y; acc.z += p[i].z; acc.w += p[i].w; }
-      }
-    }
+    const float4 t = sc_tree8(p);
+    acc = z0 == 0 ? t : sc_add4(acc, t);
   }
   if (g.bias) {
     const float4 b = *reinterpret_cast<const float4 *>(g.bias + n);
@@ -494,7 +487,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(GemmArgs g, 
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
     if (c < nv) {
-      // partials are fetched 8 at a time (independent loads in flight), summed in slice order
+      // partials are fetched 8 at a time (independent loads in flight) and summed in the canonical order (common.h: sc_tree8)
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int z0 = 0; z0 < ksplit; z0 += 8) {
         float4 p[8];
@@ -502,14 +495,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_ln_kernel(GemmArgs g, 
         for (int q = 0; q < 8; ++q) {
           const int z = min(z0 + q, ksplit - 1);
           p[q] = reinterpret_cast<const float4 *>(g.part + ((long)z * g.M + m) * g.N)[c];
+          if (z0 + q >= ksplit) p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (z0 + q < ksplit) {
-            if (z0 + q == 0) acc = p[0];
-            else { acc.x += p[q].x; acc.y += p[q].y; acc.z += p[q].z; acc.w += p[q].w; }
-          }
-        }
+        const float4 t = sc_tree8(p);
+        acc = z0 == 0 ? t : sc_add4(acc, t);
       }
       if (g.bias) {
         const float4 b = reinterpret_cast<const float4 *>(g.bias)[c];
@@ -721,19 +710,23 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
   }
   bool aligned = (K % 32 == 0) && (g.lda % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
                  (((uintptr_t)g.W & 15) == 0) && (g.conv_f1 == 0 || g.lda % 32 == 0);
-  // variant: 0 scalar, 1 skinny register-direct, 2 = 128x128 tile, 3 = 64x64 tile
+  // variant: 0 scalar, 1 skinny register-direct (tools only), 2 = 128x128 tile, 3 = 64x64 tile
+  // CANONICAL SUMMATION ORDER (round 5, bit-reproducible serving): how the K dimension of a product is cut and in which
+  // order its pieces are added is a function of (N, K) ALONE - never of M, which is the number of rows that happen to be
+  // in flight (streams of an encoder group, frames of a chunk).  Every aligned problem takes the LDS-tiled kernel (k runs
+  // in order inside a slice, both tile sizes issue the same v_mfma_f32_32x32x2_f32 chain per output element); K >= 2560
+  // (the subsampling Linear: K = 19 * d) is cut into 8 slices that the reduce kernel adds as a tree (common.h), anything
+  // shorter is one chain.  The register-direct skinny kernel (round 1-4: M <= 64) interleaves k over its waves and is
+  // kept for A/B runs only (SC_SKINNY_MAX_M).
   int variant;
   const bool can_part_any = g_ws && (N % 4 == 0) && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) &&
                             (!g.bias || (((uintptr_t)g.bias & 15) == 0)) &&
                             (size_t)M * N * sizeof(float) <= g_ws_bytes;
   int ksplit = 1;
+  const bool skinny_hook = sc_hook("SC_SKINNY_MAX_M") != nullptr;
   if ((g.flags & SC_GEMM_NAIVE) || g_force_naive || !aligned) {
     variant = 0;
-  } else if (M <= 64 || (M <= g_skinny_max_m && (K <= 256 || can_part_any))) {
-    // register-direct kernel: one stream's rows, or the decoder rows of a
-    // batch (M = S*W <= ~2k).  K is split across workgroups so that every
-    // workgroup sees <= 256 of K (one memory round trip) and >= ~256
-    // workgroups stream the weights.
+  } else if (skinny_hook && (M <= 64 || (M <= g_skinny_max_m && (K <= 256 || can_part_any))) && M <= g_skinny_max_m) {
     variant = 1;
     if (can_part_any) {
       if (M <= 64) {
@@ -747,13 +740,10 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
       if (ksplit < 1) ksplit = 1;
     }
   } else {
-    // Tiled kernels.  The GEMMs of this path are small (a few tiles per CU), so
-    // wave quantisation dominates: 570 tiles on 512 resident slots run as long
-    // as 1024.  Pick (tile, split-K) by a small cost model in cycles:
-    //   rounds = ceil(tiles*ks / slots); per round (K/(32*ks) + c0) K-steps of
-    //   8192 cycles (128^2, 2 blocks/CU) or 4096 cycles (64^2, 4 blocks/CU);
-    //   split-K adds the partial-sum round trip through the workspace.
-    const double c0 = 4.0, bytes_per_cycle = 2.0e3;  // ~4 TB/s at ~2 GHz
+    // tile size by a small cost model in cycles (wave quantisation dominates these small GEMMs): it changes which
+    // workgroup computes an element, not how
+    if (K >= 2560 && can_part_any && (size_t)8 * M * N * sizeof(float) <= g_ws_bytes) ksplit = 8;   // (callers slab M: gemm_slab_rows)
+    const double c0 = 4.0;
     double best = 1e30;
     variant = 3;
     for (int v = 2; v <= 3; ++v) {
@@ -762,17 +752,12 @@ static int gemm_dispatch(GemmArgs &g, bool force_part, int *ksplit_out, int *var
       const long slots = v == 2 ? 512 : 1024;        // resident workgroups on 256 CUs
       const double step1 = v == 2 ? 4096.0 : 1024.0;   // cycles per K-step, one workgroup on a CU
       const int per_cu = v == 2 ? 2 : 4;
-      const int ksmax = (can_part_any && K >= 256) ? (K / 128 < 8 ? K / 128 : 8) : 1;
-      for (int ks = 1; ks <= ksmax; ++ks) {
-        if ((size_t)ks * M * N * sizeof(float) > g_ws_bytes) break;
-        const long work = tiles * ks;
-        const long full = work / slots, rest = work % slots;
-        const double steps = (double)cdiv(K / 32, ks) + c0;
-        double t = full * steps * step1 * per_cu;
-        if (rest) t += steps * step1 * (double)cdiv((int)rest, 256);
-        if (ks > 1) t += (double)M * N * 4.0 * (ks + 2) / bytes_per_cycle + 12000.0;  // reduce pass + its launch
-        if (t < best) { best = t; variant = v; ksplit = ks; }
-      }
+      const long work = tiles * ksplit;
+      const long full = work / slots, rest = work % slots;
+      const double steps = (double)cdiv(K / 32, ksplit) + c0;
+      double t = full * steps * step1 * per_cu;
+      if (rest) t += steps * step1 * (double)cdiv((int)rest, 256);
+      if (t < best) { best = t; variant = v; }
     }
   }
   const bool can_part = can_part_any && variant != 0;
@@ -816,21 +801,35 @@ extern "C" int sc_prof_collect(double *ms, double *flops, long long *n) {
   return sc_prof_collect2(ms, flops, nullptr, n);
 }
 
+// rows per launch: a split-K product (K >= 2560: 8 slices, gemm_dispatch) whose partial sums do not fit the workspace is
+// computed in row slabs - the K split, and with it the summation order, never gives way to the row count
+static int gemm_slab_rows(int M, int N, int K) {
+  if (K < 2560 || !g_ws || (size_t)8 * M * N * sizeof(float) <= g_ws_bytes) return M;
+  const long fit = (long)(g_ws_bytes / ((size_t)8 * N * sizeof(float))) / 128 * 128;
+  return fit >= 128 ? (int)fit : M;
+}
+
 extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const float *W,
                        const float *bias, float *C, const int32_t *c_rows, int ldc, int M, int N,
                        int K, int flags, int conv_f1, void *stream) {
   SC_CHECK_ARG(A && W && C, "null pointer");
   SC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && lda > 0 && ldc >= N, "bad dimensions");
   if (M == 0) return SC_OK;
-  GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, conv_f1, nullptr, K};
   hipStream_t st = (hipStream_t)stream;
   resolve_workspace(stream);
   ProfScope prof = sc_prof_begin(st);
-  int ksplit = 0, variant = 0;
-  gemm_dispatch(g, false, &ksplit, &variant, st);
-  if (ksplit > 0) {
-    const long n4 = (long)M * (N / 4);
-    gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
+  int variant = 0;
+  const int slab = gemm_slab_rows(M, N, K);
+  for (int m0 = 0; m0 < M; m0 += slab) {
+    const int mm = M - m0 < slab ? M - m0 : slab;
+    GemmArgs g{a_rows ? A : A + (long)m0 * lda, a_rows ? a_rows + m0 : nullptr, lda, W, bias, c_rows ? C : C + (long)m0 * ldc,
+               c_rows ? c_rows + m0 : nullptr, ldc, mm, N, K, flags, conv_f1, nullptr, K};
+    int ksplit = 0;
+    gemm_dispatch(g, false, &ksplit, &variant, st);
+    if (ksplit > 0) {
+      const long n4 = (long)mm * (N / 4);
+      gemm_splitk_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(g, ksplit);
+    }
   }
   // algorithmic bytes: read A and W once, write C (read it too for the residual form)
   sc_prof_end(prof, variant, 2.0 * M * N * K,
@@ -928,6 +927,9 @@ struct FfnArgs {
   int w_form;   // 0: fp32 weights; 1: W1p / W2p hold fp16 elements (same fragment order): fp16 MFMA inputs, fp32 accumulation;
                 // 2: W1p / W2p hold the fp16 hi | lo SPLIT of the fp32 weights (see WF below)
   int act_half; // PRO: PH and part hold fp16 elements (same element offsets; sc_search.act_half)
+  int dbg_stamp;   // SC_PHASE_DBG builds: this launch leaves phase stamps (common.h)
+  int pgrp;     // PRO: heads per partial product of PH the consumer still has to group: 4 = one partial per head (sum aligned groups
+                // of four first), 1 = the producer summed them (common.h: canonical order of the head partials)
 };
 
 // WF = 1 (WH): fp16 weights (the same fragment order, 2-byte elements) and fp16 MFMA inputs (v_mfma_f32_16x16x16_f16: the
@@ -1050,22 +1052,29 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
         }
         return *reinterpret_cast<const float4 *>(p.PH + elem);
       };
-      if (p.nph == 2) {   // four heads per workgroup upstream (decoder_layer.hip: HPW): two partial products per row
+      // canonical order of the head partials (common.h): aligned groups of four heads in head order, the groups in order.
+      // pgrp = 1: the producer (four heads per workgroup) has summed each group already
+      if (p.pgrp == 1 && p.nph == 2) {
         const float4 p0 = ldp((row * 2) * D + 4 * c4);
         const float4 p1 = ldp((row * 2 + 1) * D + 4 * c4);
-        y = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+        y = sc_add4(p0, p1);
       } else
       for (int z0 = 0; z0 < p.nph; z0 += 8) {
         float4 pv[8];
 #pragma unroll
-        for (int z = 0; z < 8; ++z)
+        for (int z = 0; z < 8; ++z) {
           pv[z] = ldp((row * p.nph + min(z0 + z, p.nph - 1)) * D + 4 * c4);
+          if (z0 + z >= p.nph) pv[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (p.pgrp == 4) {
+          const float4 g0 = sc_seq4(pv[0], pv[1], pv[2], pv[3]);
+          y = z0 == 0 ? g0 : sc_add4(y, g0);
+          if (z0 + 4 < p.nph) y = sc_add4(y, sc_seq4(pv[4], pv[5], pv[6], pv[7]));
+        } else {
 #pragma unroll
-        for (int z = 0; z < 8; ++z)
-          if (z0 + z < p.nph) {
-            if (z0 + z == 0) y = pv[0];
-            else { y.x += pv[z].x; y.y += pv[z].y; y.z += pv[z].z; y.w += pv[z].w; }
-          }
+          for (int z = 0; z < 8; ++z)
+            if (z0 + z < p.nph) y = (z0 + z == 0) ? pv[0] : sc_add4(y, pv[z]);
+        }
       }
       const float4 x = make_float4(xi.x + (y.x + pb.x), xi.y + (y.y + pb.y), xi.z + (y.z + pb.z), xi.w + (y.w + pb.w));
       if (grp == 0 && m0 + i < p.M) *reinterpret_cast<float4 *>(p.Xout + row * D + 4 * c4) = x;
@@ -1237,6 +1246,25 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
     if (cc + 1 < p.cpw) load_b1(chunk + 1);  // next chunk's GEMM 1 weights, overlapped with GEMM 2
     __syncthreads();
+    // ---- canonical summation order (bit-reproducible serving): every 128-wide hidden chunk is ONE accumulation chain that
+    // starts from zero, the chunks' results are added as a balanced binary tree over the chunk index - so the result does not
+    // depend on how many chunks a workgroup takes (cpw = 1: the consumer adds neighbours; cpw = 2: they are added here), i.e.
+    // not on the row count that the tile shape is chosen by.  The first chunk's result is parked in the LDS row tile, which
+    // is free from here on (every wave is past the last GEMM 1), and the second chunk's is added to it below.
+    const bool tree_last = cc > 0 && cc + 1 == p.cpw;
+    if (tree_last) {
+#pragma unroll
+      for (int rt = 0; rt < RTT; ++rt)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] =
+                WS ? acc2[rt][t][j] + acc2c[WS ? rt : 0][WS ? t : 0][j] * (1.f / 2048.f) : acc2[rt][t][j];
+          acc2[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (WS) acc2c[WS ? rt : 0][WS ? t : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     // ---- GEMM 2: partial y[RT x D/8] of this wave ----
     if constexpr (WS) {
       constexpr int NS = RTT * KI2;
@@ -1300,9 +1328,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
 #pragma unroll
     for (int t = 0; t < NT2; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        Xs[(rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r] =
-            WS ? acc2[rt][t][j] + acc2c[WS ? rt : 0][WS ? t : 0][j] * (1.f / 2048.f) : acc2[rt][t][j];
+      for (int j = 0; j < 4; ++j) {
+        float *xp = Xs + (rt * 16 + 4 * kk + j) * LDX + (wave * NT2 + t) * 16 + r;
+        const float v = WS ? acc2[rt][t][j] + acc2c[WS ? rt : 0][WS ? t : 0][j] * (1.f / 2048.f) : acc2[rt][t][j];
+        *xp = p.cpw > 1 ? *xp + v : v;   // (cpw > 1: the element this lane parked above + the last chunk's chain)
+      }
   __syncthreads();
   SC_STAMP(PRO ? 2 : 3, PRO ? 7 : 2);
   float *dst = p.part + ((long)grp * p.M + m0) * D;
@@ -1321,7 +1351,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
       }
     }
   }
-  SC_STAMP(PRO ? 2 : 3, PRO ? 8 : 3);
+  SC_STAMP_END(PRO ? 2 : 3, PRO ? 8 : 3);
 }
 SC_PHASE_GETTER(sc_phase_debug_ffn)
 
@@ -1721,7 +1751,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     int best_rtt = 5, best_cpw = nch;
     long slab = M - m_done;
     double best = 1e30;
-    for (int cpw = 1; cpw <= nch; cpw *= 2) {
+    for (int cpw = 1; cpw <= 2; cpw *= 2) {   // (the canonical summation order covers one chunk or an aligned pair per workgroup)
       if (nch % cpw) continue;
       const int ngrp = nch / cpw;
       long fit = ws_rows_per_part / ngrp;
@@ -1742,7 +1772,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     SC_CHECK_ARG(!ho || (slab == M && !rows && !ln_out && !Wq), "context hand-off: all rows in one slab, no row table / LayerNorm");
     if (const char *f = sc_hook("SC_FFN_FORCE")) {   // tools/ffn_sweep.py: "rtt,cpw"
       int r = 0, c = 0;
-      if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && nch % c == 0 &&
+      if (sscanf(f, "%d,%d", &r, &c) == 2 && r >= 1 && r <= 5 && c >= 1 && c <= 2 && nch % c == 0 &&
           (long)(M - m_done) * (nch / c) <= ws_rows_per_part) {
         best_rtt = r;
         best_cpw = c;
@@ -1752,6 +1782,7 @@ static int ffn_run(const float *XN, const int32_t *rows, int M, int D, int F, co
     const int ngrp = nch / best_cpw;
     FfnArgs p{XN, rows ? rows + m_done : nullptr, W1p, b1, W2p, g_ws, (int)slab, F, best_cpw};
     p.w_form = w_form;
+    p.dbg_stamp = sc_phase_take(3);
     // without a row table the slab is addressed by offsetting the base pointers
     const float *xn_base = rows ? XN : XN + (long)m_done * D;
     p.XN = xn_base;
@@ -1869,7 +1900,7 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   // more partial groups - the model fitted for sc_ffn_ln (tools/ffn_sweep.py)
   int best_rtt = 5, best_cpw = nch;
   double best = 1e30;
-  for (int cpw = 1; cpw <= nch; cpw *= 2) {
+  for (int cpw = 1; cpw <= 2; cpw *= 2) {   // (canonical summation order: one chunk or an aligned pair per workgroup)
     if (nch % cpw || nch / cpw > max_part) continue;
     const int ngrp = nch / cpw;
     for (int rtt = 1; rtt <= ffn_rtt_max(D, wf); ++rtt) {
@@ -1882,7 +1913,7 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   SC_CHECK_ARG(best < 1e29, "max_part too small");
   if (const char *f = sc_hook("SC_DEC_FFN_FORCE")) {   // A/B runs: "min_rows,rtt,cpw" for buckets of at least min_rows rows
     int mr = 0, r = 0, c = 0;
-    if (sscanf(f, "%d,%d,%d", &mr, &r, &c) == 3 && M >= mr && r >= 1 && r <= ffn_rtt_max(D, wf) && c >= 1 && nch % c == 0 &&
+    if (sscanf(f, "%d,%d,%d", &mr, &r, &c) == 3 && M >= mr && r >= 1 && r <= ffn_rtt_max(D, wf) && c >= 1 && c <= 2 && nch % c == 0 &&
         nch / c <= max_part) {
       best_rtt = r;
       best_cpw = c;
@@ -1891,7 +1922,8 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   const int ngrp = nch / best_cpw;
   const int nph = sb.H / sc_dec_layer_hpw(sb);   // partial products per row left by sc_dec_layer_cross (decoder_layer.hip)
   FfnArgs p{nullptr, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F,
-            best_cpw, sb.ph2, nph, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf, (sb.act_half & 2) ? 1 : 0};
+            best_cpw, sb.ph2, nph, w.bo2, xin, xout, w.ln3_g, w.ln3_b, sb.ln_eps, sb.S * sb.W, wf, (sb.act_half & 2) ? 1 : 0,
+            sc_phase_take(2), nph == sb.H ? 4 : 1};
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof = sc_prof_begin(st);
   if (D == 256) launch_ffn_rtt<256, true>(p, best_rtt, ngrp, st);

@@ -1280,10 +1280,11 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
 static bool dec_fused_ok(const sc_search &sb) {
   if (const char *e = sc_hook("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size
     return atoi(e) != 0 && sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.out_w_q;
-  int max_rows = SC_FUSED_MAX_ROWS;
-  if (const char *e = sc_hook("SC_FUSED_MAX")) max_rows = atoi(e);   // tools: threshold sweep
-  // (round 4) beyond that limit the form needs the four-heads-per-workgroup variant (decoder_layer.hip: HPW)
-  if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > max_rows && sc_dec_layer_hpw(sb) < 2) return false;
+  // (round 5) the form is a function of the MODEL, never of the bucket size: the six-launch layers sum in another order,
+  // and which bucket a stream decodes in depends on who else is on the GPU.  SC_FUSED_MAX (tools only) restores the old
+  // row threshold for A/B runs.
+  if (const char *e = sc_hook("SC_FUSED_MAX"))
+    if ((sb.rowmap ? sb.n_rows : sb.S * sb.W) > atoi(e) && sc_dec_layer_hpw(sb) < 2) return false;
   return sc_dec_layer_fused_supported(sb.d, sb.H, sb.W, sb.F) && sb.ph1 && sb.ph2 && sb.ffn_part &&
          sb.max_ffn_part >= 1 && sb.out_w_q && sb.V % sb.d == 0 && sb.layers && sb.layers[0].wqkv_pp &&
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;

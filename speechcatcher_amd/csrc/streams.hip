@@ -1212,6 +1212,9 @@ int tick_collect(sc_streams *b) {
     const bool accept = !(stop_eos || stop_bbd || stop_all);
     const bool take = stop_eos || stop_all || accept;
     if (kv_full && take && !(!accept && r.pidx > 1 && r.pvalid)) {   // (not accepted + rewind pending: finish_block goes back to H_in)
+      if (sc_hook("SC_DEBUG_POOL"))
+        fprintf(stderr, "[scasr] pool exhausted: stream %d L %d nhyp %d T %d fin %d pidx %d flags %d kv_rows %d iter %ld\n", s, r.L, r.nhyp,
+                r.T, (int)r.fin, r.pidx, f, b->sb.kv_rows, b->iter);
       fault_stream(b, s, SC_ERR_CAPACITY, "self-attention K|V pool exhausted (kv_pool_rows / max_tokens)");
       continue;
     }

@@ -18,7 +18,8 @@ def main():
     name_col = "kernel_name" if "kernel_name" in scol else "display_name"
     kcols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
     qcol = "queue_id" if "queue_id" in kcols else ("stream_id" if "stream_id" in kcols else None)
-    rows = list(cur.execute(f"select s.{name_col}, d.start, d.end, {('d.' + qcol) if qcol else '0'} from {kd} d "
+    gcol = "d.grid_size_x * d.grid_size_y / (d.workgroup_size_x * d.workgroup_size_y)" if "grid_size_x" in kcols and "workgroup_size_x" in kcols else "0"
+    rows = list(cur.execute(f"select s.{name_col} || ' wgs=' || cast({gcol} as text), d.start, d.end, {('d.' + qcol) if qcol else '0'} from {kd} d "
                             f"join {ks} s on d.kernel_id = s.id order by d.start"))
     # only the decode stream's queue (continuous batching: encoder groups run beside it on another stream)
     import re
@@ -52,7 +53,7 @@ def main():
     prev_end = seg[0][1]
     agg = {}
     for i, (name, s, e) in enumerate(seg):
-        short = name.split("(")[0].replace("void ", "")[:60]
+        short = name.split("(")[0].replace("void ", "")[:60] + (" " + name[name.rindex(" wgs="):] if " wgs=" in name else "")
         if i < max_rows:
             print(f"{(s - seg[0][1]) / 1e3:9.1f} us  gap {(s - prev_end) / 1e3:6.2f}  dur {(e - s) / 1e3:7.2f}  {short}")
         g = agg.setdefault(short, [0, 0.0, 0.0])
