@@ -164,6 +164,9 @@ typedef struct sc_search {
   int32_t kv_rows;   /* rows of the self-attention K|V pool per (stream, layer), <= 65536 */
   int32_t *kvflags;  /* [S] written by sc_beam_prune: 1 = the stream's pool is exhausted (its next step would compute
                         garbage: the host fails the stream with SC_ERR_CAPACITY), 0 = fine */
+  float *ctc_rs;     /* [2][S][TCAP][W] log(exp r^n + exp r^b) of ctc_r, frame by frame (round 5): written wherever ctc_r is
+                        (sc_ctc_extend_state, sc_ctc_gather_state) and read by the prefix scan, whose W x K lanes all
+                        needed this sum of THEIR hypothesis at every frame - 2 of the 7 transcendentals per frame and lane */
 } sc_search;
 
 const char *sc_last_error(void);
@@ -415,6 +418,9 @@ int sc_fuse_topw(const sc_search *sb, void *stream);
 int sc_beam_prune(const sc_search *sb, void *stream);
 /* CTCPrefixScorer.select_state (scorers.py:382-431) */
 int sc_ctc_gather_state(const sc_search *sb, void *stream);
+/* ... behind sc_ctc_prefix_scan_split(sb, split_min): the streams whose scan was split over T (the same rule: at least
+ * split_min frames to walk) left the start states of their CTC_NSEG = 32 segments instead of 16-frame checkpoints */
+int sc_ctc_gather_state_split(const sc_search *sb, int split_min, void *stream);
 /* one full beam-search step = all of the above in order (beam_search.py:701-758) */
 int sc_decode_step(const sc_search *sb, void *stream);
 /* ... with the CTC prefix scan of streams that have >= scan_split_min frames to walk split over T

@@ -244,6 +244,8 @@ class SpecBackend:
             for t in range(max(told, 1), T):
                 r[t, 0, :nh] = LOGZERO
                 r[t, 1, :nh] = r[t - 1, 1, :nh] + xb[t]
+                if getattr(sb, "ctc_rs", None) is not None:      # log(exp r^n + exp r^b): r^n is logzero here
+                    sb.ctc_rs[cur, s, t, :nh] = r[t, 1, :nh]
 
     def dec_embed(self, sb):
         """transformer_decoder.py:231 + positional_encoding.py:64-74"""
@@ -723,6 +725,8 @@ class SpecBackend:
             for i in range(nout):
                 h, k = int(sb.sel[s, i, 0]), int(sb.sel[s, i, 1])
                 sb.ctc_r[o, s, :T, :, i] = sb._rnew_full[s][:T, :, h * K + k]
+                if getattr(sb, "ctc_rs", None) is not None:
+                    sb.ctc_rs[o, s, :T, i] = torch.logsumexp(sb.ctc_r[o, s, :T, :, i], 1)
 
     def decode_step(self, sb):
         """One beam-search step for every active stream

@@ -49,7 +49,7 @@ class Search(C.Structure):
                              "dec_norm_g", "dec_norm_b", "out_w", "out_b", "layers", "rowmap")]
         + [("n_rows", C.c_int32), ("out_w_q", vp), ("ph1", vp), ("ph2", vp), ("ffn_part", vp),
            ("max_ffn_part", C.c_int32), ("tct", C.c_int32), ("ctcxT", vp), ("kv_half", C.c_int32), ("stat_rows", vp),
-           ("out_w_qh", vp), ("act_half", C.c_int32), ("kv_rows", C.c_int32), ("kvflags", vp)]
+           ("out_w_qh", vp), ("act_half", C.c_int32), ("kv_rows", C.c_int32), ("kvflags", vp), ("ctc_rs", vp)]
     )
 
 
@@ -145,6 +145,7 @@ _SIGS = {
     "sc_fuse_topw": (C.c_int, [vp, vp]),
     "sc_beam_prune": (C.c_int, [vp, vp]),
     "sc_ctc_gather_state": (C.c_int, [vp, vp]),
+    "sc_ctc_gather_state_split": (C.c_int, [vp, C.c_int, vp]),
     "sc_decode_step": (C.c_int, [vp, vp]),
     "sc_decode_step_ex": (C.c_int, [vp, C.c_int, vp]),
     "sc_ctc_prefix_scan_split": (C.c_int, [vp, C.c_int, vp]),

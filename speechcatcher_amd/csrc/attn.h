@@ -66,29 +66,44 @@ __device__ __forceinline__ void mattn_init(MAttn<DK> &a) {
 }
 
 typedef _Float16 sc_half2 __attribute__((ext_vector_type(2)));
+// SC_KV_NT (A/B switch, default 0): the K|V rows of a walk are read ONCE by ONE workgroup - with non-temporal loads they do
+// not displace the weight fragments that all workgroups of an XCD share in its 4 MB L2
+#ifndef SC_KV_NT
+#define SC_KV_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T sc_ld_stream(const T *p) {
+#if SC_KV_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 template <int N, bool KVH>
 __device__ __forceinline__ void kv_loadn(const float *base, long elem, float *out) {
   static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 elements");
   if (KVH) {
     const _Float16 *h = reinterpret_cast<const _Float16 *>(base) + elem;
     if (N == 4) {
-      const sc_half4 v = *reinterpret_cast<const sc_half4 *>(h);
+      const sc_half4 v = sc_ld_stream(reinterpret_cast<const sc_half4 *>(h));
       out[0] = (float)v.x; out[1] = (float)v.y; out[2] = (float)v.z; out[3] = (float)v.w;
     } else if (N == 2) {
-      const sc_half2 v = *reinterpret_cast<const sc_half2 *>(h);
+      const sc_half2 v = sc_ld_stream(reinterpret_cast<const sc_half2 *>(h));
       out[0] = (float)v.x; out[1] = (float)v.y;
     } else {
-      out[0] = (float)*h;
+      out[0] = (float)sc_ld_stream(h);
     }
   } else {
     if (N == 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(base + elem);
+      const sc_f32x4 v = sc_ld_stream(reinterpret_cast<const sc_f32x4 *>(base + elem));
       out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
     } else if (N == 2) {
-      const float2 v = *reinterpret_cast<const float2 *>(base + elem);
+      const sc_f32x2 v = sc_ld_stream(reinterpret_cast<const sc_f32x2 *>(base + elem));
       out[0] = v.x; out[1] = v.y;
     } else {
-      out[0] = base[elem];
+      out[0] = sc_ld_stream(base + elem);
     }
   }
 }

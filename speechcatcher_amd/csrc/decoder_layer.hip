@@ -157,6 +157,19 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #ifndef SC_LAYER_NTW
 #define SC_LAYER_NTW 4
 #endif
+// A/B switches of the four-heads-per-workgroup form (tools/build_variant.sh <name> "-DSC_EARLY_KV=0 ..."; defaults = the product):
+#ifndef SC_EARLY_LIST
+#define SC_EARLY_LIST 1   // 1: the self-attention's row list is built in the prologue (0: after the projection, round 4)
+#endif
+#ifndef SC_EARLY_KV
+#define SC_EARLY_KV 1     // 1: a wave's first batch of K|V tiles is requested behind the projection's MFMAs (needs SC_EARLY_LIST)
+#endif
+#ifndef SC_HPW_NTW
+#define SC_HPW_NTW 2      // tiles per wave in flight in the four-head form's SELF walk (2 | 4; the arithmetic is the same: canonical batches)
+#endif
+#ifndef SC_HPW_NTW_CROSS
+#define SC_HPW_NTW_CROSS 2   // ... in its CROSS walk
+#endif
 template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1, bool WH = false>
 __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // (HPW > 1, round 5: of the first 512 positions, one per thread of the workgroup - the list is BUILT before the prologue's
   // partial sums have arrived, see early_list below)
   int slp[WM] = {};
-  if ((PF || HPW > 1) && SELF) {
+  if ((PF || (HPW > 1 && SC_EARLY_LIST)) && SELF) {
     const int *anc0 = ANC(cur, s);
     const int pt = HPW > 1 ? tid : gt;
     const bool live0 = pt < (HPW > 1 ? PCS : PCH) && pt < L - 1;
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   }
   int U0 = 0;   // HPW > 1, SELF: entries of the row list of the first 512 positions
   auto early_list = [&]() {
-    if constexpr (HPW > 1 && SELF)
+    if constexpr (HPW > 1 && SELF && SC_EARLY_LIST)
       U0 = mattn_build_rows<WM, true, NTH, PCS>(srows, swtot, ANC(cur, s), 0, L - 1, W, nh, tid, lane, tid >> 6, slp);
   };
   float touch = 0.f, kvtouch = 0.f;
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 2);
 
-  constexpr int NTW_ = (UNR >= 8) ? SC_LAYER_NTW : 2;   // tiles per wave in flight in the attention walk
+  constexpr int NTW_ = (UNR >= 8) ? SC_LAYER_NTW : (HPW > 1 ? (SELF ? SC_HPW_NTW : SC_HPW_NTW_CROSS) : 2);   // tiles per wave in flight in the attention walk
   MBatch<DK, NTW_> kvb0;                                 // HPW > 1, SELF: the wave's first batch, requested ahead (below)
   // ------------------------------------------------------------------ projection of the head's columns
   // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     // HPW > 1, SELF (round 5): the wave's FIRST batch of K|V tiles is requested here - the rows of the cached positions do not
     // depend on this step's x, the list has been there since the prologue - and travels while the split sums are reduced
     // and the new token's row is appended (1.4 us of a 22 us kernel during which HBM idled)
-    if constexpr (HPW > 1 && SELF) {
+    if constexpr (HPW > 1 && SELF && SC_EARLY_LIST && SC_EARLY_KV) {
       const long skv0e = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;
       mattn_load<DK, NTW_, KVH>(kvb0, sb.skv, D, cdiv(U0, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
         const int e = srows[min(idx, PCS * W - 1)];
@@ -546,8 +559,13 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
       };
       // positions [0, 512): the list was built in the prologue, every wave's first batch is in its registers
+      if constexpr (!SC_EARLY_LIST)
+        U0 = mattn_build_rows<WM, false, NTH, PCS>(srows, swtot, anc, 0, Lc, W, nh, tid, lane, tid >> 6, slp);
       urows += U0;
-      mattn_walk<DK, NTW, KVH, true>(st, qs, sb.skv, D, cdiv(U0, 16), wave, lane, rowfn, &kvb0);
+      if constexpr (SC_EARLY_LIST && SC_EARLY_KV)
+        mattn_walk<DK, NTW, KVH, true>(st, qs, sb.skv, D, cdiv(U0, 16), wave, lane, rowfn, &kvb0);
+      else
+        mattn_walk<DK, NTW, KVH>(st, qs, sb.skv, D, cdiv(U0, 16), wave, lane, rowfn);
       for (int c0 = PCS; c0 < Lc; c0 += PCS) {
         __syncthreads();  // the list is rebuilt for the next positions
         const int U = mattn_build_rows<WM, false, NTH, PCS>(srows, swtot, anc, c0, Lc, W, nh, tid, lane, tid >> 6, slp);

@@ -475,6 +475,59 @@ int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const flo
   return SC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tail of the decoder, first half (round 5): x = x_in + b2 + tree sum of the last layer's feed-forward partial sums (by row
+// id, canonical order: common.h), after_norm -> XN.  One wave per row.  The output layer is then ONE tiled GEMM over all
+// rows (sc_gemm): the row-panel kernel that did both (reduce_ln_proj_kernel) re-reduced every panel's partial sums in each
+// of its column-block workgroups and re-streamed the 1 MB output matrix per 16-row panel - 44 MB of traffic for 7.6 MB of
+// operands, 36 us at a full bucket for 4.3 us of matrix work.
+__global__ __launch_bounds__(256) void reduce_ln_rows_kernel(const float *__restrict__ part, int npart, long part_M, const float *__restrict__ b2,
+                                                             const float *__restrict__ Xin, float *__restrict__ Xout, const int *__restrict__ rows,
+                                                             int M, int D, const float *__restrict__ g, const float *__restrict__ be, float eps,
+                                                             float *__restrict__ XN, int part_half) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long row = rows ? rows[m] : m;
+  const int c4 = lane;                 // D / 4 <= 64 float4 pieces per row
+  const bool act = c4 < D / 4;
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act) {
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z0 = 0; z0 < npart; z0 += 8) {
+      float4 p[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long pe = ((long)min(z0 + q, npart - 1) * part_M + row) * D + 4 * c4;
+        if (part_half) {
+          const rp_h4 h = *reinterpret_cast<const rp_h4 *>(reinterpret_cast<const _Float16 *>(part) + pe);
+          p[q] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+          p[q] = *reinterpret_cast<const float4 *>(part + pe);
+        }
+        if (z0 + q >= npart) p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float4 t = sc_tree8(p);
+      y = z0 == 0 ? t : sc_add4(y, t);
+    }
+    const float4 xi = *reinterpret_cast<const float4 *>(Xin + row * D + 4 * c4);
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b2) bb = *reinterpret_cast<const float4 *>(b2 + 4 * c4);
+    x = make_float4(xi.x + (y.x + bb.x), xi.y + (y.y + bb.y), xi.z + (y.z + bb.z), xi.w + (y.w + bb.w));
+    if (Xout) *reinterpret_cast<float4 *>(Xout + row * D + 4 * c4) = x;
+  }
+  const float s = act ? (x.x + x.y) + (x.z + x.w) : 0.f;
+  const float mean = wave_sum(s) / (float)D;
+  const float a = x.x - mean, b = x.y - mean, c = x.z - mean, e = x.w - mean;
+  const float q2 = act ? (a * a + b * b) + (c * c + e * e) : 0.f;
+  const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + eps);
+  if (act) {
+    const float4 gm = *reinterpret_cast<const float4 *>(g + 4 * c4), bt = *reinterpret_cast<const float4 *>(be + 4 * c4);
+    *reinterpret_cast<float4 *>(XN + row * D + 4 * c4) =
+        make_float4(a * rstd * gm.x + bt.x, b * rstd * gm.y + bt.y, c * rstd * gm.z + bt.z, e * rstd * gm.w + bt.w);
+  }
+}
+
 // Tail of the head-parallel decoder (decoder_layer.hip): sum of the last layer's feed-forward partial sums
 // (by row id) + b2 + residual, after_norm, output layer -> sb->logits (transformer_decoder.py:243-249).
 extern "C" int sc_dec_output_logits(const sc_search *sbp, const float *xin, float *xout, const float *ffn_part,
@@ -485,6 +538,17 @@ extern "C" int sc_dec_output_logits(const sc_search *sbp, const float *xin, floa
   const int M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   const bool hm = (sb.act_half & 4) != 0 && sb.out_w_qh != nullptr;
   SC_CHECK_ARG(!(sb.act_half & 4) || hm, "fp16 output layer needs out_w_qh");
+  if (!hm && sb.d % 4 == 0 && sb.d <= 256 && sb.dq && sb.out_w && !sc_hook("SC_LOGITS_PANEL")) {
+    // (round 5) reduce + after_norm once per row, then the output layer as one tiled GEMM over the bucket's rows - the
+    // same two launches for every bucket size (the form must not depend on the row count: common.h)
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof = sc_prof_begin(st);
+    reduce_ln_rows_kernel<<<cdiv(M, 4), 256, 0, st>>>(ffn_part, n_ffn_part, (long)sb.S * sb.W, sb.layers[sb.n_layers - 1].b2, xin, xout,
+                                                      sb.rowmap, M, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, sb.dq, (sb.act_half & 2) ? 1 : 0);
+    SC_CHECK_LAUNCH();
+    sc_prof_end(prof, SC_PROF_PROJ_LN_PROJ, 0.0, 4.0 * (double)M * sb.d * (2 + n_ffn_part));
+    return sc_gemm(sb.dq, sb.rowmap, sb.d, sb.out_w, sb.out_b, sb.logits, sb.rowmap, sb.V, M, sb.V, sb.d, 0, 0, stream);
+  }
   return sc_launch_reduce_ln_proj(ffn_part, n_ffn_part, sb.S * sb.W, sb.layers[sb.n_layers - 1].b2, xin, xout,
                                   sb.rowmap, M, sb.d, sb.dec_norm_g, sb.dec_norm_b, sb.ln_eps, nullptr,
                                   hm ? (const float *)sb.out_w_qh : sb.out_w_q, sb.out_b, sb.logits, sb.V,

@@ -371,7 +371,8 @@ __global__ void ctx_blkinfo_kernel(const int *jobs, int ns, int nblk, int *blkin
     for (int i = 0; i < nbk; ++i) {
       const bool last = i == nbk - 1;
       reinterpret_cast<int4 *>(blkinfo)[b0 + i] =
-          make_int4(last ? -1 : b0 + i + 1, (i == 0 && !has) ? 1 : 0, last ? srow : -1, (last && has) ? b0 : -1);
+          make_int4(last ? -1 : b0 + i + 1, ((i == 0 && !has) ? 1 : 0) | 2 /* bit 1: the block belongs to a chain */, last ? srow : -1,
+                    (last && has) ? b0 : -1);
     }
   }
 }

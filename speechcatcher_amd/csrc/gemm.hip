@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
 // block encoder (contextual_block_encoder_layer.py:252-267; ctx_handoff_kernel, encoder.hip: slot 0 of every block <- last row of the stream's previous block, the
 // first block's from / the last block's to the per-stream state): the thread that owns element n of a block's LAST row
 // also writes it where the chain sends it; slot-0 rows are written by nobody else (their own sums are discarded by the
-// hand-off anyway).  blkinfo[blk] = {next block of the chain or -1, 1 if first block of a chain without saved state,
+// hand-off anyway).  blkinfo[blk] = {next block of the chain or -1, bit 0: first block of a chain without saved state | bit 1: in a chain,
 // state row base (stream * n_layers) if last block else -1, first block of the chain if last and the state is valid else -1}
 __global__ __launch_bounds__(256) void ffn_reduce_handoff_kernel(GemmArgs g, int ksplit, ScHandoff h) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -437,9 +437,11 @@ __global__ __launch_bounds__(256) void ffn_reduce_handoff_kernel(GemmArgs g, int
   if (idx >= (long)g.M * n4) return;
   const int m = idx / n4, n = (idx % n4) * 4;
   const int blk = m / h.R, r = m % h.R;
-  if (r == 0) return;
   int4 info = make_int4(-1, 0, -1, -1);
-  if (r == h.R - 1) info = *reinterpret_cast<const int4 *>(h.blkinfo + 4 * blk);
+  if (r == h.R - 1 || r == 0) info = *reinterpret_cast<const int4 *>(h.blkinfo + 4 * blk);
+  // slot 0 of a block that belongs to a chain is written by the chain (its own sums are discarded by the hand-off); a
+  // block OUTSIDE every chain (info.y bit 1 clear: not covered by the job table) keeps the plain reduce for its slot 0
+  if (r == 0 && (info.y & 2)) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int z0 = 0; z0 < ksplit; z0 += 8) {
     float4 p[8];
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void ffn_reduce_handoff_kernel(GemmArgs g, int
   *dst = acc;
   if (r != h.R - 1) return;
   if (info.x >= 0) *reinterpret_cast<float4 *>(g.C + (long)info.x * h.R * g.ldc + n) = acc;
-  if (info.y) *reinterpret_cast<float4 *>(g.C + (long)blk * h.R * g.ldc + n) = acc;
+  if (info.y & 1) *reinterpret_cast<float4 *>(g.C + (long)blk * h.R * g.ldc + n) = acc;
   if (info.z >= 0) {
     float4 *st = reinterpret_cast<float4 *>(h.state + (long)(info.z + h.layer) * g.N + n);
     if (info.w >= 0) *reinterpret_cast<float4 *>(g.C + (long)info.w * h.R * g.ldc + n) = *st;

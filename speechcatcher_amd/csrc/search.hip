@@ -14,6 +14,7 @@
 #define XPOS(pp, s, h) (sb.xpos + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
 #define ANC(pp, s) (sb.anc + ((long)(pp) * sb.S + (s)) * sb.LCAP * sb.W)
 #define CTCR(pp, s) (sb.ctc_r + ((long)(pp) * sb.S + (s)) * sb.TCAP * 2 * sb.W)
+#define CTCRS(pp, s) (sb.ctc_rs + ((long)(pp) * sb.S + (s)) * sb.TCAP * sb.W)   // log(exp r^n + exp r^b) per frame (scasr.h)
 
 // ---------------------------------------------------------------------------
 // CTC state extension: r^n[t] = logzero, r^b[t] = r^b[t-1] + x[t, blank]
@@ -24,6 +25,7 @@ __global__ void ctc_extend_state_kernel(sc_search sb) {
   const int T = CTRL(s, SC_C_T), told = CTRL(s, SC_C_TOLD), nh = CTRL(s, SC_C_NHYP);
   if (h >= nh || told >= T) return;
   float *r = CTCR(CTRL(s, SC_C_CUR), s);
+  float *rs = CTCRS(CTRL(s, SC_C_CUR), s);
   const float *x = sb.ctcx + (long)s * sb.TCAP * sb.V;
   const int t0 = told < 1 ? 1 : told;
   float rb = r[((long)(t0 - 1) * 2 + 1) * sb.W + h];
@@ -31,6 +33,7 @@ __global__ void ctc_extend_state_kernel(sc_search sb) {
     rb = rb + x[(long)t * sb.V + sb.blank];
     r[((long)t * 2 + 0) * sb.W + h] = SC_LOGZERO;
     r[((long)t * 2 + 1) * sb.W + h] = rb;
+    rs[(long)t * sb.W + h] = rb;   // lse2(logzero, rb) == rb exactly: exp2 of -1e10 is 0, log of 1 is 0
   }
 }
 
@@ -590,7 +593,7 @@ extern "C" int sc_logsoftmax_topk(const sc_search *sbp, void *stream) {
 // line per lane and frame); 45 us at T = 400; T = 4500 is a 180 s segment of the CLI.
 struct CtcChunkT {
   float4 xc[4], xb[4];
-  float pn[16], pb[16];
+  float pn[16], pb[16];   // pn: log(exp r^n + exp r^b) of the prefix at t-1 (sc_search.ctc_rs; round 5 - was r^n), pb: its r^b
 };
 // Forward variables of the candidates are kept at CHECKPOINT frames only (t % 16 == 15): ctc_rnew [S][tck][2][W*K],
 // tck = ceil(TCAP / 16).  The W x K candidates of a stream used to write r[t] for EVERY frame (3.2 KB per frame at beam
@@ -599,14 +602,24 @@ struct CtcChunkT {
 // recurrence (ctc_frame below, bit for bit) over 16 frames per thread, all segments in parallel.
 #define SC_CTC_CK 16
 __host__ __device__ static inline int ctc_tck(int TCAP) { return (TCAP + SC_CTC_CK - 1) / SC_CTC_CK; }
-// one frame of Watanabe Alg. 2 for one (hypothesis, candidate): (r_n, r_b) at t-1 -> t; pn / pb = r of the PREFIX at t-1
-__device__ __forceinline__ void ctc_frame(float &r_n, float &r_b, float pn, float pb, bool same, float xc, float xb, float &phi) {
-  const float rs = lse2(pn, pb);
-  phi = same ? pb : rs;          // select, not a branch: lanes of a wave differ in `same`
+// one frame of Watanabe Alg. 2 for one (hypothesis, candidate): (r_n, r_b) at t-1 -> t; pb = r^b of the PREFIX at t-1
+// prs = log(exp r^n + exp r^b) of the PREFIX at t-1: the same for the K candidates of a hypothesis - it comes from
+// sc_search.ctc_rs (round 5) instead of two transcendentals per frame and lane
+__device__ __forceinline__ void ctc_frame(float &r_n, float &r_b, float prs, float pb, bool same, float xc, float xb, float &phi) {
+  phi = same ? pb : prs;         // select, not a branch: lanes of a wave differ in `same`
   const float nr_n = lse2(r_n, phi) + xc;
   const float nr_b = lse2(r_n, r_b) + xb;
   r_n = nr_n;
   r_b = nr_b;
+}
+// running log-sum-exp (pm = maximum so far, ps = sum of exp(term - pm)) + one term v.  One of the two exponentials of the
+// textbook update is exp(0) = 1: only the other one is evaluated (round 5: the scan is bound by its transcendentals -
+// 8 per frame and lane until round 4, 7 with this)
+__device__ __forceinline__ void ctc_psi_add(float &pm, float &ps, float v) {
+  const float d = v - pm;
+  const float e = sc_exp_neg(-fabsf(d));
+  ps = d > 0.f ? ps * e + 1.f : ps + e;
+  pm = sc_max_raw(pm, v);
 }
 // a stream's scan is split over T (ctc_prefix_scan_tpar_kernel) when it has at least split_min frames to walk
 __device__ __forceinline__ bool ctc_scan_is_split(int T, int L, int split_min) {
@@ -615,6 +628,10 @@ __device__ __forceinline__ bool ctc_scan_is_split(int T, int L, int split_min) {
   if (start > T) start = T;
   return split_min > 0 && T - start >= split_min;
 }
+#define CTC_NSEG 32   // segments per (hypothesis, candidate) pair of the T-parallel scan
+// (the T-parallel form parks CTC_NSEG segment states per pair where the checkpoints live: the hosts switch it off for tables
+// that short - ctc_split_min_ok)
+static inline int ctc_split_min_ok(int TCAP, int split_min) { return ctc_tck(TCAP) >= CTC_NSEG ? split_min : 0; }
 
 __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search sb, int split_min) {
   const int s = blockIdx.y;
@@ -634,6 +651,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
   const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
   const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
   const float *__restrict__ rp = CTCR(cur, s);
+  const float *__restrict__ rsp = CTCRS(cur, s);
   float *rn = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * (W * K);   // checkpoints: r[16 j + 15] at row j
   const int WK = W * K;
   const int out_len = L - 1;
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
       for (int i = 0; i < 16; ++i) {
         int t = tb + i;
         t = t < T ? (t < 1 ? 1 : t) : T - 1;
-        q.pn[i] = rp[((long)(t - 1) * 2) * W + h];
+        q.pn[i] = rsp[(long)(t - 1) * W + h];
         q.pb[i] = rp[((long)(t - 1) * 2 + 1) * W + h];
       }
     }
@@ -676,18 +694,15 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
     const float4 c4 = q.xc[i >> 2], b4 = q.xb[i >> 2];
     const float xc = (i & 3) == 0 ? c4.x : (i & 3) == 1 ? c4.y : (i & 3) == 2 ? c4.z : c4.w;
     const float xb = (i & 3) == 0 ? b4.x : (i & 3) == 1 ? b4.y : (i & 3) == 2 ? b4.z : b4.w;
-    const float pn = has ? q.pn[i] : SC_LOGZERO;
+    const float prs = has ? q.pn[i] : cum;    // (no prefix state: r^n is logzero, r^n (+) r^b = the running blank sum)
     const float pb = has ? q.pb[i] : cum;     // r_prev[t-1]
     float phi;
-    ctc_frame(r_n, r_b, pn, pb, same, xc, xb, phi);
+    ctc_frame(r_n, r_b, prs, pb, same, xc, xb, phi);
     if ((i & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {   // (chunks are 16-frame aligned: i == 15 <=> t % 16 == 15; compile-time per unrolled frame)
       rn[((long)(t / SC_CTC_CK) * 2) * WK + e] = r_n;
       rn[((long)(t / SC_CTC_CK) * 2 + 1) * WK + e] = r_b;
     }
-    const float v = phi + xc;       // branch-free running log-sum-exp
-    const float m = sc_max_raw(pm, v);
-    ps = ps * sc_exp_neg(pm - m) + sc_exp_neg(v - m);
-    pm = m;
+    ctc_psi_add(pm, ps, phi + xc);
     if (!has) cum += xb;
   };
   auto advance = [&](const CtcChunkT &q, int tb) {
@@ -716,9 +731,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
     }
   }
   float psi = pm + logf(ps);
-  const float pn_last = has ? rp[((long)(T - 1) * 2) * W + h] : SC_LOGZERO;
-  const float pb_last = has ? rp[((long)(T - 1) * 2 + 1) * W + h] : cum;
-  const float rsum_last = lse2(pn_last, pb_last);
+  const float rsum_last = has ? rsp[(long)(T - 1) * W + h] : cum;
   if (c == sb.eos) psi = rsum_last;
   if (c == sb.blank) psi = SC_LOGZERO;
   sb.psi[row * K + k] = psi;
@@ -732,12 +745,13 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_colmajor_kernel(sc_search
 //     n_end = A * n0 + Un,      b_end = C * n0 + D * b0 + Ub
 // with five coefficients that a thread accumulates over its segment WITHOUT knowing the start state (log domain:
 // A += xc, D += xb, Un = lse(Un, phi) + xc, C = lse(A, C) + xb, Ub = lse(Un, Ub) + xb).  A workgroup holds 16
-// (hypothesis, candidate) pairs x 32 segments: pass 1 = coefficients (+ the segment's share of psi, which does not
-// depend on the state at all), a 16-step combine in LDS gives every segment its start state, pass 2 re-walks the
-// segment with the plain recurrence and stores r[t].  Twice the arithmetic, 1/16 of the dependent chain.
-// Rounding differs from the sequential walk at the level of the fp32 log-add-exps (same magnitudes).
+// (hypothesis, candidate) pairs x 32 segments: ONE pass = coefficients (+ the segment's share of psi, which does not
+// depend on the state at all), a 32-step combine in LDS gives every segment its start state - stored; the forward
+// variables of the W winners are rebuilt from them by ctc_gather_state_kernel (round 5; rounds 2-4 re-walked all W x K
+// pairs here: twice the arithmetic).  Rounding differs from the sequential walk at the level of the fp32 log-add-exps
+// (same magnitudes).  WHICH form a stream's scan takes is a function of ITS table (frames to walk >= the threshold),
+// never of the number of streams in the step: the same audio gives the same bits whoever else is on the GPU.
 // ---------------------------------------------------------------------------
-#define CTC_NSEG 32   // segments per (hypothesis, candidate) pair
 #define CTC_EB (256 / CTC_NSEG)   // pairs per workgroup
 __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb, int split_min) {
   __shared__ float co[8][CTC_NSEG][CTC_EB];    // A, C, D, Un, Ub, psi max, psi sum, blank sum of every (segment, pair)
@@ -763,22 +777,14 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
   const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
   const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
   const float *__restrict__ rp = CTCR(cur, s);
+  const float *__restrict__ rsp = CTCRS(cur, s);
   float *rn = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * (W * K);   // checkpoints: r[16 j + 15] at row j
   const int WK = W * K;
   const int out_len = L - 1;
   int start = out_len > 1 ? out_len : 1;
   if (start > T) start = T;
-  if (valid)
-    for (int j = p; SC_CTC_CK * j + SC_CTC_CK - 1 < start - 1; j += CTC_NSEG) {   // frames before start-1: logzero
-      rn[((long)j * 2) * WK + e] = SC_LOGZERO;
-      rn[((long)j * 2 + 1) * WK + e] = SC_LOGZERO;
-    }
   const float r_n0 = (out_len == 0) ? xcol[0] : SC_LOGZERO;  // r[start-1][n]; start == 1 when out_len == 0
   const float r_b0 = SC_LOGZERO;
-  if (valid && p == 0 && ((start - 1) & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {
-    rn[((long)((start - 1) / SC_CTC_CK) * 2) * WK + e] = r_n0;
-    rn[((long)((start - 1) / SC_CTC_CK) * 2 + 1) * WK + e] = r_b0;
-  }
   // segments: boundaries at multiples of 16 frames (the loads are 16-frame chunks)
   const int base = start & ~15;
   const int seg = 16 * cdiv(T - base, 16 * CTC_NSEG);
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
       for (int i = 0; i < 16; ++i) {
         int t = tb + i;
         t = t < T ? (t < 1 ? 1 : t) : T - 1;
-        q.pn[i] = rp[((long)(t - 1) * 2) * W + h];
+        q.pn[i] = rsp[(long)(t - 1) * W + h];
         q.pb[i] = rp[((long)(t - 1) * 2 + 1) * W + h];
       }
     }
@@ -849,9 +855,8 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
     float cu = cum;
     walk(t_lo, t_hi, [&](const CtcChunkT &q, int i, int) {
       const float xc = comp(q.xc[i >> 2], i), xb = comp(q.xb[i >> 2], i);
-      const float pn = has ? q.pn[i] : SC_LOGZERO;
       const float pb = has ? q.pb[i] : cu;     // r_prev[t-1]
-      const float phi = same ? pb : lse2(pn, pb);
+      const float phi = same ? pb : (has ? q.pn[i] : cu);
       const float nUb = lse2(Un, Ub) + xb;
       const float nC = lse2(A, C) + xb;
       Un = lse2(Un, phi) + xc;
@@ -859,10 +864,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
       C = nC;
       A += xc;
       D += xb;
-      const float v = phi + xc;       // branch-free running log-sum-exp
-      const float m = sc_max_raw(pm, v);
-      ps = ps * sc_exp_neg(pm - m) + sc_exp_neg(v - m);
-      pm = m;
+      ctc_psi_add(pm, ps, phi + xc);
       if (!has) cu += xb;
     });
   }
@@ -889,9 +891,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
       float total = 0.f;   // !has: blank sum over all T frames
       if (!has)
         for (int q = 0; q < CTC_NSEG; ++q) total += co[7][q][el];
-      const float pn_last = has ? rp[((long)(T - 1) * 2) * W + h] : SC_LOGZERO;
-      const float pb_last = has ? rp[((long)(T - 1) * 2 + 1) * W + h] : total;
-      const float rsum_last = lse2(pn_last, pb_last);
+      const float rsum_last = has ? rsp[(long)(T - 1) * W + h] : total;
       if (c == sb.eos) psi = rsum_last;
       if (c == sb.blank) psi = SC_LOGZERO;
       sb.psi[row * K + k] = psi;
@@ -899,22 +899,12 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
     }
   }
   __syncthreads();
-  // ---- pass 2: the plain recurrence from the segment's start state, r[t] stored ----
-  {
-    float r_n = st0[0][p][el], r_b = st0[1][p][el];
-    float cu = has ? 0.f : cum0[p][el];
-    walk(t_lo, t_hi, [&](const CtcChunkT &q, int i, int t) {
-      const float xc = comp(q.xc[i >> 2], i), xb = comp(q.xb[i >> 2], i);
-      const float pn = has ? q.pn[i] : SC_LOGZERO;
-      const float pb = has ? q.pb[i] : cu;
-      float phi;
-      ctc_frame(r_n, r_b, pn, pb, same, xc, xb, phi);
-      if (valid && (t & (SC_CTC_CK - 1)) == SC_CTC_CK - 1) {
-        rn[((long)(t / SC_CTC_CK) * 2) * WK + e] = r_n;
-        rn[((long)(t / SC_CTC_CK) * 2 + 1) * WK + e] = r_b;
-      }
-      if (!has) cu += xb;
-    });
+  // ---- (round 5) no second pass: the start state of every segment goes to rows 0 .. CTC_NSEG-1 of the stream's ctc_rnew
+  // (the sequential kernel keeps its 16-frame checkpoints there); ctc_gather_state_kernel re-walks the W WINNERS' segments
+  // from them - the candidates' r[t] were computed twice here only to be thrown away for all but W of the W x K pairs
+  if (valid) {
+    rn[((long)p * 2) * WK + e] = st0[0][p][el];
+    rn[((long)p * 2 + 1) * WK + e] = st0[1][p][el];
   }
 }
 
@@ -922,6 +912,7 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
 extern "C" int sc_ctc_prefix_scan_split(const sc_search *sbp, int split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0, "the prefix scan needs the column-major table copy (sc_search.ctcxT)");
+  split_min = ctc_split_min_ok(sbp->TCAP, split_min);
   dim3 grid(cdiv(sbp->W * sbp->K, 256), sbp->S);
   ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   if (split_min > 0)
@@ -1184,21 +1175,28 @@ extern "C" int sc_beam_prune(const sc_search *sbp, void *stream) {
 // variables from the checkpoints the scan left (see SC_CTC_CK above): thread = (winner i, 16-frame segment j) walks its
 // segment with the scan's own recurrence from the checkpoint in front of it (or from the scan's initial state in the
 // segment that holds frame start-1) and writes r[t] of all its frames into the other side of ctc_r.
-__global__ __launch_bounds__(256) void ctc_gather_state_kernel(sc_search sb) {
+__global__ __launch_bounds__(256) void ctc_gather_state_kernel(sc_search sb, int split_min) {
   const int s = blockIdx.y;
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int W = sb.W, K = sb.K, V = sb.V, T = SC_CTC_T(s), nh = CTRL(s, SC_C_NHYP), L = CTRL(s, SC_C_L);
   const int nout = nh * W < W ? nh * W : W;
   const int cur = CTRL(s, SC_C_CUR), o = 1 - cur;
   const bool has = CTRL(s, SC_C_HAS);
-  const int nseg = cdiv(T, SC_CTC_CK);
   const int WK = W * K, tct = sb.tct;
   float *dst = CTCR(o, s);
+  float *dst_rs = CTCRS(o, s);
   const float *__restrict__ rp = CTCR(cur, s);
+  const float *__restrict__ rsp = CTCRS(cur, s);
   const float *ck = sb.ctc_rnew + (long)s * ctc_tck(sb.TCAP) * 2 * WK;
   const int out_len = L - 1;
   int start = out_len > 1 ? out_len : 1;
   if (start > T) start = T;
+  // the stream's scan was split over T (ctc_prefix_scan_tpar_kernel): CTC_NSEG segments with the scan's own boundaries,
+  // their start states in rows 0 .. CTC_NSEG-1 of ck; otherwise 16-frame segments behind the checkpoints
+  const bool split = ctc_scan_is_split(T, L, split_min);
+  const int base = start & ~15;
+  const int seg = split ? 16 * cdiv(T - base, 16 * CTC_NSEG) : SC_CTC_CK;
+  const int nseg = split ? CTC_NSEG : cdiv(T, SC_CTC_CK);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nout * nseg; idx += gridDim.x * blockDim.x) {
     const int i = idx % nout, j = idx / nout;
     const int h = sb.sel[((long)s * W + i) * 2], k = sb.sel[((long)s * W + i) * 2 + 1];
@@ -1207,68 +1205,95 @@ __global__ __launch_bounds__(256) void ctc_gather_state_kernel(sc_search sb) {
     const bool same = c == YSEQ(cur, s, h)[L - 1];
     const float *__restrict__ xcol = sb.ctcxT + ((long)s * V + c) * tct;
     const float *__restrict__ xblk = sb.ctcxT + ((long)s * V + sb.blank) * tct;
-    const int t0 = j * SC_CTC_CK, t1 = min(t0 + SC_CTC_CK, T);
+    // frames [t_lo, t_hi) of this thread and the state in front of them
+    int t_lo, t_hi;
     float r_n, r_b;
-    int begin;
-    if (t0 <= start - 1) {   // the segment that holds frame start-1 (or lies in front of it)
-      r_n = (out_len == 0) ? xcol[0] : SC_LOGZERO;
-      r_b = SC_LOGZERO;
-      for (int t = t0; t < min(start - 1, t1); ++t) {
-        dst[((long)t * 2) * W + i] = SC_LOGZERO;
-        dst[((long)t * 2 + 1) * W + i] = SC_LOGZERO;
+    if (split) {
+      t_lo = max(start, base + j * seg);
+      t_hi = min(T, base + (j + 1) * seg);
+      r_n = ck[((long)j * 2) * WK + e];
+      r_b = ck[((long)j * 2 + 1) * WK + e];
+      if (j == 0) {   // ... and the frames in front of the walk: logzero, then the initial state at start-1
+        for (int t = 0; t < start - 1; ++t) {
+          dst[((long)t * 2) * W + i] = SC_LOGZERO;
+          dst[((long)t * 2 + 1) * W + i] = SC_LOGZERO;
+          dst_rs[(long)t * W + i] = lse2(SC_LOGZERO, SC_LOGZERO);
+        }
+        dst[((long)(start - 1) * 2) * W + i] = (out_len == 0) ? xcol[0] : SC_LOGZERO;
+        dst[((long)(start - 1) * 2 + 1) * W + i] = SC_LOGZERO;
+        dst_rs[(long)(start - 1) * W + i] = lse2((out_len == 0) ? xcol[0] : SC_LOGZERO, SC_LOGZERO);
       }
-      if (start - 1 < t1) {
-        dst[((long)(start - 1) * 2) * W + i] = r_n;
-        dst[((long)(start - 1) * 2 + 1) * W + i] = r_b;
-      }
-      begin = start;
     } else {
-      r_n = ck[((long)(j - 1) * 2) * WK + e];
-      r_b = ck[((long)(j - 1) * 2 + 1) * WK + e];
-      begin = t0;
+      const int t0 = j * SC_CTC_CK, t1 = min(t0 + SC_CTC_CK, T);
+      if (t0 <= start - 1) {   // the segment that holds frame start-1 (or lies in front of it)
+        r_n = (out_len == 0) ? xcol[0] : SC_LOGZERO;
+        r_b = SC_LOGZERO;
+        for (int t = t0; t < min(start - 1, t1); ++t) {
+          dst[((long)t * 2) * W + i] = SC_LOGZERO;
+          dst[((long)t * 2 + 1) * W + i] = SC_LOGZERO;
+          dst_rs[(long)t * W + i] = lse2(SC_LOGZERO, SC_LOGZERO);
+        }
+        if (start - 1 < t1) {
+          dst[((long)(start - 1) * 2) * W + i] = r_n;
+          dst[((long)(start - 1) * 2 + 1) * W + i] = r_b;
+          dst_rs[(long)(start - 1) * W + i] = lse2(r_n, r_b);
+        }
+        t_lo = start;
+      } else {
+        r_n = ck[((long)(j - 1) * 2) * WK + e];
+        r_b = ck[((long)(j - 1) * 2 + 1) * WK + e];
+        t_lo = t0;
+      }
+      t_hi = t1;
     }
-    // all inputs of the segment are requested before the recurrence starts (16 frames x {table column, blank column,
-    // r of the prefix}: independent of the recurrence - issued inside the loop they cost one L2 round trip per frame)
-    float xc[SC_CTC_CK], xb[SC_CTC_CK], pn[SC_CTC_CK], pb[SC_CTC_CK];
-#pragma unroll
-    for (int q = 0; q < SC_CTC_CK / 4; ++q) {
-      const int t4 = min(t0 + 4 * q, tct - 4);   // (t0 is a multiple of 16, tct of 4: aligned; frames >= T are not used)
-      const float4 c4 = *reinterpret_cast<const float4 *>(xcol + t4), b4 = *reinterpret_cast<const float4 *>(xblk + t4);
-      xc[4 * q] = c4.x; xc[4 * q + 1] = c4.y; xc[4 * q + 2] = c4.z; xc[4 * q + 3] = c4.w;
-      xb[4 * q] = b4.x; xb[4 * q + 1] = b4.y; xb[4 * q + 2] = b4.z; xb[4 * q + 3] = b4.w;
-    }
-#pragma unroll
-    for (int q = 0; q < SC_CTC_CK; ++q) {
-      const int tp = min(max(t0 + q - 1, 0), T - 1);
-      pn[q] = has ? rp[((long)tp * 2) * W + h] : SC_LOGZERO;
-      pb[q] = has ? rp[((long)tp * 2 + 1) * W + h] : 0.f;
-    }
+    if (t_lo >= t_hi) continue;
     float cum = 0.f;   // !has: running blank log-prob sum of the initial (state None) hypothesis, in the scan's order
     if (!has)
-      for (int t = 0; t < begin && t < t1; ++t) cum += xblk[t];
+      for (int t = 0; t < t_lo; ++t) cum += xblk[t];
+    for (int tb = t_lo & ~(SC_CTC_CK - 1); tb < t_hi; tb += SC_CTC_CK) {
+      // all inputs of 16 frames are requested before the recurrence walks them (table column, blank column, r of the
+      // prefix: independent of the recurrence - issued inside the loop they cost one L2 round trip per frame)
+      float xc[SC_CTC_CK], xb[SC_CTC_CK], pn[SC_CTC_CK], pb[SC_CTC_CK];
 #pragma unroll
-    for (int q = 0; q < SC_CTC_CK; ++q) {
-      const int t = t0 + q;
-      if (t >= begin && t < t1) {
-        float phi;
-        ctc_frame(r_n, r_b, pn[q], has ? pb[q] : cum, same, xc[q], xb[q], phi);
-        dst[((long)t * 2) * W + i] = r_n;
-        dst[((long)t * 2 + 1) * W + i] = r_b;
-        if (!has) cum += xb[q];
+      for (int q = 0; q < SC_CTC_CK / 4; ++q) {
+        const int t4 = min(tb + 4 * q, tct - 4);   // (tb is a multiple of 16, tct of 4: aligned; frames >= T are not used)
+        const float4 c4 = *reinterpret_cast<const float4 *>(xcol + t4), b4 = *reinterpret_cast<const float4 *>(xblk + t4);
+        xc[4 * q] = c4.x; xc[4 * q + 1] = c4.y; xc[4 * q + 2] = c4.z; xc[4 * q + 3] = c4.w;
+        xb[4 * q] = b4.x; xb[4 * q + 1] = b4.y; xb[4 * q + 2] = b4.z; xb[4 * q + 3] = b4.w;
+      }
+#pragma unroll
+      for (int q = 0; q < SC_CTC_CK; ++q) {
+        const int tp = min(max(tb + q - 1, 0), T - 1);
+        pn[q] = has ? rsp[(long)tp * W + h] : 0.f;          // r^n (+) r^b of the prefix (ctc_frame)
+        pb[q] = has ? rp[((long)tp * 2 + 1) * W + h] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < SC_CTC_CK; ++q) {
+        const int t = tb + q;
+        if (t >= t_lo && t < t_hi) {
+          float phi;
+          ctc_frame(r_n, r_b, has ? pn[q] : cum, has ? pb[q] : cum, same, xc[q], xb[q], phi);
+          dst[((long)t * 2) * W + i] = r_n;
+          dst[((long)t * 2 + 1) * W + i] = r_b;
+          dst_rs[(long)t * W + i] = lse2(r_n, r_b);
+          if (!has) cum += xb[q];
+        }
       }
     }
   }
 }
 
-extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) {
+extern "C" int sc_ctc_gather_state_split(const sc_search *sbp, int split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4, "the state rebuild needs the column-major table copy (sc_search.ctcxT)");
   int gx = cdiv(ctc_tck(sbp->TCAP) * sbp->W, 256);
   if (gx > 16) gx = 16;
-  ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp);
+  ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp, ctc_split_min_ok(sbp->TCAP, split_min));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
+
+extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) { return sc_ctc_gather_state_split(sbp, 0, stream); }
 
 // ---------------------------------------------------------------------------
 // The head-parallel layer kernels (decoder_layer.hip: 3 launches per layer) are used for compaction buckets of at
@@ -1324,6 +1349,6 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
   if (use_ctc) SC_TRY(sc_ctc_prefix_scan_split(sbp, scan_split_min, stream));
   SC_TRY(sc_fuse_topw(sbp, stream));
   SC_TRY(sc_beam_prune(sbp, stream));
-  if (use_ctc) SC_TRY(sc_ctc_gather_state(sbp, stream));
+  if (use_ctc) SC_TRY(sc_ctc_gather_state_split(sbp, scan_split_min, stream));
   return SC_OK;
 }

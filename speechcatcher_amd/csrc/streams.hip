@@ -212,9 +212,17 @@ struct sc_streams {
   int32_t *rm_host[2] = {nullptr, nullptr};     // pinned rowmap images (double-buffered: one may still be in a copy queue)
   int rm_idx = 0;
   bool rm_dirty = false;                        // rm_host[rm_idx] differs from the device rowmap
-  int scan_split_min = 256, scan_split_streams = 48;   // T-parallel CTC scan: frames to walk >=, bucket streams <=
+  // T-parallel CTC scan: frames to walk >= scan_split_min (tools: and bucket streams <= scan_split_streams, 0 = any).  1024
+  // (round 5; 256 with a 48-stream bucket limit until round 4): WHICH form a stream's scan takes must depend on that
+  // stream alone (bit-reproducible serving), and with every stream of a full bucket in it the T-parallel form costs more
+  // than the sequential walk (3181 against 3258 audio-s/s at 390 frames to walk, profiles/r05_ab_scan_logits.txt) - it is
+  // for the long tables of CLI segments (T = 4500: 61 against 588 us per step)
+  int scan_split_min = 1024, scan_split_streams = 0;
   bool scan_long = false;                       // this step: a live stream has >= scan_split_min frames to walk
-  int step_split_min() const { return (scan_long && n_rows_step <= scan_split_streams * W) ? scan_split_min : 0; }
+  // (round 5) the T-parallel kernel is part of a step whenever ONE live stream has a table long enough for it - whatever the
+  // size of the bucket: which form a stream's scan takes must depend on that stream alone (bit-reproducible serving);
+  // scan_split_streams (tools) restores the old bucket limit for A/B runs
+  int step_split_min() const { return (scan_long && (scan_split_streams <= 0 || n_rows_step <= scan_split_streams * W)) ? scan_split_min : 0; }
   int graph_key() const { return n_rows_step * 2 + (step_split_min() > 0 ? 1 : 0); }
   int enc_start_thr = 0;         // sc_push: launch the planned encoder group when at most this many streams are still decoding
   int enc_batch_min = 0;         // sc_submit: launch the open encoder group when it holds this many streams (sc_streams_set_encoder_batch)
@@ -1793,6 +1801,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(sb.anc, (size_t)2 * S * b->LCAP * W);
   A(sb.score, 2 * n); A(sb.sc_dec, 2 * n); A(sb.sc_ctc, 2 * n);
   A(sb.ctc_r, (size_t)2 * S * b->TCAP * 2 * W);
+  A(sb.ctc_rs, (size_t)2 * S * b->TCAP * W);
   A(sb.ctc_s, 2 * n);
   A(sb.ctc_rnew, (size_t)S * ((b->TCAP + 15) / 16) * 2 * W * K);   // checkpoints every 16 frames (search.hip: SC_CTC_CK)
   A(sb.dx, n * d); A(sb.dxn, n * d); A(sb.dqkv, n * 3 * d); A(sb.datt, n * d); A(sb.dq, n * d); A(sb.dffh, n * F);

@@ -199,6 +199,7 @@ class StreamBatch:
         self.sc_dec = z(2, S, W, dtype=f64)
         self.sc_ctc = z(2, S, W, dtype=f64)
         self.ctc_r = z(2, S, self.TCAP, 2, W)
+        self.ctc_rs = z(2, S, self.TCAP, W)      # log(exp r^n + exp r^b) of ctc_r per frame (scasr.h: sc_search.ctc_rs)
         self.ctc_s = z(2, S, W)
         self.ctc_rnew = z(S, (self.TCAP + 15) // 16, 2, W * K)     # checkpoints: r of the candidates at frames t % 16 == 15
         # ctrl rows and the compaction row map share one buffer: one upload per step

@@ -235,7 +235,7 @@ class HipBackend:
         s.blank, s.eos, s.sos = cfg.blank_id, cfg.eos_id, cfg.sos_id
         s.w_dec, s.w_ctc, s.ln_eps = sb.search.decoder_weight, sb.search.ctc_weight, cfg.ln_eps
         for name in ("ctrl", "flags", "ctcx", "ckv", "skv", "yseq", "xpos", "anc", "score", "sc_dec",
-                     "sc_ctc", "ctc_r", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv", "datt", "dq", "dffh",
+                     "sc_ctc", "ctc_r", "ctc_rs", "ctc_s", "ctc_rnew", "dx", "dxn", "dqkv", "datt", "dq", "dffh",
                      "logits", "logp", "pre_ids", "psi", "psi_eos", "cand_score", "cand_tok", "cand_ctc",
                      "sel"):
             setattr(s, name, getattr(sb, name).data_ptr())
@@ -313,8 +313,9 @@ class HipBackend:
     def beam_prune(self, sb):
         self._sb_call("sc_beam_prune", sb)
 
-    def ctc_gather_state(self, sb):
-        self._sb_call("sc_ctc_gather_state", sb)
+    def ctc_gather_state(self, sb, split_min=0):
+        """split_min: the value the step's ctc_prefix_scan ran with (streams split over T leave segment states, not checkpoints)"""
+        self._sb_call("sc_ctc_gather_state_split", sb, int(split_min))
 
     def decode_step(self, sb):
         """One beam-search step; replayed from a hipGraph after the first call

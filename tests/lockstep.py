@@ -62,12 +62,12 @@ class LockstepBackend(SpecBackend):
     OUTPUTS = {
         "logmel": ["featbuf"], "conv1": ["c1"], "gemm": [5], "gemm_ln": [5, 13], "proj_ln_proj": [4, 8, 11], "ffn_ln": [9, 12], "ffn_ln_proj": [10, 15], "copy_rows": [2], "layernorm": [2],
         "log_softmax_rows": [0], "block_pack": ["xblk"], "ctx_handoff": [0, 4], "enc_attention": [1],
-        "ctc_extend_state": ["ctc_r", "ctcxT"], "dec_embed": ["dx"], "dec_self_attn": ["datt", "skv"],
+        "ctc_extend_state": ["ctc_r", "ctc_rs", "ctcxT"], "dec_embed": ["dx"], "dec_self_attn": ["datt", "skv"],
         "dec_cross_attn": ["datt"], "logsoftmax_topk": ["logp", "pre_ids"],
         "ctc_prefix_scan": ["psi", "psi_eos", "ctc_rnew"],
         "fuse_topw": ["cand_tok", "cand_score", "cand_ctc"],
         "beam_prune": ["yseq", "xpos", "score", "sc_dec", "sc_ctc", "anc", "ctc_s", "sel", "flags", "kvflags"],
-        "ctc_gather_state": ["ctc_r"],
+        "ctc_gather_state": ["ctc_r", "ctc_rs"],
         # head-parallel decoder layers: (sb, li, xin, xout[, npart]) / (sb, xin, xout, npart)
         "dec_layer_self": [3, "skv", "ph1"], "dec_layer_cross": [3, "ph2"], "dec_layer_ffn": [3, "ffn_part"],
         "dec_output_logits": [2, "logits"],

@@ -657,7 +657,9 @@ def _scan_setup(hip, S, T, L, has, seed=0):
     (incl. the last token, eos and blank) and, if `has`, random forward variables of the previous prefix."""
     from oracle.kernel_spec import SpecBackend
     from test_engine_spec import make_batch
-    kw = dict(n_streams=S, max_frames=T + 12, max_tokens=L + 8, pcm_capacity=1 << 12)
+    # (max_frames >= 512: the T-parallel scan parks 32 segment states per pair where the 16-frame checkpoints live and is
+    # switched off for tables shorter than that)
+    kw = dict(n_streams=S, max_frames=max(T + 12, 512 if T >= 64 else 0), max_tokens=L + 8, pcm_capacity=1 << 12)
     sc = make_batch("TINY", 1234, "meanstd", 10, False, backend=SpecBackend(), **kw)
     sg = make_batch("TINY", 1234, "meanstd", 10, False, backend=hip, device="cuda:0", **kw)
     g = torch.Generator().manual_seed(seed)
@@ -677,9 +679,10 @@ def _scan_setup(hip, S, T, L, has, seed=0):
     if has:
         r = torch.randn(S, sc.TCAP, 2, W, generator=g) * 3.0 - 30.0
         sc.ctc_r[0].copy_(r)
+        sc.ctc_rs[0].copy_(torch.logsumexp(r, 2))        # (scasr.h: sc_search.ctc_rs is kept wherever ctc_r is written)
     sc.ctrl.copy_(torch.tensor([[1, 0, 0, T, L, W, int(has), 0]] * S, dtype=torch.int32))
     for k, v in vars(sc).items():
-        if isinstance(v, torch.Tensor) and k in ("ctcx", "ctcxT", "pre_ids", "yseq", "ctc_r", "ctrl"):
+        if isinstance(v, torch.Tensor) and k in ("ctcx", "ctcxT", "pre_ids", "yseq", "ctc_r", "ctc_rs", "ctrl"):
             getattr(sg, k).copy_(v)
     return sc, sg
 
@@ -704,12 +707,28 @@ def test_ctc_prefix_scan_long_table(hip, T, L, has, split):
     tol = 2e-4 + 2e-6 * T      # T dependent log-add-exps in fp32 on values of magnitude 1e1..1e4
     assert float((psi_c[fin] - psi_g[fin]).abs().max()) <= tol * max(1.0, float(psi_c[fin].abs().max()) * 1e-2)
     np.testing.assert_allclose(sg.psi_eos.cpu().numpy(), sc.psi_eos.numpy(), rtol=1e-5, atol=1e-3)
-    nck = T // 16                                   # checkpoints: r at the frames t % 16 == 15
-    rc = sc.ctc_rnew.view(2, -1, 2, W * K)[:, :nck]
-    rg = sg.ctc_rnew.cpu().view(2, -1, 2, W * K)[:, :nck]
+    # the forward variables: W winners (hypothesis h, candidate k) through ctc_gather_state - the GPU rebuilds their r[t] at
+    # every frame from what its scan left (16-frame checkpoints, or the segment states of the T-parallel form: round 5)
+    g = torch.Generator().manual_seed(7)
+    for s_ in range(sc.S):
+        sel = torch.stack([torch.randint(0, W, (W,), generator=g), torch.randint(0, K, (W,), generator=g)], 1).to(torch.int32)
+        sc.sel[s_].copy_(sel)
+        sg.sel[s_].copy_(sel)
+    SpecBackend().ctc_gather_state(sc)
+    hip.ctc_gather_state(sg, split_min=split)
+    torch.cuda.synchronize()
+    rc = sc.ctc_r[1, :, :T]
+    rg = sg.ctc_r[1, :, :T].cpu()
     live = rc > -1e9
     assert torch.equal(live, rg > -1e9)
     assert float(((rc - rg).abs() / rc.abs().clamp(min=1.0))[live].max()) <= 1e-4
+    if split == 0:                                      # checkpoints of the sequential scan: r at the frames t % 16 == 15
+        nck = T // 16
+        rc = sc.ctc_rnew.view(2, -1, 2, W * K)[:, :nck]
+        rg = sg.ctc_rnew.cpu().view(2, -1, 2, W * K)[:, :nck]
+        live = rc > -1e9
+        assert torch.equal(live, rg > -1e9)
+        assert float(((rc - rg).abs() / rc.abs().clamp(min=1.0))[live].max()) <= 1e-4
 
 
 def test_ctc_prefix_scan_time_at_long_tables(hip):

@@ -8,7 +8,7 @@ import sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
-       "-fno-fast-math", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-fno-fast-math", *sys.argv[3:], "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
 rows = []
