@@ -20,8 +20,8 @@ ARGS="$EXTRA --legs none"
 # between them, so that durations, counters and bench.py's algorithmic bytes belong to the SAME launches
 rm -rf /tmp/pk; rocprofv3 --kernel-trace --output-format rocpd -d /tmp/pk -- python3 bench.py $ARGS --roofline-csv gpurun_out/${TAG}_bench_${NAME}_roofline_leg.csv > gpurun_out/${TAG}_${NAME}_prof_kernel.log 2>&1
 python tools/rocpd_stats.py $(find /tmp/pk -name "*.db" | head -1) gpurun_out/${TAG}_bench_${NAME}_kernel_stats.csv > /dev/null
-rm -rf /tmp/pf; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/pf -- python3 bench.py $ARGS --steps 6 > gpurun_out/${TAG}_${NAME}_prof_fetch.log 2>&1
-rm -rf /tmp/pw; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/pw -- python3 bench.py $ARGS --steps 6 > gpurun_out/${TAG}_${NAME}_prof_write.log 2>&1
+rm -rf /tmp/pf; rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d /tmp/pf -- python3 bench.py $ARGS > gpurun_out/${TAG}_${NAME}_prof_fetch.log 2>&1
+rm -rf /tmp/pw; rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d /tmp/pw -- python3 bench.py $ARGS > gpurun_out/${TAG}_${NAME}_prof_write.log 2>&1
 python tools/pmc_traffic_csv.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) gpurun_out/${TAG}_bench_${NAME}_pmc_hbm_traffic.csv > /dev/null 2>&1 || echo "pmc join failed"
 python tools/roofline_window.py gpurun_out/${TAG}_bench_${NAME}_roofline_leg.csv $(find /tmp/pk -name "*.db" | head -1) $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) gpurun_out/${TAG}_bench_${NAME}_roofline_window.csv > /dev/null || echo "roofline window join failed"
 rm -rf /tmp/ps; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format rocpd -d /tmp/ps -- python3 bench.py $ARGS --steps 6 --roofline-steps 0 > gpurun_out/${TAG}_${NAME}_prof_sq.log 2>&1
