@@ -43,6 +43,9 @@ void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 
 // search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel)
 int sc_decode_step_form(const sc_search *sb);
+// N / ncb products that share A in one launch, block j of the columns stored at C + j * cb_stride (gemm.hip)
+int sc_gemm_colblocks(const float *A, const int32_t *a_rows, int lda, const float *W, const float *bias, float *C,
+                      const int32_t *c_rows, int ldc, int M, int N, int K, int ncb, long cb_stride, int flags, void *stream);
 
 // decoder_layer.hip: heads per workgroup of the head-parallel layer kernels for the bucket sb.n_rows (1, 2 or 4): the
 // consumer of their partial products (the next layer kernel, sc_dec_layer_ffn) reduces sb.H / hpw of them per row

@@ -40,6 +40,10 @@ struct GemmArgs {
   int M, N, K, flags, conv_f1;
   float *part;  // split-K partial sums [ksplit][M][N] (workspace), or null
   int kslice;   // K extent handled by one block along grid.z (multiple of 32)
+  // column blocks (sc_gemm_colblocks): output column n lands in block n / ncb at C + block * cb_stride, column n % ncb of
+  // the row (ncb = 0: plain).  One launch for the cross-attention K|V rows of ALL decoder layers (streams.hip: project_rows)
+  int ncb;
+  long cb_stride;
 };
 
 __device__ __forceinline__ long gemm_kofs(const GemmArgs &g, int k0) {
@@ -272,17 +276,18 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs g) {
       const bool nv = n < g.N;
       const int nn = nv ? n : g.N - 1;
       const float bv = g.bias ? g.bias[nn] : 0.f;
+      const long coff = g.ncb > 0 ? (long)(nn / g.ncb) * g.cb_stride + nn % g.ncb : (long)nn;
       float old[16];
       if (resid) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) old[r] = g.C[roff[r] + nn];
+        for (int r = 0; r < 16; ++r) old[r] = g.C[roff[r] + coff];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[i][j][r] + bv;
         if (relu) v = fmaxf(v, 0.f);
         if (resid) v = old[r] + v;
-        if (rok[r] && nv) g.C[roff[r] + nn] = v;
+        if (rok[r] && nv) g.C[roff[r] + coff] = v;
       }
     }
   }
@@ -836,6 +841,34 @@ extern "C" int sc_gemm(const float *A, const int32_t *a_rows, int lda, const flo
   // algorithmic bytes: read A and W once, write C (read it too for the residual form)
   sc_prof_end(prof, variant, 2.0 * M * N * K,
               4.0 * ((double)M * K + (double)N * K + (double)M * N * ((flags & SC_GEMM_RESIDUAL) ? 2.0 : 1.0)));
+  SC_CHECK_LAUNCH();
+  return SC_OK;
+}
+
+// C block j (columns j*ncb .. of the product, j < N / ncb) = A W[j*ncb ..]^T + bias[j*ncb ..], block j stored at
+// C + j * cb_stride with rows through c_rows / ldc like sc_gemm: `N / ncb` products that share A in ONE launch (K < 2560:
+// a single k chain per element - the same sums, bit for bit, as one sc_gemm per block).  W: [N][K], the blocks' weights
+// one behind the other.  Returns SC_ERR_ARG when the problem does not take the tiled kernel (the caller loops instead).
+int sc_gemm_colblocks(const float *A, const int32_t *a_rows, int lda, const float *W, const float *bias, float *C,
+                      const int32_t *c_rows, int ldc, int M, int N, int K, int ncb, long cb_stride, int flags, void *stream) {
+  SC_CHECK_ARG(A && W && C, "null pointer");
+  SC_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K < 2560 && lda > 0 && ncb > 0 && N % ncb == 0 && ncb % 128 == 0 && ldc >= ncb,
+               "bad dimensions");
+  SC_CHECK_ARG(!(flags & (SC_GEMM_RESIDUAL | SC_GEMM_NAIVE)) && (K % 32 == 0) && (lda % 4 == 0) &&
+                   (((uintptr_t)A & 15) == 0) && (((uintptr_t)W & 15) == 0),
+               "not a tiled problem");
+  if (M == 0) return SC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  resolve_workspace(stream);
+  if (sc_hook("SC_GEMM_NAIVE") || sc_hook("SC_SKINNY_MAX_M") || sc_hook("SC_KV_PER_LAYER")) return SC_ERR_ARG;   // A/B and test forms
+  ProfScope prof = sc_prof_begin(st);
+  GemmArgs g{A, a_rows, lda, W, bias, C, c_rows, ldc, M, N, K, flags, 0, nullptr, K, ncb, cb_stride};
+  int ksplit = 0, variant = 0;
+  float *ws_keep = g_ws;
+  g_ws = nullptr;   // no split-K form here
+  gemm_dispatch(g, false, &ksplit, &variant, st);
+  g_ws = ws_keep;
+  sc_prof_end(prof, variant, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
   SC_CHECK_LAUNCH();
   return SC_OK;
 }

@@ -77,6 +77,7 @@ struct sc_engine {
   std::vector<sc_enc_layer> enc;
   std::vector<sc_dec_layer> dec;
   std::vector<const float *> wkv, bkv;
+  float *wkv_all = nullptr, *bkv_all = nullptr;   // the layers' K|V weights [Ld * 2d][d] and biases one behind the other (project_rows)
 
   const float *f(const std::string &name, bool required = true) const {
     auto it = t.find(name);
@@ -89,6 +90,8 @@ struct sc_engine {
   ~sc_engine() {
     for (auto &kv : t)
       if (kv.second.owned && kv.second.ptr) (void)hipFree(kv.second.ptr);
+    if (wkv_all) (void)hipFree(wkv_all);
+    if (bkv_all) (void)hipFree(bkv_all);
   }
 };
 
@@ -856,7 +859,12 @@ int project_rows(sc_streams *b, EncGroup &g) {
     const int32_t *kvt;
     RC_TRY(b->itensor(g.kv_dst, &kvt));   // one row table for all layers: layer li's rows start li*TCAP rows further
     const int m = (int)g.kv_dst.size();
+    // all layers in one launch (same sums: one k chain per element); per layer when that form does not apply
+    const bool all = e->wkv_all && (2 * d) % 128 == 0;
     if (!b->sb.kv_half) {
+      if (all && sc_gemm_colblocks(b->enc, ar, d, e->wkv_all, e->bkv_all, const_cast<float *>(b->sb.ckv), kvt, 2 * d, m, Ld * 2 * d, d,
+                                   2 * d, (long)b->TCAP * 2 * d, b->gemm_flags, b->es) == SC_OK)
+        return SC_OK;
       for (int li = 0; li < Ld; ++li)
         RC_TRY(sc_gemm(b->enc, ar, d, e->wkv[li], e->bkv[li], const_cast<float *>(b->sb.ckv) + (size_t)li * b->TCAP * 2 * d,
                        kvt, 2 * d, m, 2 * d, d, b->gemm_flags, 0, b->es));
@@ -864,9 +872,11 @@ int project_rows(sc_streams *b, EncGroup &g) {
       // fp16 cache: project into the fp32 staging buffer (dense rows), then convert + scatter all layers at once
       for (int r0 = 0; r0 < m; r0 += b->kv_stage_rows) {
         const int mm = std::min(b->kv_stage_rows, m - r0);
-        for (int li = 0; li < Ld; ++li)
-          RC_TRY(sc_gemm(b->enc, ar + r0, d, e->wkv[li], e->bkv[li], b->kv_stage + (size_t)li * mm * 2 * d, nullptr, 2 * d,
-                         mm, 2 * d, d, b->gemm_flags, 0, b->es));
+        if (!(all && sc_gemm_colblocks(b->enc, ar + r0, d, e->wkv_all, e->bkv_all, b->kv_stage, nullptr, 2 * d, mm, Ld * 2 * d, d, 2 * d,
+                                       (long)mm * 2 * d, b->gemm_flags, b->es) == SC_OK))
+          for (int li = 0; li < Ld; ++li)
+            RC_TRY(sc_gemm(b->enc, ar + r0, d, e->wkv[li], e->bkv[li], b->kv_stage + (size_t)li * mm * 2 * d, nullptr, 2 * d,
+                           mm, 2 * d, d, b->gemm_flags, 0, b->es));
         RC_TRY(sc_kv_rows_to_half(b->kv_stage, kvt + r0, mm, Ld, b->TCAP, 2 * d, const_cast<float *>(b->sb.ckv), b->es));
       }
     }
@@ -1612,6 +1622,23 @@ extern "C" int sc_engine_create(const sc_config *cfg, const sc_named_tensor *ten
     e->bkv[i] = e->f(p + "bkv");
     if (!e->wkv[i] || !e->bkv[i]) { delete e; return SC_ERR_ARG; }
   }
+  {
+    // one weight matrix for the cross-attention K|V rows of all decoder layers: project_rows runs ONE product per group
+    // instead of one per layer (14 launches of ~600 x 512 x 256 at 6 TFLOP/s in round 4).  A copy: 2 MB per layer at d = 256
+    const size_t d = cfg->d_model, per = 2 * d * d, Ld = cfg->dec_layers;
+    if (Ld > 1 && hipMalloc(&e->wkv_all, Ld * per * sizeof(float)) == hipSuccess &&
+        hipMalloc(&e->bkv_all, Ld * 2 * d * sizeof(float)) == hipSuccess) {
+      bool ok = true;
+      for (size_t i = 0; i < Ld && ok; ++i)
+        ok = hipMemcpy(e->wkv_all + i * per, e->wkv[i], per * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess &&
+             hipMemcpy(e->bkv_all + i * 2 * d, e->bkv[i], 2 * d * sizeof(float), hipMemcpyDeviceToDevice) == hipSuccess;
+      if (!ok) { (void)hipFree(e->wkv_all); (void)hipFree(e->bkv_all); e->wkv_all = e->bkv_all = nullptr; }
+    } else {
+      (void)hipGetLastError();
+      if (e->wkv_all) (void)hipFree(e->wkv_all);
+      e->wkv_all = e->bkv_all = nullptr;
+    }
+  }
   *out = e;
   return SC_OK;
   SC_API_END
@@ -1711,7 +1738,8 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   const size_t m_enc = (size_t)b->max_blocks * R, n = (size_t)S * W;
   int rc = SC_OK;
 #define A(ptr, count) if (rc == SC_OK) rc = b->alloc(&ptr, (size_t)(count))
-  if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, -1) != hipSuccess) {
+  // (SC_PRIO_DEC / SC_PRIO_ENC: test hooks for the priority A/B of profiles/r05_ab_priority.txt)
+  if (hipStreamCreateWithPriority(&b->stream, hipStreamNonBlocking, sc_hook("SC_PRIO_DEC") ? atoi(sc_hook("SC_PRIO_DEC")) : -1) != hipSuccess) {
     sc_set_error("sc_streams_create: hipStreamCreate failed");
     delete b;
     return SC_ERR_LAUNCH;
@@ -1866,7 +1894,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
         for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
         er = hipExtStreamCreateWithCUMask(&b->stream_enc, 8, mask);
       } else {
-        er = hipStreamCreateWithPriority(&b->stream_enc, hipStreamNonBlocking, 0);
+        er = hipStreamCreateWithPriority(&b->stream_enc, hipStreamNonBlocking, sc_hook("SC_PRIO_ENC") ? atoi(sc_hook("SC_PRIO_ENC")) : 0);
       }
       if (er == hipSuccess && hipMalloc(&b->ws_enc, (size_t)128 << 20) == hipSuccess) {
         b->owned.push_back(b->ws_enc);

@@ -557,6 +557,31 @@ def test_native_xl_batch_equals_python_engine():
         assert all(abs(x["score"] - y["score"]) < 5e-4 for x, y in zip(nat[s], py[s])), s
 
 
+@pytest.mark.parametrize("dims,kv", [("XL", "float32"), ("XL", "float16"), ("TINY", "float32")])
+def test_kv_rows_of_all_layers_in_one_launch(dims, kv, monkeypatch):
+    """project_rows (csrc/streams.hip) computes the cross-attention K|V rows of ALL decoder layers with one product over the
+    layers' weights, one behind the other (sc_gemm_colblocks), instead of one sc_gemm per layer.  Same k chain per element:
+    the hypotheses AND their scores are the same bits as with the per-layer launches (SC_KV_PER_LAYER)."""
+    from test_engine_spec import make_batch
+    S, chunk, beam, n = 6, 10240, 10 if dims == "XL" else 5, 5
+    audio = [synth.synth_audio(500 + i, chunk * n) for i in range(S)]
+
+    def run():
+        sb = make_batch(dims, 1234, "meanstd", beam, False, n_streams=S, backend="native", device="cuda:0", max_frames=200,
+                        max_tokens=600, pcm_capacity=1 << 17, kv_dtype=kv)
+        for k in range(n):
+            sb.push([(s, audio[s][k * chunk:(k + 1) * chunk], k == n - 1) for s in range(S)])
+        return [sb.hypotheses(s) for s in range(S)]
+
+    one = run()
+    monkeypatch.setenv("SC_KV_PER_LAYER", "1")
+    per = run()
+    assert any(len(h[0]["yseq"]) > 3 for h in one)
+    for s in range(S):
+        assert [h["yseq"] for h in one[s]] == [h["yseq"] for h in per[s]], s
+        assert [h["score"] for h in one[s]] == [h["score"] for h in per[s]], s
+
+
 @pytest.mark.parametrize("vosk,continuous", [(False, False), (True, False), (False, True), (True, True)])
 def test_native_server_sessions_equal_private_oracle_sessions(vosk, continuous):
     """continuous: the server loop over sc_submit / sc_poll - every client is answered as soon as ITS chunk is decoded"""
