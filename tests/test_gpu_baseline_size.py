@@ -269,9 +269,12 @@ def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward + encoder attention-projection weights / MFMA
     inputs and fp16 K|V caches
     (hipGraph replay on, token positions read back) against the fp32 engine on the same audio: the best hypothesis
-    keeps its token ids AND positions for at least 98 % of the streams, the whole beam for 96 % (fp16 rounding of the
+    keeps its token ids AND positions for at least 97 % of the streams, the whole beam for 95 % (fp16 rounding of the
     feed-forward reorders hypotheses whose fp32 scores are closer than its error; no fp16 run of the reference's native
-    decoder exists to compare with: speechcatcher.py:205-210 disables it)."""
+    decoder exists to compare with: speechcatcher.py:205-210 disables it).  The counts of the run, and for every moved
+    stream where the fp16 engine's best hypothesis sits in the fp32 beam and how many leading tokens the two best
+    hypotheses share, are written to gpurun_out/r05_fp16_mode_256.json (round 5: 6 / 8 of 256; one move is a reordering
+    inside the final beam 9e-6 apart, five are beam cuts at an earlier step - the two best hypotheses share 35-95 % of their leading tokens)."""
     S, n, beam = 256, 7, 10
     audio = np.stack([synth.synth_audio(900 + s, CHUNK * n) for s in range(S)])
     kw = dict(n_streams=S, max_frames=200, max_tokens=160, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
@@ -296,8 +299,24 @@ def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     best_differs = [s for s in range(S) if hyp(a, s, 0) != hyp(b, s, 0)]
     beam_differs = [s for s in range(S) if {hyp(a, s, j) for j in range(beam)} != {hyp(b, s, j) for j in range(beam)}]
     print(f"fp16 mode: best hypothesis moved on {len(best_differs)} of {S} streams, beam set on {len(beam_differs)}")
-    # rounds 2-3 measured 4 / 6 streams; with the round-4 kernel forms (other fp32 summation order of the partial products,
-    # other near-ties) 6 / 9: a statistic of random-weight near-ties - bar 3 % / 5 %
+    # where the fp16 engine's best hypothesis sits in the fp32 beam, and how far below the fp32 best
+    margins = {}
+    for s in best_differs:
+        at = [j for j in range(beam) if hyp(a, s, j) == hyp(b, s, 0)]
+        ia, ib = hyp(a, s, 0)[0], hyp(b, s, 0)[0]
+        common = next((k for k in range(min(len(ia), len(ib))) if ia[k] != ib[k]), min(len(ia), len(ib)))
+        margins[s] = {"fp32_rank": at[0] if at else -1, "fp32_margin": float(a["score"][s, 0] - a["score"][s, at[0]]) if at else None,
+                      "common_prefix": common, "len_fp32": len(ia), "len_fp16": len(ib)}
+    print("  the hypothesis the fp16 engine ranks first, in the fp32 run:", margins)
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/r05_fp16_mode_256.json", "w") as fh:
+        json.dump({"streams": S, "chunks": n, "best_moved": best_differs, "beam_moved": beam_differs,
+                   "fp16_best_in_the_fp32_run": {str(k): v for k, v in margins.items()}}, fh)
+    # rounds 2-3 measured 4 / 6 streams, round 4 (other fp32 summation order of the partial products, other near-ties)
+    # 6 / 9, round 5 (canonical order) 6 / 8: a statistic of random-weight near-ties, 2.3 % / 3.1 % - bar 3 % / 5 %
+    # (2 % / 4 % = 5 / 10 streams would sit ON the measured count: the bar has to clear the statistic it bounds)
     assert len(best_differs) <= S * 3 // 100 and len(beam_differs) <= S // 20, (best_differs, beam_differs)
     same = [s for s in range(S) if s not in best_differs]
     assert np.abs(a["score"][same, 0] - b["score"][same, 0]).max() < 0.5
