@@ -2,6 +2,7 @@
 sc_get_hyps / sc_reset) against the fixtures of the real reference, the oracle sessions, and a plain C host
 program that links libscasr.so - no Python in the decode loop."""
 import json
+import os
 import shutil
 import subprocess
 
@@ -555,6 +556,27 @@ def test_native_xl_batch_equals_python_engine():
         # (not bit-equal: the C++ engine projects the CTC / cross-attention K|V rows inside the encoder stage, in other
         # GEMM batches - another split-K summation order - than the Python engine does at block start)
         assert all(abs(x["score"] - y["score"]) < 5e-4 for x, y in zip(nat[s], py[s])), s
+
+
+@pytest.mark.parametrize("dims,steps,streams,seed", [("TINY", 80, 24, 3), ("TINY", 80, 24, 4), ("XL", 50, 12, 5)])
+def test_random_sessions_are_bit_reproducible(dims, steps, streams, seed):
+    """tools/soak_continuous.py, short: randomised sessions (chunk lengths 300..24000 samples, finals, resets, oversized
+    chunks that fail alone, random poll sizes and encoder-batch thresholds, lock-step calls mixed in) served with
+    continuous batching against the SAME calls one stream at a time - every reply carries the same hypotheses with
+    BIT-IDENTICAL scores, whatever shared the GPU with it (the script asserts both).  The long runs of the round:
+    profiles/r05_soak_continuous.txt."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SC_TEST_HOOKS="1")
+    env.pop("SOAK_ALLOW_INEXACT", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_continuous.py"), str(steps), str(streams), str(seed), dims],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("soak ok") and "scores bit-identical in" in last, last
+    a, b = last.split("scores bit-identical in ")[1].split(" compared")[0].split(" of ")
+    assert a == b and int(a) > 50, last
 
 
 @pytest.mark.parametrize("dims,kv", [("XL", "float32"), ("XL", "float16"), ("TINY", "float32")])

@@ -1,8 +1,11 @@
 """Soak test of the tick engine: randomised sessions (random chunk lengths 300..24000 samples, random finals, resets,
 oversized chunks that must fail alone, random poll sizes and encoder-batch thresholds, sc_push calls mixed in) on S
 stream slots for N steps - continuous batching (sc_submit / sc_poll) against a second batch that gets the SAME calls
-through sc_push one stream at a time.  Every reply must carry the same hypotheses.  Tiny dims, beam 5.
-    gpurun -- 'python tools/soak_continuous.py [steps=400] [streams=32] [seed=0]'"""
+through sc_push one stream at a time.  Every reply must carry the same hypotheses; (round 5) the scores are counted as
+bit-identical or not, and they MUST be identical (one summation order for every sum of the path)
+unless SOAK_ALLOW_INEXACT is set.
+Tiny dims, beam 5 (XL: beam 10).
+    gpurun -- 'python tools/soak_continuous.py [steps=400] [streams=32] [seed=0] [TINY|XL]'"""
 import os
 import sys
 
@@ -17,17 +20,19 @@ from test_engine_spec import make_batch  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+DIMS = sys.argv[4] if len(sys.argv) > 4 else "TINY"
+BEAM = 10 if DIMS == "XL" else 5
 rng = np.random.default_rng(seed)
 kw = dict(n_streams=S, max_frames=500, max_tokens=420, pcm_capacity=1 << 16, max_chunk_samples=24000, strict_reference=bool(seed % 2))
-a = make_batch("TINY", 1234, "meanstd", 5, bool(seed % 3 == 1), backend="native", **kw)      # continuous
-b = make_batch("TINY", 1234, "meanstd", 5, bool(seed % 3 == 1), backend="native", **kw)      # reference: one sc_push per call
+a = make_batch(DIMS, 1234, "meanstd", BEAM, bool(seed % 3 == 1), backend="native", **kw)      # continuous
+b = make_batch(DIMS, 1234, "meanstd", BEAM, bool(seed % 3 == 1), backend="native", **kw)      # reference: one sc_push per call
 fed, utt, next_utt = [0] * S, list(range(S)), S
-n_calls = n_faults = n_final = longest = 0
+n_calls = n_faults = n_final = longest = n_inexact = n_cmp = 0
 pending = {}
 
 
 def check(s, res_a):
-    global n_faults, longest
+    global n_faults, longest, n_inexact, n_cmp
     chunk, fin = pending.pop(s)
     res_b = b.push([(s, chunk, fin)], isolate_faults=True)[s]
     fa, fb = isinstance(res_a, Exception), isinstance(res_b, Exception)
@@ -39,6 +44,10 @@ def check(s, res_a):
     ha, hb = a.hypotheses(s), b.hypotheses(s)
     assert [(h["yseq"], h["xpos"]) for h in ha] == [(h["yseq"], h["xpos"]) for h in hb], s
     assert all(abs(x["score"] - y["score"]) < 2e-3 * max(1.0, abs(y["score"])) for x, y in zip(ha, hb)), s
+    n_cmp += 1
+    if any(x["score"] != y["score"] for x, y in zip(ha, hb)):
+        n_inexact += 1
+        assert os.environ.get("SOAK_ALLOW_INEXACT"), (s, [x["score"] for x in ha], [y["score"] for y in hb])
     longest = max([longest] + [len(h["yseq"]) for h in ha])
     return fin
 
@@ -87,4 +96,5 @@ while a.outstanding:
     for s, r in a.poll(1).items():
         check(s, r)
 print(f"soak ok: {steps} steps, {n_calls} calls, {n_faults} isolated faults, {n_final} utterances ended, longest hypothesis {longest} tokens, "
-      f"{a.stats['dec_steps']} decode iterations (one stream at a time: {b.stats['dec_steps']})")
+      f"{a.stats['dec_steps']} decode iterations (one stream at a time: {b.stats['dec_steps']}); scores bit-identical in "
+      f"{n_cmp - n_inexact} of {n_cmp} compared replies ({DIMS} dims)")
