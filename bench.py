@@ -70,12 +70,12 @@ ENCODER_BATCH = 0      # --encoder-batch N: sc_streams_set_encoder_batch (0: the
 KV_DTYPE = "float32"   # --kv-dtype float16: K|V caches in fp16 (BASELINE configs[4]'s storage mode), never the default
 
 
-def make_weights(device, ffn_dtype=None):
+def make_weights(device, ffn_dtype=None, cfg=XL):
     from speechcatcher_amd.weights import PackedWeights
     ffn_dtype = ffn_dtype or FFN_DTYPE
-    sd = synth.make_state_dict(XL, 1234)
-    mean, std = synth.stats_to_mean_std(synth.make_stats(XL, kind="meanstd"))
-    return PackedWeights(sd, XL, device, mean, std, ffn_dtype=ffn_dtype,
+    sd = synth.make_state_dict(cfg, 1234)
+    mean, std = synth.stats_to_mean_std(synth.make_stats(cfg, kind="meanstd"))
+    return PackedWeights(sd, cfg, device, mean, std, ffn_dtype=ffn_dtype,
                          proj_dtype=ffn_dtype,   # the encoder's attention projections in the same form
                          # float16 = the whole fp16 mode of BASELINE configs[4]: the decoder's projections / output layer and
                          # the partial products between its kernels as well (effective together with --kv-dtype float16)
@@ -909,6 +909,16 @@ def main():
                           "default).  On random weights it ends most blocks after ~1.3 decode steps (real speech: 3-5), so this is an "
                           "upper bound for a real checkpoint as the headline (detection off, ~9 steps per block) is a lower bound")
 
+    l_like = None
+    if extended and not args.no_other_mode and world == 1 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
+        from speechcatcher_amd.config import L_LIKE
+        w_l = make_weights(device, cfg=L_LIKE)
+        l_like = leg(args.mode, weights=w_l)
+        del w_l
+        l_like["note"] = ("NOT the headline: the per-GPU share of BASELINE configs[3] (`en_streaming_transformer_l`, 128 streams per GPU) on "
+                          "ASSUMED stand-in dims (speechcatcher_amd/config.py: L_LIKE = d 256, 4 heads of 64, 18 + 8 blocks; the real "
+                          "config.yaml is not available offline).  Head dim 64 is outside the instantiated decoder layer kernels: the "
+                          "decoder runs the six-launch form (stand-alone attention + projection kernels)")
     queued = None
     if extended and not args.no_other_mode and world == 1 and args.mode == "continuous" and args.queue_depth == 1:
         queued = leg("continuous", depth=2)
@@ -1010,7 +1020,7 @@ def main():
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
         "exact_steps": exact, "chunk_sizes": chunk_legs, "one_eighth_of_host_cores": pinned,
-        "kv_cache_fp16": kv16, "fp16_mode": fp16_mode, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "long_context": long_ctx,
+        "kv_cache_fp16": kv16, "fp16_mode": fp16_mode, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "l_like_dims": l_like, "long_context": long_ctx,
         "legs": args.legs,
     }
     if args.mode == "continuous":
