@@ -547,6 +547,97 @@ __global__ __launch_bounds__(256) void enc_attention_split_kernel(const float *q
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same attention on the matrix cores (round 5; head dim 32, R <= 48): one workgroup per (block, head), wave w < 3
+// owns the 16 query rows w of the block's 48-row tile.  S = Q K^T as 3 x 8 v_mfma_f32_16x16x4_f32 per wave, the row
+// softmax in the accumulator layout (a row's 48 scores sit in the 16 lanes of one lane group x 3 tiles: two 4-step
+// shuffles), P through LDS into the A-operand layout, O = P V as 2 x 12 MFMAs, rows scaled by 1 / sum at the end.  The
+// kernel trace of the 128-stream run had the VALU form at 10.3 us per layer, 8 % of the encoder side, for 0.3 % of its
+// FLOPs: its exp / FMA chains over 11 keys per wave, not its launch.
+// ---------------------------------------------------------------------------
+typedef float encf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void enc_attention_mfma_kernel(const float *qkv, float *att, int nblk, int R, int H, int d,
+                                                                 int masked) {
+  constexpr int DK = 32, RT = 48, LQ = DK + 1, LP = RT + 1;
+  __shared__ float Qs[RT * LQ], Ks[RT * LQ], Vs[RT * DK], Ps[RT * LP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int blk = blockIdx.x / H, head = blockIdx.x % H;
+  const float *base = qkv + (long)blk * R * 3 * d + head * DK;
+  for (int e = tid; e < RT * (DK / 4); e += 256) {
+    const int row = e / (DK / 4), c4 = e % (DK / 4);
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;   // rows >= R: zeros (never a key with weight, never stored)
+    if (row < R) {
+      const float *src = base + (long)row * 3 * d;
+      q4 = reinterpret_cast<const float4 *>(src)[c4];
+      k4 = reinterpret_cast<const float4 *>(src + d)[c4];
+      v4 = reinterpret_cast<const float4 *>(src + 2 * d)[c4];
+    }
+    float *qd = Qs + row * LQ + 4 * c4, *kd = Ks + row * LQ + 4 * c4;
+    qd[0] = q4.x; qd[1] = q4.y; qd[2] = q4.z; qd[3] = q4.w;
+    kd[0] = k4.x; kd[1] = k4.y; kd[2] = k4.z; kd[3] = k4.w;
+    reinterpret_cast<float4 *>(Vs)[row * (DK / 4) + c4] = v4;
+  }
+  __syncthreads();
+  if (wave >= 3) return;
+  const int rt = wave;
+  const int nkeys = masked ? R - 1 : R;
+  encf32x4 sacc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) sacc[t] = encf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < DK / 4; ++s) {
+    const float a = Qs[(16 * rt + r) * LQ + 4 * s + kk];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) sacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Ks[(16 * t + r) * LQ + 4 * s + kk], sacc[t], 0, 0, 0);
+  }
+  // sacc[t][j] = q(row 16 rt + 4 kk + j) . k(key 16 t + r)
+  const float scale = sqrtf((float)DK);
+  float inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float sc[3], m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      sc[t] = (16 * t + r < nkeys) ? sacc[t][j] / scale : -INFINITY;
+      m = fmaxf(m, sc[t]);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float pr = (16 * t + r < nkeys) ? expf(sc[t] - m) : 0.f;
+      l += pr;
+      Ps[(16 * rt + 4 * kk + j) * LP + 16 * t + r] = pr;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) l += __shfl_xor(l, o, 16);
+    inv[j] = 1.0f / l;
+  }
+  // rows 16 rt .. of Ps are written and read by this wave alone: a wave's DS operations execute in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  encf32x4 oacc[2];
+  oacc[0] = encf32x4{0.f, 0.f, 0.f, 0.f};
+  oacc[1] = encf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < RT / 4; ++s) {
+    const float a = Ps[(16 * rt + r) * LP + 4 * s + kk];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Vs[(4 * s + kk) * DK + 16 * t + r], oacc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 16 * rt + 4 * kk + j;
+    if (row >= R) continue;
+    const bool zero = masked && row == 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) att[((long)blk * R + row) * d + head * DK + 16 * t + r] = zero ? 0.f : oacc[t][j] * inv[j];
+  }
+}
+
 extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, int H, int d,
                                 int masked, void *stream) {
   SC_CHECK_ARG(qkv && att, "null pointer");
@@ -556,9 +647,12 @@ extern "C" int sc_enc_attention(const float *qkv, float *att, int nblk, int R, i
   const int dk = d / H;
   const int grid = cdiv(nblk * H, 4);
   hipStream_t st = (hipStream_t)stream;
-  const char *sp = sc_hook("SC_ENC_ATTN");   // =wave: one wave per (block, head) (A/B switch)
+  const char *sp = sc_hook("SC_ENC_ATTN");   // =wave: one wave per (block, head); =split: keys over 4 waves, VALU (A/B switches)
   const bool split = !(sp && !strcmp(sp, "wave"));
-  if (dk == 32 && split) {   // LDS: the merge buffer [4][64][dk+2] (>= the K + V + Q staging it aliases)
+  const bool mfma = dk == 32 && R <= 48 && !(masked && R < 2) && !sp;   // (a function of the model's dims alone)
+  if (mfma) {
+    enc_attention_mfma_kernel<<<nblk * H, 256, 0, st>>>(qkv, att, nblk, R, H, d, masked);
+  } else if (dk == 32 && split) {   // LDS: the merge buffer [4][64][dk+2] (>= the K + V + Q staging it aliases)
     enc_attention_split_kernel<32><<<nblk * H, 256, 4 * 64 * (32 + 2) * sizeof(float), st>>>(qkv, att, nblk, R, H, d,
                                                                                             masked);
   } else if (dk == 16 && split) {

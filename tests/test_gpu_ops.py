@@ -307,13 +307,17 @@ def test_ffn_fused_split_weights(hip, M, D, F):
 @pytest.mark.parametrize("H,dk,R,nblk,masked", [(8, 32, 42, 5, True), (8, 32, 42, 130, True), (8, 32, 7, 3, False),
                                                 (8, 32, 1, 2, False), (8, 32, 2, 2, True), (8, 32, 64, 2, False),
                                                 (4, 16, 42, 3, True), (4, 64, 42, 3, True)])
-@pytest.mark.parametrize("kernel", ["split", "wave"])
+@pytest.mark.parametrize("kernel", ["default", "split", "wave"])
 def test_enc_attention(hip, monkeypatch, H, dk, R, nblk, masked, kernel):
     """Encoder block attention (multi_head_attention.py:92-133 with the mask of
-    contextual_block_transformer_encoder.py:524-528): the 4-waves-per-(block, head) kernel with the keys split
-    over the waves, and the one-wave-per-unit kernel it replaced (still used for d_k = 64)."""
+    contextual_block_transformer_encoder.py:524-528): the default form (d_k = 32, R <= 48: on the matrix cores, round 5;
+    otherwise one of the next two), the 4-waves-per-(block, head) kernel with the keys split over the waves, and the
+    one-wave-per-unit kernel it replaced (still used for d_k = 64)."""
     from oracle.kernel_spec import SpecBackend
-    monkeypatch.setenv("SC_ENC_ATTN", kernel)
+    if kernel == "default":
+        monkeypatch.delenv("SC_ENC_ATTN", raising=False)
+    else:
+        monkeypatch.setenv("SC_ENC_ATTN", kernel)
     d = H * dk
     qkv = _rand(nblk * R, 3 * d, seed=201)
     qkv[:, :d] *= 3.0   # peaked softmax rows as well
