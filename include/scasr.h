@@ -173,7 +173,7 @@ const char *sc_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes incompatibly.  sc_version()
  * returns the revision the LIBRARY was built with; a host compares the two before it passes any struct
  * (speechcatcher_amd/_abi.py does at load time, the C hosts in tests/ at start-up). */
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 int sc_version(void);
 
 /* hipGraph capture / replay of any sequence of the launches below on a
@@ -320,7 +320,8 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
 #define SC_PROF_FFN_PRO 9 /* ffn_fused_kernel<.., PRO>: sc_dec_layer_ffn (head-partial reduce + norm3 prologue) */
 #define SC_PROF_LAYER_SELF 10  /* dec_layer_attn_kernel<.., SELF>: sc_dec_layer_self (head-parallel layer, small buckets) */
 #define SC_PROF_LAYER_CROSS 11 /* dec_layer_attn_kernel<.., cross>: sc_dec_layer_cross */
-#define SC_PROF_KINDS 12
+#define SC_PROF_LAYER_STREAM 12 /* dec_layer_stream_kernel: sc_dec_layer_stream (stream-resident layer, large buckets; round 6) */
+#define SC_PROF_KINDS 13
 /* decoder layers run as head-parallel launches (sc_dec_layer_*) for compaction buckets up to this many rows */
 #define SC_FUSED_MAX_ROWS 960
 /* ... with one head per workgroup; from SC_HPW_MIN_ROWS rows on with FOUR heads per workgroup (1024 threads: the
@@ -329,6 +330,12 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
  * 3055 / 3035 audio-s/s; strict lock-step, where the medium buckets count (tools/ab_hpw_strict.sh, 96 / 320 / 480 / 640 /
  * 960 / never): 2038 / 2137 / 2159 / 2126 / 2195 / 2151 - four heads from half of a 128-stream batch on */
 #define SC_HPW_MIN_ROWS 640
+/* (round 6) ... and from SC_STREAM_MIN_ROWS rows on in the STREAM-RESIDENT form (decoder_stream.hip: one 1024-thread workgroup per
+ * stream runs both attentions of a layer for all heads, two launches per layer): a full 128-stream bucket then holds 128 of the
+ * 256 compute units and the encoder groups run beside the decode chain instead of between its kernels.  Same bits as the
+ * other two forms (canonical summation, common.h).  SC_STREAM_FFN_CUS: compute units its feed-forward launch is sized for. */
+#define SC_STREAM_MIN_ROWS 640
+#define SC_STREAM_FFN_CUS 256
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);
 int sc_prof_collect(double *ms, double *flops, long long *n);
@@ -446,6 +453,18 @@ int sc_dec_layer_cross(const sc_search *sb, int layer, const float *x_in, float 
  * feed_forward.py:48-50) as partial sums ffn_part[z][row], z < *n_part (HOST out; <= max_part). */
 int sc_dec_layer_ffn(const sc_search *sb, int layer, const float *x_in, float *x_out, float *ffn_part,
                      int max_part, int *n_part /*HOST*/, void *stream);
+/* ---- stream-resident decoder layers: 2 launches per layer (round 6; decoder_layer.py:80-132) -------------------
+ * d = 256, 8 heads of 32, W <= 10, fp32 weights.  One workgroup per stream: no partial products between the attentions. */
+int sc_dec_layer_stream_supported(int d, int H, int W, int F);
+/* A': x = x_in + b2[layer-1] + sum_z ffn_part[z][row] (layer 0: embed*sqrt(d)+PE); self-attention block (norm1, q|k|v of all
+ * heads, K|V row appended, attention through the ancestor table, linear_out + residual: decoder_layer.py:85-101);
+ * cross-attention block (norm2, q, attention over the stream's encoder K|V, linear_out + residual: :106-115) -> x_out;
+ * xn_out = norm3(x_out) (:117). */
+int sc_dec_layer_stream(const sc_search *sb, int layer, const float *x_in, float *x_out, float *xn_out,
+                        const float *ffn_part, int n_ffn_part, void *stream);
+/* C': feed-forward of the rows xn (feed_forward.py:48-50) as partial sums ffn_part[z][row] by row id, z < *n_part. */
+int sc_dec_layer_ffn_xn(const sc_search *sb, int layer, const float *xn, float *ffn_part, int max_part,
+                        int *n_part /*HOST*/, void *stream);
 /* tail: x = x_in + b2[last] + sum_z ffn_part -> x_out; logits = after_norm(x) . out_w^T + out_b
  * (transformer_decoder.py:243-249); needs sb->out_w_q. */
 int sc_dec_output_logits(const sc_search *sb, const float *x_in, float *x_out, const float *ffn_part,

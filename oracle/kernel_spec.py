@@ -529,6 +529,57 @@ class SpecBackend:
         sb.ffn_part[0, r] = hid @ lw["w2"].t()
         return 1
 
+    # decode_step(): the stream-resident form of the layers (csrc/decoder_stream.hip, round 6) - 2 ops per layer
+    stream_layers = False
+
+    def dec_layer_stream(self, sb, li, xin, xout, xn_out, npart):
+        """sc_dec_layer_stream: x (embedding for layer 0, else residual + feed-forward partial sums + b2 of the layer
+        before); self-attention block (decoder_layer.py:85-101), cross-attention block (:106-115) -> xout;
+        xn_out = norm3(xout) (:117).  xn_out may be sb.dq (the spec's own q scratch: overwritten last)."""
+        w, cfg = sb.w, sb.cfg
+        d, W = cfg.d_model, sb.W
+        lw = w.dec[li]
+        sq = math.sqrt(d)
+        ln = torch.nn.functional.layer_norm
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            if li == 0:
+                hyp = torch.clamp(torch.arange(W), max=nh - 1)
+                tok = sb.yseq[cur, s, hyp, L - 1].to(torch.long)
+                x = w.embed[tok] * sq + w.pe[L - 1]
+            else:
+                y = sb.ffn_part[0, rows].clone()
+                for z in range(1, npart):
+                    y = y + sb.ffn_part[z, rows]
+                x = xin[rows] + (y + w.dec[li - 1]["b2"])
+            xout[rows] = x
+            sb.dqkv[rows] = ln(x, (d,), lw["ln1_g"], lw["ln1_b"], cfg.ln_eps) @ lw["wqkv"].t() + lw["bqkv"]
+        self.dec_self_attn(sb, li)     # dqkv -> K|V rows appended to skv, context of rows < nh in datt
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            y = torch.zeros(W, d)
+            y[:nh] = sb.datt[rows][:nh] @ lw["wo"].t()
+            x = xout[rows] + (y + lw["bo"])
+            xout[rows] = x
+            sb.dq[rows] = ln(x, (d,), lw["ln2_g"], lw["ln2_b"], cfg.ln_eps) @ lw["wq"].t() + lw["bq"]
+        self.dec_cross_attn(sb, li)
+        for s, cur, T, L, nh in self._active_rows(sb):
+            rows = slice(s * W, (s + 1) * W)
+            y = torch.zeros(W, d)
+            y[:nh] = sb.datt[rows][:nh] @ lw["wo2"].t()
+            x = xout[rows] + (y + lw["bo2"])
+            xout[rows] = x
+            xn_out[rows] = ln(x, (d,), lw["ln3_g"], lw["ln3_b"], cfg.ln_eps)
+
+    def dec_layer_ffn_xn(self, sb, li, xn):
+        """sc_dec_layer_ffn_xn over the compacted rows: feed-forward of the rows xn (feed_forward.py:48-50) as partial
+        sums by row id - the spec writes ONE partial sum (returns 1)."""
+        lw = sb.w.dec[li]
+        r = sb.rowmap[:int(sb.n_rows_step)].to(torch.long)
+        hid = torch.relu(xn[r] @ lw["w1"].t() + lw["b1"])
+        sb.ffn_part[0, r] = hid @ lw["w2"].t()
+        return 1
+
     def dec_output_logits(self, sb, xin, xout, npart):
         """sc_dec_output_logits: residual + feed-forward partial sums + b2 -> xout; after_norm, output layer
         (transformer_decoder.py:243-249)."""
@@ -734,7 +785,15 @@ class SpecBackend:
         w, cfg = sb.w, sb.cfg
         n, d = int(sb.n_rows_step), cfg.d_model
         rows = sb.rowmap[:n]
-        if getattr(sb, "ph1", None) is not None and self.fused_layers:
+        if getattr(sb, "ph1", None) is not None and self.fused_layers and self.stream_layers:
+            # stream-resident layer kernels, 2 ops per layer (sc_decode_step: buckets of >= SC_STREAM_MIN_ROWS rows)
+            xa, xb, npart = sb.dx, sb.dxn, 0
+            for li in range(len(w.dec)):
+                self.dec_layer_stream(sb, li, xa, xb, sb.dq, npart)
+                npart = self.dec_layer_ffn_xn(sb, li, sb.dq)
+                xa, xb = xb, xa
+            self.dec_output_logits(sb, xa, xb, npart)
+        elif getattr(sb, "ph1", None) is not None and self.fused_layers:
             # head-parallel layer kernels, 3 ops per layer (sc_decode_step takes this path for the same models)
             xa, xb, npart = sb.dx, sb.dxn, 0
             for li in range(len(w.dec)):

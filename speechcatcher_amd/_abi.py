@@ -9,6 +9,7 @@ The library is built in-tree (speechcatcher_amd/libscasr.so) by
 missing - there is no CPU fallback in the product path.
 """
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -154,6 +155,9 @@ _SIGS = {
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "sc_dec_layer_stream_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sc_dec_layer_stream": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
+    "sc_dec_layer_ffn_xn": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     # stream-level API
     "sc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(NamedTensor), C.c_int, C.c_int, C.POINTER(vp)]),
     "sc_engine_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
@@ -195,7 +199,7 @@ EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 
 # revision of include/scasr.h these ctypes mirrors were written against (SC_ABI_VERSION): a library built from another
 # revision would be handed mis-laid-out structs
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -225,19 +229,24 @@ def load():
     # binds to the same HIP runtime instance (two runtimes in one process do
     # not see each other's device / streams).
     import torch  # noqa: F401
-    if not LIB_PATH.exists():
+    lib_path = LIB_PATH
+    # A/B runs of library VARIANTS (tools/ab_libs.sh, tools/build_variant.sh): honoured only with the test hooks on - a
+    # production process always loads the in-tree product build (the variants used to be copied over it)
+    if os.environ.get("SC_TEST_HOOKS") == "1" and os.environ.get("SC_LIB_VARIANT"):
+        lib_path = Path(os.environ["SC_LIB_VARIANT"]).resolve()
+    if not lib_path.exists():
         raise ScasrError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            f"{lib_path} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback for the product path.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(lib_path))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
     got = lib.sc_version()
     if got != ABI_VERSION:
-        raise ScasrError(f"{LIB_PATH} was built from ABI revision {got} of include/scasr.h, this binding is revision "
+        raise ScasrError(f"{lib_path} was built from ABI revision {got} of include/scasr.h, this binding is revision "
                          f"{ABI_VERSION}: rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
     _lib = lib
     return lib

@@ -50,6 +50,9 @@ int sc_gemm_colblocks(const float *A, const int32_t *a_rows, int lda, const floa
 // decoder_layer.hip: heads per workgroup of the head-parallel layer kernels for the bucket sb.n_rows (1, 2 or 4): the
 // consumer of their partial products (the next layer kernel, sc_dec_layer_ffn) reduces sb.H / hpw of them per row
 int sc_dec_layer_hpw(const sc_search &sb);
+// decoder_stream.hip: 1 when this bucket's decoder layers run in the stream-resident form (one workgroup per stream, two
+// launches per layer), 0: the head-parallel launches of decoder_layer.hip
+int sc_dec_layer_stream_form(const sc_search &sb);
 
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,

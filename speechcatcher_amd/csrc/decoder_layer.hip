@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       }
 #pragma unroll
       for (int q = 0; q < QN; ++q) {
-        const int e = tid + NTH * q, i = e / C4, c4 = e % C4;
+        const int e = tid + NTH * q, i = e / C4;
         if (i < W)
           xv[q] = make_float4(xi[q].x + (yv[q].x + pbv[q].x), xi[q].y + (yv[q].y + pbv[q].y), xi[q].z + (yv[q].z + pbv[q].z),
                               xi[q].w + (yv[q].w + pbv[q].w));

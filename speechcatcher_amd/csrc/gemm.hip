@@ -1382,6 +1382,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(FfnArgs p) {
             h16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
       } else {
         float *o = PRO ? p.part + ((long)grp * p.part_rows + rowid[i]) * D : dst + (long)i * D;
+        // (round 6) the prologue-less form behind the stream-resident decoder layer (sc_dec_layer_ffn_xn): split sums by ROW ID too
+        if (!PRO && p.part_rows > 0) o = p.part + ((long)grp * p.part_rows + (p.rows ? p.rows[m0 + i] : m0 + i)) * D;
         *reinterpret_cast<float4 *>(o + 4 * c4) = v;
       }
     }
@@ -1966,6 +1968,64 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   // algorithmic: 4*D*F flop per row; x + H head partials read, W1 + W2 read once, x and the partials written
   // algorithmic: 4*D*F flop per row; weights once + x in + x out - the head partials read and the
   // split sums written are TRAFFIC of this decomposition, not algorithmic bytes
+  sc_prof_end(prof, SC_PROF_FFN_PRO, 4.0 * (double)M * D * F, 4.0 * (2.0 * (double)M * D + 2.0 * (double)D * F));
+  SC_CHECK_LAUNCH();
+  *n_part = ngrp;
+  return SC_OK;
+}
+
+// (round 6) launch C' of the stream-resident form (decoder_stream.hip): the same feed-forward WITHOUT a prologue - its input
+// rows xn = LayerNorm3(x'') were written by sc_dec_layer_stream, which owns complete rows.  Split sums by row id into
+// ffn_part[grp][S*W][d]; the consumer (sc_dec_layer_stream of the next layer or sc_dec_output_logits) adds b2 and the residual.
+extern "C" int sc_dec_layer_ffn_xn(const sc_search *sbp, int layer, const float *xn, float *ffn_part, int max_part, int *n_part,
+                                   void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xn && ffn_part && n_part, "null");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(layer >= 0 && layer < sb.n_layers, "layer out of range");
+  const int D = sb.d, F = sb.F;
+  SC_CHECK_ARG(sc_ffn_ln_supported(D, F), "unsupported dimensions");
+  const sc_dec_layer &w = sb.layers[layer];
+  const int32_t *rows = sb.rowmap;
+  const int M = rows ? sb.n_rows : sb.S * sb.W;
+  SC_CHECK_ARG(M > 0 && M <= sb.S * sb.W && max_part >= 1, "n_rows / max_part out of range");
+  const int nch = F / 128;
+  const int wf = (w.w1_s && w.w2_s) ? 2 : (w.w1_h && w.w2_h) ? 1 : 0;
+  const void *w1x = wf == 2 ? w.w1_s : wf == 1 ? w.w1_h : (const void *)w.w1_p;
+  const void *w2x = wf == 2 ? w.w2_s : wf == 1 ? w.w2_h : (const void *)w.w2_p;
+  // tile height and chunks per workgroup: the attention launches of this form hold ONE compute unit per stream and the encoder
+  // groups run beside them, so the grid is sized for the compute units the decode chain has to itself (SC_STREAM_FFN_CUS)
+  int cus = SC_STREAM_FFN_CUS;
+  if (const char *e = sc_hook("SC_STREAM_FFN_CUS")) cus = atoi(e);
+  int best_rtt = 5, best_cpw = nch;
+  double best = 1e30;
+  for (int cpw = 1; cpw <= 2; cpw *= 2) {   // (canonical summation order: one chunk or an aligned pair per workgroup)
+    if (nch % cpw || nch / cpw > max_part) continue;
+    const int ngrp = nch / cpw;
+    for (int rtt = 1; rtt <= ffn_rtt_max(D, wf); ++rtt) {
+      const long wgs = (long)ngrp * ((M + 16 * rtt - 1) / (16 * rtt));
+      const double rounds = (double)((wgs + cus - 1) / cus);
+      const double t = rounds * (2.5 + 4.0 * rtt * cpw) + 1.5 + 2.0 * (double)M * D * 4.0 * ngrp / 3.0e6;
+      if (t < best) { best = t; best_rtt = rtt; best_cpw = cpw; }
+    }
+  }
+  SC_CHECK_ARG(best < 1e29, "max_part too small");
+  if (const char *f = sc_hook("SC_DEC_FFN_FORCE")) {   // A/B runs: "min_rows,rtt,cpw"
+    int mr = 0, r = 0, c = 0;
+    if (sscanf(f, "%d,%d,%d", &mr, &r, &c) == 3 && M >= mr && r >= 1 && r <= ffn_rtt_max(D, wf) && c >= 1 && c <= 2 && nch % c == 0 &&
+        nch / c <= max_part) {
+      best_rtt = r;
+      best_cpw = c;
+    }
+  }
+  const int ngrp = nch / best_cpw;
+  FfnArgs p{xn, rows, (const float *)w1x, w.b1, (const float *)w2x, ffn_part, M, F, best_cpw};
+  p.part_rows = sb.S * sb.W;
+  p.w_form = wf;
+  p.dbg_stamp = sc_phase_take(3);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof = sc_prof_begin(st);
+  if (D == 256) launch_ffn_rtt<256, false>(p, best_rtt, ngrp, st);
+  else launch_ffn_rtt<128, false>(p, best_rtt, ngrp, st);
   sc_prof_end(prof, SC_PROF_FFN_PRO, 4.0 * (double)M * D * F, 4.0 * (2.0 * (double)M * D + 2.0 * (double)D * F));
   SC_CHECK_LAUNCH();
   *n_part = ngrp;

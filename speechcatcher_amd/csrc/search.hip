@@ -1326,7 +1326,17 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
   const sc_search &sb = *sbp;
   const int n = sb.rowmap ? sb.n_rows : sb.S * sb.W;
   int rc;
-  if (dec_fused_ok(sb)) {
+  if (dec_fused_ok(sb) && sc_dec_layer_stream_form(sb)) {
+    // (round 6) stream-resident form, 2 launches per layer: x'' ping-pongs dx <-> dxn, LayerNorm3(x'') travels in dq
+    float *xa = sb.dx, *xb = sb.dxn;
+    int npart = 0;
+    for (int li = 0; li < sb.n_layers; ++li) {
+      SC_TRY(sc_dec_layer_stream(sbp, li, xa, xb, sb.dq, sb.ffn_part, npart, stream));
+      SC_TRY(sc_dec_layer_ffn_xn(sbp, li, sb.dq, sb.ffn_part, sb.max_ffn_part, &npart, stream));
+      float *t = xa; xa = xb; xb = t;
+    }
+    SC_TRY(sc_dec_output_logits(sbp, xa, xb, sb.ffn_part, npart, stream));
+  } else if (dec_fused_ok(sb)) {
     // 3 launches per layer; x ping-pongs dx <-> dxn
     float *xa = sb.dx, *xb = sb.dxn;
     int npart = 0;

@@ -297,6 +297,15 @@ class HipBackend:
                       C.byref(n))
         return int(n.value)
 
+    # stream-resident decoder layers: 2 launches per layer (csrc/decoder_stream.hip)
+    def dec_layer_stream(self, sb, li, xin, xout, xn_out, npart):
+        self._sb_call("sc_dec_layer_stream", sb, li, _p(xin), _p(xout), _p(xn_out), _p(sb.ffn_part), int(npart))
+
+    def dec_layer_ffn_xn(self, sb, li, xn):
+        n = C.c_int(0)
+        self._sb_call("sc_dec_layer_ffn_xn", sb, li, _p(xn), _p(sb.ffn_part), int(sb.ffn_part.shape[0]), C.byref(n))
+        return int(n.value)
+
     def dec_output_logits(self, sb, xin, xout, npart):
         self._sb_call("sc_dec_output_logits", sb, _p(xin), _p(xout), _p(sb.ffn_part), int(npart))
 

@@ -9,7 +9,8 @@ from oracle.kernel_spec import SpecBackend
 FINE_OPS = ["logmel", "conv1", "gemm", "gemm_ln", "proj_ln_proj", "ffn_ln", "ffn_ln_proj", "copy_rows", "layernorm", "log_softmax_rows", "block_pack",
             "ctx_handoff", "enc_attention", "ctc_extend_state", "dec_embed", "dec_self_attn",
             "dec_cross_attn", "logsoftmax_topk", "ctc_prefix_scan", "fuse_topw", "beam_prune",
-            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits"]
+            "ctc_gather_state", "dec_layer_self", "dec_layer_cross", "dec_layer_ffn", "dec_output_logits",
+            "dec_layer_stream", "dec_layer_ffn_xn"]
 
 
 class LockstepBackend(SpecBackend):
@@ -71,6 +72,8 @@ class LockstepBackend(SpecBackend):
         # head-parallel decoder layers: (sb, li, xin, xout[, npart]) / (sb, xin, xout, npart)
         "dec_layer_self": [3, "skv", "ph1"], "dec_layer_cross": [3, "ph2"], "dec_layer_ffn": [3, "ffn_part"],
         "dec_output_logits": [2, "logits"],
+        # stream-resident decoder layers: (sb, li, xin, xout, xn_out, npart) / (sb, li, xn)
+        "dec_layer_stream": [3, 4, "skv"], "dec_layer_ffn_xn": ["ffn_part"],
     }
     FULL_SYNC = ("logmel", "ctc_extend_state", "dec_embed")
 

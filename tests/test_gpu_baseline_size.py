@@ -264,6 +264,36 @@ def test_serving_is_bit_reproducible():
         same_bits(ref, o, f"stream {s} in the batch of 128 against its solo run", rows_a=[s], rows_b=[0])
 
 
+@pytest.mark.parametrize("S,n", [(72, 14), (128, 30)])
+def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeypatch, S, n):
+    """Round 6: the stream-resident form of the decoder layers (csrc/decoder_stream.hip: one workgroup per stream, both
+    attentions of a layer in one launch, two launches per layer) against the head-parallel launches it replaces at large
+    buckets (four heads per workgroup, three launches per layer): the same audio in strict lock-step must give IDENTICAL
+    token ids, positions and float64 totals - every sum follows the canonical order of csrc/common.h.  n = 30 chunks reach
+    T = 480 frames / ~220 tokens (several tiles per attention slot, ragged buckets at the end of every chunk step).
+    Reference semantics: decoder_layer.py:80-132, multi_head_attention.py:63-133."""
+    beam = 10
+    audio = np.stack([synth.synth_audio(7000 + s, CHUNK * n) for s in range(S)])
+    kw = dict(max_frames=16 * n + 80, max_tokens=480, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+
+    def run(form):
+        monkeypatch.setenv("SC_DEC_STREAM", form)
+        sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", n_streams=S, **kw)
+        _feed(sb, audio, n)
+        o = sb.hypotheses_arrays(list(range(S)))
+        sb.close()
+        return o
+
+    a, b = run("1"), run("0")
+    assert a["lens"][:, 0].min() >= (60 if n < 20 else 150), int(a["lens"][:, 0].min())
+    for key in ("n_hyps", "lens", "ids", "xpos"):
+        assert np.array_equal(a[key], b[key]), key
+    for key in ("score", "score_dec", "score_ctc"):
+        x, y = a[key], b[key]
+        bad = np.nonzero(x.view(np.int64) != y.view(np.int64))
+        assert len(bad[0]) == 0, (key, len(bad[0]), float(np.abs(x - y).max()))
+
+
 def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     """(also: the split-precision form `split16` on the same 256 streams - identical beams, see the end.)
     Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward + encoder attention-projection weights / MFMA

@@ -571,7 +571,7 @@ def test_every_kernel_lockstep_tiny_multiblock(hip):
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
 
-@pytest.mark.parametrize("layers", ["head_parallel", "head_parallel_hpw4", "six_launch"])
+@pytest.mark.parametrize("layers", ["head_parallel", "head_parallel_hpw4", "stream_resident", "six_launch"])
 def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
     """XL dims (d=256, 8 heads, 30+14 layers), first 5 calls of the fixture utterance; the forms of the decoder layers:
     3 launches per layer with one head per workgroup (small buckets), with four / two heads per workgroup (large
@@ -584,9 +584,13 @@ def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
     if hpw > 1:
         monkeypatch.setenv("SC_ATTN_DEEP", "0")      # (the few-streams variant runs one head per workgroup)
     monkeypatch.setattr(LockstepBackend, "fused_layers", layers != "six_launch")
+    # (round 6) the stream-resident form: one workgroup per stream, both attentions of a layer in one launch
+    monkeypatch.setenv("SC_DEC_STREAM", "1" if layers == "stream_resident" else "0")
+    monkeypatch.setattr(LockstepBackend, "stream_layers", layers == "stream_resident")
     ls = _lockstep_run(hip, "xl_c10240_b10_bbd0", n_calls=4 if layers == "six_launch" else 5, atol=5e-4, rtol=5e-4)
     _dump(ls, "lockstep_xl_" + layers)
-    assert ("dec_layer_self" in ls.calls) == (layers != "six_launch")
+    assert ("dec_layer_self" in ls.calls) == (layers in ("head_parallel", "head_parallel_hpw4"))
+    assert ("dec_layer_stream" in ls.calls) == (layers == "stream_resident")
     assert not ls.failures, ls.failures[:10]
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 

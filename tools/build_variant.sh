@@ -7,7 +7,7 @@ NAME=$1; EXTRA=$2; ROOT=$(cd "$(dirname "$0")/.." && pwd); SRC=${3:-$ROOT/speech
 OBJ=/tmp/scasr_build_$NAME; mkdir -p $OBJ $ROOT/build_ab
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-variable $EXTRA"
 pids=()
-for f in gemm encoder search decoder_panel decoder_layer conformer streams; do
+for f in gemm encoder search decoder_panel decoder_layer decoder_stream conformer streams; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

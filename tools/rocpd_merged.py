@@ -26,7 +26,7 @@ def main():
     print(f"{len(sel)} kernels in [{-back:.1f} ms, {-back + length:.1f} ms] from the end of the trace")
     for r in sel:
         others = sum(1 for o in rows if o[3] != r[3] and o[1] <= r[1] < o[2])
-        name = r[0].replace("_Z21dec_layer_attn_kernelILi256ELi32ELi10E", "dec_attn<").replace("_Z16ffn_fused_kernelILi256E", "ffn<")[:46]
+        name = r[0].replace("_Z21dec_layer_attn_kernelILi256ELi32ELi10E", "dec_attn<").replace("_Z16ffn_fused_kernelILi256E", "ffn<").replace("_Z23dec_layer_stream_kernelI", "dec_stream<")[:46]
         print(f"{(r[1] - t0) / 1e3:9.1f} us  dur {(r[2] - r[1]) / 1e3:7.2f}  q{r[3]}  other-queue kernels running at start: {others}  wgs {r[4]:5d}  {name}")
 
 

@@ -27,7 +27,8 @@ def main():
     t_end = max(r[2] for r in rows)
     rows = [r for r in rows if r[1] >= t_end - last_ms * 1e6]
     t0 = rows[0][1]
-    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1")
+    # a decode iteration starts with the FIRST variant of a layer kernel (head-parallel or, round 6, stream-resident)
+    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1|dec_layer_stream_kernelILb1E")
     hpw = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb[01]ELi\d+ELb[01]ELb[01]ELi(\d+)")
     dq = [r[3] for r in rows if first.search(r[0])]
     eq = [r[3] for r in rows if "logmel_kernel" in r[0]]
@@ -39,7 +40,7 @@ def main():
             if first.search(name) or not phases or phases[-1][0] != "dec" and not any(p[0] == "dec" for p in phases[-2:]):
                 if first.search(name):
                     m = hpw.search(name)
-                    per = 2 if m and m.group(1) == "4" else 8
+                    per = 1 if "dec_layer_stream" in name else (2 if m and m.group(1) == "4" else 8)
                     phases.append(["dec", s, e, 0.0, wgs // per, 0])
             cand = [p for p in phases if p[0] == "dec"]
             if cand:

@@ -23,7 +23,7 @@ def main():
                             f"join {ks} s on d.kernel_id = s.id order by d.start"))
     # only the decode stream's queue (continuous batching: encoder groups run beside it on another stream)
     import re
-    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?(ELb[01])?EEv")
+    first = re.compile(r"dec_layer_attn_kernelILi\d+ELi\d+ELi\d+ELb1ELi\d+ELb1ELb[01](ELi\d+)?(ELb[01])?EEv|dec_layer_stream_kernelILb1E")
     dq = [r[3] for r in rows if "dec_embed" in r[0] or first.search(r[0])]
     if dq:
         q = max(set(dq), key=dq.count)
@@ -41,7 +41,8 @@ def main():
         which = cand[-2] - len(starts) if len(cand) > 1 else -3
     if which == "full":   # the last step of a (nearly) full bucket: its decoder FFN runs 48-row tiles (RTT = 3)
         cand = [k for k, i in enumerate(starts[:-1])
-                if any("ffn_fused_kernelILi256ELi3ELb1" in r[0] for r in rows[i:starts[k + 1]])]
+                if any("ffn_fused_kernelILi256ELi3ELb1" in r[0] or
+                       ("dec_layer_stream_kernel" in r[0] and int(r[0].rsplit("wgs=", 1)[1]) >= 100) for r in rows[i:starts[k + 1]])]
         which = cand[-2] - len(starts) if len(cand) > 1 else -3
     which = int(which)
     a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
