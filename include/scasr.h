@@ -334,7 +334,7 @@ int sc_set_stream_workspace(void *stream, void *ptr, size_t bytes);
  * stream runs both attentions of a layer for all heads, two launches per layer): a full 128-stream bucket then holds 128 of the
  * 256 compute units and the encoder groups run beside the decode chain instead of between its kernels.  Same bits as the
  * other two forms (canonical summation, common.h).  SC_STREAM_FFN_CUS: compute units its feed-forward launch is sized for. */
-#define SC_STREAM_MIN_ROWS 640
+#define SC_STREAM_MIN_ROWS 1281
 #define SC_STREAM_FFN_CUS 256
 int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, long long *n, int nkinds);
 int sc_prof_enable(int sample_every);

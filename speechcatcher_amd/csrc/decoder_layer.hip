@@ -170,6 +170,9 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #ifndef SC_HPW_NTW_CROSS
 #define SC_HPW_NTW_CROSS 2   // ... in its CROSS walk
 #endif
+#ifndef SC_HPW_TOUCH
+#define SC_HPW_TOUCH 0       // 1: the four-head form requests a dword of every weight line ahead of its prologue (rounds 4-5)
+#endif
 template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1, bool WH = false>
 __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
@@ -215,6 +218,10 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // LayerNorm parameters: issued first, parked in LDS once the partial sums (issued later, returned later) are in
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < D / 2) gbv = *reinterpret_cast<const float4 *>((tid < D / 4 ? p.ln_g : p.ln_b) + 4 * (tid % (D / 4)));
+  // (round 6) the bias elements of this thread's share of the split-K reduce: requested here, they used to be one more
+  // dependent round trip in the middle of the kernel (the elements e = gt + 256 k of the WM x NT*16 tile)
+  constexpr int NBP = (WM * ((SELF ? 3 : 1) * (DK / 16)) * 16 + 255) / 256;
+  float bpre[NBP];   // (requested behind the prologue, when its registers are free: they travel during the projection)
   // PF (few streams active: registers are plentiful): the projection's B fragments are fetched into registers
   // right here instead, so that the MFMAs behind the LayerNorm wait for nothing.
   constexpr bool PF = UNR >= 8;
@@ -253,7 +260,11 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       pfb[t * 2 + 1] = wq[64];
     }
   };
-  {
+  // (round 6) NOT in the four-head form: at the buckets it serves every XCD's L2 holds the fragments anyway (32 workgroups per
+  // XCD read the same ones), and the 384 KB of lines a workgroup touched stood IN FRONT of its partial sums in the load queue
+  // (loads return in issue order) - the stream-resident kernel fetches the same rows in 4.3 us where this prologue took 11
+  constexpr bool TOUCH = HPW == 1 || SC_HPW_TOUCH;
+  if constexpr (TOUCH) {
     if (PF) {
       if (FIRST) prefetch_w();
     } else {
@@ -387,6 +398,11 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
       }
     }
     if (EARLY) prefetch_w();
+#pragma unroll
+    for (int k = 0; k < NBP; ++k) {
+      const int n = (gt + 256 * k) % (((SELF ? 3 : 1) * (DK / 16)) * 16);
+      bpre[k] = p.bp[(n / DK) * D + head * DK + n % DK];
+    }
     if (tid < D / 2) *reinterpret_cast<float4 *>(gb + 4 * tid) = gbv;
     if (touch == 123456.789f) Xn[0] = touch;   // never true: keeps the warm-up loads (they have returned by now:
     __syncthreads();                           // loads return in order and the partial sums were waited for)
@@ -497,7 +513,10 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
     for (int e = WM * DK + gt; e < 16 * DK; e += 256) qs[e] = 0.f;   // hypothesis rows the MFMA tiles pad with
-    for (int e = gt; e < WM * NT * 16; e += 256) {
+#pragma unroll
+    for (int k = 0; k < NBP; ++k) {
+      const int e = gt + 256 * k;
+      if (e >= WM * NT * 16) break;
       const int w = e / (NT * 16), n = e % (NT * 16);
       const int which = n / DK, c = n % DK;
       float v = 0.f;
@@ -506,7 +525,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
         v += Ps[(1 * WM + w) * LDP + n];
         v += Ps[(2 * WM + w) * LDP + n];
         v += Ps[(3 * WM + w) * LDP + n];
-        v += p.bp[which * D + head * DK + c];
+        v += bpre[k];
       }
       if (which == 0) {
         qs[w * DK + c] = v / scale;

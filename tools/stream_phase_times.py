@@ -64,3 +64,23 @@ for idx, (no, rows) in enumerate(launches):
         for i, n in enumerate(names):
             print(f"       {n:52s} in phase: mean {d[:, i].mean():6.2f}  max {d[:, i].max():6.2f} us   reached its end at: mean {rel[:, i + 1].mean():6.2f}  "
                   f"first {rel[:, i + 1].min():6.2f}  last {rel[:, i + 1].max():6.2f} us")
+
+# finer stamps inside the merges (kind 1; shader ticks relative to stamp 5 / 9 of the same workgroup are not comparable across
+# kinds on the real-time axis, so: differences between consecutive kind-1 stamps, and kind-1 slot 8 / 0 against kind-0 slot 5)
+k1 = a[1]
+names1 = ["self: partials stored -> behind the barrier + wave sync", "self: fragments requested", "self: merge arithmetic", "self: context stored",
+          "cross: (wave sync)", "cross: fragments requested", "cross: merge arithmetic", "cross: context stored"]
+for slot in range(RING):
+    t0_, t1_ = a[0][slot], k1[slot]
+    live = (t1_[:, 0] != 0) & (t1_[:, 3] > t1_[:, 0]) & (t0_[:, 0] != 0)
+    if not live.any():
+        continue
+    r0, r1 = t0_[live].astype(np.float64), t1_[live].astype(np.float64)
+    tpu = 2400.0
+    print("merge detail (one launch, mean us over workgroups): walk end -> partials stored %.2f | stored -> barrier passed %.2f | fragments requested %.2f | "
+          "merge arithmetic %.2f | context stored %.2f | -> behind the workgroup barrier %.2f || cross: walk end -> wave sync %.2f | requested %.2f | arithmetic %.2f | stored %.2f | -> barrier %.2f" % (
+              ((r1[:, 8] - r0[:, 5]) / tpu).mean(), ((r1[:, 0] - r1[:, 8]) / tpu).mean(), ((r1[:, 1] - r1[:, 0]) / tpu).mean(),
+              ((r1[:, 2] - r1[:, 1]) / tpu).mean(), ((r1[:, 3] - r1[:, 2]) / tpu).mean(), ((r0[:, 6] - r1[:, 3]) / tpu).mean(),
+              ((r1[:, 4] - r0[:, 9]) / tpu).mean(), ((r1[:, 5] - r1[:, 4]) / tpu).mean(), ((r1[:, 6] - r1[:, 5]) / tpu).mean(),
+              ((r1[:, 7] - r1[:, 6]) / tpu).mean(), ((r0[:, 10] - r1[:, 7]) / tpu).mean()))
+    break
