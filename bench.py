@@ -627,10 +627,11 @@ def main():
     lib = sb.lib
     elapsed, dec_steps_per_hop = head["elapsed"], head["dec_steps_per_hop"]
     state = state_of(sb)
+    kv_rows = sb.kv_rows
 
     # Roofline leg: the SAME workload continues in the SAME mode for a few more steps with hipGraph replay switched
     # off, so that every launch of the hot kernels can be bracketed by HIP events on its launch stream.
-    NK = 12   # scasr.h: SC_PROF_KINDS
+    NK = 13   # scasr.h: SC_PROF_KINDS
     ms, fl, by = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_double * NK)()
     nn = (C.c_longlong * NK)()
     ev_over_ms, xattn_bytes, xattn_flops = 0.0, {}, {}
@@ -670,12 +671,15 @@ def main():
         # a row = K|V of all heads = 2d elements
         esz = 2 if KV_DTYPE == "float16" else 4
         rowb = 2 * XL.d_model * esz
+        # (kind 12, the stream-resident layer kernel of batches > 128 streams: both attentions of a layer in one launch)
         xattn_bytes = {7: float(rows["cross_rows"][0]) * rowb, 11: float(rows["cross_rows"][1]) * rowb,
-                       6: float(rows["self_distinct_rows"][0]) * rowb, 10: float(rows["self_distinct_rows"][1]) * rowb}
+                       6: float(rows["self_distinct_rows"][0]) * rowb, 10: float(rows["self_distinct_rows"][1]) * rowb,
+                       12: float(rows["cross_rows"][2] + rows["self_distinct_rows"][2]) * rowb}
         # ... and the attention's own flops: q.k + p.v = 4 d per (hypothesis, key, layer) - keys = the T frames / the L tokens
         fa = 4.0 * XL.d_model * args.beam
         xattn_flops = {7: fa * rows["cross_rows"][0], 11: fa * rows["cross_rows"][1],
-                       6: fa * rows["self_positions"][0], 10: fa * rows["self_positions"][1]}
+                       6: fa * rows["self_positions"][0], 10: fa * rows["self_positions"][1],
+                       12: fa * (rows["cross_rows"][2] + rows["self_positions"][2])}
 
     if dist is not None:
         t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
@@ -708,7 +712,8 @@ def main():
              "dec_attn_flash_kernel<cross> (stand-alone decoder cross-attention: six-launch layers)", "rowtile_proj_kernel<256,*>",
              "ffn_fused_kernel<256,*,PRO> (decoder layer FFN: reduce of the head partials + norm3 prologue)",
              "dec_layer_attn_kernel<self> (decoder layer: reduce + norm1 + Q|K|V + self-attention + out-projection; 1 or 4 heads per workgroup)",
-             "dec_layer_attn_kernel<cross> (decoder layer: reduce + norm2 + q + cross-attention + out-projection; 1 or 4 heads per workgroup)"]
+             "dec_layer_attn_kernel<cross> (decoder layer: reduce + norm2 + q + cross-attention + out-projection; 1 or 4 heads per workgroup)",
+             "dec_layer_stream_kernel (stream-resident decoder layer: both attentions of a layer for all heads, one workgroup per stream; batches > 128 streams)"]
     net = [max(ms[i] - nn[i] * ev_over_ms, 0.0) for i in range(NK)]
     tot_ms = max(sum(net), 1e-9)
     # every kind against BOTH roofs: algorithmic flops (incl. the attention's q.k / p.v) at the f32 matrix peak, algorithmic
@@ -874,7 +879,8 @@ def main():
         try:
             core = ["--streams", str(S), "--steps", str(args.steps), "--warmup", str(args.warmup), "--preroll", str(args.preroll),
                     "--beam", str(args.beam), "--bbd", str(args.bbd), "--chunk", str(CHUNK), "--mode", args.mode,
-                    "--kv-dtype", KV_DTYPE, "--ffn-dtype", FFN_DTYPE, "--queue-depth", str(args.queue_depth)]
+                    "--kv-dtype", KV_DTYPE, "--ffn-dtype", FFN_DTYPE, "--queue-depth", str(args.queue_depth),
+                    "--encoder-batch", str(args.encoder_batch), "--poll-group", str(args.poll_group)]
             pinned = pinned_leg(core)
             if "value" in pinned:
                 pinned["over_headline"] = round(pinned["value"] / value, 4)
@@ -901,6 +907,37 @@ def main():
         fp16_mode["note"] = ("NOT the headline: BASELINE configs[4]'s mode (`--ffn-dtype float16 --kv-dtype float16`).  No fp16 run of the "
                              "reference's native decoder exists (speechcatcher.py:205-210 disables it): parity for this mode is the ids of the "
                              "six XL fixtures + a bound on the share of streams whose best hypothesis moves (tests/test_gpu_baseline_size.py)")
+
+    # wider batches on the one GPU (round 6): 256 streams in fp32 - the regime of the stream-resident decoder layers (one workgroup
+    # per stream: a 256-stream bucket is ONE round of the 256 compute units) - and, with --legs all, the per-GPU share of BASELINE
+    # configs[4] (256 streams, fp16 mode).  Same window, same closed loop, their own audio.
+    wide = None
+    if not args.no_other_mode and world == 1 and S == 128 and CHUNK == 10240 and KV_DTYPE == "float32" and FFN_DTYPE == "float32":
+        wide = {}
+        S2 = 256
+        audio2 = make_audio(S2, total_steps)
+        steps2 = max(8, args.steps // 2)
+        for name, wdt, kvd in (("streams_256_f32", None, None),) + ((("config4_share_256_fp16", "float16", "float16"),) if extended else ()):
+            try:
+                wx = make_weights(device, wdt) if wdt else w
+                sbx, r = measure(wx, audio2, S2, args.beam, bool(args.bbd), args.preroll, args.warmup, steps2, S2 // 8, args.mode, total_steps,
+                                 kv_dtype=kvd, depth=args.queue_depth)
+                kvr = sbx.kv_rows
+                sbx.close()
+                del sbx
+                if wdt:
+                    del wx
+                wide[name] = {"value": round(r["value"], 2), "unit": "audio_s/s", "streams": S2, "steps": steps2,
+                              "ms_per_step": round(r["elapsed"] / steps2 * 1e3, 3), "over_headline": round(r["value"] / value, 4),
+                              "decode_iterations_per_step": round(r.get("iterations_per_step", 0.0), 2),
+                              "self_attention_kv_pool_rows_per_stream_and_layer": kvr}
+            except Exception as e:  # noqa: BLE001
+                wide[name] = {"error": repr(e)}
+        del audio2
+        wide["note"] = ("NOT the headline (BASELINE configs[2] names 128 streams per GPU): the same closed loop with 256 streams on the one GPU.  "
+                        "fp32: buckets of more than 128 streams take the stream-resident decoder layers (csrc/decoder_stream.hip, two launches "
+                        "per layer, bit-identical results).  config4_share (--legs all): 256 streams in the fp16 mode = one GPU's share of "
+                        "BASELINE configs[4]")
 
     bbd_on = None
     if extended and not args.no_other_mode and world == 1 and not args.bbd:
@@ -1002,6 +1039,7 @@ def main():
                                f"(batched encoder + batched beam), beam {args.beam}, chunk {CHUNK} samples, bbd {args.bbd}",
                    "streams_per_gpu": S, "chunk_samples": CHUNK, "beam": args.beam, "bbd": args.bbd,
                    "mode": args.mode, "queue_depth": args.queue_depth, "semantics": semantics,
+                   "self_attention_kv_pool_rows_per_stream_and_layer": kv_rows,
                    "step": (f"one step = one {CHUNK}-sample chunk of EVERY stream = {S} calls / replies; the clock stops when "
                             f"{S} x steps replies have been delivered" if args.mode == "continuous" else
                             f"one step = one batched call with a {CHUNK}-sample chunk of every stream"),
@@ -1020,7 +1058,8 @@ def main():
         "decode_steps_per_hop": round(dec_steps_per_hop, 2),
         "whole_step": whole, "roofline": roof, "cpu_baseline": cpu, "single_stream": single,
         "resident_no_readback": resident, ("strict_lock_step" if args.mode == "continuous" else "continuous"): other,
-        "exact_steps": exact, "chunk_sizes": chunk_legs, "one_eighth_of_host_cores": pinned,
+        "value_exact_steps": (exact or {}).get("value"),
+        "exact_steps": exact, "chunk_sizes": chunk_legs, "one_eighth_of_host_cores": pinned, "wider_batches": wide,
         "kv_cache_fp16": kv16, "fp16_mode": fp16_mode, "ffn_split16": split16, "bbd_on": bbd_on, "queue_depth_2": queued, "l_like_dims": l_like, "long_context": long_ctx,
         "legs": args.legs,
     }

@@ -152,7 +152,7 @@ typedef struct sc_search {
   int32_t kv_half;
   /* measurement aid (bench.py: algorithmic bytes of the self-attention): when not NULL, every self-attention launch
    * adds the DISTINCT (position, slot) K|V rows it walked for a stream (plus its new rows) to stat_rows[0]
-   * (sc_dec_self_attn) / stat_rows[1] (sc_dec_layer_self) - one atomic per (stream, layer), by head 0 */
+   * (sc_dec_self_attn) / stat_rows[1] (sc_dec_layer_self) / stat_rows[2] (sc_dec_layer_stream) - one atomic per (stream, layer) */
   unsigned long long *stat_rows;
   /* fp16 decoder mode (BASELINE configs[4]; opt-in, never the parity mode): out_w_qh = fp16 copy of out_w_q (the
    * output layer with fp16 MFMA inputs) or NULL; act_half bit 0 (1): the layer kernels use the fp16 weight copies
@@ -610,6 +610,10 @@ int sc_get_hyps_batch(sc_streams *streams, const int *stream_ids, int n, int nbe
 /* Speech2TextStreaming.reset (speech2text_streaming.py:252-263); not while the stream has a chunk outstanding */
 int sc_reset(sc_streams *streams, int stream);
 int sc_stream_info(const sc_streams *streams, int stream, sc_stream_info_t *out);
+/* rows of the self-attention K|V pool per (stream, layer) this batch was created with (sc_stream_options.kv_pool_rows, or the
+ * default: one row per (position, hypothesis) within min(a quarter of the free device memory, SC_KV_POOL_DEFAULT_MAX_GIB)) */
+#define SC_KV_POOL_DEFAULT_MAX_GIB 24
+int sc_streams_kv_rows(const sc_streams *streams);
 int sc_streams_stats(const sc_streams *streams, long *enc_calls, long *dec_steps, long *dec_blocks);
 /* measurement aid: encoder-layer hipGraphs captured so far (one per shape of an encoder group) and the host seconds
  * that took */
@@ -626,13 +630,14 @@ int sc_streams_host_times(sc_streams *streams, double *launch_s, double *wait_s)
 /* ... and by compaction bucket: seconds[17], iterations[17] (index = bucket size in units of n_streams/16) */
 int sc_streams_bucket_times(sc_streams *streams, double *seconds, long *iterations);
 long sc_streams_take_xattn_rows(sc_streams *streams);
-/* ... split by the kernel that read them: rows[0] dec_attn_flash (large buckets), rows[1] sc_dec_layer_cross */
+/* ... split by the kernel that read them (HOST [3]): rows[0] dec_attn_flash, rows[1] sc_dec_layer_cross, rows[2] sc_dec_layer_stream */
 int sc_streams_take_xattn_rows_by_kernel(sc_streams *streams, long *rows);
 /* all attention counters since the last call (returned and cleared), each summed over decode iterations, active streams
- * and decoder layers, [0] stand-alone attention kernels / [1] head-parallel layer kernels:
- *   out[0..1] encoder K|V rows the cross-attention read, out[2..3] token positions the self-attention covered (L per
- *   hypothesis: the algorithmic length), out[4..5] DISTINCT self-attention K|V rows read (device counter) */
-int sc_streams_take_attn_counters(sc_streams *streams, long *out /*HOST [6]*/);
+ * and decoder layers, by the form of the decoder layers that did the work - [0] stand-alone attention kernels (six launches per
+ * layer) / [1] head-parallel layer kernels / [2] stream-resident layer kernel:
+ *   out[0..2] encoder K|V rows the cross-attention read, out[3..5] token positions the self-attention covered (L per
+ *   hypothesis: the algorithmic length), out[6..8] DISTINCT self-attention K|V rows read (device counter) */
+int sc_streams_take_attn_counters(sc_streams *streams, long *out /*HOST [9]*/);
 /* the batch's HIP stream and its device PCM ring [n_streams][capacity] (bench: inputs resident in HBM) */
 void *sc_streams_hip_stream(sc_streams *streams);
 float *sc_streams_pcm(sc_streams *streams, long *capacity);

@@ -155,6 +155,7 @@ _SIGS = {
     "sc_dec_layer_cross": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "sc_dec_layer_ffn": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     "sc_dec_output_logits": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "sc_streams_kv_rows": (C.c_int, [vp]),
     "sc_dec_layer_stream_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sc_dec_layer_stream": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "sc_dec_layer_ffn_xn": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),

@@ -41,7 +41,7 @@ struct ProfScope { bool on; hipEvent_t a, b; hipStream_t st; };
 ProfScope sc_prof_begin(hipStream_t st);
 void sc_prof_end(ProfScope &p, int kind, double flops, double bytes);
 
-// search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel)
+// search.hip: form of the decoder layers sc_decode_step picks for sb->n_rows (0 six-launch, 1 head-parallel, 2 stream-resident)
 int sc_decode_step_form(const sc_search *sb);
 // N / ncb products that share A in one launch, block j of the columns stored at C + j * cb_stride (gemm.hip)
 int sc_gemm_colblocks(const float *A, const int32_t *a_rows, int lda, const float *W, const float *bias, float *C,

@@ -37,6 +37,7 @@
 #define SC_STAMP_ON (p.dbg_stamp)
 #include "common.h"
 #include "attn.h"
+#include <mutex>
 
 #define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
 #define YSEQ(pp, s, h) (sb.yseq + (((long)(pp) * sb.S + (s)) * sb.W + (h)) * sb.LCAP)
@@ -727,12 +728,15 @@ static void launch_dec_layer_variant(const DecLayerArgs &p, int ns, hipStream_t 
   // fewer XCDs and costs 1 % at 128 streams, so larger buckets keep their natural spread
   const dim3 grid(ns <= 2 ? 8 : ns, sb.H / HPW);
   const size_t lds = (size_t)dl_lds_floats(D, DK, sb.W, WM, SELF, HPW) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW, WH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  // the attribute is set ONCE per instantiation, to the largest size any beam <= WM of it can ask for (it used to be
+  // the size of whichever beam width came first - a beam-5 engine followed by a beam-10 one in the same process), thread-safe
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&]() {
+    const size_t lds_max = (size_t)dl_lds_floats(D, DK, WM, WM, SELF, HPW) * sizeof(float);
+    if (lds_max > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW, WH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+  });
   dec_layer_attn_kernel<D, DK, WM, SELF, UNR, FIRST, KVH, HPW, WH><<<grid, 256 * HPW, lds, st>>>(p);
 }
 

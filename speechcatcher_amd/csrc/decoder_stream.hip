@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void dec_layer_stream_kernel(DecStreamArgs 
       urows += U;
       walk4(sb.skv, cdiv(U, 16), rowfn);
     }
-    if (sb.stat_rows && tid == 0) atomicAdd(&sb.stat_rows[1], (unsigned long long)urows);
+    if (sb.stat_rows && tid == 0) atomicAdd(&sb.stat_rows[2], (unsigned long long)urows);
     // the new token: hypothesis h attends to its own row (slot h at position L-1, still in LDS) only
     if (lane < 16) {
       const int h = lane;

@@ -1939,6 +1939,9 @@ extern "C" int sc_dec_layer_ffn(const sc_search *sbp, int layer, const float *xi
   double best = 1e30;
   for (int cpw = 1; cpw <= 2; cpw *= 2) {   // (canonical summation order: one chunk or an aligned pair per workgroup)
     if (nch % cpw || nch / cpw > max_part) continue;
+    //  the consumers' batches of 8 are a balanced tree over the chunk index for up to 16 partials only: a model with
+    // linear_units > 2048 always takes aligned pairs, so that the shape - and with it the order - never depends on the row count
+    if (nch > 16 && nch % 2 == 0 && cpw != 2) continue;
     const int ngrp = nch / cpw;
     for (int rtt = 1; rtt <= ffn_rtt_max(D, wf); ++rtt) {
       const long wgs = (long)ngrp * ((M + 16 * rtt - 1) / (16 * rtt));
@@ -2000,6 +2003,7 @@ extern "C" int sc_dec_layer_ffn_xn(const sc_search *sbp, int layer, const float 
   double best = 1e30;
   for (int cpw = 1; cpw <= 2; cpw *= 2) {   // (canonical summation order: one chunk or an aligned pair per workgroup)
     if (nch % cpw || nch / cpw > max_part) continue;
+    if (nch > 16 && nch % 2 == 0 && cpw != 2) continue;   // (see sc_dec_layer_ffn)
     const int ngrp = nch / cpw;
     for (int rtt = 1; rtt <= ffn_rtt_max(D, wf); ++rtt) {
       const long wgs = (long)ngrp * ((M + 16 * rtt - 1) / (16 * rtt));

@@ -4,6 +4,8 @@
 // per-stream ctrl rows (see scasr.h), so one launch serves all streams.
 #include "common.h"
 #include "attn.h"
+#include <mutex>
+#include <unordered_map>
 
 #define CTRL(s, f) sb.ctrl[(s) * 8 + (f)]
 // rows of the CTC table / forward variables seen by a decode step (scasr.h: SC_C_TCTC)
@@ -908,11 +910,28 @@ __global__ __launch_bounds__(256) void ctc_prefix_scan_tpar_kernel(sc_search sb,
   }
 }
 
+// The scan and the state rebuild must agree on which streams were split over T (the T-parallel scan parks 32 segment START
+// states in ctc_rnew where the sequential scan leaves its 16-frame checkpoints): the effective split_min of the LAST scan of a
+// batch (keyed by its ctc_rnew buffer) is remembered here and sc_ctc_gather_state_split refuses another value - since ABI 5 the
+// legacy sc_ctc_gather_state() behind a split scan silently rebuilt the state from the wrong kind of rows.
+static std::mutex g_scan_split_mutex;
+static std::unordered_map<const void *, int> g_scan_split;   // ctc_rnew -> effective split_min of its last scan
+static void scan_split_note(const sc_search *sbp, int eff) {
+  std::lock_guard<std::mutex> lk(g_scan_split_mutex);
+  g_scan_split[sbp->ctc_rnew] = eff;
+}
+static int scan_split_last(const sc_search *sbp) {   // -1: no scan of this batch seen yet
+  std::lock_guard<std::mutex> lk(g_scan_split_mutex);
+  auto it = g_scan_split.find(sbp->ctc_rnew);
+  return it == g_scan_split.end() ? -1 : it->second;
+}
+
 // split_min > 0: streams with at least split_min frames to walk take the T-parallel kernel
 extern "C" int sc_ctc_prefix_scan_split(const sc_search *sbp, int split_min, void *stream) {
   SC_CHECK_ARG(sbp, "null");
   SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4 && sbp->tct % 4 == 0, "the prefix scan needs the column-major table copy (sc_search.ctcxT)");
   split_min = ctc_split_min_ok(sbp->TCAP, split_min);
+  scan_split_note(sbp, split_min);
   dim3 grid(cdiv(sbp->W * sbp->K, 256), sbp->S);
   ctc_prefix_scan_colmajor_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(*sbp, split_min);
   if (split_min > 0)
@@ -1288,7 +1307,13 @@ extern "C" int sc_ctc_gather_state_split(const sc_search *sbp, int split_min, vo
   SC_CHECK_ARG(sbp->ctcxT && sbp->tct >= 4, "the state rebuild needs the column-major table copy (sc_search.ctcxT)");
   int gx = cdiv(ctc_tck(sbp->TCAP) * sbp->W, 256);
   if (gx > 16) gx = 16;
-  ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp, ctc_split_min_ok(sbp->TCAP, split_min));
+  const int eff = ctc_split_min_ok(sbp->TCAP, split_min), last = scan_split_last(sbp);
+  if (last >= 0 && last != eff) {
+    sc_set_error("sc_ctc_gather_state_split: the last prefix scan of this batch ran with split_min = %d, the rebuild was asked for %d - "
+                 "streams split over T leave segment states, not checkpoints: pass the scan's value (sc_ctc_gather_state() = 0)", last, eff);
+    return SC_ERR_ARG;
+  }
+  ctc_gather_state_kernel<<<dim3(gx, sbp->S), 256, 0, (hipStream_t)stream>>>(*sbp, eff);
   SC_CHECK_LAUNCH();
   return SC_OK;
 }
@@ -1315,9 +1340,9 @@ static bool dec_fused_ok(const sc_search &sb) {
          sb.layers[0].wq_pp && sb.layers[0].wo_pp && sb.layers[0].w1_p;
 }
 
-// which form of the decoder layers sc_decode_step runs for this bucket: 0 six launches per layer, 1 head-parallel
+// which form of the decoder layers sc_decode_step runs for this bucket: 0 six launches per layer, 1 head-parallel, 2 stream-resident
 // (3 launches) - streams.hip accounts the cross-attention's K|V traffic by kernel family
-int sc_decode_step_form(const sc_search *sbp) { return dec_fused_ok(*sbp) ? 1 : 0; }
+int sc_decode_step_form(const sc_search *sbp) { return dec_fused_ok(*sbp) ? (sc_dec_layer_stream_form(*sbp) ? 2 : 1) : 0; }
 
 extern "C" int sc_decode_step(const sc_search *sbp, void *stream) { return sc_decode_step_ex(sbp, 0, stream); }
 

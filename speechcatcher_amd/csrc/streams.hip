@@ -294,9 +294,9 @@ struct sc_streams {
   bool decode_prepared = false;
   std::map<int, hipGraphExec_t> dec_graphs;
   std::map<std::vector<long>, hipGraphExec_t> enc_graphs;
-  long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows[2] = {0, 0};   // [0] flash kernels, [1] layer kernels
-  long sattn_pos[2] = {0, 0};              // token positions the self-attention covered (sum of L over steps, streams, layers)
-  unsigned long long *stat_rows = nullptr; // device [2]: distinct self-attention K|V rows read (sc_search.stat_rows)
+  long dec_steps = 0, dec_blocks = 0, enc_calls = 0, xattn_rows[3] = {0, 0, 0};   // [0] flash kernels, [1] head-parallel layer kernels, [2] stream-resident layer kernel
+  long sattn_pos[3] = {0, 0, 0};           // token positions the self-attention covered (sum of L over steps, streams, layers)
+  unsigned long long *stat_rows = nullptr; // device [3]: distinct self-attention K|V rows read (sc_search.stat_rows)
   double t_launch = 0, t_wait = 0;               // seconds in the step loop: issuing, waiting for the flags
   double t_bucket[17] = {0};                     // ... by compaction bucket (n_rows_step / (row_bucket*W))
   long n_bucket[17] = {0};
@@ -1186,10 +1186,10 @@ int tick_issue(sc_streams *b, bool *progress) {
   }
   RC_TRY(decode_step_launch(b));
   HIP_TRY(hipEventRecord(b->ev_iter[b->iter & 1], b->stream));
-  const bool fused = sc_decode_step_form(&b->sb) != 0;
+  const int form = sc_decode_step_form(&b->sb);   // 0 six launches per layer, 1 head-parallel, 2 stream-resident
   for (int s : active) {   // bench roofline: K|V rows the cross-attention reads, positions the self-attention covers
-    b->xattn_rows[fused ? 1 : 0] += (long)b->run[s].T * Ld;
-    b->sattn_pos[fused ? 1 : 0] += (long)b->run[s].L * Ld;
+    b->xattn_rows[form] += (long)b->run[s].T * Ld;
+    b->sattn_pos[form] += (long)b->run[s].L * Ld;
   }
   b->tick_t1 = std::chrono::steady_clock::now();
   b->inflight = true;
@@ -1807,7 +1807,11 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
       rows = floor_rows;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const size_t per_row = (size_t)S * c.dec_layers * 2 * d * sizeof(float) / kvdiv;
-        rows = std::max<long>(floor_rows, (long)std::min<size_t>((size_t)full, free_b / 4 / per_row));
+        // ... and never more than SC_KV_POOL_DEFAULT_MAX_GIB by default, whatever happens to be free (a size that
+        // follows "free memory" alone depends on allocation order and on who else uses the device; the chosen row count is
+        // reported by sc_streams_kv_rows and in the bench line)
+        const size_t budget = std::min<size_t>(free_b / 4, (size_t)SC_KV_POOL_DEFAULT_MAX_GIB << 30);
+        rows = std::max<long>(floor_rows, (long)std::min<size_t>((size_t)full, budget / per_row));
       } else {
         (void)hipGetLastError();
       }
@@ -1837,7 +1841,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   A(sb.pre_ids, n * K); A(sb.psi, n * K); A(sb.psi_eos, n);
   A(sb.cand_score, n * W); A(sb.cand_tok, n * W); A(sb.cand_ctc, n * W);
   A(sb.sel, n * 2);
-  A(b->stat_rows, 2);
+  A(b->stat_rows, 3);
   sb.stat_rows = b->stat_rows;
   if (sc_dec_layer_fused_supported(d, c.dec_heads, W, F) && V % d == 0 && e->dec[0].wqkv_pp && e->f("out_w_q", false)) {
     A(sb.ph1, n * c.dec_heads * d);
@@ -2365,31 +2369,36 @@ extern "C" int sc_streams_set_graphs(sc_streams *b, int on) {
   b->use_graphs = on != 0;
   return SC_OK;
 }
+extern "C" int sc_streams_kv_rows(const sc_streams *b) { return b ? b->sb.kv_rows : 0; }
+
 extern "C" long sc_streams_take_xattn_rows(sc_streams *b) {
   if (!b) return 0;
-  const long v = b->xattn_rows[0] + b->xattn_rows[1];
-  b->xattn_rows[0] = b->xattn_rows[1] = 0;
+  const long v = b->xattn_rows[0] + b->xattn_rows[1] + b->xattn_rows[2];
+  b->xattn_rows[0] = b->xattn_rows[1] = b->xattn_rows[2] = 0;
   return v;
 }
 extern "C" int sc_streams_take_xattn_rows_by_kernel(sc_streams *b, long *rows) {
   SC_CHECK_ARG(b && rows, "null");
-  rows[0] = b->xattn_rows[0];
-  rows[1] = b->xattn_rows[1];
-  b->xattn_rows[0] = b->xattn_rows[1] = 0;
+  for (int i = 0; i < 3; ++i) {
+    rows[i] = b->xattn_rows[i];
+    b->xattn_rows[i] = 0;
+  }
   return SC_OK;
 }
 
 extern "C" int sc_streams_take_attn_counters(sc_streams *b, long *out) {
   SC_CHECK_ARG(b && out, "null");
-  unsigned long long dr[2] = {0, 0};
+  unsigned long long dr[3] = {0, 0, 0};
   HIP_TRY(hipSetDevice(b->eng->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(dr, b->stat_rows, sizeof dr, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(b->stat_rows, 0, sizeof dr));
-  out[0] = b->xattn_rows[0]; out[1] = b->xattn_rows[1];
-  out[2] = b->sattn_pos[0]; out[3] = b->sattn_pos[1];
-  out[4] = (long)dr[0]; out[5] = (long)dr[1];
-  b->xattn_rows[0] = b->xattn_rows[1] = b->sattn_pos[0] = b->sattn_pos[1] = 0;
+  for (int i = 0; i < 3; ++i) {
+    out[i] = b->xattn_rows[i];
+    out[3 + i] = b->sattn_pos[i];
+    out[6 + i] = (long)dr[i];
+    b->xattn_rows[i] = b->sattn_pos[i] = 0;
+  }
   return SC_OK;
 }
 

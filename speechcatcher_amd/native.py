@@ -358,18 +358,23 @@ class NativeStreamBatch:
         return int(self.lib.sc_streams_take_xattn_rows(self.handle))
 
     def take_attn_counters(self):
-        """{cross_rows, self_positions, self_distinct_rows}: [stand-alone kernels, layer kernels], summed over decode
-        iterations, active streams and decoder layers since the last call"""
-        r = (C.c_long * 6)()
+        """{cross_rows, self_positions, self_distinct_rows}: [stand-alone kernels, head-parallel layer kernels, stream-resident
+        layer kernel], summed over decode iterations, active streams and decoder layers since the last call"""
+        r = (C.c_long * 9)()
         _abi.check(self.lib.sc_streams_take_attn_counters(self.handle, r), "sc_streams_take_attn_counters")
-        return {"cross_rows": [int(r[0]), int(r[1])], "self_positions": [int(r[2]), int(r[3])],
-                "self_distinct_rows": [int(r[4]), int(r[5])]}
+        return {"cross_rows": [int(r[0]), int(r[1]), int(r[2])], "self_positions": [int(r[3]), int(r[4]), int(r[5])],
+                "self_distinct_rows": [int(r[6]), int(r[7]), int(r[8])]}
 
     def take_xattn_rows_by_kernel(self):
-        """(rows read by the dec_attn_flash launches, rows read by the sc_dec_layer_cross launches)"""
-        r = (C.c_long * 2)()
+        """(rows read by the dec_attn_flash launches, by the sc_dec_layer_cross launches, by the sc_dec_layer_stream launches)"""
+        r = (C.c_long * 3)()
         _abi.check(self.lib.sc_streams_take_xattn_rows_by_kernel(self.handle, r), "sc_streams_take_xattn_rows_by_kernel")
-        return int(r[0]), int(r[1])
+        return int(r[0]), int(r[1]), int(r[2])
+
+    @property
+    def kv_rows(self) -> int:
+        """rows of the self-attention K|V pool per (stream, layer) this batch was created with"""
+        return int(self.lib.sc_streams_kv_rows(self.handle))
 
     @property
     def hip_stream(self) -> int:

@@ -739,6 +739,29 @@ def test_ctc_prefix_scan_long_table(hip, T, L, has, split):
         assert float(((rc - rg).abs() / rc.abs().clamp(min=1.0))[live].max()) <= 1e-4
 
 
+def test_split_scan_followed_by_the_legacy_state_rebuild_is_refused(hip):
+    """since the T-parallel scan parks SEGMENT START states where the sequential scan leaves its 16-frame
+    checkpoints, sc_ctc_gather_state() (split_min = 0) behind sc_ctc_prefix_scan_split(sb, n > 0) rebuilt the CTC state from
+    the wrong kind of rows without an error.  The library remembers the effective split_min of a batch's last scan and
+    refuses a rebuild that names another one; the matching value and the un-split pair still work.
+    Reference: the state the next step's scan starts from (ctc_prefix_score_full.py:293-330 select_state)."""
+    from speechcatcher_amd._abi import ScasrError
+    sc, sg = _scan_setup(hip, 2, 450, 120, True)
+    W, K = sc.W, sc.K
+    g = torch.Generator().manual_seed(11)
+    for s_ in range(sc.S):
+        sg.sel[s_].copy_(torch.stack([torch.randint(0, W, (W,), generator=g), torch.randint(0, K, (W,), generator=g)], 1).to(torch.int32))
+    hip.ctc_prefix_scan(sg, split_min=48)
+    with pytest.raises(ScasrError, match="split_min"):
+        hip.ctc_gather_state(sg)                 # the legacy entry point: split_min = 0
+    hip.ctc_gather_state(sg, split_min=48)       # the scan's own value
+    hip.ctc_prefix_scan(sg)
+    with pytest.raises(ScasrError, match="split_min"):
+        hip.ctc_gather_state(sg, split_min=48)
+    hip.ctc_gather_state(sg)
+    torch.cuda.synchronize()
+
+
 def test_ctc_prefix_scan_time_at_long_tables(hip):
     """Time per launch of the scan at T = 4500 (8 active streams, hypotheses of 300 tokens): the column-streaming
     kernel and its T-parallel form; numbers -> gpurun_out/r03_ctc_scan_timing.json (round 2 also timed the row-gather
