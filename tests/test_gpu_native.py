@@ -76,6 +76,58 @@ def test_native_short_utterances_and_the_reference_exception():
     check_against_blocks(sb, 0, js["9000"]["blocks"][-1])
 
 
+@pytest.mark.parametrize("chunk", [400, 640, 1000])
+def test_native_sub_window_chunks_call_by_call(chunk):
+    """the reference's own degenerate inputs on the C++ engine.  BASELINE's metric says "640-sample chunks":
+    such a call yields 2 feature frames, the reference skips the encoder and drops the frames (beam_search.py:551-559), every
+    non-final call returns one empty hypothesis and the final call dies in Conv2d (speech2text_streaming.py:328-338, 362-383;
+    fixture tests/golden/tiny_short.json["640"], tests/golden/frontend.json sizes 400 / 640 / 1000).  Here: a 64 000-sample
+    utterance through sc_push in calls of 400 / 640 / 1000 samples - the carried-over waveform length of every call against
+    the reference's frontend fixture, and, against the oracle run call by call on the same audio, the number of results of every
+    call, the hypotheses (ids exact, scores 1e-3), the encoder calls, and the exception of the final call."""
+    import torch
+    from helpers import oracle_model
+    from oracle.ref_port import RefPortStreaming
+    from speechcatcher_amd.speech2text_streaming import hyps_to_results
+    from test_engine_spec import make_batch
+    ref = json.loads((GOLDEN / "frontend.json").read_text())[str(chunk)]
+    short = json.loads((GOLDEN / "tiny_short.json").read_text())
+    audio = synth.synth_audio(7, 64000)
+    ora = RefPortStreaming(oracle_model("TINY", 1234, "meanstd"), beam_size=5)
+    sb = make_batch("TINY", 1234, "meanstd", 5, False, backend="native", max_frames=256, max_tokens=200, pcm_capacity=1 << 17)
+    n_calls = (len(audio) + chunk - 1) // chunk
+    assert n_calls == len(ref["counts"])
+    for k in range(n_calls):
+        a = audio[k * chunk:(k + 1) * chunk]
+        fin = k == n_calls - 1
+        try:
+            want = ora(torch.from_numpy(a), is_final=fin)
+            want_exc = None
+        except RuntimeError as e:
+            want, want_exc = None, e
+        if want_exc is not None:
+            assert fin and chunk in (400, 640)               # (the reference's Conv2d on < 7 frames: quirk A3)
+            with pytest.raises(RuntimeError):
+                sb.push([(0, a, fin)])
+            assert sb.st[0].T_enc == 0                       # ... and the stream has been reset
+            break
+        out = sb.push([(0, a, fin)])
+        got = hyps_to_results(sb.hypotheses(0), fin, fin, None, "native") if out[0] else []
+        assert len(got) == len(want), (chunk, k)
+        for g, w in zip(got, want):
+            assert g[2] == w[2], (chunk, k)
+        if not fin:
+            assert sb.st[0].pcm_buffered == ref["buffers"][k], (chunk, k)
+            hy, oh = sb.hypotheses(0), ora.running_hyps
+            if oh is not None:     # (None until the oracle's first decode block)
+                assert [h["yseq"] for h in hy] == [list(h.yseq) for h in oh], (chunk, k)
+                np.testing.assert_allclose([h["score"] for h in hy], [float(h.score) for h in oh], atol=1e-3, rtol=0)
+    if chunk == 640:     # the literal fixture: the encoder never ran, every call answered one empty hypothesis
+        assert sb.stats["enc_calls"] == short["640"]["enc_calls"] == 0
+    if chunk == 400:
+        assert sb.stats["enc_calls"] == 0
+
+
 def test_native_reset_quirk_and_calls_after_final():
     from test_engine_spec import run_after_final, run_reset_quirk
     run_reset_quirk(backend="native", score_tol=1e-3)
