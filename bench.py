@@ -955,8 +955,8 @@ def main():
         del w_l
         l_like["note"] = ("NOT the headline: the per-GPU share of BASELINE configs[3] (`en_streaming_transformer_l`, 128 streams per GPU) on "
                           "ASSUMED stand-in dims (speechcatcher_amd/config.py: L_LIKE = d 256, 4 heads of 64, 18 + 8 blocks; the real "
-                          "config.yaml is not available offline).  Head dim 64 is outside the instantiated decoder layer kernels: the "
-                          "decoder runs the six-launch form (stand-alone attention + projection kernels)")
+                          "config.yaml is not available offline).  Head dim 64 runs the head-parallel layer kernels since round 6 "
+                          "(three launches per layer, one head per workgroup; rounds 1-5: the six-launch form, 5798 audio-s/s)")
     queued = None
     if extended and not args.no_other_mode and world == 1 and args.mode == "continuous" and args.queue_depth == 1:
         queued = leg("continuous", depth=2)

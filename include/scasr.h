@@ -438,7 +438,8 @@ int sc_decode_step_ex(const sc_search *sb, int scan_split_min, void *stream);
  * workgroups read x_in while the owner of a row writes x_out.  Grid (stream, head) for the two attention
  * launches; every workgroup sums the producer's partial products itself (fixed order) and recomputes the
  * LayerNorm of its stream's W rows, so neither the LayerNorms nor the attention output projections need
- * launches of their own.  d in {128, 256}, head dim in {16, 32}, W <= 16, sc_ffn_ln_supported(d, F). */
+ * launches of their own.  d in {128, 256}, head dim in {16, 32} and (round 6, d = 256) 64 - the reference's geometry when
+ * config.yaml names no heads (speech2text_streaming.py:221-227) -, W <= 16, sc_ffn_ln_supported(d, F). */
 int sc_dec_layer_fused_supported(int d, int H, int W, int F);
 /* A: x = x_in + b2[layer-1] + sum_z ffn_part[z][row]  (layer 0: embed*sqrt(d)+PE, transformer_decoder.py:231;
  * x_in / ffn_part unused) -> x_out; q|k|v = norm1(x) . Wqkv^T + b of every head; K|V row appended to the

@@ -134,7 +134,7 @@ __host__ __device__ static inline int dl_region_floats(int D, int DK, int W, int
   const int xn = hpw > 1 ? 0 : 16 * (D + 4);
   const int ps = 4 * WM * (nt * 16 + 4);                 // (the MFMA tiles' rows >= WM are padding: not stored)
   const int attn = mattn_partial_floats(DK, self ? 5 : 4) + ((self && hpw == 1) ? 512 * W : 0) + 8;   // partial states, row list, wtot
-  const int outp = 16 * 36 + WM * (D + 4);
+  const int outp = 16 * (32 * (DK > 32 ? DK / 32 : 1) + 4) + WM * (D + 4);   // A tile of the head's k blocks + staging
   int r = xn > ps ? xn : ps;
   r = r > outp ? r : outp;
   return r > attn ? r : attn;
@@ -175,7 +175,7 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #define SC_HPW_TOUCH 0       // 1: the four-head form requests a dword of every weight line ahead of its prologue (rounds 4-5)
 #endif
 template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1, bool WH = false>
-__global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
+__global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 4) : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
   const bool acth = (p.sb.act_half & 2) != 0;                       // partial products in fp16
   constexpr int NTH = 256 * HPW;   // threads: HPW head groups of 4 waves
@@ -183,7 +183,13 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
                                  // thread one position (128 until round 4: half as many build phases per walk now)
   constexpr int LDX = D + 4, KI = D / 32, KPW = KI / 4;
   constexpr int NTQ = DK / 16, NT = (SELF ? 3 : 1) * NTQ, LDP = NT * 16 + 4;
-  static_assert(KI % 4 == 0 && (DK == 16 || DK == 32), "d_model must be a multiple of 128, head dim 16 or 32");
+  static_assert(KI % 4 == 0 && (DK == 16 || DK == 32 || DK == 64), "d_model must be a multiple of 128, head dim 16, 32 or 64");
+  // (round 6) head dim 64 - the reference's geometry when config.yaml names no heads (4 heads of 64 at d = 256,
+  // speech2text_streaming.py:221-227, 236-244): its 12 column tiles of q|k|v are projected in passes of NTP tiles (the weight
+  // fragments of one pass in registers at a time); one pass, i.e. the code of rounds 2-5, for head dims 16 and 32
+  constexpr int NTP = NT > 6 ? 4 : NT, NPASS = NT / NTP;
+  static_assert(NT % NTP == 0, "whole passes");
+  static_assert(DK <= 32 || HPW == 1, "head dim 64 runs one head per workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const sc_search &sb = p.sb;
   // grid.x runs over the compaction bucket: the k-th stream of rowmap's active-first order (scasr.h: rowmap)
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // requested as soon as the x rows are in LDS and travels during the LayerNorm; the output projection's fragments
   // travel during the merge of the attention's partial states.
   constexpr bool EARLY = HPW > 1;
-  BF pfb[(PF || EARLY) ? NT * 2 : 1];   // k-block 0 of this wave; the later ones are fetched behind the MFMAs of their predecessor
+  BF pfb[(PF || EARLY) ? NTP * 2 : 1];   // k-block 0 of this wave (first pass); the later ones are fetched behind the MFMAs of their predecessor
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
   // (HPW > 1, round 5: of the first 512 positions, one per thread of the workgroup - the list is BUILT before the prologue's
   // partial sums have arrived, see early_list below)
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // the LayerNorm needs first)
   auto prefetch_w = [&]() {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NTP; ++t) {
       const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
       const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + wave * KPW) * 128 + lane;
       pfb[t * 2] = wq[0];
@@ -452,41 +458,50 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto load_b = [&](int ki, BF (&b0)[NT], BF (&b1)[NT]) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
-        const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
-        b0[t] = wq[0];
-        b1[t] = wq[64];
+    for (int ps = 0; ps < NPASS; ++ps) {   // (one pass for head dims 16 / 32)
+      auto load_b = [&](int ki, BF (&b0)[NTP], BF (&b1)[NTP]) {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+          const int tt = ps * NTP + t;
+          const int tile = ((tt / NTQ) * D + head * DK) / 16 + (tt % NTQ);
+          const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
+          b0[t] = wq[0];
+          b1[t] = wq[64];
+        }
+      };
+      BF b0[NTP], b1[NTP];
+      f32x4 accp[NTP];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) accp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((PF || EARLY) && ps == 0) {
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+          b0[t] = pfb[t * 2];
+          b1[t] = pfb[t * 2 + 1];
+        }
+      } else {
+        load_b(wave * KPW, b0, b1);
       }
-    };
-    BF b0[NT], b1[NT];
-    if (PF || EARLY) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        b0[t] = pfb[t * 2];
-        b1[t] = pfb[t * 2 + 1];
-      }
-    } else {
-      load_b(wave * KPW, b0, b1);
-    }
+      for (int kq = 0; kq < KPW; ++kq) {
+        const int ki = wave * KPW + kq;
+        const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
+        const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+        BF n0[NTP], n1[NTP];
+        if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
+        if constexpr (WH) dl_mfma8_il_h<NTP>(accp, a0, a1, b0, b1);
+        else dl_mfma8_il<NTP>(accp, a0, a1, b0, b1);
+        if (kq + 1 < KPW) {
 #pragma unroll
-    for (int kq = 0; kq < KPW; ++kq) {
-      const int ki = wave * KPW + kq;
-      const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
-      const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
-      BF n0[NT], n1[NT];
-      if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
-      if constexpr (WH) dl_mfma8_il_h<NT>(acc, a0, a1, b0, b1);
-      else dl_mfma8_il<NT>(acc, a0, a1, b0, b1);
-      if (kq + 1 < KPW) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          b0[t] = n0[t];
-          b1[t] = n1[t];
+          for (int t = 0; t < NTP; ++t) {
+            b0[t] = n0[t];
+            b1[t] = n1[t];
+          }
         }
       }
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) acc[ps * NTP + t] = accp[t];
     }
     // HPW > 1, SELF (round 5): the wave's FIRST batch of K|V tiles is requested here - the rows of the cached positions do not
     // depend on this step's x, the list has been there since the prologue - and travels while the split sums are reduced
@@ -545,14 +560,17 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // take tiles round-robin and leave one partial state each (+ one for the new token's own row, SELF)
   // PF: the output projection's B fragments travel while the attention runs
   constexpr int TWO = D / 16 / 4;
-  BF ob[(PF || EARLY) ? TWO * 2 : 1];
+  constexpr int KBO = DK > 32 ? DK / 32 : 1;   // k blocks of 32 input columns the head's share of the output projection spans
+  BF ob[(PF || EARLY) ? KBO * TWO * 2 : 1];
   auto prefetch_o = [&]() {
 #pragma unroll
-    for (int t = 0; t < TWO; ++t) {
-      const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32) * 128 + lane;
-      ob[2 * t] = wq[0];
-      ob[2 * t + 1] = wq[64];
-    }
+    for (int kb2 = 0; kb2 < KBO; ++kb2)
+#pragma unroll
+      for (int t = 0; t < TWO; ++t) {
+        const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TWO + t) * KI + (head * DK) / 32 + kb2) * 128 + lane;
+        ob[(kb2 * TWO + t) * 2] = wq[0];
+        ob[(kb2 * TWO + t) * 2 + 1] = wq[64];
+      }
   };
   if (PF) prefetch_o();
   constexpr int NTW = NTW_;   // tiles per wave and batch
@@ -645,36 +663,41 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? 4 : 1) void dec
   // holds this head's DK columns (the columns of a neighbouring head in the same block meet zeros of the A tile);
   // B operands from the fragment-packed copy of Wo, result staged through LDS for full-line stores.
   {
-    constexpr int LDA = 36, NTO = D / 16, TW = NTO / 4, LDO = D + 4;
+    constexpr int KW = 32 * KBO, LDA = KW + 4, NTO = D / 16, TW = NTO / 4, LDO = D + 4;
     float *As = region;              // [16][LDA]
     float *Os = region + 16 * LDA;   // [WM][LDO] (the tiles' rows >= WM are padding: not stored)
     const int kb = (head * DK) / 32, koff = (head * DK) % 32;
-    for (int e = gt; e < 16 * 32; e += 256) {
-      const int w = e / 32, c = e % 32;
+    for (int e = gt; e < 16 * KW; e += 256) {
+      const int w = e / KW, c = e % KW;
       As[w * LDA + c] = (w < WM && c >= koff && c < koff + DK) ? ctx[w * DK + c - koff] : 0.f;
     }
     const int r = lane & 15, kk = lane >> 4;
     static_assert(TW == TWO, "tiles per wave");
-    BF b0[TW], b1[TW];
+    BF b0[KBO][TW], b1[KBO][TW];
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-      if (PF || EARLY) {
-        b0[t] = ob[2 * t];
-        b1[t] = ob[2 * t + 1];
-      } else {
-        const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TW + t) * KI + kb) * 128 + lane;
-        b0[t] = wq[0];
-        b1[t] = wq[64];
+    for (int kb2 = 0; kb2 < KBO; ++kb2)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        if (PF || EARLY) {
+          b0[kb2][t] = ob[(kb2 * TW + t) * 2];
+          b1[kb2][t] = ob[(kb2 * TW + t) * 2 + 1];
+        } else {
+          const BF *wq = reinterpret_cast<const BF *>(p.wop) + ((long)(wave * TW + t) * KI + kb + kb2) * 128 + lane;
+          b0[kb2][t] = wq[0];
+          b1[kb2][t] = wq[64];
+        }
       }
-    }
     __syncthreads();
-    const float *ab = As + r * LDA + 8 * kk;
-    const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
     f32x4 oacc[TW];
 #pragma unroll
     for (int t = 0; t < TW; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (WH) dl_mfma8_il_h<TW>(oacc, a0, a1, b0, b1);
-    else dl_mfma8_il<TW>(oacc, a0, a1, b0, b1);
+#pragma unroll
+    for (int kb2 = 0; kb2 < KBO; ++kb2) {   // (one chain per head over its k blocks in order)
+      const float *ab = As + r * LDA + 32 * kb2 + 8 * kk;
+      const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+      if constexpr (WH) dl_mfma8_il_h<TW>(oacc, a0, a1, b0[kb2], b1[kb2]);
+      else dl_mfma8_il<TW>(oacc, a0, a1, b0[kb2], b1[kb2]);
+    }
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -787,6 +810,7 @@ template <bool SELF, bool FIRST>
 static int launch_dec_layer_dims(const DecLayerArgs &p, hipStream_t st) {
   const int d = p.sb.d, dk = p.sb.d / p.sb.H;
   if (d == 256 && dk == 32) return launch_dec_layer<256, 32, SELF, FIRST>(p, st);
+  if (d == 256 && dk == 64) return launch_dec_layer<256, 64, SELF, FIRST>(p, st);
   if (d == 256 && dk == 16) return launch_dec_layer<256, 16, SELF, FIRST>(p, st);
   if (d == 128 && dk == 32) return launch_dec_layer<128, 32, SELF, FIRST>(p, st);
   if (d == 128 && dk == 16) return launch_dec_layer<128, 16, SELF, FIRST>(p, st);
@@ -797,7 +821,8 @@ static int launch_dec_layer_dims(const DecLayerArgs &p, hipStream_t st) {
 extern "C" int sc_dec_layer_fused_supported(int d, int H, int W, int F) {
   if (H <= 0 || d % H) return 0;
   const int dk = d / H;
-  return (d == 256 || d == 128) && (dk == 32 || dk == 16) && W >= 1 && W <= 16 && sc_ffn_ln_supported(d, F);
+  return ((d == 256 && (dk == 64 || dk == 32 || dk == 16)) || (d == 128 && (dk == 32 || dk == 16))) && W >= 1 && W <= 16 &&
+         sc_ffn_ln_supported(d, F);
 }
 
 extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *xin, float *xout, const float *ffn_part,

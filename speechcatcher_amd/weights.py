@@ -96,7 +96,7 @@ def ffn_fused_supported(d: int, F: int) -> bool:
 def dec_layer_fused_supported(cfg, W: int) -> bool:
     """sc_dec_layer_fused_supported + the output layer condition of sc_decode_step (V a multiple of d)"""
     d, H = cfg.d_model, cfg.dec_heads
-    return (d in (128, 256) and d % H == 0 and d // H in (16, 32) and 1 <= W <= 16
+    return (d in (128, 256) and d % H == 0 and (d // H in (16, 32) or (d == 256 and d // H == 64)) and 1 <= W <= 16
             and ffn_fused_supported(d, cfg.ffn_dim) and cfg.vocab_size % d == 0)
 
 

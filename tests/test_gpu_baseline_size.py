@@ -155,7 +155,8 @@ def test_xl_128_streams_continuous_batching_in_the_headline_regime_vs_oracle():
         L = base["lens"][s, 0]
         assert base["ids"][s, 0, 0] == 1023 and (np.diff(base["xpos"][s, 0, :L]) >= 0).all() and base["xpos"][s, 0, L - 1] < T[s]
     sb.close()
-    ora = oracle_calls_parallel("XL", [4000 + s for s in tracked], CHUNK * n, CHUNK, beam, False)
+    # (one intra-op thread per oracle process: 24 processes x 8 threads oversubscribed the box - 21 minutes; ~110 s this way)
+    ora = oracle_calls_parallel("XL", [4000 + s for s in tracked], CHUNK * n, CHUNK, beam, False, threads=1)
     report = {}
     decisive = []
     for s in tracked:
@@ -381,7 +382,7 @@ def test_l_like_dims_128_streams_equal_solo_oracle_runs():
         ref = ora.running_hyps
         assert sorted(tuple(h["yseq"]) for h in got[s]) == sorted(tuple(h.yseq) for h in ref), s
         assert got[s][0]["yseq"] == list(ref[0].yseq) and got[s][0]["xpos"] == list(ref[0].xpos), s
-        assert abs(got[s][0]["score"] - ref[0].score) < 2e-3, (s, got[s][0]["score"], ref[0].score)
+        assert abs(got[s][0]["score"] - ref[0].score) < 1e-3, (s, got[s][0]["score"], ref[0].score)   # (2e-3 until round 5)
 
 
 @pytest.mark.parametrize("cfg_name", ["TINY", "XL"])

@@ -101,7 +101,7 @@ def test_native_sub_window_chunks_call_by_call(chunk):
         a = audio[k * chunk:(k + 1) * chunk]
         fin = k == n_calls - 1
         try:
-            want = ora(torch.from_numpy(a), is_final=fin)
+            want = ora(torch.from_numpy(a), is_final=fin, finalize_all=fin)
             want_exc = None
         except RuntimeError as e:
             want, want_exc = None, e
@@ -114,8 +114,8 @@ def test_native_sub_window_chunks_call_by_call(chunk):
         out = sb.push([(0, a, fin)])
         got = hyps_to_results(sb.hypotheses(0), fin, fin, None, "native") if out[0] else []
         assert len(got) == len(want), (chunk, k)
-        for g, w in zip(got, want):
-            assert g[2] == w[2], (chunk, k)
+        for g, w in zip(got, want):     # oracle: (filtered token ids, yseq, score, xpos); engine: (text, tokens, ids)
+            assert g[2] == list(w[0]), (chunk, k)
         if not fin:
             assert sb.st[0].pcm_buffered == ref["buffers"][k], (chunk, k)
             hy, oh = sb.hypotheses(0), ora.running_hyps
@@ -1023,7 +1023,7 @@ def test_m_like_dimensions_head_dim_64(engine):
         blk = {"yseq": [list(h.yseq) for h in ref], "xpos": [list(h.xpos) for h in ref],
                "score": [h.score for h in ref], "score_dec": [h.scores.get("decoder", 0.0) for h in ref],
                "score_ctc": [h.scores.get("ctc", 0.0) for h in ref], "process_idx": ora.process_idx}
-        check_against_blocks(sb, 0, blk, 5e-3)
+        check_against_blocks(sb, 0, blk, 1e-3)      # (round 6: the north star's 1e-3; 5e-3 while head dim 64 took the six-launch decoder)
         assert len(sb.hypotheses(0)[0]["yseq"]) > 5
 
 

@@ -595,6 +595,37 @@ def test_every_kernel_lockstep_xl(hip, monkeypatch, layers):
     assert not ls.int_mismatch, ls.int_mismatch[:10]
 
 
+@pytest.mark.parametrize("beam", [10, 5])
+def test_every_kernel_lockstep_head_dim_64(hip, monkeypatch, beam):
+    """the head-parallel layer kernels at the reference's DEFAULT geometry - 4 heads of 64 at d = 256, what
+    speech2text_streaming.py:221-227, 236-244 builds when config.yaml names no heads (config.M_DEFAULTS with fewer layers).
+    Until round 5 such a model took the six-launch decoder; since round 6 sc_dec_layer_fused_supported(256, 4, W, 2048) = 1
+    (q|k|v projected in three passes of four column tiles, the output projection over the head's two k blocks).  Every op of
+    the engine against its spec on identical inputs, beam 10 (10-row tiles) and beam 5 (5-row tiles)."""
+    import test_engine_spec
+    from lockstep import LockstepBackend
+    from speechcatcher_amd.config import ModelConfig
+    from speechcatcher_amd._abi import load
+    from test_engine_spec import make_batch
+    assert load().sc_dec_layer_fused_supported(256, 4, beam, 2048) == 1
+    test_engine_spec.CFGS["M4"] = ModelConfig(d_model=256, enc_heads=4, enc_layers=3, dec_heads=4, dec_layers=2)
+    monkeypatch.setenv("SC_DEC_FUSED", "1")
+    monkeypatch.setattr(LockstepBackend, "fused_layers", True)
+    ls = LockstepBackend(hip, atol=5e-4, rtol=5e-4)
+    caps = dict(max_frames=256, max_tokens=200, pcm_capacity=1 << 18)
+    sb_cpu = make_batch("M4", 1234, "meanstd", beam, False, backend=ls, **caps)
+    sb_gpu = make_batch("M4", 1234, "meanstd", beam, False, backend=hip, device="cuda:0", **caps)
+    assert sb_cpu.ph1 is not None
+    ls.attach(sb_cpu, sb_gpu)
+    audio = synth.synth_audio(77, 10240 * 6)
+    for k in range(6):
+        sb_cpu.push([(0, audio[k * 10240:(k + 1) * 10240], False)])
+    _dump(ls, f"lockstep_head_dim_64_beam{beam}")
+    assert ls.calls.get("dec_layer_self", 0) > 0 and ls.calls.get("dec_layer_cross", 0) > 0
+    assert not ls.failures, ls.failures[:10]
+    assert not ls.int_mismatch, ls.int_mismatch[:10]
+
+
 def test_encoder_layers_rowtile(hip, monkeypatch):
     """sc_encoder_layers with the row-tile projections (norm1 + q|k|v, output Linear + residual + norm2 in one
     launch each) and with the LayerNorm + GEMM launches they replace, both against the spec encoder."""
