@@ -455,7 +455,7 @@ _PMC_FAMILY = {"ffn_fused_kernel<256,*>": "ffn_fused_kernelILi256ELi{}ELb0ELi0",
                "rowtile_proj_kernel<256,*>": "rowtile_proj_kernelILi256"}
 
 
-ROOFLINE_WINDOW_CSV = os.path.join("profiles", "r05_bench_default_roofline_window.csv")
+ROOFLINE_WINDOW_CSV = os.path.join("profiles", "r06_bench_default_roofline_window.csv")
 
 
 def pmc_traffic(kind_name):

@@ -15,7 +15,7 @@
 // model/attention/multi_head_attention.py:63-133, transformer_decoder.py:231 (embedding).
 //
 // Why this shape on MI355X: the decode step is a chain of ~90 dependent launches of 7-11 us each when few
-// streams are active (profiles/r02_*timeline*), so launches are what to remove.  A LayerNorm needs complete
+// streams are active (docs/profiles_r1-r3/r02_*timeline*), so launches are what to remove.  A LayerNorm needs complete
 // rows and an output projection needs all heads, which used to force a launch boundary after every attention.
 // Here every (stream, head) workgroup REDUCES THE PRODUCER'S PARTIAL SUMS ITSELF (W <= 16 rows x d: 10 KB per
 // partial, L2-resident - blockIdx.x is the stream, so the H workgroups of a stream share an XCD and its L2)

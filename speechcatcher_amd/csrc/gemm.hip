@@ -660,7 +660,7 @@ extern "C" int sc_prof_collect_kinds(double *ms, double *flops, double *bytes, l
 }
 
 static int g_bk64 = 0;               // SC_GEMM_BK=64: 64-deep K tiles for the 64x64 kernel (A/B switch)
-static int g_skinny_max_m = 64;     // SC_SKINNY_MAX_M overrides (A-B tests: the LDS-tiled kernel wins for M > 64, profiles/r01_gemm_skinny_ab.txt)
+static int g_skinny_max_m = 64;     // SC_SKINNY_MAX_M overrides (A-B tests: the LDS-tiled kernel wins for M > 64, docs/profiles_r1-r3/r01_gemm_skinny_ab.txt)
 // split-K workspaces: one per HIP stream (independent StreamBatches run
 // concurrently on their own streams), plus a default for unregistered streams
 struct Workspace { float *ptr; size_t bytes; };

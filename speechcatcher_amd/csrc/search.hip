@@ -1325,7 +1325,7 @@ extern "C" int sc_ctc_gather_state(const sc_search *sbp, void *stream) { return 
 // most SC_FUSED_MAX_ROWS hypothesis rows.  They win where the step is a chain of latency-bound launches (few
 // active streams); at large buckets every (stream, head) workgroup re-reading all partial sums of its stream costs
 // as much fabric traffic as the launches save, and the six-launch form (row panels + stand-alone attention) is
-// level or faster (profiles/r02_fused_threshold_sweep.txt, tools/fused_threshold_sweep.sh: strict lock-step
+// level or faster (docs/profiles_r1-r3/r02_fused_threshold_sweep.txt, tools/fused_threshold_sweep.sh: strict lock-step
 // 27.21 / 26.95 / 26.65 / 27.01 ms per chunk step with the limit at 320 / 640 / 960 / 1280 rows).
 static bool dec_fused_ok(const sc_search &sb) {
   if (const char *e = sc_hook("SC_DEC_FUSED"))   // tests: "0" forces the six-launch layers, "1" the fused ones at any size

@@ -1879,7 +1879,7 @@ extern "C" int sc_streams_create(sc_engine *e, const sc_stream_options *o, sc_st
   b->es = b->stream;
   {
     // The encoder stage starts when at most 7 % of the streams are still in the step loop (small batches: at once).
-    // Measured at 128 streams (profiles/r02_encoder_overlap_sweep.txt): serial 33.4 ms per chunk step; started with
+    // Measured at 128 streams (docs/profiles_r1-r3/r02_encoder_overlap_sweep.txt): serial 33.4 ms per chunk step; started with
     // the first decode iteration 32.2 (its large grids delay the full-batch decode kernels); at 50 % / 25 % / 10 % /
     // 7 % / 3 % of the streams 31.3 / 31.1 / 30.5 / 30.5 / 30.8.  SC_ENC_START overrides the percentage.
     const char *th = sc_hook("SC_ENC_START");

@@ -1113,7 +1113,7 @@ def test_native_pcm_ring_compaction_and_mixed_push_submit():
 def test_rccl_collectives_with_a_world_of_one():
     """The path's collectives (timing all_reduce MAX, all_gather of the final-text payload: ids + positions + length +
     score) through RCCL on the GPU with a world of ONE rank - two RCCL ranks on one device are refused
-    (profiles/r03_rccl_two_ranks_one_device.txt), and the test boxes have one GPU.  Runs in a child process (a process
+    (docs/profiles_r1-r3/r03_rccl_two_ranks_one_device.txt), and the test boxes have one GPU.  Runs in a child process (a process
     group per interpreter)."""
     import sys
     code = '''

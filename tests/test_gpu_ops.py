@@ -796,7 +796,7 @@ def test_split_scan_followed_by_the_legacy_state_rebuild_is_refused(hip):
 def test_ctc_prefix_scan_time_at_long_tables(hip):
     """Time per launch of the scan at T = 4500 (8 active streams, hypotheses of 300 tokens): the column-streaming
     kernel and its T-parallel form; numbers -> gpurun_out/r03_ctc_scan_timing.json (round 2 also timed the row-gather
-    kernel they replaced: 1233 us at T = 4500, profiles/r02_ctc_scan_timing.json)."""
+    kernel they replaced: 1233 us at T = 4500, docs/profiles_r1-r3/r02_ctc_scan_timing.json)."""
     import json
     import os
     out = {}

@@ -8,7 +8,7 @@
 # The profiled runs time the headline leg only (same window, same steps); the extra legs are switched off.
 # Optional: a name and extra bench arguments for a non-default mode, e.g.
 #   bash tools/prof_bench.sh r03 split16 "--ffn-dtype split16"   -> gpurun_out/r03_bench_split16*
-TAG=${1:-r05}
+TAG=${1:-r06}
 NAME=${2:-default}
 EXTRA=${3:-}
 cd $GRAFT_REPO_ROOT
