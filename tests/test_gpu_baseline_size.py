@@ -297,6 +297,29 @@ def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeyp
         assert len(bad[0]) == 0, (key, len(bad[0]), float(np.abs(x - y).max()))
 
 
+def test_fp16_mode_error_per_decode_step_is_bounded():
+    """the fp16 mode (BASELINE configs[4]; the reference has no fp16 run to compare with, quirk A9,
+    speechcatcher.py:205-212) gets a NUMBER.  tools/fp16_step_error.py: the fp32 engine drives the search, a shadow batch in the
+    fp16 mode is reset to the fp32 state before EVERY decode step (hypotheses, scores, CTC state, K|V rows converted to its
+    storage type) and takes the same step - the difference of what the step produced is one step's worth of fp16 arithmetic on
+    the same prefix, no drift, no path divergence.  Measured (8 streams x 12 chunks, profiles/r06_fp16_step_error.txt):
+        fp16 K|V only            max |d log-prob| 2.4e-5   max |d fused score| 1.2e-5
+        + fp16 feed-forward                        7.2e-5                       4.1e-5
+        + fp16 decoder projections / partials      1.0e-4                       6.1e-5
+        the whole mode                             1.2e-4                       6.7e-5
+    (fp32 engine against the oracle: 1.2e-5 per step).  Asserted here on 4 streams x 8 chunks with a factor of 4 in hand."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fp16_step_error
+    w = fp16_step_error.run_mode("float16", S=4, n=8)
+    assert w["steps"] >= 40
+    assert w["dlogp"] <= 5e-4 and w["dscore"] <= 3e-4, w
+    assert w["cand_tok_mismatch"] <= w["cand_total"] // 500, w      # (near-ties among the W x W candidates: 0.05 % measured)
+    k = fp16_step_error.run_mode("kv16", S=4, n=8)
+    assert k["dlogp"] <= 1e-4 and k["dscore"] <= 6e-5, k
+
+
 def test_xl_256_streams_fp16_mode_keeps_the_fp32_token_ids():
     """(also: the split-precision form `split16` on the same 256 streams - identical beams, see the end.)
     Per-GPU share of BASELINE configs[4]: 256 streams, fp16 feed-forward + encoder attention-projection weights / MFMA
