@@ -466,6 +466,9 @@ int sc_dec_layer_stream(const sc_search *sb, int layer, const float *x_in, float
 /* C': feed-forward of the rows xn (feed_forward.py:48-50) as partial sums ffn_part[z][row] by row id, z < *n_part. */
 int sc_dec_layer_ffn_xn(const sc_search *sb, int layer, const float *xn, float *ffn_part, int max_part,
                         int *n_part /*HOST*/, void *stream);
+/* B2 (round 6; the four-head form at large buckets): x = x_in + bo2 + sum_h ph2 -> x_out, xn_out = norm3(x) once per row
+ * (decoder_layer.py:113-117) - the feed-forward then runs without prologue (sc_dec_layer_ffn_xn) */
+int sc_dec_layer_reduce_ln(const sc_search *sb, int layer, const float *x_in, float *x_out, float *xn_out, void *stream);
 /* tail: x = x_in + b2[last] + sum_z ffn_part -> x_out; logits = after_norm(x) . out_w^T + out_b
  * (transformer_decoder.py:243-249); needs sb->out_w_q. */
 int sc_dec_output_logits(const sc_search *sb, const float *x_in, float *x_out, const float *ffn_part,

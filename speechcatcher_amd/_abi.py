@@ -158,6 +158,7 @@ _SIGS = {
     "sc_streams_kv_rows": (C.c_int, [vp]),
     "sc_dec_layer_stream_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sc_dec_layer_stream": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
+    "sc_dec_layer_reduce_ln": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "sc_dec_layer_ffn_xn": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_int), vp]),
     # stream-level API
     "sc_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(NamedTensor), C.c_int, C.c_int, C.POINTER(vp)]),

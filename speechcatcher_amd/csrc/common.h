@@ -53,6 +53,9 @@ int sc_dec_layer_hpw(const sc_search &sb);
 // decoder_stream.hip: 1 when this bucket's decoder layers run in the stream-resident form (one workgroup per stream, two
 // launches per layer), 0: the head-parallel launches of decoder_layer.hip
 int sc_dec_layer_stream_form(const sc_search &sb);
+// decoder_layer.hip: 1 when the four-head form of this bucket sums the cross-attention's partial products in a launch of its own
+// (sc_dec_layer_reduce_ln) and runs the feed-forward without prologue (sc_dec_layer_ffn_xn)
+int sc_dec_layer_split_ffn(const sc_search &sb);
 
 // decoder_panel.hip: reduce of the fused-FFN partial sums + LayerNorm + projection (sc_ffn_ln_proj)
 int sc_launch_reduce_ln_proj(const float *part, int npart, int part_M, const float *b2, const float *Xin, float *Xout,

@@ -850,6 +850,103 @@ extern "C" int sc_dec_layer_self(const sc_search *sbp, int layer, const float *x
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// (round 6) launch B2 of the four-head form at large buckets: the cross-attention's output projection summed ONCE per row -
+//   x'' = x' + ((p0 + p1) + bo2) -> xout;   xn = LayerNorm3(x'') -> xn_out
+// so that the feed-forward runs WITHOUT its prologue (sc_dec_layer_ffn_xn, gemm.hip).  ffn_fused_kernel<PRO> repeats this sum
+// and the LayerNorm in each of the 8 chunk-group workgroups of a row tile (144 KB of residual + partials per workgroup, 31 MB
+// through the fabric per launch, 8.5 of its 36 us at a full bucket); here 20 workgroups of 64 rows read every element once.
+// Same arithmetic, element for element: the sum in the canonical order of the head partials (common.h), the LayerNorm with 16
+// lanes per row and the summation order of the layer kernels / ffn_fused_kernel<PRO> - the bits do not depend on which of
+// the two paths a bucket takes.
+__global__ __launch_bounds__(256) void dec_head_reduce_ln_kernel(const float *__restrict__ ph, int nph, int pgrp, const float *__restrict__ pbias,
+                                                                 const float *__restrict__ xin, float *__restrict__ xout, float *__restrict__ xn,
+                                                                 const int *__restrict__ rows, int M, const float *__restrict__ g,
+                                                                 const float *__restrict__ be, float eps) {
+  constexpr int D = 256, Q4 = D / 64;
+  const int m = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const long row = rows ? rows[min(m, M - 1)] : min(m, M - 1);
+  float4 x[Q4];
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q4; ++q) {
+    const int c4 = sub + 16 * q;
+    const float4 xi = *reinterpret_cast<const float4 *>(xin + row * D + 4 * c4);
+    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pbias) pb = *reinterpret_cast<const float4 *>(pbias + 4 * c4);
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pgrp == 1 && nph == 2) {
+      y = sc_add4(*reinterpret_cast<const float4 *>(ph + (row * 2) * D + 4 * c4), *reinterpret_cast<const float4 *>(ph + (row * 2 + 1) * D + 4 * c4));
+    } else {
+      for (int z0 = 0; z0 < nph; z0 += 8) {
+        float4 pv[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          pv[z] = *reinterpret_cast<const float4 *>(ph + (row * nph + min(z0 + z, nph - 1)) * D + 4 * c4);
+          if (z0 + z >= nph) pv[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (pgrp == 4) {
+          const float4 g0 = sc_seq4(pv[0], pv[1], pv[2], pv[3]);
+          y = z0 == 0 ? g0 : sc_add4(y, g0);
+          if (z0 + 4 < nph) y = sc_add4(y, sc_seq4(pv[4], pv[5], pv[6], pv[7]));
+        } else {
+#pragma unroll
+          for (int z = 0; z < 8; ++z)
+            if (z0 + z < nph) y = (z0 + z == 0) ? pv[0] : sc_add4(y, pv[z]);
+        }
+      }
+    }
+    x[q] = make_float4(xi.x + (y.x + pb.x), xi.y + (y.y + pb.y), xi.z + (y.z + pb.z), xi.w + (y.w + pb.w));
+    if (m < M) *reinterpret_cast<float4 *>(xout + row * D + 4 * c4) = x[q];
+    sum += (x[q].x + x[q].y) + (x[q].z + x[q].w);
+  }
+  const float mean = group_sum<16>(sum) / (float)D;
+  float q2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q4; ++q) {
+    const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, e = x[q].w - mean;
+    q2 += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = 1.0f / sqrtf(group_sum<16>(q2) / (float)D + eps);
+  if (m < M) {
+#pragma unroll
+    for (int q = 0; q < Q4; ++q) {
+      const float4 gm = *reinterpret_cast<const float4 *>(g + 4 * (sub + 16 * q));
+      const float4 bt = *reinterpret_cast<const float4 *>(be + 4 * (sub + 16 * q));
+      *reinterpret_cast<float4 *>(xn + row * D + 4 * (sub + 16 * q)) =
+          make_float4((x[q].x - mean) * rstd * gm.x + bt.x, (x[q].y - mean) * rstd * gm.y + bt.y,
+                      (x[q].z - mean) * rstd * gm.z + bt.z, (x[q].w - mean) * rstd * gm.w + bt.w);
+    }
+  }
+}
+
+// does this bucket's four-head form sum the cross-attention's partial products in a launch of its own (then: feed-forward
+// without prologue)?  d = 256, fp32 partial products, four heads per workgroup.  SC_DEC_FFN_SPLIT = 0 | 1 (test hook).
+// MEASURED AND NOT TAKEN by default (profiles/r06_ab_split_ffn.txt): the feed-forward loses its 8.5 us prologue (36 -> ~30 us at
+// a full bucket, 27.5 -> 24.5 at 84 streams), but the launch that replaces it costs 5.5 us - a kernel boundary plus two dependent
+// round trips of a 50-workgroup kernel: 3364 / 3345 against 3373 / 3376 audio-s/s.  Kept as an A/B hook (same bits either way).
+int sc_dec_layer_split_ffn(const sc_search &sb) {
+  const char *e = sc_hook("SC_DEC_FFN_SPLIT");
+  return e && atoi(e) != 0 && sb.d == 256 && !sb.act_half && sb.dq && sc_dec_layer_hpw(sb) > 1;
+}
+
+extern "C" int sc_dec_layer_reduce_ln(const sc_search *sbp, int layer, const float *xin, float *xout, float *xn_out, void *stream) {
+  SC_CHECK_ARG(sbp && sbp->layers && xin && xout && xn_out && xin != xout && sbp->ph2, "null / aliased");
+  const sc_search &sb = *sbp;
+  SC_CHECK_ARG(layer >= 0 && layer < sb.n_layers, "layer out of range");
+  SC_CHECK_ARG(sb.d == 256 && !(sb.act_half & 2), "d = 256, fp32 partial products");
+  const sc_dec_layer &w = sb.layers[layer];
+  const int M = sb.rowmap ? sb.n_rows : sb.S * sb.W;
+  const int nph = sb.H / sc_dec_layer_hpw(sb);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof = sc_prof_begin(st);
+  dec_head_reduce_ln_kernel<<<cdiv(M, 16), 256, 0, st>>>(sb.ph2, nph, nph == sb.H ? 4 : 1, w.bo2, xin, xout, xn_out, sb.rowmap, M, w.ln3_g,
+                                                        w.ln3_b, sb.ln_eps);
+  SC_CHECK_LAUNCH();
+  sc_prof_end(prof, SC_PROF_PROJ_LN_PROJ, 0.0, 4.0 * (double)M * sb.d * (3 + nph));
+  return SC_OK;
+}
+
 extern "C" int sc_dec_layer_cross(const sc_search *sbp, int layer, const float *xin, float *xout, void *stream) {
   SC_CHECK_ARG(sbp && sbp->layers && xin && xout && xin != xout && sbp->ph1 && sbp->ph2, "null / aliased");
   const sc_search &sb = *sbp;

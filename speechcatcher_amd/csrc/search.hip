@@ -1368,6 +1368,10 @@ extern "C" int sc_decode_step_ex(const sc_search *sbp, int scan_split_min, void 
     for (int li = 0; li < sb.n_layers; ++li) {
       SC_TRY(sc_dec_layer_self(sbp, li, xa, xb, sb.ffn_part, npart, stream));
       SC_TRY(sc_dec_layer_cross(sbp, li, xb, xa, stream));
+      if (sc_dec_layer_split_ffn(sb)) {   // (round 6, large buckets) the head partials summed once per row, feed-forward without prologue
+        SC_TRY(sc_dec_layer_reduce_ln(sbp, li, xa, xb, sb.dq, stream));
+        SC_TRY(sc_dec_layer_ffn_xn(sbp, li, sb.dq, sb.ffn_part, sb.max_ffn_part, &npart, stream));
+      } else
       SC_TRY(sc_dec_layer_ffn(sbp, li, xa, xb, sb.ffn_part, sb.max_ffn_part, &npart, stream));
       float *t = xa; xa = xb; xb = t;
     }
