@@ -279,8 +279,9 @@ def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeyp
     audio = np.stack([synth.synth_audio(7000 + s, CHUNK * n) for s in range(S)])
     kw = dict(max_frames=16 * n + 80, max_tokens=480, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
 
-    def run(form):
+    def run(form, split="0"):
         monkeypatch.setenv("SC_DEC_STREAM", form)
+        monkeypatch.setenv("SC_DEC_FFN_SPLIT", split)
         sb = make_batch("XL", 1234, "meanstd", beam, False, backend="native", n_streams=S, **kw)
         _feed(sb, audio, n)
         o = sb.hypotheses_arrays(list(range(S)))
@@ -289,12 +290,14 @@ def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeyp
 
     a, b = run("1"), run("0")
     assert a["lens"][:, 0].min() >= (60 if n < 20 else 150), int(a["lens"][:, 0].min())
-    for key in ("n_hyps", "lens", "ids", "xpos"):
-        assert np.array_equal(a[key], b[key]), key
-    for key in ("score", "score_dec", "score_ctc"):
-        x, y = a[key], b[key]
-        bad = np.nonzero(x.view(np.int64) != y.view(np.int64))
-        assert len(bad[0]) == 0, (key, len(bad[0]), float(np.abs(x - y).max()))
+    # ... and the four-head form with the head partials summed in a launch of their own (sc_dec_layer_reduce_ln, an A/B hook)
+    for other, what in ((b, "four heads per workgroup"), (run("0", "1"), "four heads per workgroup, partials summed once per row")):
+        for key in ("n_hyps", "lens", "ids", "xpos"):
+            assert np.array_equal(a[key], other[key]), (what, key)
+        for key in ("score", "score_dec", "score_ctc"):
+            x, y = a[key], other[key]
+            bad = np.nonzero(x.view(np.int64) != y.view(np.int64))
+            assert len(bad[0]) == 0, (what, key, len(bad[0]), float(np.abs(x - y).max()))
 
 
 def test_fp16_mode_error_per_decode_step_is_bounded():
