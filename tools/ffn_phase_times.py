@@ -15,6 +15,7 @@ import bench  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 PRE = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+DETAIL = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 w = bench.make_weights("cuda:0")
 total = PRE + 14
 sb = bench.build_native(w, S, 10, False, total)
@@ -52,3 +53,8 @@ for slot in range(RING):
     d = np.diff(t, axis=1) / tpu
     print(f"launch {no:4d}: grid {int(rows[0, 13]):4d}, {len(rows):3d} workgroups, span {rel[:, -1].max():6.2f} us, workgroup mean {span_t.mean() / tpu:6.2f} max {span_t.max() / tpu:6.2f}, "
           f"starts within {start.max():.2f} us | phases (mean / max): " + " | ".join(f"{n}: {d[:, i].mean():.2f} / {d[:, i].max():.2f}" for i, n in enumerate(names)))
+    if slot == 0 or DETAIL:
+        wg = np.nonzero(live & (t_all[:, 12] == no))[0]
+        order = np.argsort(start)
+        print("   start time (us) by workgroup id, every 16th:", " ".join(f"{w}:{start[i]:.1f}" for i, w in enumerate(wg) if w % 16 == 0))
+        print("   start time by XCD (id % 8): " + " ".join(f"x{x}: {start[wg % 8 == x].min():.1f}-{start[wg % 8 == x].max():.1f}" for x in range(8)))
