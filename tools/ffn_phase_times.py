@@ -54,6 +54,12 @@ for slot in range(RING):
     print(f"launch {no:4d}: grid {int(rows[0, 13]):4d}, {len(rows):3d} workgroups, span {rel[:, -1].max():6.2f} us, workgroup mean {span_t.mean() / tpu:6.2f} max {span_t.max() / tpu:6.2f}, "
           f"starts within {start.max():.2f} us | phases (mean / max): " + " | ".join(f"{n}: {d[:, i].mean():.2f} / {d[:, i].max():.2f}" for i, n in enumerate(names)))
     if slot == 0 or DETAIL:
+        raw = rows[:, :12].astype(np.float64)
+        if (raw[:, 10] > 0).all():
+            seq = [0, 1, 4, 5, 6, 7, 8, 9, 10, 2, 3]
+            dd = np.diff(raw[:, seq], axis=1) / tpu
+            lab = ["tile->LDS", "GEMM1 c0", "relu+LDS+barrier", "GEMM2 c0", "GEMM1 c1", "relu+barriers", "GEMM2 c1", "(to stamp 10)", "stage", "store"]
+            print("   inner (mean us): " + " | ".join(f"{l} {dd[:, i].mean():.2f}" for i, l in enumerate(lab)))
         wg = np.nonzero(live & (t_all[:, 12] == no))[0]
         order = np.argsort(start)
         print("   start time (us) by workgroup id, every 16th:", " ".join(f"{w}:{start[i]:.1f}" for i, w in enumerate(wg) if w % 16 == 0))
