@@ -700,7 +700,6 @@ extern "C" int sc_dec_layer_stream_supported(int d, int H, int W, int F) {
 int sc_dec_layer_stream_form(const sc_search &sb) {
   if (!sc_dec_layer_stream_supported(sb.d, sb.H, sb.W, sb.F) || sb.act_half || !sb.dq || !sb.ffn_part) return 0;
   if (!sb.layers || !sb.layers[0].wqkv_pp || !sb.layers[0].wq_pp || !sb.layers[0].wo_pp || !sb.layers[0].wo2_pp) return 0;
-  if ((long)dstream::PCS * sb.W > (long)dstream::PCS * dstream::WM) return 0;
   int min_rows = SC_STREAM_MIN_ROWS;
   if (const char *e = sc_hook("SC_STREAM_MIN")) min_rows = atoi(e);
   int on = (sb.rowmap ? sb.n_rows : sb.S * sb.W) >= min_rows;

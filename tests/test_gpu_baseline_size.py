@@ -267,8 +267,8 @@ def test_serving_is_bit_reproducible():
         same_bits(ref, o, f"stream {s} in the batch of 128 against its solo run", rows_a=[s], rows_b=[0])
 
 
-@pytest.mark.parametrize("S,n", [(72, 14), (128, 30)])
-def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeypatch, S, n):
+@pytest.mark.parametrize("S,n,kv", [(72, 14, "float32"), (128, 30, "float32"), (72, 14, "float16")])
+def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeypatch, S, n, kv):
     """Round 6: the stream-resident form of the decoder layers (csrc/decoder_stream.hip: one workgroup per stream, both
     attentions of a layer in one launch, two launches per layer) against the head-parallel launches it replaces at large
     buckets (four heads per workgroup, three launches per layer): the same audio in strict lock-step must give IDENTICAL
@@ -277,7 +277,7 @@ def test_stream_resident_layers_give_the_bits_of_the_head_parallel_forms(monkeyp
     Reference semantics: decoder_layer.py:80-132, multi_head_attention.py:63-133."""
     beam = 10
     audio = np.stack([synth.synth_audio(7000 + s, CHUNK * n) for s in range(S)])
-    kw = dict(max_frames=16 * n + 80, max_tokens=480, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK)
+    kw = dict(max_frames=16 * n + 80, max_tokens=480, pcm_capacity=CHUNK * (n + 2), max_chunk_samples=CHUNK, kv_dtype=kv)   # (fp16 K|V storage: the KVH variants)
 
     def run(form, split="0"):
         monkeypatch.setenv("SC_DEC_STREAM", form)
