@@ -129,8 +129,13 @@ def test_precomputed_feature_input_matches_oracle():
     np.testing.assert_allclose([h["score"] for h in got], [h.score for h in ref], atol=1e-3, rtol=0)
 
 
-def test_other_model_dimensions_spec_vs_oracle():
-    """d=128 / 4 heads / 3+2 layers: engine (spec backend) against the reference port."""
+@pytest.mark.parametrize("stream_layers", [False, True])
+def test_other_model_dimensions_spec_vs_oracle(stream_layers, monkeypatch):
+    """d=128 / 4 heads / 3+2 layers: engine (spec backend) against the reference port.  stream_layers: the decode step as
+    the two ops per layer of the stream-resident form (oracle/kernel_spec.py dec_layer_stream / dec_layer_ffn_xn, round 6:
+    the per-op references of csrc/decoder_stream.hip in the lock-step GPU test) instead of the three head-parallel ones."""
+    from oracle.kernel_spec import SpecBackend
+    monkeypatch.setattr(SpecBackend, "stream_layers", stream_layers)
     import helpers
     import test_engine_spec
     from oracle.ref_port import RefPortStreaming
