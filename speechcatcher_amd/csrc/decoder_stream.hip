@@ -91,7 +91,6 @@ namespace dstream {
 constexpr int D = 256, DK = 32, H = 8, WM = 10, NTH = 512;
 constexpr int LDX = D + 4, KI = D / 32, C4 = D / 4;
 constexpr int PCS = 512;               // positions per row list (canonical)
-constexpr int LDP = 100;               // row stride of the projection's parked partial (6 tiles of 16 + 4)
 constexpr int LDC = 36;                // row stride of a head's context tile (A operand of the output projection)
 constexpr int NPS = 5;                 // partial attention states per head (self: 4 slots + the new token's row)
 constexpr int LPO = DK + 1;
@@ -104,9 +103,8 @@ constexpr int O_ROWS = O_ANCS + 16;              // [PCS * WM] row list + [16] w
 constexpr int O_QS = O_ROWS + PCS * WM + 16;     // [H][16][DK] queries / sqrt(dk)
 constexpr int O_KVC = O_QS + H * 16 * DK;        // union: kvn [H][WM][2 DK] (self: new token's k|v)  |  ctx [H][16][LDC]
 constexpr int KVC = (H * WM * 2 * DK > H * 16 * LDC) ? H * WM * 2 * DK : H * 16 * LDC;
-constexpr int O_U = O_KVC + KVC;                 // union: parked projection partial [H][WM][LDP]  |  partial states [H][AP]
-constexpr int UF = (H * WM * LDP > H * AP) ? H * WM * LDP : H * AP;
-constexpr int LDS_FLOATS = O_U + UF;
+constexpr int O_U = O_KVC + KVC;                 // partial attention states [H][AP] (free during the walks)
+constexpr int LDS_FLOATS = O_U + H * AP;
 }   // namespace dstream
 
 // partial state of a wave -> slot `slot` of its head (compact: only the WM live hypothesis rows of pO are kept; the
