@@ -196,6 +196,13 @@ static __device__ long long sc_phase_stamps[4][SC_PHASE_RING][SC_PHASE_WGS][16];
   } while (0)
 #define SC_STAMP(k, i) SC_STAMP_AT(k, i, ((i) == 0 ? 14 : -1))
 #define SC_STAMP_END(k, i) SC_STAMP_AT(k, i, 15)
+// ... by the thread for which `cond` holds (one per workgroup): the free row entries 9..11 - e.g. when the waves of a role are done
+#define SC_STAMP_BY(k, i, cond)                                                               \
+  do {                                                                                        \
+    const int wg__ = blockIdx.x + gridDim.x * blockIdx.y;                                     \
+    if ((cond) && (SC_STAMP_ON) && wg__ < SC_PHASE_WGS && (int)(gridDim.x * gridDim.y) >= SC_PHASE_MIN_GRID)           \
+      sc_phase_stamps[k][((SC_STAMP_ON) - 1) & (SC_PHASE_RING - 1)][wg__][i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
 // ... behind a wait for everything the wave has in flight: the stamp then closes a memory round trip (changes the timing
 // a little: the loads of the next stage are not under way yet)
 #define SC_STAMP_WAIT(k, i)                                                                   \
@@ -222,6 +229,7 @@ static __device__ long long sc_phase_stamps[4][SC_PHASE_RING][SC_PHASE_WGS][16];
 #else
 #define SC_STAMP(k, i) do {} while (0)
 #define SC_STAMP_END(k, i) do {} while (0)
+#define SC_STAMP_BY(k, i, cond) do {} while (0)
 #define SC_STAMP_WAIT(k, i) do {} while (0)
 #define SC_PHASE_GETTER(name)                                                                 \
   static inline int sc_phase_take(int) { return 0; }

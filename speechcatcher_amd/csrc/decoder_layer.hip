@@ -174,6 +174,30 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 #ifndef SC_HPW_TOUCH
 #define SC_HPW_TOUCH 0       // 1: the four-head form requests a dword of every weight line ahead of its prologue (rounds 4-5)
 #endif
+// (round 6, A/B switch, default OFF: measured flat) SELF kernel of the four-head form with its q|k|v projection split over
+// the four waves of a head by COLUMN TILES instead of by K quarter.  One wave projects k, one v - two column tiles over all
+// of K, one MFMA chain per K quarter, the quarters added in registers in the canonical order, + bias, straight into the new
+// token's row; two waves share q (K quarters 0-1 and 2-3) and leave P0+P1, P2, P3 in LDS, which the q hand-off adds in the
+// same order: no reduce of all 96 columns through LDS.  The roles rotate over the head groups, so that every SIMD (wave w
+// of every group) carries one wave of each role.  Same sums in the same order - bit-identical to the K-split form
+// (tests/test_gpu_baseline_size.py -k stream_resident with this switch on: identical token ids and float64 totals).
+// What it measured (docs/r06_findings.md section 6, profiles/r06_phase_times_role_projection.txt): the hand-off costs 0.45 us
+// where the reduce cost 2.0, but the projection itself stays at 12-13 us for 5.5 us of matrix work in EITHER form - a wave
+// waits ~2.1 us for every refill of its fragment registers (all 256 workgroups pull the same 768 KB through their XCD's L2
+// at once: tools/probes/l2_shared_weights_probe.hip), and 128 registers per lane hold two K quarters at most (four: spills,
+// 18 us).  3373 / 3386 against 3388 / 3402 audio-s/s in one job: not the product.
+#ifndef SC_SELF_ROLES
+#define SC_SELF_ROLES 0
+#endif
+#ifndef SC_ROLE_PF
+#define SC_ROLE_PF 2         // k-blocks of weight fragments a wave holds (= one K quarter; 4 = two quarters: spills)
+#endif
+#ifndef SC_ROLE_PRIO
+#define SC_ROLE_PRIO 0       // 1: instruction priority by head group during the projection (younger waves first: same total)
+#endif
+#ifndef SC_ROLE_UNROLL
+#define SC_ROLE_UNROLL 0     // 1: the loop over the K quarters unrolled (instruction footprint: no difference)
+#endif
 template <int D, int DK, int WM, bool SELF, int UNR, bool FIRST, bool KVH, int HPW = 1, bool WH = false>
 __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 4) : 1) void dec_layer_attn_kernel(DecLayerArgs p) {
   typedef typename std::conditional<WH, dl_h4, float4>::type BF;   // 4 weight elements of a fragment
@@ -198,8 +222,13 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
   if ((int)blockIdx.x >= (sb.rowmap ? sb.n_rows / sb.W : sb.S)) return;
   const int s = sb.rowmap ? sb.rowmap[blockIdx.x * sb.W] / sb.W : blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int g = tid >> 8, gt = tid & 255, wave = gt >> 6;   // head group, thread and wave inside it
+  constexpr bool ROLES = SC_SELF_ROLES && HPW > 1 && SELF && DK == 32;
+  // (ROLES: the wave's number as a scalar - its role is a scalar branch, the fragment addresses SGPR bases)
+  const int wvi = ROLES ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int g = ROLES ? wvi >> 2 : tid >> 8, gt = tid & 255, wave = ROLES ? wvi & 3 : gt >> 6;   // head group, thread and wave inside it
   const int head = blockIdx.y * HPW + g;
+  const int role = ROLES ? (wave + g) & 3 : 0;      // 0: q, K quarters 0-1   1: q, K quarters 2-3   2: k   3: v
+  const int rcb = role < 2 ? 0 : role - 1;         // the role's column block of the fused q|k|v weights
   if (!CTRL(s, SC_C_ACTIVE)) return;
   const int nh = CTRL(s, SC_C_NHYP);
   if (nh <= 0) return;
@@ -238,7 +267,9 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
   // requested as soon as the x rows are in LDS and travels during the LayerNorm; the output projection's fragments
   // travel during the merge of the attention's partial states.
   constexpr bool EARLY = HPW > 1;
-  BF pfb[(PF || EARLY) ? NTP * 2 : 1];   // k-block 0 of this wave (first pass); the later ones are fetched behind the MFMAs of their predecessor
+  BF pfb[ROLES ? SC_ROLE_PF * 4 : (PF || EARLY) ? NTP * 2 : 1];   // k-block 0 of this wave (first pass); the later ones are fetched behind the MFMAs of their predecessor
+                                                                  // (ROLES: the first SC_ROLE_PF k-blocks of the wave's two column tiles)
+  float rbias[2] = {0.f, 0.f}, qbias = 0.f;                       // ROLES: bias of the lane's column of either tile (k, v); of the thread's q column in the hand-off
   // ... and the ancestor slots of the first 128 positions (the row list of the self-attention starts from them)
   // (HPW > 1, round 5: of the first 512 positions, one per thread of the workgroup - the list is BUILT before the prologue's
   // partial sums have arrived, see early_list below)
@@ -258,7 +289,39 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
   float touch = 0.f, kvtouch = 0.f;
   // (loads return in issue order: the fragments are requested right BEHIND the first batch of partial sums, which
   // the LayerNorm needs first)
+  const int rki0 = role == 1 ? KI / 2 : 0;   // ROLES: the wave's first k-block
+  auto role_frag = [&](int ki, BF (&f0)[2], BF (&f1)[2]) {   // k-block ki of the wave's two column tiles
+#ifdef SC_ROLE_PROBE_L1    // timing probe only (wrong sums): every k-block = the first one, i.e. a projection whose fragment loads hit the L1
+    ki = rki0;
+#endif
+#ifdef SC_ROLE_PROBE_ROT   // timing probe only (wrong sums): every workgroup / head walks the k-blocks from another start
+    {
+      const int nkb = role < 2 ? KI / 2 : KI;
+      ki = rki0 + ((ki - rki0 + ((blockIdx.x * 3 + head) % nkb)) % nkb);
+    }
+#endif
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tile = (rcb * D + head * DK) / 16 + t;
+      const BF *wq = reinterpret_cast<const BF *>(p.wp) + ((long)tile * KI + ki) * 128 + lane;
+      f0[t] = wq[0];
+      f1[t] = wq[64];
+    }
+  };
   auto prefetch_w = [&]() {
+    if constexpr (ROLES) {
+#pragma unroll
+      for (int kb = 0; kb < SC_ROLE_PF; ++kb) {
+        BF f0[2], f1[2];
+        role_frag(rki0 + kb, f0, f1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          pfb[kb * 4 + t * 2] = f0[t];
+          pfb[kb * 4 + t * 2 + 1] = f1[t];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
       const int tile = ((t / NTQ) * D + head * DK) / 16 + (t % NTQ);
@@ -405,6 +468,12 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
       }
     }
     if (EARLY) prefetch_w();
+    if constexpr (ROLES) {
+      qbias = p.bp[head * DK + (gt & (DK - 1))];   // q hand-off: thread gt owns column gt % DK of two rows
+      if (role >= 2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) rbias[t] = p.bp[rcb * D + head * DK + t * 16 + (lane & 15)];
+    } else
 #pragma unroll
     for (int k = 0; k < NBP; ++k) {
       const int n = (gt + 256 * k) % (((SELF ? 3 : 1) * (DK / 16)) * 16);
@@ -449,6 +518,140 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
 
   constexpr int NTW_ = (UNR >= 8) ? SC_LAYER_NTW : (HPW > 1 ? (SELF ? SC_HPW_NTW : SC_HPW_NTW_CROSS) : 2);   // tiles per wave in flight in the attention walk
   MBatch<DK, NTW_> kvb0;                                 // HPW > 1, SELF: the wave's first batch, requested ahead (below)
+  const long skv0 = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;   // element offset (fp32 or fp16 pool)
+  if constexpr (ROLES) {
+    // ---------------------------------------------------------------- projection by role (SC_SELF_ROLES): two column tiles
+    // per wave, one MFMA chain per K quarter (KPW k-blocks); canonical order of a column's sum: ((P0 + P1) + P2) + P3 + bias
+    constexpr int LQP = DK + 4;                                   // q partials in LDS: [3][WM][LQP] = P0+P1 | P2 | P3,
+    float *QP = region + mattn_partial_floats(DK, 5) + 8;         // behind the attention's partial states (written later)
+    static_assert(5 * 16 * (DK + 3) + 8 + 3 * WM * LQP <= 4 * WM * (NT * 16 + 4), "the q partials fit the region (dl_region_floats: ps)");
+    const float *Xn = Xsh;
+    const int r = lane & 15, kk = lane >> 4;
+#if SC_ROLE_PRIO
+    // the issue arbiter prefers the oldest wave: the waves of head group 3 finished their FIRST K quarter 6.4 us after the
+    // barrier (group 0: 1.4) with their fragments in registers since the prologue - the younger groups go first instead
+    if (g == 1) __builtin_amdgcn_s_setprio(1);
+    else if (g == 2) __builtin_amdgcn_s_setprio(2);
+    else if (g == 3) __builtin_amdgcn_s_setprio(3);
+#endif
+    // a LOOP over the role's K quarters (KPW k-blocks each, their fragment buffers refilled KPW k-blocks ahead): the same
+    // 16 * KPW MFMAs per pass through ONE piece of code (SC_ROLE_UNROLL = 1: every quarter its own code, as the K-split form)
+    auto proj = [&](int nq, auto on_quarter) {
+      constexpr int QA = SC_ROLE_PF / KPW;   // K quarters whose fragments a wave holds (1 | 2): the loop refills QA quarters ahead
+      static_assert(SC_ROLE_PF % KPW == 0 && (QA == 1 || QA == 2), "whole K quarters in flight");
+      BF f0[SC_ROLE_PF][2], f1[SC_ROLE_PF][2];
+#pragma unroll
+      for (int kb = 0; kb < SC_ROLE_PF; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f0[kb][t] = pfb[kb * 4 + t * 2];
+          f1[kb][t] = pfb[kb * 4 + t * 2 + 1];
+        }
+#if SC_ROLE_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+      for (int q0 = 0; q0 < nq; q0 += QA) {
+#pragma unroll
+        for (int h = 0; h < QA; ++h) {
+          const int q = q0 + h;
+          f32x4 accq[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) accq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < KPW; ++kb) {
+            const int ki = rki0 + q * KPW + kb;
+            const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
+            const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+            if constexpr (WH) dl_mfma8_il_h<2>(accq, a0, a1, f0[h * KPW + kb], f1[h * KPW + kb]);
+            else dl_mfma8_il<2>(accq, a0, a1, f0[h * KPW + kb], f1[h * KPW + kb]);
+            if (q + QA < nq) role_frag(ki + SC_ROLE_PF, f0[h * KPW + kb], f1[h * KPW + kb]);   // in flight during the next quarters' MFMAs
+          }
+          on_quarter(q, accq);
+        }
+      }
+    };
+    auto store_qp = [&](int z, const f32x4 (&v)[2]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * kk + j < WM) QP[(z * WM + 4 * kk + j) * LQP + t * 16 + r] = v[t][j];
+    };
+    if (role < 2) {
+      f32x4 run[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      proj(2, [&](int Q, const f32x4 (&a)[2]) {
+        if (role == 0) {   // P0, P1 -> P0 + P1
+#pragma unroll
+          for (int t = 0; t < 2; ++t) run[t] = Q == 0 ? a[t] : run[t] + a[t];
+          if (Q == 1) store_qp(0, run);
+        } else {           // P2, P3: added by the hand-off, one after the other
+          store_qp(1 + Q, a);
+        }
+      });
+    } else {
+      f32x4 run[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      proj(4, [&](int Q, const f32x4 (&a)[2]) {
+#ifdef SC_ROLE_STAMP_Q
+        SC_STAMP_BY(0, 9 + Q, g == SC_ROLE_STAMP_Q - 1 && role == 2 && lane == 0 && Q < 3);   // (K quarters 0..2 of the k role's wave are done)
+#endif
+#pragma unroll
+        for (int t = 0; t < 2; ++t) run[t] = Q == 0 ? a[t] : run[t] + a[t];
+      });
+      // the new token's k (role 2) / v (role 3): LDS for its own attention state, and appended into its pool row - later
+      // steps read it from the cache
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = 4 * kk + j;
+          if (row < WM) {
+            const float v = row < W ? run[t][j] + rbias[t] : 0.f;
+            kvn[row * 2 * DK + (role - 2) * DK + t * 16 + r] = v;
+            if (row < nh) kv_store1<KVH>(sb.skv, skv0 + (long)ancs[row] * 2 * D + (role - 2) * D + t * 16 + r, v);
+          }
+        }
+    }
+#ifdef SC_ROLE_STAMP_Q
+#elif defined(SC_ROLE_STAMP_G3)
+    SC_STAMP_BY(0, 9, g == 3 && wave == 0 && lane == 0);
+    SC_STAMP_BY(0, 10, g == 3 && wave == 3 && lane == 0);
+    SC_STAMP_BY(0, 11, g == 1 && wave == 2 && lane == 0);
+#else
+    SC_STAMP_BY(0, 8 + wave, g == 0 && wave > 0 && lane == 0);   // (roles 1..3 of head group 0 are done)
+#endif
+#if SC_ROLE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // the wave's first batch of K|V tiles (as in the K-split form below): travels during the hand-off
+    if constexpr (SC_EARLY_LIST && SC_EARLY_KV)
+      mattn_load<DK, NTW_, KVH>(kvb0, sb.skv, D, cdiv(U0, 16), wave, lane, [&](int idx, long &ke, unsigned &hm) {
+        const int e = srows[min(idx, PCS * W - 1)];
+        hm = (unsigned)e >> 16;
+        ke = skv0 + (long)(e & 0xFFFF) * 2 * D;
+      });
+    __syncthreads();
+    SC_STAMP(0, 3);
+    {
+      const float scale = sqrtf((float)DK);
+#pragma unroll
+      for (int k = 0; k < 16 * DK / 256; ++k) {
+        const int e = gt + 256 * k, h = e / DK, c = e % DK;   // (c = gt % DK for every k)
+        float v = 0.f;   // hypothesis rows the MFMA tiles pad with
+        if (h < W) {
+          v = QP[(0 * WM + h) * LQP + c];
+          v += QP[(1 * WM + h) * LQP + c];
+          v += QP[(2 * WM + h) * LQP + c];
+          v += qbias;
+          v = v / scale;
+        }
+        qs[e] = v;
+      }
+    }
+    __syncthreads();
+    SC_STAMP(0, 4);
+  } else {
   // ------------------------------------------------------------------ projection of the head's columns
   // NT tiles of 16 output columns, K = D split over the 4 waves (KPW k-blocks of 32 each); B operands
   // straight from the fragment-packed weights (1 KB contiguous per wave load)
@@ -524,7 +727,6 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
   }
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 3);
-  const long skv0 = ((long)s * sb.n_layers + p.li) * sb.kv_rows * 2 * D + head * DK;   // element offset (fp32 or fp16 pool)
   {
     const float *Ps = region;
     const float scale = sqrtf((float)DK);
@@ -554,6 +756,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
   }
   __syncthreads();
   SC_STAMP(SELF ? 0 : 1, 4);
+  }   // !ROLES
 
   // ------------------------------------------------------------------ attention of this head (all hypotheses)
   // matrix-core form (attn.h: mattn_*): the hypotheses are the N dimension, 16 K/V rows a tile; the four waves

@@ -77,6 +77,10 @@ for fn, kinds in (("sc_phase_debug_layer", (0, 1)), ("sc_phase_debug_ffn", (2,))
             print(f"  launch {no:5d}: grid {int(rows[0, 13]):4d}, {len(rows):3d} workgroups stamped, {tpu:.0f} MHz, span {rel[:, -1].max():6.2f} us, workgroup mean "
                   f"{span_t.mean() / tpu:6.2f} max {span_t.max() / tpu:6.2f}, starts within {start.max():.2f} us | phases (mean): " +
                   " ".join(f"{x:.1f}" for x in d.mean(axis=0)))
+            extra = rows[:, 9:12].astype(np.float64)
+            if k == 0 and (extra > 0).all():   # SC_SELF_ROLES: when the waves of roles 1..3 (head group 0) finished their projection
+                print("       projection by role, done after the LayerNorm's barrier (role 1 = q, K quarters 2-3 | 2 = k | 3 = v): " +
+                      " ".join(f"{x:.2f}" for x in ((extra - t[:, 2:3]) / tpu).mean(axis=0)) + " us")
             if DETAIL or idx == len(launches) - 1:
                 for i, n in enumerate(names[k]):
                     print(f"       {n:52s} in phase: mean {d[:, i].mean():6.2f}  max {d[:, i].max():6.2f} us   reached its end at: mean {rel[:, i + 1].mean():6.2f}  "

@@ -1,0 +1,53 @@
+// Probe: throughput of v_mfma_f32_16x16x4_f32 per SIMD as a function of (waves per SIMD) x (independent accumulators per wave).
+// Build: hipcc -O3 --offload-arch=gfx950 mfma_f32_chain_probe.hip -o mfma_probe ; run on the GPU box.
+// Question behind it (round 6): the four-head self kernel's projection runs 384 MFMAs per SIMD in 11 us (64 cycles each)
+// with 4 waves per SIMD x 2 accumulator chains per wave - is that the pipe, or the chains?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(1024) void probe(float *out, long long *cyc, int iters) {
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+  }
+  __syncthreads();
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int NACC>
+void run(int threads, float *out, long long *cyc) {
+  const int iters = 256;
+  hipLaunchKernelGGL(probe<NACC>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipLaunchKernelGGL(probe<NACC>, dim3(256), dim3(threads), 0, 0, out, cyc, iters);
+  hipDeviceSynchronize();
+  long long h[256];
+  hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+  double m = 0;
+  for (int i = 0; i < 256; ++i) m += h[i];
+  m /= 256;
+  const int waves_per_simd = threads / 256;
+  const double per_simd = (double)iters * 8 * NACC * waves_per_simd;
+  // s_memtime ticks at 100 MHz on gfx950?  report both raw ticks and ticks per MFMA; calibrate with the 1-wave 8-acc case
+  printf("threads %4d (waves/SIMD %d) acc/wave %d: %.0f ticks, %.3f ticks per MFMA per SIMD\n", threads, waves_per_simd, NACC, m, m / per_simd);
+}
+int main() {
+  float *out; long long *cyc;
+  hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 256 * 8);
+  for (int threads : {256, 512, 1024}) {
+    run<1>(threads, out, cyc); run<2>(threads, out, cyc); run<4>(threads, out, cyc); run<8>(threads, out, cyc);
+  }
+  return 0;
+}
