@@ -182,10 +182,10 @@ __host__ __device__ static inline int dl_lds_floats(int D, int DK, int W, int WM
 // of every group) carries one wave of each role.  Same sums in the same order - bit-identical to the K-split form
 // (tests/test_gpu_baseline_size.py -k stream_resident with this switch on: identical token ids and float64 totals).
 // What it measured (docs/r06_findings.md section 6, profiles/r06_phase_times_role_projection.txt): the hand-off costs 0.45 us
-// where the reduce cost 2.0, but the projection itself stays at 12-13 us for 5.5 us of matrix work in EITHER form - a wave
-// waits ~2.1 us for every refill of its fragment registers (all 256 workgroups pull the same 768 KB through their XCD's L2
-// at once: tools/probes/l2_shared_weights_probe.hip), and 128 registers per lane hold two K quarters at most (four: spills,
-// 18 us).  3373 / 3386 against 3388 / 3402 audio-s/s in one job: not the product.
+// where the reduce cost 2.0, but the projection itself takes 12-13 us for 5.5 us of matrix work - in this form a wave waits
+// ~2.1 us for every refill of its fragment registers (128 registers per lane hold one K quarter; two: spills, 18 us), in
+// the K-split form the same time goes elsewhere (a probe without loads is no faster).  3373 / 3386 against 3388 / 3402
+// audio-s/s in one job: not the product.
 #ifndef SC_SELF_ROLES
 #define SC_SELF_ROLES 0
 #endif
@@ -690,9 +690,23 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
       for (int kq = 0; kq < KPW; ++kq) {
         const int ki = wave * KPW + kq;
         const float *ab = Xn + r * LDX + ki * 32 + 8 * kk;
+#ifdef SC_PROJ_PROBE_NOLDS   // timing probe only (wrong sums): the A operand without its LDS reads
+        const float4 a0 = make_float4((float)lane, 1.f, 2.f, (float)ki), a1 = make_float4(3.f, (float)kk, 4.f, 5.f);
+#else
         const float4 a0 = *reinterpret_cast<const float4 *>(ab), a1 = *reinterpret_cast<const float4 *>(ab + 4);
+#endif
         BF n0[NTP], n1[NTP];
+#ifdef SC_PROJ_PROBE_NOLOAD   // timing probe only (wrong sums): the later k-blocks re-use the fragments of the first - a projection without memory
+        if (kq + 1 < KPW) {
+#pragma unroll
+          for (int t = 0; t < NTP; ++t) {
+            n0[t] = b0[t];
+            n1[t] = b1[t];
+          }
+        }
+#else
         if (kq + 1 < KPW) load_b(ki + 1, n0, n1);   // in flight during this k-block's MFMAs
+#endif
         if constexpr (WH) dl_mfma8_il_h<NTP>(accp, a0, a1, b0, b1);
         else dl_mfma8_il<NTP>(accp, a0, a1, b0, b1);
         if (kq + 1 < KPW) {
@@ -717,7 +731,14 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
         ke = skv0e + (long)(e & 0xFFFF) * 2 * D;
       });
     }
+#ifdef SC_PROJ_STAMPS   // (9: thread 0's MFMAs issued + first K|V batch requested; 10: the youngest wave's; 11: behind the barrier)
+    SC_STAMP_BY(SELF ? 0 : 1, 9, tid == 0);
+    SC_STAMP_BY(SELF ? 0 : 1, 10, tid == NTH - 64);
+#endif
     __syncthreads();  // every wave is done reading Xn: the region becomes the partial products
+#ifdef SC_PROJ_STAMPS
+    SC_STAMP_BY(SELF ? 0 : 1, 11, tid == 0);
+#endif
     float *Ps = region;  // [4][WM][LDP]
 #pragma unroll
     for (int t = 0; t < NT; ++t)

@@ -78,7 +78,10 @@ for fn, kinds in (("sc_phase_debug_layer", (0, 1)), ("sc_phase_debug_ffn", (2,))
                   f"{span_t.mean() / tpu:6.2f} max {span_t.max() / tpu:6.2f}, starts within {start.max():.2f} us | phases (mean): " +
                   " ".join(f"{x:.1f}" for x in d.mean(axis=0)))
             extra = rows[:, 9:12].astype(np.float64)
-            if k == 0 and (extra > 0).all():   # SC_SELF_ROLES: when the waves of roles 1..3 (head group 0) finished their projection
+            if os.environ.get("SC_PROJ_STAMPS") and (extra > 0).all():
+                print("       projection: wave 0 done | youngest wave done | behind the barrier, after the LayerNorm's barrier: " +
+                      " ".join(f"{x:.2f}" for x in ((extra - t[:, 2:3]) / tpu).mean(axis=0)) + " us")
+            elif k == 0 and (extra > 0).all():   # SC_SELF_ROLES: when the waves of roles 1..3 (head group 0) finished their projection
                 print("       projection by role, done after the LayerNorm's barrier (role 1 = q, K quarters 2-3 | 2 = k | 3 = v): " +
                       " ".join(f"{x:.2f}" for x in ((extra - t[:, 2:3]) / tpu).mean(axis=0)) + " us")
             if DETAIL or idx == len(launches) - 1:

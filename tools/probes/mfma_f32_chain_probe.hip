@@ -27,6 +27,48 @@ __global__ __launch_bounds__(1024) void probe(float *out, long long *cyc, int it
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the layer kernels' pattern: 8 k-steps x NT accumulators, EVERY MFMA with its own A and B registers (a k-block of fragments)
+template <int NT>
+__global__ __launch_bounds__(1024) void probe_regs(const float *src, float *out, long long *cyc, int iters) {
+  f32x4 acc[NT];
+  float av[8], bv[NT][8];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    av[j] = src[threadIdx.x * 8 + j];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t][j] = src[8192 + (t * 8 + j) * 1024 + threadIdx.x];
+  }
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[t][j], acc[t], 0, 0, 0);
+  }
+  __syncthreads();
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int NT>
+void run_regs(int threads, const float *src, float *out, long long *cyc) {
+  const int iters = 64;
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe_regs<NT>, dim3(256), dim3(threads), 0, 0, src, out, cyc, iters);
+  hipDeviceSynchronize();
+  long long h[256];
+  hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+  double m = 0;
+  for (int i = 0; i < 256; ++i) m += h[i];
+  m /= 256;
+  const double per_simd = (double)iters * 8 * NT * (threads / 256);
+  printf("own registers per MFMA: threads %4d (waves/SIMD %d) tiles %d: %.0f ticks, %.3f ticks per MFMA per SIMD\n", threads, threads / 256, NT, m, m / per_simd);
+}
 template <int NACC>
 void run(int threads, float *out, long long *cyc) {
   const int iters = 256;
@@ -48,6 +90,11 @@ int main() {
   hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 256 * 8);
   for (int threads : {256, 512, 1024}) {
     run<1>(threads, out, cyc); run<2>(threads, out, cyc); run<4>(threads, out, cyc); run<8>(threads, out, cyc);
+  }
+  float *src;
+  hipMalloc(&src, (8192 + 64 * 1024) * 4); hipMemset(src, 0, (8192 + 64 * 1024) * 4);
+  for (int threads : {256, 1024}) {
+    run_regs<2>(threads, src, out, cyc); run_regs<6>(threads, src, out, cyc);
   }
   return 0;
 }
