@@ -709,6 +709,13 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
 #endif
         if constexpr (WH) dl_mfma8_il_h<NTP>(accp, a0, a1, b0, b1);
         else dl_mfma8_il<NTP>(accp, a0, a1, b0, b1);
+#if defined(SC_PROJ_STAMPS) && SC_PROJ_STAMPS == 2   // (9 / 10: thread 0's / the youngest wave's FIRST MFMA of the phase has its result - its fragments have arrived)
+        if (ps == 0 && kq == 0) {
+          asm volatile("s_nop 0" : "+v"(accp[0]));
+          SC_STAMP_BY(SELF ? 0 : 1, 9, tid == 0);
+          SC_STAMP_BY(SELF ? 0 : 1, 10, tid == NTH - 64);
+        }
+#endif
         if (kq + 1 < KPW) {
 #pragma unroll
           for (int t = 0; t < NTP; ++t) {
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(256 * HPW, (UNR <= 4 && WM <= 10) ? (DK > 32 ? 2 : 
         ke = skv0e + (long)(e & 0xFFFF) * 2 * D;
       });
     }
-#ifdef SC_PROJ_STAMPS   // (9: thread 0's MFMAs issued + first K|V batch requested; 10: the youngest wave's; 11: behind the barrier)
+#if defined(SC_PROJ_STAMPS) && SC_PROJ_STAMPS != 2   // (9: thread 0's MFMAs issued + first K|V batch requested; 10: the youngest wave's; 11: behind the barrier)
     SC_STAMP_BY(SELF ? 0 : 1, 9, tid == 0);
     SC_STAMP_BY(SELF ? 0 : 1, 10, tid == NTH - 64);
 #endif
